@@ -1,0 +1,575 @@
+// qz_rules.h -- Quoridor rules on 81-bit bitboards (device + host-check build).
+//
+// Everything here is per-lane / wave-uniform arithmetic with no memory traffic; the
+// wave-level orchestration (ballots, LDS work lists, stores) lives in qz_kernels.hip.
+// The same header is compiled by g++ into tests/hostcheck (QZ_HD empty) so that the
+// bitboard formulation can be checked against the oracle without a GPU; that build is
+// test-only and is never loaded by the product.
+//
+// Semantics restated from the reference (file:line = cryer/AlphaZero_Quoridor):
+//   corner()            quoridor.py:356-418  _get_intersections, incl. the row-0 NE overwrite
+//   build_moves()       quoridor.py:287-293  n/s/e/w wall tests for all 81 tiles at once
+//   jump_dests()        quoridor.py:301-351  jump branches around the opponent pawn
+//   pawn_actions()      quoridor.py:272-353  the mover's ordered pawn codes (as a 12-bit mask)
+//   flood()             quoridor.py:479-528  _bfs_to_goal == directed reachability
+//   apply_action()      quoridor.py:159-186, 217-269  step / rotate_players
+//   plane_value()       quoridor.py:58-131   state()
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define QZ_HD __host__ __device__ __forceinline__
+#else
+#define QZ_HD inline
+#endif
+
+namespace qz {
+
+// ----------------------------------------------------------------------------- boards
+struct Board {
+    uint64_t hb, vb;  // horizontal / vertical wall bits, bit ix = intersection ix
+    int p1, p2;       // pawn tiles (may be off-board on terminal boards)
+    int w1, w2;       // walls remaining
+    int cur;          // 1 | 2
+};
+
+QZ_HD uint64_t pack_meta(const Board& b) {
+    return (uint64_t)(uint8_t)(int8_t)b.p1 | ((uint64_t)(uint8_t)(int8_t)b.p2 << 8) |
+           ((uint64_t)(uint8_t)b.w1 << 16) | ((uint64_t)(uint8_t)b.w2 << 24) |
+           ((uint64_t)(uint8_t)b.cur << 32);
+}
+QZ_HD Board unpack(uint64_t hb, uint64_t vb, uint64_t meta) {
+    Board b;
+    b.hb = hb;
+    b.vb = vb;
+    b.p1 = (int)(int8_t)(meta & 0xFF);
+    b.p2 = (int)(int8_t)((meta >> 8) & 0xFF);
+    b.w1 = (int)((meta >> 16) & 0xFF);
+    b.w2 = (int)((meta >> 24) & 0xFF);
+    b.cur = (int)((meta >> 32) & 0xFF);
+    return b;
+}
+QZ_HD Board opening() {  // quoridor.py:26-56
+    Board b;
+    b.hb = 0;
+    b.vb = 0;
+    b.p1 = 4;
+    b.p2 = 76;
+    b.w1 = 10;
+    b.w2 = 10;
+    b.cur = 1;
+    return b;
+}
+// quoridor.py:193-202 (player 2 first)
+QZ_HD int winner_of(const Board& b) { return b.p2 < 9 ? 2 : (b.p1 > 71 ? 1 : 0); }
+
+QZ_HD int action_delta(int a) {  // quoridor.py:217-241
+    // N S E W NN SS EE WW NE NW SE SW
+    const int d[12] = {9, -9, 1, -1, 18, -18, 2, -2, 10, 8, -8, -10};
+    return d[a];
+}
+
+// quoridor.py:159-186: move / place, then rotate unless the game is over. returns done.
+QZ_HD bool apply_action(Board& b, int a) {
+    if (a < 12) {
+        if (b.cur == 1) b.p1 += action_delta(a);
+        else b.p2 += action_delta(a);
+    } else {
+        int w = a - 12;
+        if (w < 64) b.hb |= 1ull << w;
+        else b.vb |= 1ull << (w - 64);
+        if (b.cur == 1) b.w1 -= 1;
+        else b.w2 -= 1;
+    }
+    if (winner_of(b) != 0) return true;  // quoridor.py:176-179: no rotation
+    b.cur = 3 - b.cur;
+    return false;
+}
+
+// ----------------------------------------------------------------------------- 81-bit sets
+struct BB {
+    uint32_t w0, w1, w2;  // tiles 0-31, 32-63, 64-80
+};
+QZ_HD BB bb_zero() { return BB{0u, 0u, 0u}; }
+QZ_HD BB bb_or(BB a, BB b) { return BB{a.w0 | b.w0, a.w1 | b.w1, a.w2 | b.w2}; }
+QZ_HD BB bb_and(BB a, BB b) { return BB{a.w0 & b.w0, a.w1 & b.w1, a.w2 & b.w2}; }
+QZ_HD BB bb_andn(BB a, BB b) { return BB{a.w0 & ~b.w0, a.w1 & ~b.w1, a.w2 & ~b.w2}; }
+QZ_HD BB bb_not(BB a) { return BB{~a.w0, ~a.w1, ~a.w2 & 0x1FFFFu}; }
+QZ_HD bool bb_any(BB a) { return (a.w0 | a.w1 | a.w2) != 0u; }
+QZ_HD bool bb_eq(BB a, BB b) { return ((a.w0 ^ b.w0) | (a.w1 ^ b.w1) | (a.w2 ^ b.w2)) == 0u; }
+QZ_HD BB bb_bit(int t) {  // t in 0..80 (anything else -> empty)
+    BB r = bb_zero();
+    uint32_t m = 1u << (t & 31);
+    int w = t >> 5;
+    r.w0 = (w == 0) ? m : 0u;
+    r.w1 = (w == 1) ? m : 0u;
+    r.w2 = (w == 2 && t <= 80) ? m : 0u;
+    return r;
+}
+QZ_HD bool bb_test(BB a, int t) {  // t in 0..80
+    uint32_t w = (t < 32) ? a.w0 : ((t < 64) ? a.w1 : a.w2);
+    return (w >> (t & 31)) & 1u;
+}
+template <int K>
+QZ_HD BB bb_shl(BB a) {  // towards higher tiles; bits past tile 80 are dropped
+    BB r;
+    r.w0 = a.w0 << K;
+    r.w1 = (a.w1 << K) | (a.w0 >> (32 - K));
+    r.w2 = ((a.w2 << K) | (a.w1 >> (32 - K))) & 0x1FFFFu;
+    return r;
+}
+template <int K>
+QZ_HD BB bb_shr(BB a) {
+    BB r;
+    r.w0 = (a.w0 >> K) | (a.w1 << (32 - K));
+    r.w1 = (a.w1 >> K) | (a.w2 << (32 - K));
+    r.w2 = a.w2 >> K;
+    return r;
+}
+QZ_HD int bb_lowest(BB a) {  // index of lowest set bit; a must be non-empty
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (a.w0) return __ffs((int)a.w0) - 1;
+    if (a.w1) return 32 + __ffs((int)a.w1) - 1;
+    return 64 + __ffs((int)a.w2) - 1;
+#else
+    if (a.w0) return __builtin_ctz(a.w0);
+    if (a.w1) return 32 + __builtin_ctz(a.w1);
+    return 64 + __builtin_ctz(a.w2);
+#endif
+}
+
+// constant sets
+QZ_HD BB ROW0() { return BB{0x1FFu, 0u, 0u}; }                      // tiles 0..8
+QZ_HD BB ROW8() { return BB{0u, 0u, 0x1FF00u}; }                    // tiles 72..80
+QZ_HD BB ROW0_C1_7() { return BB{0xFEu, 0u, 0u}; }                  // tiles 1..7
+QZ_HD BB COL0() { return BB{0x08040201u, 0x80402010u, 0x00000100u}; }  // tiles 0,9,..,72
+QZ_HD BB COL8() { return BB{0x04020100u, 0x40201008u, 0x00010080u}; }  // tiles 8,17,..,80
+
+// 8x8 intersection bits -> 81-bit set with bit (9r+c) = I(r,c), r,c < 8
+QZ_HD BB spread8(uint64_t x) {
+    BB b = bb_zero();
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int r = 0; r < 8; r++) {
+        uint32_t row = (uint32_t)(x >> (8 * r)) & 0xFFu;
+        int pos = 9 * r, w = pos >> 5, off = pos & 31;
+        uint32_t lo = row << off;
+        uint32_t hi = (off > 24) ? (row >> (32 - off)) : 0u;
+        if (w == 0) {
+            b.w0 |= lo;
+            b.w1 |= hi;
+        } else if (w == 1) {
+            b.w1 |= lo;
+            b.w2 |= hi;
+        } else {
+            b.w2 |= lo;
+        }
+    }
+    return b;
+}
+
+// ----------------------------------------------------------------------------- corners
+// quoridor.py:356-418 in closed form. which: 0 NW, 1 NE, 2 SE, 3 SW.
+QZ_HD int inter_val(uint64_t hb, uint64_t vb, int r, int c) {
+    int ix = 8 * r + c;
+    return (int)((hb >> ix) & 1ull) - (int)((vb >> ix) & 1ull);
+}
+QZ_HD int corner(uint64_t hb, uint64_t vb, int t, int which) {
+    int r = t / 9, c = t - 9 * r;
+    switch (which) {
+        case 0:  // NW
+            if (c == 0) return -1;
+            if (r == 8) return 1;
+            return inter_val(hb, vb, r, c - 1);
+        case 1:  // NE
+            if (r == 8) return 1;
+            if (r == 0) return c == 0 ? inter_val(hb, vb, 0, 0) : inter_val(hb, vb, 0, c - 1);  // :388,:392
+            if (c == 8) return -1;
+            return inter_val(hb, vb, r, c);
+        case 2:  // SE
+            if (c == 8) return -1;
+            if (r == 0) return 1;
+            return inter_val(hb, vb, r - 1, c);
+        default:  // SW
+            if (r == 0) return 1;
+            if (c == 0) return -1;
+            return inter_val(hb, vb, r - 1, c - 1);
+    }
+}
+
+// ----------------------------------------------------------------------------- move sets
+// blocked-by-wall sets for the four simple moves, for all tiles at once.  Linear (OR of
+// shifts) in the spread wall sets, so a candidate wall contributes an additive delta.
+struct Blk {
+    BB n, s, e, w;
+};
+QZ_HD Blk blocked_from(BB Hs, BB Vs) {
+    Blk k;
+    BB h1 = bb_shl<1>(Hs);
+    // N: rows 1..7 use I(r,c-1)|I(r,c); row 0 uses I(0,c-1) only, plus I(0,0) for tile 0
+    k.n = bb_or(bb_andn(bb_or(Hs, h1), ROW0()), bb_and(bb_or(h1, bb_and(Hs, BB{1u, 0u, 0u})), ROW0()));
+    // S: I(r-1,c) | I(r-1,c-1)
+    k.s = bb_or(bb_shl<9>(Hs), bb_shl<10>(Hs));
+    // E: I(r,c) | I(r-1,c); row 0, cols 1..7 use I(0,c-1) instead (the :392 overwrite)
+    BB v1 = bb_shl<1>(Vs);
+    k.e = bb_or(bb_andn(bb_or(Vs, bb_shl<9>(Vs)), ROW0_C1_7()), bb_and(v1, ROW0_C1_7()));
+    // W: I(r,c-1) | I(r-1,c-1)
+    k.w = bb_or(v1, bb_shl<10>(Vs));
+    return k;
+}
+// border sentinels: N from row 8, S from row 0, E from col 8, W from col 0 never pass the
+// wall test (quoridor.py:365-392 sentinels +1/-1)
+QZ_HD Blk blocked_borders() {
+    Blk k;
+    k.n = ROW8();
+    k.s = ROW0();
+    k.e = COL8();
+    k.w = COL0();
+    return k;
+}
+QZ_HD Blk blk_or(Blk a, Blk b) { return Blk{bb_or(a.n, b.n), bb_or(a.s, b.s), bb_or(a.e, b.e), bb_or(a.w, b.w)}; }
+
+struct Jumps {
+    int a[4];   // tiles adjacent to the opponent: O-9, O+9, O-1, O+1 (or -1 when unusable)
+    BB d[4];    // on-board jump destinations from a[k]
+};
+QZ_HD BB dest_bit(int t) { return (t >= 0 && t <= 80) ? bb_bit(t) : bb_zero(); }
+// quoridor.py:301-351 for the four tiles next to the opponent O (walls hb/vb).
+QZ_HD Jumps jump_dests(uint64_t hb, uint64_t vb, int O) {
+    const int H = 1, V = -1;
+    Jumps j;
+    int onw = corner(hb, vb, O, 0), one = corner(hb, vb, O, 1), ose = corner(hb, vb, O, 2),
+        osw = corner(hb, vb, O, 3);
+    for (int k = 0; k < 4; k++) {
+        j.a[k] = -1;
+        j.d[k] = bb_zero();
+    }
+    {  // opponent north of A = O-9   (:301-314)
+        int A = O - 9;
+        if (A >= 0) {
+            int xnw = corner(hb, vb, A, 0), xne = corner(hb, vb, A, 1);
+            if (xne != H && xnw != H) {
+                j.a[0] = A;
+                BB d = bb_zero();
+                if (onw != H && one != H) d = bb_or(d, dest_bit(O + 9));
+                if (one != V && xne != V) d = bb_or(d, dest_bit(A + 10));
+                if (onw != V && xnw != V) d = bb_or(d, dest_bit(A + 8));
+                j.d[0] = d;
+            }
+        }
+    }
+    {  // opponent south of A = O+9   (:317-327)
+        int A = O + 9;
+        if (A <= 80) {
+            int xse = corner(hb, vb, A, 2), xsw = corner(hb, vb, A, 3);
+            if (xse != H && xsw != H) {
+                j.a[1] = A;
+                BB d = bb_zero();
+                if (osw != H && ose != H) d = bb_or(d, dest_bit(O - 9));
+                if (ose != V && xse != V) d = bb_or(d, dest_bit(A - 8));
+                if (osw != V && xsw != V) d = bb_or(d, dest_bit(A - 10));
+                j.d[1] = d;
+            }
+        }
+    }
+    {  // opponent east of A = O-1    (:330-339)
+        int A = O - 1;
+        if (A >= 0) {
+            int xse = corner(hb, vb, A, 2), xne = corner(hb, vb, A, 1);
+            if (xse != V && xne != V) {
+                j.a[2] = A;
+                BB d = bb_zero();
+                if (ose != V && one != V) d = bb_or(d, dest_bit(O + 1));
+                if (one != H) d = bb_or(d, dest_bit(A + 10));
+                if (ose != H) d = bb_or(d, dest_bit(A - 8));
+                j.d[2] = d;
+            }
+        }
+    }
+    {  // opponent west of A = O+1    (:342-351)
+        int A = O + 1;
+        if (A <= 80) {
+            int xsw = corner(hb, vb, A, 3), xnw = corner(hb, vb, A, 0);
+            if (xsw != V && xnw != V) {
+                j.a[3] = A;
+                BB d = bb_zero();
+                if (onw != V && osw != V) d = bb_or(d, dest_bit(O - 1));
+                if (onw != H) d = bb_or(d, dest_bit(A + 8));
+                if (osw != H) d = bb_or(d, dest_bit(A - 10));
+                j.d[3] = d;
+            }
+        }
+    }
+    return j;
+}
+
+// quoridor.py:272-353 for the side to move, as a 12-bit mask (bit = action code).  The
+// reference's emission order is ascending code order in every branch.
+QZ_HD uint32_t pawn_actions(uint64_t hb, uint64_t vb, int loc, int opp, int player) {
+    const int H = 1, V = -1;
+    int xnw = corner(hb, vb, loc, 0), xne = corner(hb, vb, loc, 1), xse = corner(hb, vb, loc, 2),
+        xsw = corner(hb, vb, loc, 3);
+    bool on = loc == opp - 9, os = loc == opp + 9, oe = loc == opp - 1, ow = loc == opp + 1;
+    int row = loc / 9;
+    uint32_t m = 0;
+    bool n = xnw != H && xne != H && !on;
+    bool s = xsw != H && xse != H && !os;
+    bool e = xne != V && xse != V && !oe;
+    bool w = xnw != V && xsw != V && !ow;
+    if (n || (player == 1 && row == 8)) m |= 1u << 0;
+    if (s || (player == 2 && row == 0)) m |= 1u << 1;
+    if (e) m |= 1u << 2;
+    if (w) m |= 1u << 3;
+    if (on && xne != H && xnw != H) {
+        int onw = corner(hb, vb, opp, 0), one = corner(hb, vb, opp, 1);
+        if ((onw != H && one != H) || (row == 7 && player == 1)) m |= 1u << 4;
+        if (one != V && xne != V) m |= 1u << 8;
+        if (onw != V && xnw != V) m |= 1u << 9;
+    } else if (os && xse != H && xsw != H) {
+        int ose = corner(hb, vb, opp, 2), osw = corner(hb, vb, opp, 3);
+        if ((osw != H && ose != H) || (row == 1 && player == 2)) m |= 1u << 5;
+        if (ose != V && xse != V) m |= 1u << 10;
+        if (osw != V && xsw != V) m |= 1u << 11;
+    } else if (oe && xse != V && xne != V) {
+        int one = corner(hb, vb, opp, 1), ose = corner(hb, vb, opp, 2);
+        if (ose != V && one != V) m |= 1u << 6;
+        if (one != H) m |= 1u << 8;
+        if (ose != H) m |= 1u << 10;
+    } else if (ow && xsw != V && xnw != V) {
+        int onw = corner(hb, vb, opp, 0), osw = corner(hb, vb, opp, 3);
+        if (onw != V && osw != V) m |= 1u << 7;
+        if (onw != H) m |= 1u << 9;
+        if (osw != H) m |= 1u << 11;
+    }
+    return m;
+}
+
+// ----------------------------------------------------------------------------- reachability
+struct Graph {
+    BB cn, cs, ce, cw;  // tiles from which N/S/E/W passes the wall test
+    BB notO;            // every tile except the opponent's (simple moves may not enter it)
+    Jumps j;
+};
+QZ_HD Graph make_graph(Blk blocked, uint64_t hb, uint64_t vb, int O) {
+    Graph g;
+    g.cn = bb_not(blocked.n);
+    g.cs = bb_not(blocked.s);
+    g.ce = bb_not(blocked.e);
+    g.cw = bb_not(blocked.w);
+    g.notO = bb_not(dest_bit(O));
+    g.j = jump_dests(hb, vb, O);
+    return g;
+}
+// one BFS layer: every tile generated from the set R (quoridor.py:488-516)
+QZ_HD BB expand(const Graph& g, BB R) {
+    BB nx = bb_shl<9>(bb_and(R, g.cn));
+    nx = bb_or(nx, bb_shr<9>(bb_and(R, g.cs)));
+    nx = bb_or(nx, bb_shl<1>(bb_and(R, g.ce)));
+    nx = bb_or(nx, bb_shr<1>(bb_and(R, g.cw)));
+    nx = bb_and(nx, g.notO);
+    for (int k = 0; k < 4; k++) {
+        if (g.j.a[k] >= 0 && bb_test(R, g.j.a[k])) nx = bb_or(nx, g.j.d[k]);
+    }
+    return nx;
+}
+// quoridor.py:479-528: can `start` reach any tile of `goal`?  (goal test on generation;
+// FIFO order is unobservable, so a layered flood gives the same answer)
+QZ_HD bool flood(const Graph& g, int start, BB goal) {
+    BB R = bb_bit(start);
+    for (int it = 0; it < 96; it++) {
+        BB nx = expand(g, R);
+        if (bb_any(bb_and(nx, goal))) return true;
+        BB R2 = bb_or(R, nx);
+        if (bb_eq(R2, R)) return false;
+        R = R2;
+    }
+    return false;
+}
+
+// edges of one concrete start->goal path, grouped by move type (tiles the move leaves from)
+struct PathEdges {
+    BB pn, ps, pe, pw;
+    bool jump;   // the path uses at least one jump edge
+    bool found;
+};
+// Layered flood that keeps every layer in `layers` (caller storage, >= 82 entries), then
+// walks one path back from the goal.  Used once per player per board; candidates that
+// remove none of these edges cannot disconnect the player (adding a wall only removes
+// edges: SURVEY Appendix A.5).
+QZ_HD PathEdges find_path(const Graph& g, int start, BB goal, BB* layers) {
+    PathEdges p;
+    p.pn = p.ps = p.pe = p.pw = bb_zero();
+    p.jump = false;
+    p.found = false;
+    BB R = bb_bit(start);
+    layers[0] = R;
+    int L = 0;
+    BB hit = bb_zero();
+    for (int it = 0; it < 81; it++) {
+        BB nx = expand(g, R);
+        hit = bb_and(nx, goal);
+        BB R2 = bb_or(R, nx);
+        if (bb_any(hit)) {
+            L = it + 1;
+            layers[L] = R2;
+            p.found = true;
+            break;
+        }
+        if (bb_eq(R2, R)) return p;
+        R = R2;
+        layers[it + 1] = R;
+    }
+    if (!p.found) return p;
+    int t = bb_lowest(hit);
+    for (int i = L; i >= 1; i--) {
+        BB prev = layers[i - 1];
+        if (bb_test(prev, t)) continue;  // already reached earlier: same tile, shallower layer
+        int s;
+        if (t >= 9 && bb_test(prev, t - 9) && bb_test(g.cn, t - 9) && bb_test(g.notO, t)) {
+            s = t - 9;
+            p.pn = bb_or(p.pn, bb_bit(s));
+        } else if (t <= 71 && bb_test(prev, t + 9) && bb_test(g.cs, t + 9) && bb_test(g.notO, t)) {
+            s = t + 9;
+            p.ps = bb_or(p.ps, bb_bit(s));
+        } else if (t >= 1 && bb_test(prev, t - 1) && bb_test(g.ce, t - 1) && bb_test(g.notO, t)) {
+            s = t - 1;
+            p.pe = bb_or(p.pe, bb_bit(s));
+        } else if (t <= 79 && bb_test(prev, t + 1) && bb_test(g.cw, t + 1) && bb_test(g.notO, t)) {
+            s = t + 1;
+            p.pw = bb_or(p.pw, bb_bit(s));
+        } else {
+            s = -1;
+            for (int k = 0; k < 4; k++) {
+                if (s < 0 && g.j.a[k] >= 0 && bb_test(prev, g.j.a[k]) && bb_test(g.j.d[k], t)) s = g.j.a[k];
+            }
+            p.jump = true;
+            if (s < 0) {  // cannot happen; fail safe = re-check every candidate
+                p.pn = p.ps = p.pe = p.pw = bb_not(bb_zero());
+                return p;
+            }
+        }
+        t = s;
+    }
+    return p;
+}
+
+// ----------------------------------------------------------------------------- candidates
+// static part of _validate_horizontal/_vertical (quoridor.py:432-444, 448-459): slot empty
+// and no same-orientation neighbour overlap, for all 64 slots at once
+QZ_HD uint64_t static_ok_h(uint64_t hb, uint64_t vb) {
+    const uint64_t C0 = 0x0101010101010101ull, C7 = 0x8080808080808080ull;
+    return ~(hb | vb) & ~((hb << 1) & ~C0) & ~((hb >> 1) & ~C7);
+}
+QZ_HD uint64_t static_ok_v(uint64_t hb, uint64_t vb) { return ~(hb | vb) & ~(vb << 8) & ~(vb >> 8); }
+
+// what a candidate wall at intersection ix adds to the blocked sets
+QZ_HD Blk candidate_delta(int ix, bool horizontal) {
+    int b = 9 * (ix >> 3) + (ix & 7);
+    BB bit = bb_bit(b);
+    return horizontal ? blocked_from(bit, bb_zero()) : blocked_from(bb_zero(), bit);
+}
+QZ_HD bool cuts(const Blk& d, const PathEdges& p) {
+    BB x = bb_or(bb_or(bb_and(d.n, p.pn), bb_and(d.s, p.ps)), bb_or(bb_and(d.e, p.pe), bb_and(d.w, p.pw)));
+    return bb_any(x);
+}
+// intersections whose value is read by the jump logic around opponent tile O
+QZ_HD bool near_opp(int ix, int O) {
+    int ir = ix >> 3, ic = ix & 7, r = O / 9, c = O - 9 * r;
+    return ir >= r - 2 && ir <= r + 1 && ic >= c - 2 && ic <= c + 1;
+}
+
+// position of an action inside the reference's ordered actions() list, given the legal
+// sets (pawn12, legalH, legalV): quoridor.py:146-157 + 423-428 (pawn codes ascending, then
+// walls interleaved h(ix), v(ix))
+QZ_HD int popc64(uint64_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __popcll(x);
+#else
+    return __builtin_popcountll(x);
+#endif
+}
+QZ_HD int order_index(uint32_t pawn12, uint64_t lh, uint64_t lv, int a) {
+    if (a < 12) return popc64(pawn12 & ((1u << a) - 1u));
+    int np = popc64(pawn12);
+    if (a < 76) {
+        int ix = a - 12;
+        uint64_t below = (ix == 0) ? 0ull : (~0ull >> (64 - ix));
+        return np + popc64(lh & below) + popc64(lv & below);
+    }
+    int ix = a - 76;
+    uint64_t below = (ix == 0) ? 0ull : (~0ull >> (64 - ix));
+    uint64_t beq = below | (1ull << ix);
+    return np + popc64(lh & beq) + popc64(lv & below);
+}
+
+// ----------------------------------------------------------------------------- per-board context
+// Wave-uniform data of one actions() call (quoridor.py:138-157).
+struct MoveCtx {
+    Board b;
+    Blk base;         // blocked sets of the walls on the board (borders included)
+    uint64_t sh, sv;  // slots passing the static tests of _validate_horizontal/_vertical
+    uint32_t pawn;    // the mover's pawn codes
+    bool walls;       // mover has walls left (quoridor.py:149-150)
+};
+QZ_HD MoveCtx make_ctx(const Board& b) {
+    MoveCtx c;
+    c.b = b;
+    c.base = blk_or(blocked_from(spread8(b.hb), spread8(b.vb)), blocked_borders());
+    c.sh = static_ok_h(b.hb, b.vb);
+    c.sv = static_ok_v(b.hb, b.vb);
+    int loc = b.cur == 1 ? b.p1 : b.p2, opp = b.cur == 1 ? b.p2 : b.p1;
+    c.pawn = pawn_actions(b.hb, b.vb, loc, opp, b.cur);
+    c.walls = (b.cur == 1 ? b.w1 : b.w2) > 0;
+    return c;
+}
+// player p's search problem in _blocks_path (quoridor.py:463-477): P1 -> row 8, P2 -> row 0,
+// the other pawn fixed as obstacle / jump pivot
+QZ_HD int side_start(const Board& b, int p) { return p == 1 ? b.p1 : b.p2; }
+QZ_HD int side_opp(const Board& b, int p) { return p == 1 ? b.p2 : b.p1; }
+QZ_HD BB side_goal(int p) { return p == 1 ? ROW8() : ROW0(); }
+
+// one concrete path of player p on the current walls (no candidate)
+QZ_HD PathEdges base_path(const MoveCtx& c, int p, BB* layers) {
+    Graph g = make_graph(c.base, c.b.hb, c.b.vb, side_opp(c.b, p));
+    return find_path(g, side_start(c.b, p), side_goal(p), layers);
+}
+// must player p's reachability be re-checked for this candidate?
+QZ_HD bool needs_check(const MoveCtx& c, const PathEdges& path, int p, int ix, const Blk& delta) {
+    if (!path.found) return false;  // p is already cut off: every candidate "blocks", no flood needed
+    return cuts(delta, path) || (path.jump && near_opp(ix, side_opp(c.b, p)));
+}
+// _bfs_to_goal for player p with the candidate wall added (quoridor.py:470-475)
+QZ_HD bool candidate_reaches(const MoveCtx& c, int p, int ix, bool horizontal, const Blk& delta) {
+    uint64_t hb = c.b.hb | (horizontal ? (1ull << ix) : 0ull);
+    uint64_t vb = c.b.vb | (horizontal ? 0ull : (1ull << ix));
+    Graph g = make_graph(blk_or(c.base, delta), hb, vb, side_opp(c.b, p));
+    return flood(g, side_start(c.b, p), side_goal(p));
+}
+
+// ----------------------------------------------------------------------------- encoder
+// quoridor.py:58-131: value of element idx (= plane*81 + row*9 + col) of state()
+QZ_HD float plane_value(const Board& b, int idx) {
+    int plane = idx / 81, cell = idx - 81 * plane;
+    if (plane >= 5) {
+        int wm = b.cur == 1 ? b.w1 : b.w2, wo = b.cur == 1 ? b.w2 : b.w1;
+        int im = wm - 1, io = wo - 1;  // Python index: -1 -> last plane (quoridor.py:79-80)
+        if (im < 0) im += 10;
+        if (io < 0) io += 10;
+        bool on = (plane == 5 + im) || (plane == 15 + io) || (plane == 25 && b.cur == 2);
+        return on ? 1.0f : 0.0f;
+    }
+    if (plane >= 3) {
+        int pm = b.cur == 1 ? b.p1 : b.p2, po = b.cur == 1 ? b.p2 : b.p1;
+        int p = plane == 3 ? pm : po;
+        if (p < 0) p += 81;
+        return cell == p ? 1.0f : 0.0f;
+    }
+    int r = cell / 9, c = cell - 9 * r;
+    if (r >= 8 || c >= 8) return 0.0f;  // np.pad(..., (0,1)) quoridor.py:83-102
+    int ix = 8 * r + c;
+    uint64_t bits = plane == 0 ? ~(b.hb | b.vb) : (plane == 1 ? b.vb : b.hb);
+    return (float)((bits >> ix) & 1ull);
+}
+
+}  // namespace qz

@@ -1,0 +1,177 @@
+/*
+ * qz_abi.h -- C ABI of libqzero_hip.so, the MI355X (gfx950) self-play engine.
+ *
+ * Drop-in boundary for the self-play data-generation path of cryer/AlphaZero_Quoridor.
+ * The reference has no FFI of its own (it is pure Python); the boundary it offers is its
+ * module surface.  Each entry point below names the reference interface it replaces
+ * (file:line into the reference repo) -- the Python mirror in
+ * alphazero_quoridor_amd/{quoridor,mcts,policy_value_net,train}.py binds these through
+ * ctypes (see INTEGRATION.md for the stub a reference maintainer would add).
+ *
+ * Conventions
+ *   - plain C types only; every pointer marked [dev] is device memory on the engine's GPU
+ *     (e.g. torch.Tensor.data_ptr()), [host] is host memory;
+ *   - return 0 on success, a negative QZ_E_* code on failure (qz_last_error() has text);
+ *     nothing throws across the ABI;
+ *   - the caller owns every buffer it passes; the library neither frees nor keeps them
+ *     past the call's stream order; tree arenas / trajectories are engine-owned and freed
+ *     by qz_engine_destroy();
+ *   - every launch goes on the hipStream_t passed as `void* stream` (NULL = default
+ *     stream) with no implicit synchronisation unless the entry point says "sync";
+ *   - there is NO CPU fallback: without a HIP device every compute entry point fails with
+ *     QZ_E_NO_DEVICE.
+ */
+#ifndef QZ_ABI_H
+#define QZ_ABI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QZ_ABI_VERSION 1
+#define QZ_N_ACTIONS 140            /* quoridor.py:12  action_space = 140            */
+#define QZ_PLANES (26 * 81)         /* quoridor.py:58-131  26x9x9 state tensor       */
+#define QZ_MASK_WORDS 5             /* 140-bit legal mask, bit a of word a/32        */
+#define QZ_NO_MOVE 255              /* "no forced move" / mcts.py:169 update_with_move(-1) */
+
+#define QZ_E_INVALID (-1)
+#define QZ_E_NO_DEVICE (-2)
+#define QZ_E_HIP (-3)
+#define QZ_E_OOM (-4)
+#define QZ_E_STATE (-5)
+
+/*
+ * Boards in HBM: structure-of-arrays, three u64 per board (24 B):
+ *   hbits[b]  bit ix <=> _intersections[ix] == +1 (horizontal)      quoridor.py:49-53
+ *   vbits[b]  bit ix <=> _intersections[ix] == -1 (vertical)
+ *   meta[b]   byte0 = _positions[1] (int8), byte1 = _positions[2] (int8; off-board wins
+ *             leave 0..80: quoridor.py:226-229), byte2/3 = _player{1,2}_walls_remaining,
+ *             byte4 = current_player (1|2), bytes 5..7 = 0          quoridor.py:27-56
+ */
+typedef struct {
+    uint64_t* hbits; /* [dev] [n] */
+    uint64_t* vbits; /* [dev] [n] */
+    uint64_t* meta;  /* [dev] [n] */
+} qz_boards;
+
+/* ------------------------------------------------------------------ library */
+int qz_version(void);
+const char* qz_last_error(void);  /* thread-local text of the last failure */
+int qz_device_count(void);        /* number of HIP devices visible (0 => nothing can run) */
+
+/* ------------------------------------------------- stateless rules kernels */
+/* Quoridor.actions() (quoridor.py:138-157, 420-528) for n live boards:
+ * mask5[n][5] <- 140-bit legal set.  The reference's ordered list is the mask read in
+ * the order pawn codes 0..11 ascending, then for ix in 0..63: 12+ix, 76+ix. */
+int qz_movegen(const qz_boards* boards, int n, uint32_t* mask5 /*[dev]*/, void* stream);
+/* Quoridor.state() (quoridor.py:58-131): planes[n][26][9][9] float32 */
+int qz_encode(const qz_boards* boards, int n, float* planes /*[dev]*/, void* stream);
+/* both in one pass over the boards (the engine's leaf kernel) */
+int qz_movegen_encode(const qz_boards* boards, int n, uint32_t* mask5 /*[dev]*/,
+                      float* planes /*[dev]*/, void* stream);
+/* Quoridor.step() + has_a_winner() (quoridor.py:159-186, 193-202, 217-269), in place.
+ * done[n] <- 1 if the move ended the game; winner[n] <- 0 | 1 | 2 */
+int qz_step(qz_boards* boards, const uint8_t* action /*[dev]*/, int n, uint8_t* done /*[dev]*/,
+            uint8_t* winner /*[dev]*/, void* stream);
+
+/* ---------------------------------------------------------------- engine */
+typedef struct qz_engine qz_engine;
+
+typedef struct {
+    int32_t n_boards;          /* concurrent games, one search tree each               */
+    int32_t n_playout;         /* mcts.py:89   playouts per move (train.py:20 = 400)   */
+    float c_puct;              /* mcts.py:89   (train.py:21 = 5)                       */
+    float temp;                /* mcts.py:129  (train.py:19 = 1.0)                     */
+    float dirichlet_alpha;     /* mcts.py:181  0.3                                     */
+    float noise_frac;          /* mcts.py:181  0.25                                    */
+    uint64_t seed;             /* Philox key; the reference uses global numpy RNG      */
+    int32_t device;            /* HIP device ordinal                                   */
+    int32_t is_selfplay;       /* mcts.py:159  1: noise + subtree reuse; 0: reset tree */
+    int32_t fix_terminal_sign; /* 0 = reproduce mcts.py:125 (winning edge backed up -1) */
+    int32_t node_cap;          /* expanded nodes per board per arena half (0 = auto)   */
+    int32_t edge_cap;          /* edges per board per arena half (0 = auto)            */
+    int32_t max_plies;         /* trajectory slots per board (0 = auto)                */
+    int32_t reserved[4];
+} qz_config;
+
+typedef struct {
+    int64_t games_finished;    /* complete games harvested so far                      */
+    int64_t plies_played;      /* real moves played (finish_move calls x live boards)  */
+    int64_t playouts;          /* leaf selections                                      */
+    int64_t leaf_terminal;     /* playouts that ended on a terminal leaf               */
+    int64_t node_overflow;     /* expansions skipped / subtrees truncated: arena full  */
+    int64_t games_aborted;     /* no legal move at the root, or trajectory full        */
+    int64_t pending_games;     /* finished, not yet harvested                          */
+    int64_t pending_plies;
+    int64_t arena_bytes;       /* device bytes owned by the engine                     */
+    int64_t reserved[3];
+} qz_stats;
+
+/* MCTSPlayer.__init__ / MCTS.__init__ (mcts.py:89-100, 159-161) for n_boards trees +
+ * Quoridor.reset() (quoridor.py:26-56) for n_boards games. */
+int qz_engine_create(const qz_config* cfg, qz_engine** out);
+int qz_engine_destroy(qz_engine* e);
+/* Quoridor.reset() on every board + fresh roots (MCTSPlayer.reset_player, mcts.py:168-169) */
+int qz_engine_reset(qz_engine* e, void* stream);
+/* load / read the root boards (the `game` argument of choose_action, mcts.py:172).
+ * reset_trees != 0 also drops every search tree. */
+int qz_engine_set_boards(qz_engine* e, const qz_boards* src, int reset_trees, void* stream);
+int qz_engine_get_boards(qz_engine* e, const qz_boards* dst, void* stream);
+
+/* MCTS._playout, first half (mcts.py:107-117): for every board descend from the root by
+ * PUCT (TreeNode.select / get_value, mcts.py:37-42, 64-70) applying Quoridor.step() to a
+ * scratch copy, then run actions() + state() on the leaf.
+ *   leaf_planes[n][26][9][9] <- network input for the leaf (zeros for terminal leaves)
+ *   leaf_mask5[n][5]         <- legal set of the leaf (may be NULL)
+ *   leaf_terminal[n]         <- 1 if the leaf is a finished game (may be NULL) */
+int qz_mcts_select(qz_engine* e, float* leaf_planes /*[dev]*/, uint32_t* leaf_mask5 /*[dev]*/,
+                   uint8_t* leaf_terminal /*[dev]*/, void* stream);
+/* same, but hands back the leaf boards instead of the planes (for host-side policy
+ * callbacks: the `game` passed to policy_value_function, mcts.py:117) */
+int qz_mcts_select_boards(qz_engine* e, const qz_boards* leaf_out, uint32_t* leaf_mask5 /*[dev]*/,
+                          uint8_t* leaf_terminal /*[dev]*/, void* stream);
+/* MCTS._playout, second half (mcts.py:119-127): TreeNode.expand (mcts.py:27-35) with
+ * priors p[n][140] (= exp(log_softmax), gathered at the legal moves, NOT renormalised:
+ * policy_value_net.py:155-162) and update_recursive(-v) (mcts.py:44-62).  Terminal leaves
+ * ignore p/v and use +-1 (mcts.py:125). */
+int qz_mcts_expand_backup(qz_engine* e, const float* p /*[dev]*/, const float* v /*[dev]*/,
+                          void* stream);
+/* MCTS.get_move_probs tail (mcts.py:141-144): pi[n][140] float64 <- softmax(log(N+1e-10)/temp)
+ * scattered to action ids (mcts.py:174-177); visits[n][140] int32 (may be NULL) */
+int qz_mcts_root_pi(qz_engine* e, double* pi /*[dev]*/, int32_t* visits /*[dev]*/, void* stream);
+/* test/inspection: per-action root-child statistics, -1 visits for non-children */
+int qz_mcts_root_children(qz_engine* e, int32_t* visits /*[dev][n][140]*/,
+                          double* q /*[dev][n][140]*/, float* prior /*[dev][n][140]*/,
+                          int32_t* root_visits /*[dev][n]*/, void* stream);
+/* MCTS.update_with_move (mcts.py:146-151) only: re-root (keep the subtree) per board;
+ * QZ_NO_MOVE = fresh root.  Boards are not stepped. */
+int qz_mcts_update_with_move(qz_engine* e, const uint8_t* moves /*[dev]*/, void* stream);
+/* MCTSPlayer.choose_action tail + one iteration of Quoridor.start_self_play's loop
+ * (mcts.py:174-187, quoridor.py:585-602): pi from root visits; move ~ 0.75*pi +
+ * 0.25*Dirichlet(alpha) (or forced_move[b] != QZ_NO_MOVE); record (board, pi) in the
+ * board's trajectory; update_with_move; Quoridor.step(move); finished games are flagged
+ * for qz_harvest.  pi_out[n][140] float32 / move_out[n] may be NULL. */
+int qz_mcts_finish_move(qz_engine* e, const uint8_t* forced_move /*[dev]*/, float* pi_out /*[dev]*/,
+                        uint8_t* move_out /*[dev]*/, void* stream);
+
+/* finished games waiting for harvest: counts[0] = games, counts[1] = plies.  SYNC. */
+int qz_harvest_counts(qz_engine* e, int64_t counts[2] /*[host]*/, void* stream);
+/* Quoridor.start_self_play tail (quoridor.py:596-610) for every finished game:
+ * one tuple per recorded ply, games in board order, plies in play order:
+ *   t_boards  <- board before the move (re-encode with qz_encode to get `state`)
+ *   t_pi      [cap][140] float32
+ *   t_z       [cap] float32: +1 if the recorded mover won else -1   (quoridor.py:599-602)
+ *   t_game    [cap] int32: running game id local to this call (may be NULL)
+ * then the boards are reset (quoridor.py:578) with fresh trees (mcts.py:168-169).
+ * `cap` must be >= counts[1] from qz_harvest_counts. */
+int qz_harvest(qz_engine* e, const qz_boards* t_boards, float* t_pi /*[dev]*/, float* t_z /*[dev]*/,
+               int32_t* t_game /*[dev]*/, int64_t cap, void* stream);
+
+int qz_engine_stats(qz_engine* e, qz_stats* out /*[host]*/, void* stream); /* SYNC */
+
+#ifdef __cplusplus
+}
+#endif
+#endif
