@@ -1,0 +1,168 @@
+"""ctypes binding of ``libqzero_hip.so`` (C ABI: ``include/qz_abi.h``).
+
+The library is built in-tree by ``make -C alphazero_quoridor_amd/csrc`` (hipcc,
+``--offload-arch=gfx950``) and loaded from ``alphazero_quoridor_amd/libqzero_hip.so``.
+There is no CPU fallback anywhere in this package: a missing library raises
+``QzLibraryError`` at load time and a missing GPU makes every compute entry point
+return ``QZ_E_NO_DEVICE`` (raised as ``QzError``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libqzero_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "qz_abi.h")
+
+N_ACTIONS = 140
+PLANES = 26 * 81
+MASK_WORDS = 5
+NO_MOVE = 255
+
+E_INVALID, E_NO_DEVICE, E_HIP, E_OOM, E_STATE = -1, -2, -3, -4, -5
+
+
+class QzError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__("libqzero_hip error %d: %s" % (code, text))
+        self.code = code
+
+
+class QzLibraryError(RuntimeError):
+    pass
+
+
+class qz_boards(C.Structure):
+    _fields_ = [("hbits", C.c_void_p), ("vbits", C.c_void_p), ("meta", C.c_void_p)]
+
+
+class qz_config(C.Structure):
+    _fields_ = [
+        ("n_boards", C.c_int32),
+        ("n_playout", C.c_int32),
+        ("c_puct", C.c_float),
+        ("temp", C.c_float),
+        ("dirichlet_alpha", C.c_float),
+        ("noise_frac", C.c_float),
+        ("seed", C.c_uint64),
+        ("device", C.c_int32),
+        ("is_selfplay", C.c_int32),
+        ("fix_terminal_sign", C.c_int32),
+        ("node_cap", C.c_int32),
+        ("edge_cap", C.c_int32),
+        ("max_plies", C.c_int32),
+        ("reserved", C.c_int32 * 4),
+    ]
+
+
+class qz_stats(C.Structure):
+    _fields_ = [
+        ("games_finished", C.c_int64),
+        ("plies_played", C.c_int64),
+        ("playouts", C.c_int64),
+        ("leaf_terminal", C.c_int64),
+        ("node_overflow", C.c_int64),
+        ("games_aborted", C.c_int64),
+        ("pending_games", C.c_int64),
+        ("pending_plies", C.c_int64),
+        ("arena_bytes", C.c_int64),
+        ("reserved", C.c_int64 * 3),
+    ]
+
+
+def build(force: bool = False) -> str:
+    """Compile libqzero_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in ("qz_kernels.hip", "qz_abi.hip", "qz_rules.h", "qz_device.h")] + [HEADER]
+    stale = force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if stale:
+        subprocess.check_call(["make", "-C", CSRC, "-s"])
+    return LIB_PATH
+
+
+_P = C.c_void_p
+_SIGNATURES = {
+    "qz_version": (C.c_int, []),
+    "qz_last_error": (C.c_char_p, []),
+    "qz_device_count": (C.c_int, []),
+    "qz_movegen": (C.c_int, [C.POINTER(qz_boards), C.c_int, _P, _P]),
+    "qz_encode": (C.c_int, [C.POINTER(qz_boards), C.c_int, _P, _P]),
+    "qz_movegen_encode": (C.c_int, [C.POINTER(qz_boards), C.c_int, _P, _P, _P]),
+    "qz_step": (C.c_int, [C.POINTER(qz_boards), _P, C.c_int, _P, _P, _P]),
+    "qz_engine_create": (C.c_int, [C.POINTER(qz_config), C.POINTER(_P)]),
+    "qz_engine_destroy": (C.c_int, [_P]),
+    "qz_engine_reset": (C.c_int, [_P, _P]),
+    "qz_engine_set_boards": (C.c_int, [_P, C.POINTER(qz_boards), C.c_int, _P]),
+    "qz_engine_get_boards": (C.c_int, [_P, C.POINTER(qz_boards), _P]),
+    "qz_engine_set_temp": (C.c_int, [_P, C.c_float]),
+    "qz_mcts_select": (C.c_int, [_P, _P, _P, _P, _P]),
+    "qz_mcts_select_boards": (C.c_int, [_P, C.POINTER(qz_boards), _P, _P, _P]),
+    "qz_mcts_expand_backup": (C.c_int, [_P, _P, _P, _P]),
+    "qz_mcts_root_pi": (C.c_int, [_P, _P, _P, _P]),
+    "qz_mcts_root_children": (C.c_int, [_P, _P, _P, _P, _P, _P]),
+    "qz_mcts_update_with_move": (C.c_int, [_P, _P, _P]),
+    "qz_mcts_finish_move": (C.c_int, [_P, _P, _P, _P, _P]),
+    "qz_harvest_counts": (C.c_int, [_P, C.POINTER(C.c_int64 * 2), _P]),
+    "qz_harvest": (C.c_int, [_P, C.POINTER(qz_boards), _P, _P, _P, C.c_int64, _P]),
+    "qz_engine_stats": (C.c_int, [_P, C.POINTER(qz_stats), _P]),
+    "qz_selftest_sqrt": (C.c_int, [_P, C.c_int, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the HIP library; never falls back to anything else."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise QzLibraryError(
+            "%s is missing. Build it with `make -C %s` (hipcc, gfx950) or "
+            "`python -c 'import __graft_entry__ as g; g.build()'`. There is no CPU fallback." % (LIB_PATH, CSRC)
+        )
+    try:
+        L = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise QzLibraryError("cannot load %s: %s" % (LIB_PATH, e)) from e
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    if L.qz_version() != 1:
+        raise QzLibraryError("ABI version mismatch: library %d, binding 1" % L.qz_version())
+    _lib = L
+    return L
+
+
+def check(rc: int):
+    if rc != 0:
+        raise QzError(rc, load().qz_last_error().decode("utf-8", "replace"))
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+# packed 24-byte board record used on the host side (AoS view of the three SoA words)
+PACKED_DTYPE = np.dtype(
+    [("hbits", "<u8"), ("vbits", "<u8"), ("p1", "i1"), ("p2", "i1"), ("w1", "u1"), ("w2", "u1"),
+     ("cur", "u1"), ("pad", "u1", (3,))]
+)
+
+
+def packed_to_soa(packed: np.ndarray):
+    """[n] PACKED_DTYPE -> three contiguous int64 arrays (bit patterns of the u64 words)."""
+    packed = np.ascontiguousarray(packed, dtype=PACKED_DTYPE).reshape(-1)
+    w = packed.view(np.uint64).reshape(-1, 3)
+    return (np.ascontiguousarray(w[:, 0]).view(np.int64), np.ascontiguousarray(w[:, 1]).view(np.int64),
+            np.ascontiguousarray(w[:, 2]).view(np.int64))
+
+
+def soa_to_packed(hb: np.ndarray, vb: np.ndarray, meta: np.ndarray) -> np.ndarray:
+    w = np.stack([np.asarray(hb).view(np.uint64), np.asarray(vb).view(np.uint64), np.asarray(meta).view(np.uint64)], axis=1)
+    return np.ascontiguousarray(w).view(PACKED_DTYPE).reshape(-1)

@@ -1,0 +1,387 @@
+// qz_abi.hip -- host side of libqzero_hip.so: the C ABI declared in include/qz_abi.h.
+// Owns the engine's HBM arenas, validates arguments, launches the kernels of
+// qz_kernels.hip on the caller's stream.  No CPU compute path exists: without a HIP
+// device every entry point reports QZ_E_NO_DEVICE.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#include "../../include/qz_abi.h"
+#include "qz_device.h"
+
+namespace qzl {
+hipError_t movegen_encode(const uint64_t*, const uint64_t*, const uint64_t*, int, uint32_t*, float*, const uint8_t*, hipStream_t);
+hipError_t step(uint64_t*, uint64_t*, uint64_t*, const uint8_t*, int, uint8_t*, uint8_t*, hipStream_t);
+hipError_t select(const EngineDev&, hipStream_t);
+hipError_t expand_backup(const EngineDev&, const float*, const float*, hipStream_t);
+hipError_t root_pi(const EngineDev&, double*, int32_t*, hipStream_t);
+hipError_t root_children(const EngineDev&, int32_t*, double*, float*, int32_t*, hipStream_t);
+hipError_t update_with_move(const EngineDev&, const uint8_t*, hipStream_t);
+hipError_t finish_move(const EngineDev&, const uint8_t*, float*, uint8_t*, hipStream_t);
+hipError_t reset(const EngineDev&, int, hipStream_t);
+hipError_t harvest(const EngineDev&, uint64_t*, uint64_t*, uint64_t*, float*, float*, int32_t*, long long, hipStream_t);
+hipError_t sqrt_table(double*, int, hipStream_t);
+}  // namespace qzl
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) return fail(QZ_E_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+struct qz_engine {
+    qz_config cfg;
+    EngineDev dev;
+    std::vector<void*> allocs;
+    int64_t bytes = 0;
+};
+
+static int device_check() {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(QZ_E_NO_DEVICE, "no HIP device visible: libqzero_hip has no CPU path");
+    }
+    return 0;
+}
+
+template <typename T>
+static int dev_alloc(qz_engine* e, T** out, size_t count) {
+    void* p = nullptr;
+    size_t bytes = count * sizeof(T);
+    if (bytes == 0) bytes = sizeof(T);
+    hipError_t err = hipMalloc(&p, bytes);
+    if (err != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(QZ_E_OOM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(err));
+    }
+    e->allocs.push_back(p);
+    e->bytes += (int64_t)bytes;
+    *out = (T*)p;
+    return 0;
+}
+
+extern "C" {
+
+int qz_version(void) { return QZ_ABI_VERSION; }
+const char* qz_last_error(void) { return g_err; }
+int qz_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+// ------------------------------------------------------------------ stateless kernels
+static int check_boards(const qz_boards* b, int n) {
+    if (n < 0) return fail(QZ_E_INVALID, "n < 0");
+    if (n > 0 && (!b || !b->hbits || !b->vbits || !b->meta)) return fail(QZ_E_INVALID, "null board arrays");
+    return 0;
+}
+
+int qz_movegen(const qz_boards* boards, int n, uint32_t* mask5, void* stream) {
+    int r;
+    if ((r = device_check()) || (r = check_boards(boards, n))) return r;
+    if (n > 0 && !mask5) return fail(QZ_E_INVALID, "mask5 is null");
+    if (n == 0) return 0;
+    HIP_TRY(qzl::movegen_encode(boards->hbits, boards->vbits, boards->meta, n, mask5, nullptr, nullptr, (hipStream_t)stream));
+    return 0;
+}
+int qz_encode(const qz_boards* boards, int n, float* planes, void* stream) {
+    int r;
+    if ((r = device_check()) || (r = check_boards(boards, n))) return r;
+    if (n > 0 && !planes) return fail(QZ_E_INVALID, "planes is null");
+    if (n == 0) return 0;
+    HIP_TRY(qzl::movegen_encode(boards->hbits, boards->vbits, boards->meta, n, nullptr, planes, nullptr, (hipStream_t)stream));
+    return 0;
+}
+int qz_movegen_encode(const qz_boards* boards, int n, uint32_t* mask5, float* planes, void* stream) {
+    int r;
+    if ((r = device_check()) || (r = check_boards(boards, n))) return r;
+    if (n > 0 && (!mask5 || !planes)) return fail(QZ_E_INVALID, "mask5/planes is null");
+    if (n == 0) return 0;
+    HIP_TRY(qzl::movegen_encode(boards->hbits, boards->vbits, boards->meta, n, mask5, planes, nullptr, (hipStream_t)stream));
+    return 0;
+}
+int qz_step(qz_boards* boards, const uint8_t* action, int n, uint8_t* done, uint8_t* winner, void* stream) {
+    int r;
+    if ((r = device_check()) || (r = check_boards(boards, n))) return r;
+    if (n > 0 && !action) return fail(QZ_E_INVALID, "action is null");
+    if (n == 0) return 0;
+    HIP_TRY(qzl::step(boards->hbits, boards->vbits, boards->meta, action, n, done, winner, (hipStream_t)stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------ engine
+int qz_engine_destroy(qz_engine* e) {
+    if (!e) return 0;
+    (void)hipSetDevice(e->cfg.device);
+    (void)hipDeviceSynchronize();
+    for (void* p : e->allocs) (void)hipFree(p);
+    delete e;
+    return 0;
+}
+
+int qz_engine_create(const qz_config* cfg, qz_engine** out) {
+    int r;
+    if (!cfg || !out) return fail(QZ_E_INVALID, "null cfg/out");
+    *out = nullptr;
+    if ((r = device_check())) return r;
+    if (cfg->n_boards <= 0 || cfg->n_playout <= 0) return fail(QZ_E_INVALID, "n_boards and n_playout must be > 0");
+    if (!(cfg->temp > 0.f)) return fail(QZ_E_INVALID, "temp must be > 0");
+    if (cfg->device < 0 || cfg->device >= qz_device_count()) return fail(QZ_E_INVALID, "device %d out of range", cfg->device);
+    HIP_TRY(hipSetDevice(cfg->device));
+    qz_engine* e = new (std::nothrow) qz_engine();
+    if (!e) return fail(QZ_E_OOM, "host allocation failed");
+    e->cfg = *cfg;
+    qz_config& c = e->cfg;
+    if (c.node_cap <= 0) c.node_cap = 2 * c.n_playout + 256;
+    if (c.edge_cap <= 0) c.edge_cap = 131 * c.n_playout + 40 * c.node_cap;
+    c.edge_cap = (c.edge_cap + 63) & ~63;
+    if (c.max_plies <= 0) c.max_plies = 2048;
+    if (c.dirichlet_alpha <= 0.f) c.dirichlet_alpha = 0.3f;
+    EngineDev& d = e->dev;
+    memset(&d, 0, sizeof(d));
+    d.n_boards = c.n_boards;
+    d.node_cap = c.node_cap;
+    d.edge_cap = c.edge_cap;
+    d.max_plies = c.max_plies;
+    d.c_puct = c.c_puct;
+    d.temp = c.temp;
+    d.dirichlet_alpha = c.dirichlet_alpha;
+    d.noise_frac = c.noise_frac;
+    d.seed = c.seed;
+    d.is_selfplay = c.is_selfplay;
+    d.fix_terminal_sign = c.fix_terminal_sign;
+    const size_t B = (size_t)c.n_boards, NC = (size_t)c.node_cap, EC = (size_t)c.edge_cap, MP = (size_t)c.max_plies;
+    int rc = 0;
+#define ALLOC(field, count) \
+    if (!rc) rc = dev_alloc(e, &d.field, (count))
+    ALLOC(root_hb, B);
+    ALLOC(root_vb, B);
+    ALLOC(root_meta, B);
+    ALLOC(leaf_hb, B);
+    ALLOC(leaf_vb, B);
+    ALLOC(leaf_meta, B);
+    ALLOC(leaf_mask, B * 5);
+    ALLOC(leaf_pnode, B);
+    ALLOC(leaf_pedge, B);
+    ALLOC(leaf_term, B);
+    ALLOC(nodes, 2 * B * NC);
+    ALLOC(eN, 2 * B * EC);
+    ALLOC(eQ, 2 * B * EC);
+    ALLOC(eP, 2 * B * EC);
+    ALLOC(eChild, 2 * B * EC);
+    ALLOC(eAct, 2 * B * EC);
+    ALLOC(tree_half, B);
+    ALLOC(n_nodes, B);
+    ALLOC(n_edges, B);
+    ALLOC(root_N, B);
+    ALLOC(ply, B);
+    ALLOC(game_serial, B);
+    ALLOC(harvest_off, B);
+    ALLOC(harvest_gid, B);
+    ALLOC(status, B);
+    ALLOC(winner, B);
+    ALLOC(traj_board, B * MP * 3);
+    ALLOC(traj_pi, B * MP * QZ_N_ACT);
+    ALLOC(counters, (size_t)QZ_C_COUNT);
+#undef ALLOC
+    if (rc) {
+        qz_engine_destroy(e);
+        return rc;
+    }
+    hipError_t he = hipMemset(d.tree_half, 0, B);
+    if (he == hipSuccess) he = hipMemset(d.game_serial, 0, B * sizeof(uint32_t));
+    if (he == hipSuccess) he = hipMemset(d.counters, 0, QZ_C_COUNT * sizeof(unsigned long long));
+    if (he == hipSuccess) he = hipMemset(d.leaf_term, 0, B);
+    if (he == hipSuccess) he = hipMemset(d.leaf_mask, 0, B * 5 * sizeof(uint32_t));
+    if (he == hipSuccess) he = qzl::reset(d, 1, nullptr);
+    if (he == hipSuccess) he = hipDeviceSynchronize();
+    if (he != hipSuccess) {
+        qz_engine_destroy(e);
+        return fail(QZ_E_HIP, "engine init failed: %s", hipGetErrorString(he));
+    }
+    *out = e;
+    return 0;
+}
+
+#define ENGINE_CHECK(e)                                          \
+    do {                                                         \
+        if (!(e)) return fail(QZ_E_INVALID, "null engine");      \
+        HIP_TRY(hipSetDevice((e)->cfg.device));                  \
+    } while (0)
+
+int qz_engine_reset(qz_engine* e, void* stream) {
+    ENGINE_CHECK(e);
+    HIP_TRY(qzl::reset(e->dev, 1, (hipStream_t)stream));
+    return 0;
+}
+
+int qz_engine_set_boards(qz_engine* e, const qz_boards* src, int reset_trees, void* stream) {
+    ENGINE_CHECK(e);
+    int r;
+    if ((r = check_boards(src, e->cfg.n_boards))) return r;
+    hipStream_t s = (hipStream_t)stream;
+    size_t nb = (size_t)e->cfg.n_boards * sizeof(uint64_t);
+    HIP_TRY(hipMemcpyAsync(e->dev.root_hb, src->hbits, nb, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(e->dev.root_vb, src->vbits, nb, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(e->dev.root_meta, src->meta, nb, hipMemcpyDeviceToDevice, s));
+    if (reset_trees) HIP_TRY(qzl::reset(e->dev, 0, s));
+    return 0;
+}
+
+int qz_engine_get_boards(qz_engine* e, const qz_boards* dst, void* stream) {
+    ENGINE_CHECK(e);
+    int r;
+    if ((r = check_boards(dst, e->cfg.n_boards))) return r;
+    hipStream_t s = (hipStream_t)stream;
+    size_t nb = (size_t)e->cfg.n_boards * sizeof(uint64_t);
+    HIP_TRY(hipMemcpyAsync(dst->hbits, e->dev.root_hb, nb, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(dst->vbits, e->dev.root_vb, nb, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(dst->meta, e->dev.root_meta, nb, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+int qz_engine_set_temp(qz_engine* e, float temp) {
+    if (!e) return fail(QZ_E_INVALID, "null engine");
+    if (!(temp > 0.f)) return fail(QZ_E_INVALID, "temp must be > 0");
+    e->cfg.temp = temp;
+    e->dev.temp = temp;
+    return 0;
+}
+
+int qz_mcts_select(qz_engine* e, float* leaf_planes, uint32_t* leaf_mask5, uint8_t* leaf_terminal, void* stream) {
+    ENGINE_CHECK(e);
+    if (!leaf_planes) return fail(QZ_E_INVALID, "leaf_planes is null");
+    hipStream_t s = (hipStream_t)stream;
+    const EngineDev& d = e->dev;
+    HIP_TRY(qzl::select(d, s));
+    HIP_TRY(qzl::movegen_encode(d.leaf_hb, d.leaf_vb, d.leaf_meta, d.n_boards, d.leaf_mask, leaf_planes, d.leaf_term, s));
+    if (leaf_mask5)
+        HIP_TRY(hipMemcpyAsync(leaf_mask5, d.leaf_mask, (size_t)d.n_boards * 5 * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    if (leaf_terminal) HIP_TRY(hipMemcpyAsync(leaf_terminal, d.leaf_term, (size_t)d.n_boards, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+int qz_mcts_select_boards(qz_engine* e, const qz_boards* leaf_out, uint32_t* leaf_mask5, uint8_t* leaf_terminal, void* stream) {
+    ENGINE_CHECK(e);
+    int r;
+    if ((r = check_boards(leaf_out, e->cfg.n_boards))) return r;
+    hipStream_t s = (hipStream_t)stream;
+    const EngineDev& d = e->dev;
+    HIP_TRY(qzl::select(d, s));
+    HIP_TRY(qzl::movegen_encode(d.leaf_hb, d.leaf_vb, d.leaf_meta, d.n_boards, d.leaf_mask, nullptr, d.leaf_term, s));
+    size_t nb = (size_t)d.n_boards * sizeof(uint64_t);
+    HIP_TRY(hipMemcpyAsync(leaf_out->hbits, d.leaf_hb, nb, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(leaf_out->vbits, d.leaf_vb, nb, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(leaf_out->meta, d.leaf_meta, nb, hipMemcpyDeviceToDevice, s));
+    if (leaf_mask5)
+        HIP_TRY(hipMemcpyAsync(leaf_mask5, d.leaf_mask, (size_t)d.n_boards * 5 * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    if (leaf_terminal) HIP_TRY(hipMemcpyAsync(leaf_terminal, d.leaf_term, (size_t)d.n_boards, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+int qz_mcts_expand_backup(qz_engine* e, const float* p, const float* v, void* stream) {
+    ENGINE_CHECK(e);
+    if (!p || !v) return fail(QZ_E_INVALID, "p/v is null");
+    HIP_TRY(qzl::expand_backup(e->dev, p, v, (hipStream_t)stream));
+    return 0;
+}
+
+int qz_mcts_root_pi(qz_engine* e, double* pi, int32_t* visits, void* stream) {
+    ENGINE_CHECK(e);
+    if (!pi && !visits) return fail(QZ_E_INVALID, "pi and visits are both null");
+    HIP_TRY(qzl::root_pi(e->dev, pi, visits, (hipStream_t)stream));
+    return 0;
+}
+
+int qz_mcts_root_children(qz_engine* e, int32_t* visits, double* q, float* prior, int32_t* root_visits, void* stream) {
+    ENGINE_CHECK(e);
+    HIP_TRY(qzl::root_children(e->dev, visits, q, prior, root_visits, (hipStream_t)stream));
+    return 0;
+}
+
+int qz_mcts_update_with_move(qz_engine* e, const uint8_t* moves, void* stream) {
+    ENGINE_CHECK(e);
+    if (!moves) return fail(QZ_E_INVALID, "moves is null");
+    HIP_TRY(qzl::update_with_move(e->dev, moves, (hipStream_t)stream));
+    return 0;
+}
+
+int qz_mcts_finish_move(qz_engine* e, const uint8_t* forced_move, float* pi_out, uint8_t* move_out, void* stream) {
+    ENGINE_CHECK(e);
+    HIP_TRY(qzl::finish_move(e->dev, forced_move, pi_out, move_out, (hipStream_t)stream));
+    return 0;
+}
+
+int qz_harvest_counts(qz_engine* e, int64_t counts[2], void* stream) {
+    ENGINE_CHECK(e);
+    if (!counts) return fail(QZ_E_INVALID, "counts is null");
+    unsigned long long h[2] = {0, 0};
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(h, e->dev.counters + QZ_C_PENDING_GAMES, sizeof(h), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    counts[0] = (int64_t)h[0];
+    counts[1] = (int64_t)h[1];
+    return 0;
+}
+
+int qz_harvest(qz_engine* e, const qz_boards* t_boards, float* t_pi, float* t_z, int32_t* t_game, int64_t cap, void* stream) {
+    ENGINE_CHECK(e);
+    if (cap < 0) return fail(QZ_E_INVALID, "cap < 0");
+    if (cap > 0 && (!t_boards || !t_boards->hbits || !t_boards->vbits || !t_boards->meta || !t_pi || !t_z))
+        return fail(QZ_E_INVALID, "null tuple buffers");
+    static uint64_t dummy = 0;
+    (void)dummy;
+    HIP_TRY(qzl::harvest(e->dev, cap ? t_boards->hbits : nullptr, cap ? t_boards->vbits : nullptr,
+                         cap ? t_boards->meta : nullptr, t_pi, t_z, t_game, (long long)cap, (hipStream_t)stream));
+    return 0;
+}
+
+int qz_engine_stats(qz_engine* e, qz_stats* out, void* stream) {
+    ENGINE_CHECK(e);
+    if (!out) return fail(QZ_E_INVALID, "out is null");
+    unsigned long long h[QZ_C_COUNT];
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(h, e->dev.counters, sizeof(h), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    memset(out, 0, sizeof(*out));
+    out->games_finished = (int64_t)h[QZ_C_GAMES];
+    out->plies_played = (int64_t)h[QZ_C_PLIES];
+    out->playouts = (int64_t)h[QZ_C_PLAYOUTS];
+    out->leaf_terminal = (int64_t)h[QZ_C_LEAF_TERMINAL];
+    out->node_overflow = (int64_t)h[QZ_C_OVERFLOW];
+    out->games_aborted = (int64_t)h[QZ_C_ABORTED];
+    out->pending_games = (int64_t)h[QZ_C_PENDING_GAMES];
+    out->pending_plies = (int64_t)h[QZ_C_PENDING_PLIES];
+    out->arena_bytes = e->bytes;
+    return 0;
+}
+
+// self-test hook used by the GPU tests: device sqrt(double(i)) for i in [0, n)
+int qz_selftest_sqrt(double* out_dev, int n, void* stream) {
+    int r;
+    if ((r = device_check())) return r;
+    HIP_TRY(qzl::sqrt_table(out_dev, n, (hipStream_t)stream));
+    return 0;
+}
+
+}  // extern "C"

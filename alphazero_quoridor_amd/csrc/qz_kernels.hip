@@ -1,0 +1,857 @@
+// qz_kernels.hip -- CDNA4 (gfx950) kernels of the Quoridor self-play engine.
+//
+// Execution shape: ONE 64-lane wavefront per board, 4 boards per 256-thread workgroup.
+// Board scalars are wave-uniform (they live in SGPRs); the 64 lanes are
+//   - the 64 wall slots of one orientation in move generation (two rounds: H, V),
+//   - the <=131 edges of a tree node in select / expand / pi (three rounds),
+//   - the 2,106 elements of the 26x9x9 state tensor in the encoder (8-byte stores).
+// Cross-lane traffic is ballots, mbcnt ranks, DPP/bpermute reductions and a small LDS
+// work list; no MFMA anywhere (integer / indexing work).
+//
+// Reference semantics: see qz_rules.h (rules) and the per-kernel comments (mcts.py).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "qz_rules.h"
+#include "qz_device.h"
+
+using namespace qz;
+
+namespace {
+
+constexpr int WPB = 4;  // waves (= boards) per workgroup
+constexpr int TPB = 64 * WPB;
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ uint32_t rfl(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+__device__ __forceinline__ uint64_t rfl64(uint64_t x) {
+    return (uint64_t)rfl((uint32_t)x) | ((uint64_t)rfl((uint32_t)(x >> 32)) << 32);
+}
+__device__ __forceinline__ uint32_t rdl(uint32_t x, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)x, l); }
+__device__ __forceinline__ BB bb_rdl(BB a, int l) { return BB{rdl(a.w0, l), rdl(a.w1, l), rdl(a.w2, l)}; }
+__device__ __forceinline__ PathEdges path_rdl(const PathEdges& p, int l) {
+    PathEdges r;
+    r.pn = bb_rdl(p.pn, l);
+    r.ps = bb_rdl(p.ps, l);
+    r.pe = bb_rdl(p.pe, l);
+    r.pw = bb_rdl(p.pw, l);
+    r.jump = rdl(p.jump ? 1u : 0u, l) != 0u;
+    r.found = rdl(p.found ? 1u : 0u, l) != 0u;
+    return r;
+}
+// number of set bits of a ballot below this lane
+__device__ __forceinline__ int rank_below(uint64_t m) {
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+__device__ __forceinline__ Board load_board(const uint64_t* hb, const uint64_t* vb, const uint64_t* meta, int b) {
+    return unpack(rfl64(hb[b]), rfl64(vb[b]), rfl64(meta[b]));
+}
+
+// ============================================================================ rules kernels
+
+struct MoveShared {
+    BB layers[WPB][2][84];     // BFS layers of the two base floods (lanes 0 / 1 of each wave)
+    uint8_t items[WPB][256];   // work list: ix | horizontal<<6 | (player-1)<<7
+    uint8_t res[WPB][256];     // flood results per work item
+};
+
+// Quoridor.actions() for one board per wave; returns the three legal sets.
+__device__ __forceinline__ void wave_movegen(const Board& bd, MoveShared& sm, int wave, int lane, uint32_t& pawn,
+                                             uint64_t& lh, uint64_t& lv) {
+    MoveCtx c = make_ctx(bd);
+    pawn = c.pawn;
+    lh = 0;
+    lv = 0;
+    if (!c.walls) return;  // quoridor.py:149-156: no wall actions without walls (wave-uniform)
+
+    // one concrete path per player on the current walls: lanes 0 and 1 in parallel
+    PathEdges mine;
+    mine.pn = mine.ps = mine.pe = mine.pw = bb_zero();
+    mine.jump = false;
+    mine.found = false;
+    if (lane < 2) mine = base_path(c, lane + 1, &sm.layers[wave][lane][0]);
+    PathEdges path1 = path_rdl(mine, 0), path2 = path_rdl(mine, 1);
+    if (!(path1.found && path2.found)) return;  // somebody is already cut off: every wall "blocks"
+
+    // lane = slot ix; round H then round V share the same lane
+    const int ix = lane;
+    bool stH = (c.sh >> ix) & 1ull, stV = (c.sv >> ix) & 1ull;
+    Blk dH = candidate_delta(ix, true), dV = candidate_delta(ix, false);
+    bool nH1 = stH && needs_check(c, path1, 1, ix, dH);
+    bool nH2 = stH && needs_check(c, path2, 2, ix, dH);
+    bool nV1 = stV && needs_check(c, path1, 1, ix, dV);
+    bool nV2 = stV && needs_check(c, path2, 2, ix, dV);
+    uint64_t mH1 = __ballot(nH1), mH2 = __ballot(nH2), mV1 = __ballot(nV1), mV2 = __ballot(nV2);
+    int o1 = __popcll(mH1), o2 = o1 + __popcll(mH2), o3 = o2 + __popcll(mV1), total = o3 + __popcll(mV2);
+    int sH1 = rank_below(mH1), sH2 = o1 + rank_below(mH2), sV1 = o2 + rank_below(mV1), sV2 = o3 + rank_below(mV2);
+    if (total > 0) {
+        if (nH1) sm.items[wave][sH1] = (uint8_t)(ix | 0x40);
+        if (nH2) sm.items[wave][sH2] = (uint8_t)(ix | 0x40 | 0x80);
+        if (nV1) sm.items[wave][sV1] = (uint8_t)(ix);
+        if (nV2) sm.items[wave][sV2] = (uint8_t)(ix | 0x80);
+        wave_sync();
+        for (int base = 0; base < total; base += 64) {  // wave-uniform trip count
+            int j = base + lane;
+            if (j < total) {
+                int it = sm.items[wave][j];
+                int cix = it & 63;
+                bool hz = (it & 0x40) != 0;
+                int p = (it & 0x80) ? 2 : 1;
+                Blk d = candidate_delta(cix, hz);
+                sm.res[wave][j] = candidate_reaches(c, p, cix, hz, d) ? 1 : 0;
+            }
+        }
+        wave_sync();
+    }
+    bool okH = stH, okV = stV;
+    if (nH1) okH = okH && sm.res[wave][sH1];
+    if (nH2) okH = okH && sm.res[wave][sH2];
+    if (nV1) okV = okV && sm.res[wave][sV1];
+    if (nV2) okV = okV && sm.res[wave][sV2];
+    lh = __ballot(okH);
+    lv = __ballot(okV);
+}
+
+__device__ __forceinline__ void store_mask(uint32_t* mask5, int b, int lane, uint32_t pawn, uint64_t lh, uint64_t lv) {
+    // 140 bits: [pawn 12][H 64][V 64]
+    if (lane < 5) {
+        uint32_t w;
+        switch (lane) {
+            case 0: w = pawn | (uint32_t)(lh << 12); break;
+            case 1: w = (uint32_t)(lh >> 20); break;
+            case 2: w = (uint32_t)(lh >> 52) | (uint32_t)(lv << 12); break;
+            case 3: w = (uint32_t)(lv >> 20); break;
+            default: w = (uint32_t)(lv >> 52); break;
+        }
+        mask5[(size_t)b * 5 + lane] = w;
+    }
+}
+
+// Quoridor.state(): 2,106 floats per board, written as 1,053 coalesced 8-byte stores
+__device__ __forceinline__ void wave_encode(const Board& bd, float* planes, int b, int lane, bool zero) {
+    float2* out = reinterpret_cast<float2*>(planes + (size_t)b * QZ_PLANES_N);
+#pragma unroll 1
+    for (int q = lane; q < QZ_PLANES_N / 2; q += 64) {
+        float2 v;
+        if (zero) {
+            v.x = 0.f;
+            v.y = 0.f;
+        } else {
+            v.x = plane_value(bd, 2 * q);
+            v.y = plane_value(bd, 2 * q + 1);
+        }
+        out[q] = v;
+    }
+}
+
+template <bool DO_MASK, bool DO_PLANES>
+__global__ __launch_bounds__(TPB) void k_movegen_encode(const uint64_t* __restrict__ hb, const uint64_t* __restrict__ vb,
+                                                        const uint64_t* __restrict__ meta, int n,
+                                                        uint32_t* __restrict__ mask5, float* __restrict__ planes,
+                                                        const uint8_t* __restrict__ terminal) {
+    __shared__ MoveShared sm;
+    const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+    const int b = (int)blockIdx.x * WPB + wave;
+    if (b >= n) return;  // whole wave leaves; no workgroup barrier is used below
+    Board bd = load_board(hb, vb, meta, b);
+    bool term = terminal ? (rfl(terminal[b]) != 0u) : false;
+    if (DO_MASK) {
+        uint32_t pawn = 0;
+        uint64_t lh = 0, lv = 0;
+        if (!term) wave_movegen(bd, sm, wave, lane, pawn, lh, lv);
+        store_mask(mask5, b, lane, pawn, lh, lv);
+    }
+    if (DO_PLANES) wave_encode(bd, planes, b, lane, term);
+}
+
+// Quoridor.step() + has_a_winner(): one thread per board, fully coalesced SoA traffic
+__global__ __launch_bounds__(256) void k_step(uint64_t* hb, uint64_t* vb, uint64_t* meta, const uint8_t* action, int n,
+                                              uint8_t* done, uint8_t* winner) {
+    int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n) return;
+    Board b = unpack(hb[i], vb[i], meta[i]);
+    int a = action[i];
+    bool d = false;
+    if (a < QZ_N_ACT) d = apply_action(b, a);
+    hb[i] = b.hb;
+    vb[i] = b.vb;
+    meta[i] = pack_meta(b);
+    if (done) done[i] = d ? 1 : 0;
+    if (winner) winner[i] = (uint8_t)winner_of(b);
+}
+
+// ============================================================================ tree kernels
+
+// wave-wide argmax with Python max() tie-breaking (first in order = smallest k)
+__device__ __forceinline__ void wave_argmax(double& v, int& k) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        double ov = __shfl_xor(v, off, 64);
+        int ok = __shfl_xor(k, off, 64);
+        if (ov > v || (ov == v && ok < k)) {
+            v = ov;
+            k = ok;
+        }
+    }
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+    return v;
+}
+// inclusive prefix sum across the wave
+__device__ __forceinline__ double wave_scan(double v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        double o = __shfl_up(v, off, 64);
+        if (lane >= off) v += o;
+    }
+    return v;
+}
+
+// MCTS._playout descent (mcts.py:107-113) + TreeNode.select/get_value (mcts.py:37-42, 64-70)
+__global__ __launch_bounds__(TPB) void k_select(EngineDev E) {
+    const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+    const int b = (int)blockIdx.x * WPB + wave;
+    if (b >= E.n_boards) return;
+    Board bd = load_board(E.root_hb, E.root_vb, E.root_meta, b);
+    TreeView T = tree_view(E, b, rfl(E.tree_half[b]));
+    uint32_t n_nodes = rfl(E.n_nodes[b]);
+    uint32_t pnode = QZ_NONE, pedge = QZ_NONE;
+    uint32_t parentN = rfl(E.root_N[b]);
+    bool done = false;
+    bool live = rfl(E.status[b]) == QZ_PLAYING;
+    if (live && n_nodes > 0) {
+        uint32_t node = 0;
+        for (int depth = 0; depth < 100000; depth++) {
+            Node nd = T.nodes[node];
+            uint32_t eoff = rfl(nd.edge_off);
+            int ne = (int)rfl(nd.n_edges);
+            double sq = sqrt((double)parentN);  // np.sqrt(self._parent._n_visits), float64
+            double best = -__builtin_inf();
+            int bestk = 0x7fffffff;
+            for (int k = lane; k < ne; k += 64) {
+                uint32_t e = eoff + (uint32_t)k;
+                uint32_t N = T.eN[e];
+                float cp = E.c_puct * T.eP[e];                      // c_puct * self._P in float32
+                double u = (double)cp * sq / (double)(1u + N);      // mcts.py:69
+                double val = T.eQ[e] + u;                           // mcts.py:70
+                if (val > best) {
+                    best = val;
+                    bestk = k;
+                }
+            }
+            wave_argmax(best, bestk);
+            uint32_t e = eoff + (uint32_t)rfl((uint32_t)bestk);
+            int a = (int)rfl(T.eAct[e]);
+            uint32_t child = rfl(T.eChild[e]);
+            uint32_t childN = rfl(T.eN[e]);
+            done = apply_action(bd, a);  // game.step(action), mcts.py:113
+            pnode = node;
+            pedge = e;
+            if (child == 0u) break;  // TreeNode.is_leaf(): never expanded (or terminal)
+            node = child;
+            parentN = childN;
+        }
+    }
+    if (lane == 0) {
+        E.leaf_hb[b] = bd.hb;
+        E.leaf_vb[b] = bd.vb;
+        E.leaf_meta[b] = pack_meta(bd);
+        E.leaf_pnode[b] = pnode;
+        E.leaf_pedge[b] = pedge;
+        // 0 live leaf; 1 terminal & winner == current_player; 2 terminal & winner != current_player;
+        // 3 board not playing (finished, waiting for harvest): ignored by expand_backup
+        uint8_t t = 0;
+        if (!live) t = 3;
+        else if (done) t = (winner_of(bd) == bd.cur) ? 1 : 2;
+        E.leaf_term[b] = t;
+    }
+}
+
+// TreeNode.expand (mcts.py:27-35) + update_recursive (mcts.py:44-62)
+__global__ __launch_bounds__(TPB) void k_expand_backup(EngineDev E, const float* __restrict__ p, const float* __restrict__ v) {
+    const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+    const int b = (int)blockIdx.x * WPB + wave;
+    if (b >= E.n_boards) return;
+    uint32_t term = rfl(E.leaf_term[b]);
+    if (term == 3u) return;
+    TreeView T = tree_view(E, b, rfl(E.tree_half[b]));
+    uint32_t pnode = rfl(E.leaf_pnode[b]), pedge = rfl(E.leaf_pedge[b]);
+    double leaf_value;
+    if (term == 0u) {
+        leaf_value = (double)v[b];
+        uint32_t m0 = rfl(E.leaf_mask[(size_t)b * 5 + 0]), m1 = rfl(E.leaf_mask[(size_t)b * 5 + 1]),
+                 m2 = rfl(E.leaf_mask[(size_t)b * 5 + 2]), m3 = rfl(E.leaf_mask[(size_t)b * 5 + 3]),
+                 m4 = rfl(E.leaf_mask[(size_t)b * 5 + 4]);
+        uint32_t pawn = m0 & 0xFFFu;
+        uint64_t lh = ((uint64_t)m0 >> 12) | ((uint64_t)m1 << 20) | ((uint64_t)(m2 & 0xFFFu) << 52);
+        uint64_t lv = ((uint64_t)m2 >> 12) | ((uint64_t)m3 << 20) | ((uint64_t)(m4 & 0xFFFu) << 52);
+        int k = __popc(pawn) + __popcll(lh) + __popcll(lv);
+        uint32_t nn = rfl(E.n_nodes[b]), neu = rfl(E.n_edges[b]);
+        if (k > 0) {
+            if (nn < (uint32_t)E.node_cap && neu + (uint32_t)k <= (uint32_t)E.edge_cap) {
+                for (int a = lane; a < QZ_N_ACT; a += 64) {
+                    uint32_t w = a < 32 ? m0 : (a < 64 ? m1 : (a < 96 ? m2 : (a < 128 ? m3 : m4)));
+                    if ((w >> (a & 31)) & 1u) {
+                        uint32_t e = neu + (uint32_t)order_index(pawn, lh, lv, a);
+                        T.eN[e] = 0u;
+                        T.eQ[e] = 0.0;
+                        T.eP[e] = p[(size_t)b * QZ_N_ACT + a];
+                        T.eChild[e] = 0u;
+                        T.eAct[e] = (uint8_t)a;
+                    }
+                }
+                if (lane == 0) {
+                    Node nd;
+                    nd.edge_off = neu;
+                    nd.n_edges = (uint32_t)k;
+                    nd.parent_node = pnode;
+                    nd.parent_edge = pedge;
+                    T.nodes[nn] = nd;
+                    if (pnode != QZ_NONE) T.eChild[pedge] = nn;
+                    E.n_nodes[b] = nn + 1u;
+                    E.n_edges[b] = neu + (uint32_t)k;
+                }
+            } else if (lane == 0) {
+                atomicAdd((unsigned long long*)&E.counters[QZ_C_OVERFLOW], 1ull);
+            }
+        }
+    } else {
+        // mcts.py:125: +1 if winner == current_player else -1 (always +1 in practice: the
+        // reference does not rotate players on a terminal move)
+        leaf_value = (term == 1u) ? 1.0 : -1.0;
+        if (E.fix_terminal_sign) leaf_value = -leaf_value;
+    }
+    if (lane == 0) {
+        double val = -leaf_value;  // node.update_recursive(-leaf_value), mcts.py:127
+        uint32_t pn = pnode, pe = pedge;
+        while (pn != QZ_NONE) {
+            uint32_t N = T.eN[pe] + 1u;  // mcts.py:51
+            double Q = T.eQ[pe];
+            Q += 1.0 * (val - Q) / (double)N;  // mcts.py:53
+            T.eN[pe] = N;
+            T.eQ[pe] = Q;
+            val = -val;  // mcts.py:61
+            Node nd = T.nodes[pn];
+            pe = nd.parent_edge;
+            pn = nd.parent_node;
+        }
+        E.root_N[b] = E.root_N[b] + 1u;  // the root is updated too
+        atomicAdd((unsigned long long*)&E.counters[QZ_C_PLAYOUTS], 1ull);
+        if (term != 0u) atomicAdd((unsigned long long*)&E.counters[QZ_C_LEAF_TERMINAL], 1ull);
+    }
+}
+
+// softmax(1/temp * log(visits + 1e-10)) over the root's children (mcts.py:6-9, 141-144).
+// Returns this lane's probabilities for edges lane, lane+64, lane+128 in pr[3].
+__device__ __forceinline__ void root_pi(const TreeView& T, const Node& root, double inv_temp, int lane, double pr[3]) {
+    int ne = (int)root.n_edges;
+    double x[3];
+    double mx = -__builtin_inf();
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        int k = lane + 64 * r;
+        x[r] = -__builtin_inf();
+        if (k < ne) {
+            x[r] = inv_temp * log((double)T.eN[root.edge_off + k] + 1e-10);
+            mx = fmax(mx, x[r]);
+        }
+    }
+    mx = wave_max(mx);
+    double s = 0.0;
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        int k = lane + 64 * r;
+        pr[r] = (k < ne) ? exp(x[r] - mx) : 0.0;
+        s += pr[r];
+    }
+    s = wave_sum(s);
+#pragma unroll
+    for (int r = 0; r < 3; r++) pr[r] = pr[r] / s;
+}
+
+__global__ __launch_bounds__(TPB) void k_root_pi(EngineDev E, double* __restrict__ pi, int32_t* __restrict__ visits) {
+    const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+    const int b = (int)blockIdx.x * WPB + wave;
+    if (b >= E.n_boards) return;
+    for (int a = lane; a < QZ_N_ACT; a += 64) {
+        if (pi) pi[(size_t)b * QZ_N_ACT + a] = 0.0;
+        if (visits) visits[(size_t)b * QZ_N_ACT + a] = -1;
+    }
+    if (rfl(E.n_nodes[b]) == 0u) return;
+    TreeView T = tree_view(E, b, rfl(E.tree_half[b]));
+    Node root = T.nodes[0];
+    double pr[3];
+    root_pi(T, root, 1.0 / (double)E.temp, lane, pr);
+    wave_sync();
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        int k = lane + 64 * r;
+        if (k < (int)root.n_edges) {
+            int a = T.eAct[root.edge_off + k];
+            if (pi) pi[(size_t)b * QZ_N_ACT + a] = pr[r];
+            if (visits) visits[(size_t)b * QZ_N_ACT + a] = (int32_t)T.eN[root.edge_off + k];
+        }
+    }
+}
+
+__global__ __launch_bounds__(TPB) void k_root_children(EngineDev E, int32_t* visits, double* q, float* prior, int32_t* root_visits) {
+    const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+    const int b = (int)blockIdx.x * WPB + wave;
+    if (b >= E.n_boards) return;
+    for (int a = lane; a < QZ_N_ACT; a += 64) {
+        if (visits) visits[(size_t)b * QZ_N_ACT + a] = -1;
+        if (q) q[(size_t)b * QZ_N_ACT + a] = 0.0;
+        if (prior) prior[(size_t)b * QZ_N_ACT + a] = 0.f;
+    }
+    if (root_visits && lane == 0) root_visits[b] = (int32_t)E.root_N[b];
+    if (rfl(E.n_nodes[b]) == 0u) return;
+    TreeView T = tree_view(E, b, rfl(E.tree_half[b]));
+    Node root = T.nodes[0];
+    wave_sync();
+    for (int k = lane; k < (int)root.n_edges; k += 64) {
+        uint32_t e = root.edge_off + k;
+        int a = T.eAct[e];
+        if (visits) visits[(size_t)b * QZ_N_ACT + a] = (int32_t)T.eN[e];
+        if (q) q[(size_t)b * QZ_N_ACT + a] = T.eQ[e];
+        if (prior) prior[(size_t)b * QZ_N_ACT + a] = T.eP[e];
+    }
+}
+
+// MCTS.update_with_move (mcts.py:146-151): keep the chosen child's subtree by copying it,
+// breadth first, into the other arena half (new root = node 0).  `edge` is the root edge of
+// the move or QZ_NONE for a fresh root.
+__device__ __forceinline__ void wave_reroot(EngineDev& E, int b, int lane, uint32_t edge) {
+    uint32_t half = rfl(E.tree_half[b]);
+    TreeView S = tree_view(E, b, half);
+    uint32_t child = 0u, childN = 0u;
+    if (edge != QZ_NONE) {
+        child = rfl(S.eChild[edge]);
+        childN = rfl(S.eN[edge]);
+    }
+    uint32_t new_nodes = 0u, new_edges = 0u;
+    if (child != 0u) {
+        TreeView D = tree_view(E, b, half ^ 1u);
+        if (lane == 0) {
+            Node r;
+            r.edge_off = child;  // temporarily: id of the source node
+            r.n_edges = S.nodes[child].n_edges;
+            r.parent_node = QZ_NONE;
+            r.parent_edge = QZ_NONE;
+            D.nodes[0] = r;
+        }
+        new_nodes = 1u;
+        wave_sync();
+        for (uint32_t i = 0; i < new_nodes; i++) {
+            uint32_t old = rfl(D.nodes[i].edge_off);
+            Node on = S.nodes[old];
+            uint32_t soff = rfl(on.edge_off);
+            int ne = (int)rfl(on.n_edges);
+            uint32_t doff = new_edges;
+            for (int base = 0; base < ne; base += 64) {
+                int k = base + lane;
+                bool act = k < ne;
+                uint32_t c = 0u;
+                if (act) c = S.eChild[soff + k];
+                bool has = act && c != 0u;
+                uint64_t m = __ballot(has);
+                uint32_t nid = new_nodes + (uint32_t)rank_below(m);
+                if (act) {
+                    D.eN[doff + k] = S.eN[soff + k];
+                    D.eQ[doff + k] = S.eQ[soff + k];
+                    D.eP[doff + k] = S.eP[soff + k];
+                    D.eAct[doff + k] = S.eAct[soff + k];
+                    D.eChild[doff + k] = has ? nid : 0u;
+                    if (has) {
+                        Node cn;
+                        cn.edge_off = c;  // source id, fixed up when the node is visited
+                        cn.n_edges = S.nodes[c].n_edges;
+                        cn.parent_node = i;
+                        cn.parent_edge = doff + (uint32_t)k;
+                        D.nodes[nid] = cn;
+                    }
+                }
+                new_nodes += (uint32_t)__popcll(m);
+            }
+            if (lane == 0) D.nodes[i].edge_off = doff;
+            new_edges += (uint32_t)ne;
+            wave_sync();
+        }
+        if (lane == 0) E.tree_half[b] = (uint8_t)(half ^ 1u);
+    }
+    if (lane == 0) {
+        E.n_nodes[b] = new_nodes;
+        E.n_edges[b] = new_edges;
+        E.root_N[b] = childN;
+    }
+}
+
+__device__ __forceinline__ void reset_board_state(EngineDev& E, int b) {  // lane 0 only
+    Board o = opening();
+    E.root_hb[b] = o.hb;
+    E.root_vb[b] = o.vb;
+    E.root_meta[b] = pack_meta(o);
+    E.n_nodes[b] = 0u;
+    E.n_edges[b] = 0u;
+    E.root_N[b] = 0u;
+    E.ply[b] = 0u;
+    E.status[b] = QZ_PLAYING;
+    E.winner[b] = 0;
+    E.game_serial[b] = E.game_serial[b] + 1u;
+}
+
+__global__ __launch_bounds__(256) void k_reset(EngineDev E, int reset_boards) {
+    int b = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (b >= E.n_boards) return;
+    if (reset_boards) {
+        reset_board_state(E, b);
+    } else {
+        E.n_nodes[b] = 0u;
+        E.n_edges[b] = 0u;
+        E.root_N[b] = 0u;
+    }
+}
+
+__global__ __launch_bounds__(TPB) void k_update_with_move(EngineDev E, const uint8_t* __restrict__ moves) {
+    const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+    const int b = (int)blockIdx.x * WPB + wave;
+    if (b >= E.n_boards) return;
+    int mv = (int)rfl(moves[b]);
+    uint32_t edge = QZ_NONE;
+    if (mv < QZ_N_ACT && rfl(E.n_nodes[b]) > 0u) {
+        TreeView T = tree_view(E, b, rfl(E.tree_half[b]));
+        Node root = T.nodes[0];
+        for (int base = 0; base < (int)root.n_edges; base += 64) {
+            int k = base + lane;
+            bool hit = k < (int)root.n_edges && T.eAct[root.edge_off + k] == mv;
+            uint64_t m = __ballot(hit);
+            if (m) edge = root.edge_off + (uint32_t)base + (uint32_t)(__ffsll((unsigned long long)m) - 1);
+        }
+    }
+    wave_reroot(E, b, lane, edge);
+}
+
+// ---------------------------------------------------------------------------- sampling
+// Philox4x32-10, keyed by the engine seed; the counter names (board, game, ply, stream, draw)
+struct Philox {
+    uint32_t k0, k1;
+    __device__ uint4 operator()(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) const {
+        uint32_t a = k0, b = k1;
+#pragma unroll
+        for (int r = 0; r < 10; r++) {
+            uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+            uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ a, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ b,
+                     n3 = (uint32_t)p0;
+            c0 = n0;
+            c1 = n1;
+            c2 = n2;
+            c3 = n3;
+            a += 0x9E3779B9u;
+            b += 0xBB67AE85u;
+        }
+        return make_uint4(c0, c1, c2, c3);
+    }
+};
+__device__ __forceinline__ double u01(uint32_t hi, uint32_t lo) {  // (0,1)
+    uint64_t x = ((uint64_t)hi << 21) ^ (uint64_t)(lo >> 11);
+    return ((double)(x & ((1ull << 53) - 1)) + 0.5) * (1.0 / 9007199254740992.0);
+}
+// Gamma(alpha, 1) for alpha < 1: Marsaglia-Tsang on alpha+1, then the U^(1/alpha) boost
+__device__ double gamma_small(const Philox& ph, uint32_t c0, uint32_t c1, uint32_t c2, double alpha) {
+    double d = alpha + 1.0 - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
+    for (uint32_t t = 0; t < 64; t++) {
+        uint4 r = ph(c0, c1, c2, 2u * t);
+        uint4 s = ph(c0, c1, c2, 2u * t + 1u);
+        double u1 = u01(r.x, r.y), u2 = u01(r.z, r.w);
+        double x = sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+        double vv = 1.0 + c * x;
+        if (vv <= 0.0) continue;
+        vv = vv * vv * vv;
+        double u = u01(s.x, s.y);
+        if (u < 1.0 - 0.0331 * x * x * x * x || log(u) < 0.5 * x * x + d * (1.0 - vv + log(vv))) {
+            double ub = u01(s.z, s.w);
+            return d * vv * pow(ub, 1.0 / alpha);
+        }
+    }
+    return alpha;
+}
+
+// MCTSPlayer.choose_action tail + one iteration of start_self_play (mcts.py:174-187,
+// quoridor.py:585-602)
+__global__ __launch_bounds__(TPB) void k_finish_move(EngineDev E, const uint8_t* __restrict__ forced, float* __restrict__ pi_out,
+                                                     uint8_t* __restrict__ move_out) {
+    const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+    const int b = (int)blockIdx.x * WPB + wave;
+    if (b >= E.n_boards) return;
+    if (move_out && lane == 0) move_out[b] = QZ_NO_MOVE_U8;
+    if (rfl(E.status[b]) != QZ_PLAYING) return;
+    Board bd = load_board(E.root_hb, E.root_vb, E.root_meta, b);
+    uint32_t ply = rfl(E.ply[b]);
+    uint32_t n_nodes = rfl(E.n_nodes[b]);
+    if (n_nodes == 0u || ply >= (uint32_t)E.max_plies) {
+        // no legal move at the root (the reference prints "board is full" and crashes in
+        // start_self_play's unpack, mcts.py:195-196) or the trajectory is full: drop the game
+        if (lane == 0) {
+            atomicAdd((unsigned long long*)&E.counters[QZ_C_ABORTED], 1ull);
+            reset_board_state(E, b);
+        }
+        return;
+    }
+    TreeView T = tree_view(E, b, rfl(E.tree_half[b]));
+    Node root = T.nodes[0];
+    uint32_t eoff = rfl(root.edge_off);
+    int ne = (int)rfl(root.n_edges);
+    double pr[3];
+    root_pi(T, root, 1.0 / (double)E.temp, lane, pr);
+
+    // record (board, pi) BEFORE the move (quoridor.py:589-591)
+    float* tp = E.traj_pi + ((size_t)b * E.max_plies + ply) * QZ_N_ACT;
+    for (int a = lane; a < QZ_N_ACT; a += 64) {
+        tp[a] = 0.f;
+        if (pi_out) pi_out[(size_t)b * QZ_N_ACT + a] = 0.f;
+    }
+    wave_sync();
+    int act[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        int k = lane + 64 * r;
+        act[r] = -1;
+        if (k < ne) {
+            act[r] = T.eAct[eoff + k];
+            tp[act[r]] = (float)pr[r];
+            if (pi_out) pi_out[(size_t)b * QZ_N_ACT + act[r]] = (float)pr[r];
+        }
+    }
+    if (lane == 0) {
+        uint64_t* tb = E.traj_board + ((size_t)b * E.max_plies + ply) * 3;
+        tb[0] = bd.hb;
+        tb[1] = bd.vb;
+        tb[2] = pack_meta(bd);
+    }
+
+    // the move
+    int chosen_k = -1;
+    int fm = forced ? (int)rfl(forced[b]) : QZ_NO_MOVE_U8;
+    if (fm < QZ_N_ACT) {
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            uint64_t m = __ballot(act[r] == fm);
+            if (m) chosen_k = 64 * r + (__ffsll((unsigned long long)m) - 1);
+        }
+        if (chosen_k < 0) chosen_k = 0;  // illegal forced move: fall back to the first child
+    } else {
+        Philox ph{(uint32_t)E.seed, (uint32_t)(E.seed >> 32)};
+        uint32_t serial = rfl(E.game_serial[b]);
+        double w[3];
+        if (E.is_selfplay) {
+            // 0.75*probs + 0.25*Dirichlet(alpha * ones(k)) (mcts.py:181)
+            double g[3], gs = 0.0;
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                int k = lane + 64 * r;
+                g[r] = (k < ne) ? gamma_small(ph, (uint32_t)b, serial, (ply << 8) | (uint32_t)k, (double)E.dirichlet_alpha) : 0.0;
+                gs += g[r];
+            }
+            gs = wave_sum(gs);
+#pragma unroll
+            for (int r = 0; r < 3; r++) w[r] = (1.0 - (double)E.noise_frac) * pr[r] + (double)E.noise_frac * (g[r] / gs);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 3; r++) w[r] = pr[r];
+        }
+        // np.random.choice(acts, p=w): cdf = cumsum(w); idx = searchsorted(cdf/cdf[-1], u, 'right')
+        double carry = 0.0, cdf[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            cdf[r] = carry + wave_scan(w[r], lane);
+            carry = __shfl(cdf[r], 63, 64);
+        }
+        uint4 ur = ph((uint32_t)b, serial, (ply << 8) | 0xFFu, 0xC401CEu);
+        double target = u01(ur.x, ur.y) * carry;
+        int cnt = 0;
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            int k = lane + 64 * r;
+            cnt += __popcll(__ballot(k < ne && cdf[r] <= target));
+        }
+        chosen_k = cnt < ne ? cnt : ne - 1;
+    }
+    uint32_t edge = eoff + (uint32_t)chosen_k;
+    int mv = (int)rfl(T.eAct[edge]);
+    if (move_out && lane == 0) move_out[b] = (uint8_t)mv;
+
+    // update_with_move(move) in self-play, update_with_move(-1) otherwise (mcts.py:182,187)
+    wave_reroot(E, b, lane, E.is_selfplay ? edge : QZ_NONE);
+
+    // self.step(move); has_a_winner() (quoridor.py:593-596)
+    bool done = apply_action(bd, mv);
+    if (lane == 0) {
+        E.root_hb[b] = bd.hb;
+        E.root_vb[b] = bd.vb;
+        E.root_meta[b] = pack_meta(bd);
+        E.ply[b] = ply + 1u;
+        atomicAdd((unsigned long long*)&E.counters[QZ_C_PLIES], 1ull);
+        if (done) {
+            E.status[b] = QZ_FINISHED;
+            E.winner[b] = (uint8_t)winner_of(bd);
+            atomicAdd((unsigned long long*)&E.counters[QZ_C_PENDING_GAMES], 1ull);
+            atomicAdd((unsigned long long*)&E.counters[QZ_C_PENDING_PLIES], (unsigned long long)(ply + 1u));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------- harvest
+// exclusive prefix over finished boards (board order) -> tuple offsets / game ids
+__global__ __launch_bounds__(1024) void k_harvest_scan(EngineDev E) {
+    __shared__ uint32_t s_p[1024], s_g[1024];
+    __shared__ uint32_t base_p, base_g;
+    if (threadIdx.x == 0) {
+        base_p = 0;
+        base_g = 0;
+    }
+    __syncthreads();
+    for (int start = 0; start < E.n_boards; start += 1024) {
+        int b = start + (int)threadIdx.x;
+        bool fin = b < E.n_boards && E.status[b] == QZ_FINISHED;
+        uint32_t np = fin ? E.ply[b] : 0u, ng = fin ? 1u : 0u;
+        s_p[threadIdx.x] = np;
+        s_g[threadIdx.x] = ng;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            uint32_t ap = 0, ag = 0;
+            if ((int)threadIdx.x >= off) {
+                ap = s_p[threadIdx.x - off];
+                ag = s_g[threadIdx.x - off];
+            }
+            __syncthreads();
+            s_p[threadIdx.x] += ap;
+            s_g[threadIdx.x] += ag;
+            __syncthreads();
+        }
+        if (fin) {
+            E.harvest_off[b] = base_p + s_p[threadIdx.x] - np;
+            E.harvest_gid[b] = base_g + s_g[threadIdx.x] - ng;
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) {
+            base_p += s_p[1023];
+            base_g += s_g[1023];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        E.counters[QZ_C_GAMES] += base_g;
+        E.counters[QZ_C_PENDING_GAMES] = 0;
+        E.counters[QZ_C_PENDING_PLIES] = 0;
+    }
+}
+
+// quoridor.py:596-610: z = +1 where the recorded mover is the winner, else -1; then reset
+__global__ __launch_bounds__(TPB) void k_harvest_copy(EngineDev E, uint64_t* t_hb, uint64_t* t_vb, uint64_t* t_meta,
+                                                      float* __restrict__ t_pi, float* __restrict__ t_z,
+                                                      int32_t* __restrict__ t_game, long long cap) {
+    const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+    const int b = (int)blockIdx.x * WPB + wave;
+    if (b >= E.n_boards) return;
+    if (rfl(E.status[b]) != QZ_FINISHED) return;
+    uint32_t n = rfl(E.ply[b]), off = rfl(E.harvest_off[b]), gid = rfl(E.harvest_gid[b]);
+    int win = (int)rfl(E.winner[b]);
+    for (uint32_t i = 0; i < n; i++) {
+        long long o = (long long)off + i;
+        if (o >= cap) break;
+        const uint64_t* tb = E.traj_board + ((size_t)b * E.max_plies + i) * 3;
+        const float* tp = E.traj_pi + ((size_t)b * E.max_plies + i) * QZ_N_ACT;
+        for (int a = lane; a < QZ_N_ACT; a += 64) t_pi[(size_t)o * QZ_N_ACT + a] = tp[a];
+        if (lane == 0) {
+            uint64_t m = tb[2];
+            t_hb[o] = tb[0];
+            t_vb[o] = tb[1];
+            t_meta[o] = m;
+            int mover = (int)((m >> 32) & 0xFF);
+            t_z[o] = (mover == win) ? 1.0f : -1.0f;
+            if (t_game) t_game[o] = (int32_t)gid;
+        }
+    }
+    wave_sync();
+    if (lane == 0) reset_board_state(E, b);
+}
+
+__global__ void k_sqrt_table(double* out, int n) {  // self-test helper: device sqrt(double(i))
+    int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i < n) out[i] = sqrt((double)i);
+}
+
+}  // namespace
+
+// ============================================================================ launchers
+namespace qzl {
+
+static inline dim3 wave_grid(int n) { return dim3((unsigned)((n + WPB - 1) / WPB)); }
+
+hipError_t movegen_encode(const uint64_t* hb, const uint64_t* vb, const uint64_t* meta, int n, uint32_t* mask5,
+                          float* planes, const uint8_t* terminal, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    if (mask5 && planes)
+        hipLaunchKernelGGL((k_movegen_encode<true, true>), wave_grid(n), dim3(TPB), 0, s, hb, vb, meta, n, mask5, planes, terminal);
+    else if (mask5)
+        hipLaunchKernelGGL((k_movegen_encode<true, false>), wave_grid(n), dim3(TPB), 0, s, hb, vb, meta, n, mask5, planes, terminal);
+    else
+        hipLaunchKernelGGL((k_movegen_encode<false, true>), wave_grid(n), dim3(TPB), 0, s, hb, vb, meta, n, mask5, planes, terminal);
+    return hipGetLastError();
+}
+hipError_t step(uint64_t* hb, uint64_t* vb, uint64_t* meta, const uint8_t* action, int n, uint8_t* done, uint8_t* winner,
+                hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_step, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, hb, vb, meta, action, n, done, winner);
+    return hipGetLastError();
+}
+hipError_t select(const EngineDev& E, hipStream_t s) {
+    hipLaunchKernelGGL(k_select, wave_grid(E.n_boards), dim3(TPB), 0, s, E);
+    return hipGetLastError();
+}
+hipError_t expand_backup(const EngineDev& E, const float* p, const float* v, hipStream_t s) {
+    hipLaunchKernelGGL(k_expand_backup, wave_grid(E.n_boards), dim3(TPB), 0, s, E, p, v);
+    return hipGetLastError();
+}
+hipError_t root_pi(const EngineDev& E, double* pi, int32_t* visits, hipStream_t s) {
+    hipLaunchKernelGGL(k_root_pi, wave_grid(E.n_boards), dim3(TPB), 0, s, E, pi, visits);
+    return hipGetLastError();
+}
+hipError_t root_children(const EngineDev& E, int32_t* visits, double* q, float* prior, int32_t* root_visits, hipStream_t s) {
+    hipLaunchKernelGGL(k_root_children, wave_grid(E.n_boards), dim3(TPB), 0, s, E, visits, q, prior, root_visits);
+    return hipGetLastError();
+}
+hipError_t update_with_move(const EngineDev& E, const uint8_t* moves, hipStream_t s) {
+    hipLaunchKernelGGL(k_update_with_move, wave_grid(E.n_boards), dim3(TPB), 0, s, E, moves);
+    return hipGetLastError();
+}
+hipError_t finish_move(const EngineDev& E, const uint8_t* forced, float* pi_out, uint8_t* move_out, hipStream_t s) {
+    hipLaunchKernelGGL(k_finish_move, wave_grid(E.n_boards), dim3(TPB), 0, s, E, forced, pi_out, move_out);
+    return hipGetLastError();
+}
+hipError_t reset(const EngineDev& E, int reset_boards, hipStream_t s) {
+    hipLaunchKernelGGL(k_reset, dim3((unsigned)((E.n_boards + 255) / 256)), dim3(256), 0, s, E, reset_boards);
+    return hipGetLastError();
+}
+hipError_t harvest(const EngineDev& E, uint64_t* t_hb, uint64_t* t_vb, uint64_t* t_meta, float* t_pi, float* t_z,
+                   int32_t* t_game, long long cap, hipStream_t s) {
+    hipLaunchKernelGGL(k_harvest_scan, dim3(1), dim3(1024), 0, s, E);
+    hipLaunchKernelGGL(k_harvest_copy, wave_grid(E.n_boards), dim3(TPB), 0, s, E, t_hb, t_vb, t_meta, t_pi, t_z, t_game, cap);
+    return hipGetLastError();
+}
+hipError_t sqrt_table(double* out, int n, hipStream_t s) {
+    hipLaunchKernelGGL(k_sqrt_table, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out, n);
+    return hipGetLastError();
+}
+
+}  // namespace qzl

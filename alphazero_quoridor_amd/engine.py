@@ -1,0 +1,252 @@
+"""SelfPlayEngine -- thousands of concurrent Quoridor games, one MCTS tree each, on one GPU.
+
+Host-side driver of the kernels behind ``include/qz_abi.h``.  One playout *step* advances
+every board by one playout (mcts.py:103-127):
+
+    qz_mcts_select          descend by PUCT, actions() + state() on the leaf   (HIP)
+    leaf evaluator          policy-value net on the [B,26,9,9] leaf batch      (PyTorch-ROCm)
+    qz_mcts_expand_backup   expand with the priors, back the value up          (HIP)
+
+so the leaf batch is exactly B, and each tree sees its playouts strictly one after the other
+(the reference's sequential semantics; no virtual loss).  ``n_playout`` steps make one ply;
+``finish_move`` then turns root visits into pi, samples the move, records (board, pi),
+re-roots the tree and steps the real board; finished games are harvested as
+(board, pi, z) tuples and their slots restart immediately (continuous refill).
+
+All launches go on torch's current stream, so a whole step can be captured into a HIP graph
+(``capture_steps``) and replayed with one host call.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _cabi
+from .boards import DeviceBoards
+
+
+@dataclass
+class TupleBatch:
+    """Finished-game tuples in the compact wire format (588 B / ply): the board before the
+    move (re-encode with ``states()`` to get the reference's float planes), pi, z."""
+
+    boards: DeviceBoards
+    pi: torch.Tensor      # [n,140] float32
+    z: torch.Tensor       # [n] float32 (+1 recorded mover won / -1)
+    game: torch.Tensor    # [n] int32, id of the game inside this batch
+    n_games: int
+
+    def __len__(self):
+        return int(self.pi.shape[0])
+
+    def states(self) -> torch.Tensor:
+        from . import rules
+
+        return rules.encode(self.boards)
+
+    def to_reference_tuples(self):
+        """list[(float64[26,9,9], float64[140], float64)] exactly like
+        Quoridor.start_self_play's zip (quoridor.py:610) / TrainPipeline.data_buffer."""
+        if len(self) == 0:
+            return []
+        st = self.states().cpu().numpy().astype(np.float64)
+        pi = self.pi.cpu().numpy().astype(np.float64)
+        z = self.z.cpu().numpy().astype(np.float64)
+        return [(st[i], pi[i], z[i]) for i in range(len(self))]
+
+
+class SelfPlayEngine:
+    def __init__(self, n_boards, n_playout=400, c_puct=5.0, temp=1.0, is_selfplay=1, seed=0, device="cuda:0",
+                 fix_terminal_sign=False, node_cap=0, edge_cap=0, max_plies=0, dirichlet_alpha=0.3, noise_frac=0.25):
+        if not torch.cuda.is_available():
+            raise _cabi.QzError(_cabi.E_NO_DEVICE, "no HIP device: the engine has no CPU path")
+        self.L = _cabi.load()
+        self.device = torch.device(device)
+        self.n_boards = int(n_boards)
+        self.n_playout = int(n_playout)
+        cfg = _cabi.qz_config()
+        cfg.n_boards = self.n_boards
+        cfg.n_playout = self.n_playout
+        cfg.c_puct = float(c_puct)
+        cfg.temp = float(temp)
+        cfg.dirichlet_alpha = float(dirichlet_alpha)
+        cfg.noise_frac = float(noise_frac)
+        cfg.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        cfg.device = self.device.index if self.device.index is not None else 0
+        cfg.is_selfplay = int(is_selfplay)
+        cfg.fix_terminal_sign = int(bool(fix_terminal_sign))
+        cfg.node_cap, cfg.edge_cap, cfg.max_plies = int(node_cap), int(edge_cap), int(max_plies)
+        self.cfg = cfg
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            torch.cuda.init()
+            _cabi.check(self.L.qz_engine_create(C.byref(cfg), C.byref(h)))
+        self.h = h
+        B = self.n_boards
+        dev = self.device
+        # caller-owned I/O buffers of the step (device resident, reused every step)
+        self.planes = torch.zeros((B, 26, 9, 9), dtype=torch.float32, device=dev)
+        self.leaf_mask = torch.zeros((B, 5), dtype=torch.int32, device=dev)
+        self.leaf_term = torch.zeros(B, dtype=torch.uint8, device=dev)
+        self.moves = torch.full((B,), 255, dtype=torch.uint8, device=dev)
+        self.pi = torch.zeros((B, 140), dtype=torch.float32, device=dev)
+        self._graph = None
+        self._graph_steps = 0
+
+    # ------------------------------------------------------------------ plumbing
+    def _s(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._graph = None
+            with torch.cuda.device(self.device):
+                self.L.qz_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        _cabi.check(self.L.qz_engine_reset(self.h, self._s()))
+
+    def set_boards(self, boards: DeviceBoards, reset_trees=True):
+        assert boards.n == self.n_boards
+        _cabi.check(self.L.qz_engine_set_boards(self.h, boards.byref(), int(reset_trees), self._s()))
+
+    def get_boards(self) -> DeviceBoards:
+        out = DeviceBoards(self.n_boards, self.device)
+        _cabi.check(self.L.qz_engine_get_boards(self.h, out.byref(), self._s()))
+        return out
+
+    def set_temp(self, temp: float):
+        _cabi.check(self.L.qz_engine_set_temp(self.h, float(temp)))
+
+    # ------------------------------------------------------------------ one playout step
+    def select(self):
+        """-> leaf planes [B,26,9,9] (also fills leaf_mask / leaf_term)."""
+        _cabi.check(self.L.qz_mcts_select(self.h, self.planes.data_ptr(), self.leaf_mask.data_ptr(),
+                                          self.leaf_term.data_ptr(), self._s()))
+        return self.planes
+
+    def select_boards(self) -> DeviceBoards:
+        """-> leaf boards (for host-side policy callbacks); fills leaf_mask / leaf_term."""
+        out = DeviceBoards(self.n_boards, self.device)
+        _cabi.check(self.L.qz_mcts_select_boards(self.h, out.byref(), self.leaf_mask.data_ptr(),
+                                                 self.leaf_term.data_ptr(), self._s()))
+        return out
+
+    def expand_backup(self, p: torch.Tensor, v: torch.Tensor):
+        assert p.dtype == torch.float32 and v.dtype == torch.float32 and p.is_contiguous() and v.is_contiguous()
+        assert p.shape == (self.n_boards, 140) and v.numel() == self.n_boards
+        _cabi.check(self.L.qz_mcts_expand_backup(self.h, p.data_ptr(), v.data_ptr(), self._s()))
+
+    def playout_step(self, evaluator):
+        p, v = evaluator(self.select())
+        self.expand_backup(p, v)
+
+    def capture_steps(self, evaluator, steps_per_graph=1, warmup=3):
+        """Capture `steps_per_graph` playout steps (select -> net -> expand/backup) into one
+        HIP graph.  The evaluator must be allocation-stable (static shapes)."""
+        s = torch.cuda.Stream(device=self.device)
+        s.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                self.playout_step(evaluator)
+        torch.cuda.current_stream(self.device).wait_stream(s)
+        torch.cuda.synchronize(self.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(steps_per_graph):
+                self.playout_step(evaluator)
+        self._graph, self._graph_steps = g, int(steps_per_graph)
+        return warmup  # playouts already spent on the current roots
+
+    def run_playouts(self, evaluator, n=None):
+        """MCTS.get_move_probs's loop (mcts.py:135-139) for every board."""
+        n = self.n_playout if n is None else int(n)
+        done = 0
+        if self._graph is not None:
+            while n - done >= self._graph_steps:
+                self._graph.replay()
+                done += self._graph_steps
+        for _ in range(n - done):
+            self.playout_step(evaluator)
+
+    # ------------------------------------------------------------------ end of a ply
+    def finish_move(self, forced=None):
+        """-> (moves uint8 [B] (255 = board idle), pi float32 [B,140])."""
+        fp = 0
+        if forced is not None:
+            self._forced = forced.to(device=self.device, dtype=torch.uint8).contiguous()
+            fp = self._forced.data_ptr()
+        _cabi.check(self.L.qz_mcts_finish_move(self.h, fp, self.pi.data_ptr(), self.moves.data_ptr(), self._s()))
+        return self.moves, self.pi
+
+    def update_with_move(self, moves: torch.Tensor):
+        self._upd = moves.to(device=self.device, dtype=torch.uint8).contiguous()
+        _cabi.check(self.L.qz_mcts_update_with_move(self.h, self._upd.data_ptr(), self._s()))
+
+    def root_pi(self):
+        pi = torch.empty((self.n_boards, 140), dtype=torch.float64, device=self.device)
+        visits = torch.empty((self.n_boards, 140), dtype=torch.int32, device=self.device)
+        _cabi.check(self.L.qz_mcts_root_pi(self.h, pi.data_ptr(), visits.data_ptr(), self._s()))
+        return pi, visits
+
+    def root_children(self):
+        B, dev = self.n_boards, self.device
+        visits = torch.empty((B, 140), dtype=torch.int32, device=dev)
+        q = torch.empty((B, 140), dtype=torch.float64, device=dev)
+        prior = torch.empty((B, 140), dtype=torch.float32, device=dev)
+        root_n = torch.empty(B, dtype=torch.int32, device=dev)
+        _cabi.check(self.L.qz_mcts_root_children(self.h, visits.data_ptr(), q.data_ptr(), prior.data_ptr(),
+                                                 root_n.data_ptr(), self._s()))
+        return visits, q, prior, root_n
+
+    def pending(self):
+        """(finished games, their plies) waiting for harvest.  Synchronises the stream."""
+        c = (C.c_int64 * 2)()
+        _cabi.check(self.L.qz_harvest_counts(self.h, C.byref(c), self._s()))
+        return int(c[0]), int(c[1])
+
+    def harvest(self):
+        """Collect every finished game as tuples and restart those boards.  -> TupleBatch | None"""
+        games, plies = self.pending()
+        if games == 0:
+            return None
+        tb = DeviceBoards(plies, self.device)
+        pi = torch.empty((plies, 140), dtype=torch.float32, device=self.device)
+        z = torch.empty(plies, dtype=torch.float32, device=self.device)
+        gid = torch.empty(plies, dtype=torch.int32, device=self.device)
+        _cabi.check(self.L.qz_harvest(self.h, tb.byref(), pi.data_ptr(), z.data_ptr(), gid.data_ptr(), plies, self._s()))
+        return TupleBatch(tb, pi, z, gid, games)
+
+    def stats(self) -> dict:
+        st = _cabi.qz_stats()
+        _cabi.check(self.L.qz_engine_stats(self.h, C.byref(st), self._s()))
+        return {k: int(getattr(st, k)) for k, _ in st._fields_ if k != "reserved"}
+
+    # ------------------------------------------------------------------ whole plies / games
+    def play_ply(self, evaluator, n_playout=None, forced=None):
+        self.run_playouts(evaluator, n_playout)
+        return self.finish_move(forced)
+
+    def collect_games(self, evaluator, n_games, max_plies=None):
+        """Play until at least `n_games` complete games were harvested. -> list[TupleBatch]"""
+        out, got, plies = [], 0, 0
+        while got < n_games:
+            self.play_ply(evaluator)
+            plies += 1
+            tb = self.harvest()
+            if tb is not None:
+                out.append(tb)
+                got += tb.n_games
+            if max_plies is not None and plies >= max_plies:
+                break
+        return out

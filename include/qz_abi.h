@@ -119,6 +119,8 @@ int qz_engine_reset(qz_engine* e, void* stream);
  * reset_trees != 0 also drops every search tree. */
 int qz_engine_set_boards(qz_engine* e, const qz_boards* src, int reset_trees, void* stream);
 int qz_engine_get_boards(qz_engine* e, const qz_boards* dst, void* stream);
+/* the `temp` argument of get_move_probs / choose_action (mcts.py:129,172) for later calls */
+int qz_engine_set_temp(qz_engine* e, float temp);
 
 /* MCTS._playout, first half (mcts.py:107-117): for every board descend from the root by
  * PUCT (TreeNode.select / get_value, mcts.py:37-42, 64-70) applying Quoridor.step() to a
@@ -170,6 +172,11 @@ int qz_harvest(qz_engine* e, const qz_boards* t_boards, float* t_pi /*[dev]*/, f
                int32_t* t_game /*[dev]*/, int64_t cap, void* stream);
 
 int qz_engine_stats(qz_engine* e, qz_stats* out /*[host]*/, void* stream); /* SYNC */
+
+/* self-test hook for the GPU tests: out[i] <- device sqrt((double)i), i < n.  The PUCT term
+ * uses np.sqrt(parent visits) in float64 (mcts.py:69); the test checks the device result is
+ * correctly rounded. */
+int qz_selftest_sqrt(double* out /*[dev]*/, int n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,32 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+if GOLDEN not in sys.path:
+    sys.path.insert(0, GOLDEN)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
+
+
+@pytest.fixture(scope="session")
+def gpu_device():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("a -m gpu test was selected but torch sees no HIP device")
+    from alphazero_quoridor_amd import _cabi
+
+    _cabi.load()  # fails loudly if libqzero_hip.so is missing
+    return torch.device("cuda:0")

@@ -77,14 +77,24 @@ def hash_value(h):
     return float(((r2 >> 8) - 8388608) / 16777216.0)
 
 
+def _legal(game):
+    # the reference evaluates the policy on terminal leaves too (mcts.py:117) and its real
+    # policy_value_fn crashes there on off-board winning jumps (IndexError);
+    # the output is ignored for terminal leaves (mcts.py:121-125), so the stubs swallow it.
+    try:
+        return game.actions()
+    except IndexError:
+        return []
+
+
 def hash_policy_py(game):
-    legal = game.actions()
+    legal = _legal(game)
     h = state_hash_game(game)
     return zip(legal, [hash_prior(h, a) for a in legal]), hash_value(h)
 
 
 def uniform_policy_py(game):
-    legal = game.actions()
+    legal = _legal(game)
     n = len(legal)
     p = np.float32(1.0 / n) if n else np.float32(0)
     return zip(legal, [p] * n), 0.0

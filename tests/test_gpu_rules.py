@@ -1,0 +1,126 @@
+"""GPU parity: HIP rules kernels (through the C ABI) vs the CPU oracle and the golden
+fixtures recorded from the real reference.  Bit-exact: integer / bit work."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _load_positions(golden_dir):
+    d = np.load(golden_dir + "/rules_positions.npz")
+    return d
+
+
+def test_movegen_matches_golden_and_oracle(gpu_device, golden_dir):
+    import oracle
+    from alphazero_quoridor_amd import rules
+    from alphazero_quoridor_amd.boards import DeviceBoards
+
+    d = _load_positions(golden_dir)
+    live = d["winner"] * 0 == 0  # every recorded position is a live board before its move
+    boards = d["board"][live]
+    db = DeviceBoards.from_packed(boards, gpu_device)
+    mask = rules.movegen(db).cpu().numpy().view(np.uint32)
+    # (1) golden: ordered action lists recorded from quoridor.Quoridor.actions()
+    bad = 0
+    for i in range(len(boards)):
+        exp = list(d["actions"][i][: d["n_actions"][i]])
+        got = rules.mask_to_actions(mask[i])
+        if exp != got:
+            bad += 1
+    assert bad == 0, "%d of %d masks differ from the reference" % (bad, len(boards))
+    # (2) oracle on the same inputs
+    omask, status = oracle.movegen_batch(boards)
+    assert (status >= 0).all()
+    assert np.array_equal(omask, mask)
+
+
+def test_encode_matches_golden_and_oracle(gpu_device, golden_dir):
+    import oracle
+    from alphazero_quoridor_amd import rules
+    from alphazero_quoridor_amd.boards import DeviceBoards
+
+    d = _load_positions(golden_dir)
+    boards = d["board"]
+    db = DeviceBoards.from_packed(boards, gpu_device)
+    planes = rules.encode(db).cpu().numpy()
+    assert set(np.unique(planes)) <= {0.0, 1.0}
+    bits = np.packbits(planes.astype(np.uint8).reshape(len(boards), -1), axis=1)
+    assert np.array_equal(bits, d["state_bits"])
+    assert np.array_equal(planes, oracle.encode_batch(boards))
+
+
+def test_fused_movegen_encode_equals_separate(gpu_device, golden_dir):
+    from alphazero_quoridor_amd import rules
+    from alphazero_quoridor_amd.boards import DeviceBoards
+
+    d = _load_positions(golden_dir)
+    boards = d["board"][:4099]  # not a multiple of the 4-board workgroup
+    db = DeviceBoards.from_packed(boards, gpu_device)
+    m1 = rules.movegen(db)
+    p1 = rules.encode(db)
+    m2, p2 = rules.movegen_encode(db)
+    assert torch.equal(m1, m2) and torch.equal(p1, p2)
+
+
+def test_step_matches_golden(gpu_device, golden_dir):
+    import oracle
+    from alphazero_quoridor_amd import rules
+    from alphazero_quoridor_amd.boards import DeviceBoards
+
+    for name in ("rules_positions.npz", "rules_steps.npz"):
+        d = np.load(golden_dir + "/" + name)
+        ok = d["action"] < 140
+        boards, action = d["board"][ok], d["action"][ok]
+        db = DeviceBoards.from_packed(boards, gpu_device)
+        done, winner = rules.step(db, torch.from_numpy(action))
+        got = db.to_packed()
+        exp = d["next_board"][ok]
+        assert np.array_equal(got.view(np.uint64), exp.view(np.uint64)), name
+        assert np.array_equal(done.cpu().numpy(), d["done"][ok]), name
+        assert np.array_equal(winner.cpu().numpy(), d["winner"][ok]), name
+        ob, odone, owin = oracle.step_batch(boards, action)
+        assert np.array_equal(ob.view(np.uint64), got.view(np.uint64))
+
+
+def test_random_positions_vs_oracle(gpu_device):
+    """Seeded synthetic positions (dense walls, adjacent pawns) at a size the oracle does in
+    seconds; masks and planes must be identical."""
+    import oracle
+    from alphazero_quoridor_amd import _cabi, rules
+    from alphazero_quoridor_amd.boards import DeviceBoards
+    from synth import synth_positions
+
+    boards = synth_positions(20000, seed=0x5EED)
+    db = DeviceBoards.from_packed(boards, gpu_device)
+    mask, planes = rules.movegen_encode(db)
+    omask, status = oracle.movegen_batch(boards)
+    assert (status >= 0).all()
+    assert np.array_equal(mask.cpu().numpy().view(np.uint32), omask)
+    assert np.array_equal(planes.cpu().numpy(), oracle.encode_batch(boards))
+
+
+def test_edge_sizes(gpu_device):
+    from alphazero_quoridor_amd import rules
+    from alphazero_quoridor_amd.boards import DeviceBoards, opening_packed
+
+    # empty batch
+    db = DeviceBoards.from_packed(opening_packed(0), gpu_device)
+    assert rules.movegen(db).shape == (0, 5)
+    # single board: the opening has 131 legal actions, first ten as in SURVEY A.4
+    db = DeviceBoards.from_packed(opening_packed(1), gpu_device)
+    acts = rules.mask_to_actions(rules.movegen(db).cpu().numpy()[0])
+    assert len(acts) == 131 and acts[:10] == [0, 2, 3, 12, 76, 13, 77, 14, 78, 15]
+    planes = rules.encode(db).cpu().numpy()[0]
+    assert planes.reshape(26, 81).sum(axis=1).tolist() == [64, 0, 0, 1, 1] + [0] * 9 + [81] + [0] * 9 + [81, 0]
+
+
+def test_device_sqrt_is_correctly_rounded(gpu_device):
+    """PUCT uses np.sqrt(parent visits) in float64 (mcts.py:69)."""
+    from alphazero_quoridor_amd import _cabi
+
+    n = 1 << 20
+    out = torch.empty(n, dtype=torch.float64, device=gpu_device)
+    _cabi.check(_cabi.load().qz_selftest_sqrt(out.data_ptr(), n, torch.cuda.current_stream().cuda_stream))
+    assert np.array_equal(out.cpu().numpy(), np.sqrt(np.arange(n, dtype=np.float64)))
