@@ -1,0 +1,251 @@
+"""Policy-value network for the self-play path, kept in PyTorch-ROCm.
+
+Mirror of the reference's ``policy_value_net`` module surface (policy_value_net.py:110-200):
+``PolicyValueNet(model_file=None, use_gpu=True)`` with ``policy_value``, ``policy_value_fn``,
+``train_step``, ``get_policy_param``, ``save_model``.  The nn.Module keeps the reference's
+parameter names so ``ckpt/<name>.pth`` state_dicts interchange.
+
+What is new here is the batched leaf evaluator used by the engine (``LeafEvaluator``):
+one forward on a device-resident [B,26,9,9] leaf batch with no host round trip, in one of
+three BatchNorm modes:
+
+  "per_leaf"  every sample normalised with its own statistics -- what the reference's
+              policy_value_fn does (module left in train mode, batch of one:
+              policy_value_net.py:154 with no .eval() anywhere).  Batch-invariant.  DEFAULT.
+  "batch"     batch statistics, like the reference's policy_value (policy_value_net.py:127-143)
+  "eval"      running statistics (standard inference; BN folded into the convolutions)
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+N_ACTIONS = 140
+IN_PLANES = 26
+WIDTH = 64
+N_RES = 5
+BN_EPS = 1e-5
+
+
+class BasicBlock(nn.Module):
+    """conv-bn-relu-conv-bn-(+x)-relu (policy_value_net.py:20-48); names conv1/bn1/conv2/bn2."""
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        y = self.relu(self.bn1(self.conv1(x)))
+        y = self.bn2(self.conv2(y))
+        y = y + (x if self.downsample is None else self.downsample(x))
+        return self.relu(y)
+
+
+class policy_value_net(nn.Module):  # noqa: N801 -- the reference's class name
+    """26x9x9 -> (log-softmax over 140 actions, tanh value); policy_value_net.py:51-99."""
+
+    def __init__(self, block=BasicBlock, inplanes=IN_PLANES, planes=WIDTH, stride=1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        for i in range(1, N_RES + 1):
+            setattr(self, "res%d" % i, block(planes, planes))
+        self.conv2 = nn.Conv2d(planes, 4, 3, stride, 1, bias=False)  # value head
+        self.bn2 = nn.BatchNorm2d(4)
+        self.fc1 = nn.Linear(4 * 81, 128)
+        self.fc2 = nn.Linear(128, 1)
+        self.conv3 = nn.Conv2d(planes, 2, 3, stride, 1, bias=False)  # policy head
+        self.bn3 = nn.BatchNorm2d(2)
+        self.fc3 = nn.Linear(2 * 81, N_ACTIONS)
+
+    def trunk(self, x):
+        x = self.relu(self.bn1(self.conv1(x)))
+        for i in range(1, N_RES + 1):
+            x = getattr(self, "res%d" % i)(x)
+        return x
+
+    def forward(self, x):
+        t = self.trunk(x)
+        v = self.relu(self.bn2(self.conv2(t))).reshape(-1, 4 * 81)
+        v = torch.tanh(self.fc2(self.fc1(v)))  # no activation between fc1 and fc2 (:89-90)
+        p = self.relu(self.bn3(self.conv3(t))).reshape(-1, 2 * 81)
+        p = F.log_softmax(self.fc3(p), dim=1)
+        return p, v
+
+
+# --------------------------------------------------------------------------------------
+class LeafEvaluator:
+    """planes [B,26,9,9] float32 (device) -> (p [B,140] float32, v [B] float32), both
+    contiguous and device resident: the `p`/`v` arguments of qz_mcts_expand_backup.
+
+    p = exp(log_softmax(logits)) as in policy_value_net.py:155 (not renormalised over the
+    legal moves: the expand kernel gathers it at the legal actions, policy_value_net.py:162).
+    """
+
+    def __init__(self, net: nn.Module, bn_mode="per_leaf", dtype=torch.float32, channels_last=False):
+        assert bn_mode in ("per_leaf", "batch", "eval")
+        self.net = net
+        self.bn_mode = bn_mode
+        self.dtype = dtype
+        self.channels_last = channels_last
+        self._layers = None
+        self.refresh()
+
+    # weights may change between self-play rounds (training).  Cached tensors are updated IN
+    # PLACE so that a captured HIP graph keeps pointing at live data.
+    def refresh(self):
+        n, dt = self.net, self.dtype
+        mf = torch.channels_last if self.channels_last else torch.contiguous_format
+
+        def conv_w(w):
+            return w.detach().to(dt).contiguous(memory_format=mf).clone(memory_format=torch.preserve_format)
+
+        names = [("conv1", "bn1")]
+        for i in range(1, N_RES + 1):
+            names += [("res%d.conv1" % i, "res%d.bn1" % i), ("res%d.conv2" % i, "res%d.bn2" % i)]
+        names += [("conv2", "bn2"), ("conv3", "bn3")]
+        mods = dict(n.named_modules())
+        layers = []
+        for cn, bn in names:
+            conv, b = mods[cn], mods[bn]
+            if self.bn_mode == "eval":
+                scale = (b.weight / torch.sqrt(b.running_var + b.eps)).detach()
+                w = conv_w(conv.weight.detach() * scale.view(-1, 1, 1, 1))
+                bias = (b.bias - b.running_mean * scale).detach().to(dt).clone()
+                layers.append([w, bias, None, None])
+            else:
+                layers.append([conv_w(conv.weight), None, b.weight.detach().to(dt).clone(), b.bias.detach().to(dt).clone()])
+        fc = [[m.weight.detach().to(dt).clone(), m.bias.detach().to(dt).clone()] for m in (n.fc1, n.fc2, n.fc3)]
+        if getattr(self, "_layers", None) is None:
+            self._layers, self._fc = layers, fc
+        else:
+            for old, new in zip(self._layers + self._fc, layers + fc):
+                for o, t in zip(old, new):
+                    if o is not None:
+                        o.copy_(t)
+
+    def _cbn(self, x, i, relu=True, residual=None):
+        w, bias, gamma, beta = self._layers[i]
+        y = F.conv2d(x, w, bias, 1, 1)
+        if self.bn_mode == "per_leaf":
+            # BatchNorm2d in training mode on a batch of one == per-sample statistics over
+            # the 81 positions (biased variance), then the affine transform
+            y = F.instance_norm(y, None, None, gamma, beta, True, 0.0, BN_EPS)
+        elif self.bn_mode == "batch":
+            y = F.batch_norm(y, None, None, gamma, beta, True, 0.0, BN_EPS)
+        if residual is not None:
+            y = y + residual
+        return F.relu(y) if relu else y
+
+    @torch.no_grad()
+    def __call__(self, planes: torch.Tensor):
+        x = planes.to(self.dtype)
+        if self.channels_last:
+            x = x.contiguous(memory_format=torch.channels_last)
+        x = self._cbn(x, 0)
+        li = 1
+        for _ in range(N_RES):
+            y = self._cbn(x, li)
+            x = self._cbn(y, li + 1, relu=True, residual=x)
+            li += 2
+        B = x.shape[0]
+        v = self._cbn(x, li).reshape(B, 4 * 81)
+        p = self._cbn(x, li + 1).reshape(B, 2 * 81)
+        (w1, b1), (w2, b2), (w3, b3) = self._fc
+        v = torch.tanh(F.linear(F.linear(v, w1, b1), w2, b2)).reshape(B)
+        p = torch.exp(F.log_softmax(F.linear(p, w3, b3).float(), dim=1))
+        return p.contiguous(), v.float().contiguous()
+
+
+# --------------------------------------------------------------------------------------
+def set_learning_rate(optimizer, lr):
+    for group in optimizer.param_groups:
+        group["lr"] = lr
+
+
+class PolicyValueNet:
+    """Drop-in for the reference's PolicyValueNet (policy_value_net.py:110-200).
+
+    use_gpu=True requires a HIP device (as the reference's .cuda() does); use_gpu=False keeps
+    the *network* on the CPU for checkpoint work and numerics tests -- game logic still runs
+    on the GPU (the rules engine has no CPU path).
+    """
+
+    def __init__(self, model_file=None, use_gpu=True, bn_mode="per_leaf", device=None):
+        self.use_gpu = use_gpu
+        self.l2_const = 1e-4
+        if device is None:
+            device = "cuda:0" if use_gpu else "cpu"
+        self.device = torch.device(device)
+        self.policy_value_net = policy_value_net(BasicBlock, IN_PLANES, WIDTH).to(self.device)
+        self.optimizer = torch.optim.Adam(self.policy_value_net.parameters(), weight_decay=self.l2_const)
+        self.bn_mode = bn_mode
+        if model_file:
+            path = model_file if os.path.exists(str(model_file)) else "ckpt/%s.pth" % model_file
+            self.policy_value_net.load_state_dict(torch.load(path, map_location=self.device))
+        self._evaluator = None
+
+    # engine-facing ---------------------------------------------------------------
+    def evaluator(self, bn_mode=None, dtype=torch.float32, channels_last=False) -> LeafEvaluator:
+        key = (bn_mode or self.bn_mode, dtype, channels_last)
+        if self._evaluator is None or self._evaluator[0] != key:
+            self._evaluator = (key, LeafEvaluator(self.policy_value_net, key[0], dtype, channels_last))
+        return self._evaluator[1]
+
+    def weights_changed(self):
+        if self._evaluator is not None:
+            self._evaluator[1].refresh()
+
+    # reference API -----------------------------------------------------------------
+    def policy_value(self, state_batch):
+        """batch of states -> (act_probs float32 [B,140], value float32 [B,1]) as numpy
+        (policy_value_net.py:127-143; module in train mode => batch statistics)."""
+        x = torch.as_tensor(np.asarray(state_batch), dtype=torch.float32, device=self.device)
+        with torch.no_grad():
+            logp, v = self.policy_value_net(x)
+        return np.exp(logp.cpu().numpy()), v.cpu().numpy()
+
+    def policy_value_fn(self, game):
+        """game -> (iterable[(action, prob)], value) (policy_value_net.py:145-164)."""
+        legal = game.actions()
+        x = torch.as_tensor(np.ascontiguousarray(game.state()).reshape(1, 26, 9, 9), dtype=torch.float32,
+                            device=self.device)
+        with torch.no_grad():
+            logp, v = self.policy_value_net(x)
+        probs = np.exp(logp.cpu().numpy().reshape(-1))
+        return zip(legal, probs[legal]), float(v.reshape(-1)[0])
+
+    def train_step(self, state_batch, mcts_probs, winner_batch, lr):
+        """loss = (z - v)^2 - pi^T log p (+ L2 via weight decay); returns (loss, entropy) as
+        Python floats (policy_value_net.py:166-192, with the torch>=0.4 `.item()` fix)."""
+        s = torch.as_tensor(np.asarray(state_batch), dtype=torch.float32, device=self.device)
+        pi = torch.as_tensor(np.asarray(mcts_probs), dtype=torch.float32, device=self.device)
+        z = torch.as_tensor(np.asarray(winner_batch), dtype=torch.float32, device=self.device)
+        self.optimizer.zero_grad()
+        set_learning_rate(self.optimizer, lr)
+        logp, v = self.policy_value_net(s)
+        loss = F.mse_loss(v.view(-1), z) - torch.mean(torch.sum(pi * logp, 1))
+        loss.backward()
+        self.optimizer.step()
+        with torch.no_grad():
+            entropy = -torch.mean(torch.sum(torch.exp(logp) * logp, 1))
+        self.weights_changed()
+        return loss.item(), entropy.item()
+
+    def get_policy_param(self):
+        return self.policy_value_net.state_dict()
+
+    def save_model(self, model_file):
+        os.makedirs("ckpt", exist_ok=True)
+        torch.save(self.policy_value_net.state_dict(), "ckpt/%s.pth" % model_file)

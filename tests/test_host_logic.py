@@ -1,0 +1,181 @@
+"""CPU tier: host-side logic that needs no GPU -- the C-ABI library loads and exports every
+symbol include/qz_abi.h declares, compute entry points refuse to run without a device (no
+silent fallback), wire format + all-gather of finished tuples on gloo (world_size 2), the
+network mirror against the reference fixture."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from alphazero_quoridor_amd import _cabi
+
+    _cabi.build()
+    return _cabi.load()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from alphazero_quoridor_amd import _cabi
+
+    header = open(os.path.join(ROOT, "include", "qz_abi.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(qz_[a-z_]+)\s*\(", header)))
+    assert len(declared) >= 24
+    for name in declared:
+        assert hasattr(lib, name), "libqzero_hip.so does not export %s" % name
+    assert sorted(_cabi.exported_symbols()) == declared  # the binding covers the whole header
+    assert lib.qz_version() == 1
+    # struct layouts agree with the header (sizes the C side was compiled with)
+    assert C.sizeof(_cabi.qz_config) == 72 and C.sizeof(_cabi.qz_stats) == 96 and C.sizeof(_cabi.qz_boards) == 24
+
+
+def test_no_cpu_fallback(lib):
+    """Without a HIP device every compute entry point fails loudly."""
+    from alphazero_quoridor_amd import _cabi
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu tier")
+    assert lib.qz_device_count() == 0
+    b = _cabi.qz_boards(1, 1, 1)
+    for rc in (lib.qz_movegen(C.byref(b), 1, 1, None), lib.qz_encode(C.byref(b), 1, 1, None),
+               lib.qz_step(C.byref(b), 1, 1, None, None, None)):
+        assert rc == _cabi.E_NO_DEVICE
+    assert b"no CPU path" in lib.qz_last_error()
+    cfg = _cabi.qz_config()
+    cfg.n_boards, cfg.n_playout, cfg.temp = 4, 4, 1.0
+    h = C.c_void_p()
+    assert lib.qz_engine_create(C.byref(cfg), C.byref(h)) == _cabi.E_NO_DEVICE and not h
+    from alphazero_quoridor_amd.engine import SelfPlayEngine
+    from alphazero_quoridor_amd.quoridor import Quoridor
+
+    with pytest.raises(_cabi.QzError):
+        SelfPlayEngine(4)
+    with pytest.raises(_cabi.QzError):
+        Quoridor().actions()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "alphazero_quoridor_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text and "qz_oracle" not in text, f
+                assert "hostcheck" not in text or f == "qz_rules.h", f
+
+
+def test_packed_layout_and_action_order():
+    from alphazero_quoridor_amd import _cabi, rules
+    from alphazero_quoridor_amd.boards import opening_packed
+
+    rec = opening_packed(3)
+    hb, vb, meta = _cabi.packed_to_soa(rec)
+    assert meta[0] == 4 | (76 << 8) | (10 << 16) | (10 << 24) | (1 << 32)
+    assert _cabi.soa_to_packed(hb, vb, meta).tobytes() == rec.tobytes()
+    assert rules.ACTION_ORDER[:16] == [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 76, 13, 77]
+    assert sorted(rules.ACTION_ORDER) == list(range(140))
+
+
+def test_tuple_wire_format_roundtrip():
+    from alphazero_quoridor_amd import dist as qd
+
+    n = 37
+    g = torch.Generator().manual_seed(1)
+    hb = torch.randint(-2**62, 2**62, (n,), generator=g)
+    vb = torch.randint(-2**62, 2**62, (n,), generator=g)
+    meta = torch.randint(0, 2**40, (n,), generator=g)
+    pi = torch.rand((n, 140), generator=g)
+    z = torch.where(torch.rand(n, generator=g) > 0.5, 1.0, -1.0)
+    buf = qd.pack_tuples(hb, vb, meta, pi, z)
+    assert buf.shape == (n, 588) and buf.dtype == torch.uint8
+    h2, v2, m2, p2, z2 = qd.unpack_tuples(buf)
+    assert torch.equal(h2, hb) and torch.equal(v2, vb) and torch.equal(m2, meta) and torch.equal(p2, pi) and torch.equal(z2, z)
+    assert qd.allgather_tuples(buf) is buf  # world size 1: no collective
+
+
+_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from alphazero_quoridor_amd import dist as qd
+rank, local, world = qd.init_from_env(device_type="cpu")
+assert world == 2 and dist.get_backend() == "gloo"
+n = 5 if rank == 0 else 11            # ragged contribution
+g = torch.Generator().manual_seed(100 + rank)
+hb = torch.randint(0, 2**40, (n,), generator=g); vb = hb + 1; meta = hb + 2
+pi = torch.rand((n, 140), generator=g); z = torch.full((n,), 1.0 if rank == 0 else -1.0)
+out = qd.allgather_tuples(qd.pack_tuples(hb, vb, meta, pi, z))
+h2, v2, m2, p2, z2 = qd.unpack_tuples(out)
+assert out.shape == (16, 588)
+assert torch.equal(z2, torch.cat([torch.ones(5), -torch.ones(11)]))
+lo = 0 if rank == 0 else 5
+assert torch.equal(h2[lo:lo + n], hb) and torch.equal(p2[lo:lo + n], pi)
+# every rank holds the identical replay content: compare a checksum across ranks
+s = out.to(torch.int64).sum().reshape(1)
+both = [torch.zeros(1, dtype=torch.int64) for _ in range(2)]
+dist.all_gather(both, s)
+assert both[0].item() == both[1].item()
+# an empty contribution from one rank must not hang or break the gather
+e = qd.allgather_tuples(qd.pack_tuples(hb[:0], vb[:0], meta[:0], pi[:0], z[:0]) if rank == 0 else qd.pack_tuples(hb, vb, meta, pi, z))
+assert e.shape[0] == 11
+assert qd.shard_seed(7, 0) != qd.shard_seed(7, 1)
+dist.destroy_process_group()
+print("RANK_OK", rank)
+'''
+
+
+def test_allgather_of_finished_tuples_gloo_world2(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    r = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+         "--master-port", "29517", str(script), ROOT],
+        env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "RANK_OK 0" in r.stdout and "RANK_OK 1" in r.stdout
+
+
+def test_network_mirror_matches_reference_fixture_cpu():
+    """The nn.Module (state_dict-compatible with the reference) and the three BatchNorm modes
+    of the leaf evaluator against outputs recorded from the reference; fp32, tolerance 1e-5."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from _stubs import det_fill_state_dict
+    from alphazero_quoridor_amd.policy_value_net import LeafEvaluator, PolicyValueNet
+
+    TOL = 1e-5
+    d = np.load(os.path.join(ROOT, "tests", "golden", "net_fixture.npz"))
+    pvn = PolicyValueNet(use_gpu=False)
+    sd = pvn.policy_value_net.state_dict()
+    assert len(sd) == 84 and sum(v.numel() for k, v in sd.items() if "num_batches" not in k and "running" not in k) == 453041
+    pvn.policy_value_net.load_state_dict(det_fill_state_dict(sd, 2024))
+    x = torch.from_numpy(np.unpackbits(d["states"], axis=1)[:, :2106].reshape(64, 26, 9, 9).astype(np.float32))
+    pvn.policy_value_net.eval()
+    with torch.no_grad():
+        logp, v = pvn.policy_value_net(x)
+    assert np.abs(logp.numpy() - d["eval_logp"]).max() < TOL and np.abs(v.numpy() - d["eval_v"]).max() < TOL
+    pvn.policy_value_net.train()
+    p, v = LeafEvaluator(pvn.policy_value_net, "eval")(x)
+    assert np.abs(p.numpy() - np.exp(d["eval_logp"])).max() < TOL and np.abs(v.numpy() - d["eval_v"].reshape(-1)).max() < TOL
+    p, v = LeafEvaluator(pvn.policy_value_net, "batch")(x)
+    assert np.abs(p.numpy() - d["train_p"]).max() < TOL and np.abs(v.numpy() - d["train_v"].reshape(-1)).max() < TOL
+    p, v = LeafEvaluator(pvn.policy_value_net, "per_leaf")(x[:16])
+    for i in range(16):
+        acts = d["leaf_acts"][i]
+        k = int((acts != 255).sum())
+        assert np.abs(p[i].numpy()[acts[:k]] - d["leaf_p"][i][:k]).max() < TOL and abs(v[i].item() - d["leaf_v"][i]) < TOL
+    # train_step works on a modern torch (the reference's .data[0] does not) and refreshes the evaluator
+    ev = LeafEvaluator(pvn.policy_value_net, "per_leaf")
+    pvn._evaluator = (("per_leaf", torch.float32, False), ev)
+    before = ev(x[:4])[0].clone()
+    loss, ent = pvn.train_step(x[:32].numpy(), np.full((32, 140), 1 / 140, dtype=np.float32), np.ones(32, dtype=np.float32), 1e-2)
+    assert isinstance(loss, float) and isinstance(ent, float)
+    assert not torch.equal(ev(x[:4])[0], before)

@@ -1,0 +1,239 @@
+"""CPU tier: pins the oracle (oracle/, plain-C restatement) against the golden fixtures that
+tests/golden/gen_golden.py recorded from the REAL reference.  No GPU, no reference needed.
+Also checks the bitboard formulation used by the HIP kernels (tests/hostcheck, a g++ build of
+alphazero_quoridor_amd/csrc/qz_rules.h) against the oracle."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = os.path.join(HERE, "golden")
+
+
+def load(name):
+    return np.load(os.path.join(G, name))
+
+
+# ------------------------------------------------------------------ rules: F1 / F2 / BFS
+def test_get_intersections_all_tiles():
+    d = load("rules_intersections.npz")
+    for w, exp in zip(d["walls"], d["out"]):
+        for t in range(81):
+            got = oracle.get_intersections(w, t)
+            assert [got["NW"], got["NE"], got["SE"], got["SW"]] == exp[t].tolist(), (t, w.tolist())
+
+
+def test_valid_pawn_actions_every_pair():
+    d = load("rules_pawn.npz")
+    L = oracle.lib()
+    out = (C.c_int * 12)()
+    n_cases = 0
+    for w, exp in zip(d["walls"], d["out"]):
+        a = (C.c_int8 * 64)(*[int(x) for x in w])
+        for loc in range(81):
+            for opp in range(81):
+                if loc == opp:
+                    continue
+                for player in (1, 2):
+                    n = L.qzo_valid_pawn_actions(a, loc, opp, player, out)
+                    e = exp[loc, opp, player - 1]
+                    k = int((e >= 0).sum())
+                    assert n == k and list(out[:n]) == e[:k].tolist(), (loc, opp, player)
+                    n_cases += 1
+    assert n_cases == 32 * 81 * 80 * 2
+
+
+def test_bfs_to_goal():
+    d = load("rules_bfs.npz")
+    for i in range(len(d["walls"])):
+        w, p1, p2 = d["walls"][i], int(d["p1"][i]), int(d["p2"][i])
+        assert oracle.bfs_to_goal(w, 8, p1, p2, 1) == bool(d["reach1"][i])
+        assert oracle.bfs_to_goal(w, 0, p2, p1, 2) == bool(d["reach2"][i])
+
+
+# ------------------------------------------------------------------ positions: F3 / F4 / F5
+@pytest.fixture(scope="module")
+def positions():
+    return load("rules_positions.npz")
+
+
+def test_actions_ordered_lists(positions):
+    d = positions
+    mask, status = oracle.movegen_batch(d["board"])
+    assert len(d["board"]) > 15000
+    for i in range(len(d["board"])):
+        exp = d["actions"][i][: d["n_actions"][i]].tolist()
+        assert status[i] == len(exp)
+        assert oracle.mask_to_actions(mask[i]) == exp, i
+    # a few through the scalar API too (ordered list straight from qzo_actions)
+    for i in range(0, len(d["board"]), 97):
+        g = oracle.OracleGame.from_packed(d["board"][i])
+        assert g.actions() == d["actions"][i][: d["n_actions"][i]].tolist()
+
+
+def test_opening_position():
+    g = oracle.OracleGame()
+    a = g.actions()
+    assert len(a) == 131 and a[:10] == [0, 2, 3, 12, 76, 13, 77, 14, 78, 15]
+    s = g.state()
+    assert s.reshape(26, 81).sum(axis=1).tolist() == [64, 0, 0, 1, 1] + [0] * 9 + [81] + [0] * 9 + [81, 0]
+
+
+def test_state_planes(positions):
+    d = positions
+    planes = oracle.encode_batch(d["board"])
+    bits = np.packbits(planes.astype(np.uint8).reshape(len(planes), -1), axis=1)
+    assert np.array_equal(bits, d["state_bits"])
+
+
+def test_step_transitions(positions):
+    for d in (positions, load("rules_steps.npz")):
+        ok = d["action"] < 140
+        nb, done, winner = oracle.step_batch(d["board"][ok], d["action"][ok])
+        assert np.array_equal(nb.view(np.uint64), d["next_board"][ok].view(np.uint64))
+        assert np.array_equal(done, d["done"][ok])
+        assert np.array_equal(winner, d["winner"][ok])
+
+
+def test_offboard_winning_jumps(positions):
+    """NN from row 7 over a pawn on row 8 / SS from row 1 leave the board and win."""
+    d = positions
+    nb = d["next_board"]
+    off = (nb["p1"] > 80) | (nb["p2"] < 0)
+    assert off.sum() >= 18
+    assert (d["done"][off] == 1).all()
+    assert ((d["winner"][off] == 1) == (nb["p1"][off] > 80)).all()
+
+
+# ------------------------------------------------------------------ bitboard formulation (hostcheck)
+@pytest.fixture(scope="module")
+def hostcheck():
+    src = os.path.join(HERE, "hostcheck", "hostcheck.cpp")
+    so = os.path.join(HERE, "hostcheck", "libqz_hostcheck.so")
+    hdr = os.path.join(HERE, "..", "alphazero_quoridor_amd", "csrc", "qz_rules.h")
+    if not os.path.exists(so) or max(os.path.getmtime(src), os.path.getmtime(hdr)) > os.path.getmtime(so):
+        subprocess.check_call(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-o", so, src])
+    return C.CDLL(so)
+
+
+def _soa(boards):
+    w = np.ascontiguousarray(boards).view(np.uint64).reshape(-1, 3)
+    return [np.ascontiguousarray(w[:, k]) for k in range(3)]
+
+
+def test_bitboard_movegen_equals_oracle(hostcheck, positions):
+    import sys
+    sys.path.insert(0, G)
+    from synth import synth_positions
+
+    boards = np.concatenate([positions["board"], synth_positions(6000, seed=77)])
+    hb, vb, meta = _soa(boards)
+    n = len(boards)
+    omask, status = oracle.movegen_batch(boards)
+    assert (status >= 0).all()
+    for mode in (0, 1):  # 0 = path-cut pruning (what the kernel does), 1 = brute force
+        m = np.zeros((n, 5), dtype=np.uint32)
+        floods = C.c_int64(0)
+        hostcheck.hc_movegen(hb.ctypes.data_as(C.c_void_p), vb.ctypes.data_as(C.c_void_p), meta.ctypes.data_as(C.c_void_p),
+                             n, m.ctypes.data_as(C.c_void_p), mode, C.byref(floods))
+        assert np.array_equal(m, omask), "mode %d" % mode
+    # ordered list from the mask through order_index (the expand kernel's slot rule)
+    out = (C.c_int * 140)()
+    for i in range(0, n, 53):
+        k = hostcheck.hc_ordered(omask[i].ctypes.data_as(C.c_void_p), out)
+        assert list(out[:k]) == oracle.mask_to_actions(omask[i])
+
+
+def test_bitboard_corners_pawn_reach(hostcheck):
+    d = load("rules_intersections.npz")
+    for w, exp in zip(d["walls"], d["out"]):
+        if (np.abs(w) == 1).all():
+            pass
+        hb = sum(1 << i for i in range(64) if w[i] == 1)
+        vb = sum(1 << i for i in range(64) if w[i] == -1)
+        for t in range(81):
+            got = [hostcheck.hc_corner(C.c_uint64(hb), C.c_uint64(vb), t, k) for k in range(4)]
+            assert got == exp[t].tolist(), (t,)
+    d = load("rules_pawn.npz")
+    hostcheck.hc_pawn_actions.restype = C.c_uint32
+    for w, exp in zip(d["walls"][:8], d["out"][:8]):
+        hb = sum(1 << i for i in range(64) if w[i] == 1)
+        vb = sum(1 << i for i in range(64) if w[i] == -1)
+        for loc in range(81):
+            for opp in range(81):
+                if loc == opp:
+                    continue
+                for player in (1, 2):
+                    e = exp[loc, opp, player - 1]
+                    e = e[e >= 0].tolist()
+                    m = hostcheck.hc_pawn_actions(C.c_uint64(hb), C.c_uint64(vb), loc, opp, player)
+                    got = [a for a in range(12) if (m >> a) & 1]
+                    assert got == e and e == sorted(e), (loc, opp, player)
+    d = load("rules_bfs.npz")
+    for i in range(len(d["walls"])):
+        w, p1, p2 = d["walls"][i], int(d["p1"][i]), int(d["p2"][i])
+        hb = sum(1 << k for k in range(64) if w[k] == 1)
+        vb = sum(1 << k for k in range(64) if w[k] == -1)
+        assert hostcheck.hc_reach(C.c_uint64(hb), C.c_uint64(vb), p1, p2, 1) == int(d["reach1"][i])
+        assert hostcheck.hc_reach(C.c_uint64(hb), C.c_uint64(vb), p1, p2, 2) == int(d["reach2"][i])
+
+
+# ------------------------------------------------------------------ MCTS: F6
+def test_mcts_visit_counts_and_q():
+    d = load("mcts_stub.npz")
+    assert len(d["board"]) >= 300
+    for i in range(len(d["board"])):
+        g = oracle.OracleGame.from_packed(d["board"][i])
+        m = oracle.OracleMCTS(str(d["policy"][i]), c_puct=float(d["c_puct"][i]), n_playout=int(d["n_playout"][i]))
+        acts, visits, probs = m.get_move_probs(g, float(d["temp"][i]))
+        k = int(d["k"][i])
+        a2, v2, q2, p2 = m.root_children()
+        assert acts == d["acts"][i][:k].tolist()
+        assert np.array_equal(visits, d["visits"][i][:k])
+        assert np.array_equal(q2, d["q"][i][:k])          # float64 Q, bit for bit
+        assert np.array_equal(p2, d["p"][i][:k])          # float32 priors
+        assert m.root_visits() == d["root_visits"][i]
+        assert m.node_count() == d["nodes"][i] and m.max_depth() == d["depth"][i]
+        assert np.allclose(probs, d["probs"][i][:k], rtol=0, atol=1e-12)  # libm vs numpy exp/log
+
+
+def test_mcts_terminal_sign_bug_reproduced():
+    """mcts.py:125 + quoridor.py:176-181: a one-move win is backed up as -1 for the mover."""
+    g = oracle.OracleGame.from_fields(np.zeros(64), 67, 40, 0, 0, 1)  # P1 one step from row 8
+    m = oracle.OracleMCTS("uniform", c_puct=5, n_playout=60)
+    acts, visits, _ = m.get_move_probs(g, 1.0)
+    _, _, q, _ = m.root_children()
+    i = acts.index(0)
+    assert q[i] == -1.0 and visits[i] == visits.min()
+    m2 = oracle.OracleMCTS("uniform", c_puct=5, n_playout=60, fix_terminal_sign=True)
+    acts2, visits2, _ = m2.get_move_probs(g, 1.0)
+    assert m2.root_children()[2][acts2.index(0)] == 1.0 and visits2[acts2.index(0)] == visits2.max()
+
+
+# ------------------------------------------------------------------ episodes: F7
+def test_episode_traces():
+    d = load("episodes_stub.npz")
+    for e in range(int(d["n"])):
+        key = lambda k: d["e%d_%s" % (e, k)]  # noqa: E731
+        moves, pis, players, z = key("moves"), key("pis"), key("players"), key("z")
+        m = oracle.OracleMCTS(str(key("policy")), c_puct=5, n_playout=int(key("n_playout")))
+        g = oracle.OracleGame()
+        for t in range(len(moves)):
+            assert g.packed().tobytes() == key("boards")[t].tobytes()
+            assert g.get_current_player() == players[t]
+            acts, visits, probs = m.get_move_probs(g, 1.0)
+            pi = np.zeros(140)
+            pi[acts] = probs
+            assert np.allclose(pi, pis[t], rtol=0, atol=1e-12), (e, t)
+            m.update_with_move(int(moves[t]))  # subtree reuse (mcts.py:182)
+            assert m.root_visits() == key("root_n")[t]
+            done = g.step(int(moves[t]))
+            assert done == (t == len(moves) - 1)
+        end, winner = g.has_a_winner()
+        assert end and winner == int(key("winner"))
+        assert np.array_equal(np.where(players == winner, 1.0, -1.0), z)  # quoridor.py:599-602
