@@ -100,6 +100,8 @@ _SIGNATURES = {
     "qz_engine_get_boards": (C.c_int, [_P, C.POINTER(qz_boards), _P]),
     "qz_engine_set_temp": (C.c_int, [_P, C.c_float]),
     "qz_mcts_select": (C.c_int, [_P, _P, _P, _P, _P]),
+    "qz_mcts_descend": (C.c_int, [_P, _P]),
+    "qz_mcts_leaf_inputs": (C.c_int, [_P, _P, _P, _P, _P]),
     "qz_mcts_select_boards": (C.c_int, [_P, C.POINTER(qz_boards), _P, _P, _P]),
     "qz_mcts_expand_backup": (C.c_int, [_P, _P, _P, _P]),
     "qz_mcts_root_pi": (C.c_int, [_P, _P, _P, _P]),

@@ -268,17 +268,28 @@ int qz_engine_set_temp(qz_engine* e, float temp) {
     return 0;
 }
 
-int qz_mcts_select(qz_engine* e, float* leaf_planes, uint32_t* leaf_mask5, uint8_t* leaf_terminal, void* stream) {
+int qz_mcts_descend(qz_engine* e, void* stream) {
+    ENGINE_CHECK(e);
+    HIP_TRY(qzl::select(e->dev, (hipStream_t)stream));
+    return 0;
+}
+
+int qz_mcts_leaf_inputs(qz_engine* e, float* leaf_planes, uint32_t* leaf_mask5, uint8_t* leaf_terminal, void* stream) {
     ENGINE_CHECK(e);
     if (!leaf_planes) return fail(QZ_E_INVALID, "leaf_planes is null");
     hipStream_t s = (hipStream_t)stream;
     const EngineDev& d = e->dev;
-    HIP_TRY(qzl::select(d, s));
     HIP_TRY(qzl::movegen_encode(d.leaf_hb, d.leaf_vb, d.leaf_meta, d.n_boards, d.leaf_mask, leaf_planes, d.leaf_term, s));
     if (leaf_mask5)
         HIP_TRY(hipMemcpyAsync(leaf_mask5, d.leaf_mask, (size_t)d.n_boards * 5 * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
     if (leaf_terminal) HIP_TRY(hipMemcpyAsync(leaf_terminal, d.leaf_term, (size_t)d.n_boards, hipMemcpyDeviceToDevice, s));
     return 0;
+}
+
+int qz_mcts_select(qz_engine* e, float* leaf_planes, uint32_t* leaf_mask5, uint8_t* leaf_terminal, void* stream) {
+    int r = qz_mcts_descend(e, stream);
+    if (r) return r;
+    return qz_mcts_leaf_inputs(e, leaf_planes, leaf_mask5, leaf_terminal, stream);
 }
 
 int qz_mcts_select_boards(qz_engine* e, const qz_boards* leaf_out, uint32_t* leaf_mask5, uint8_t* leaf_terminal, void* stream) {

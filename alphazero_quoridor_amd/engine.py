@@ -129,10 +129,19 @@ class SelfPlayEngine:
         _cabi.check(self.L.qz_engine_set_temp(self.h, float(temp)))
 
     # ------------------------------------------------------------------ one playout step
-    def select(self):
-        """-> leaf planes [B,26,9,9] (also fills leaf_mask / leaf_term)."""
-        _cabi.check(self.L.qz_mcts_select(self.h, self.planes.data_ptr(), self.leaf_mask.data_ptr(),
-                                          self.leaf_term.data_ptr(), self._s()))
+    def select(self, want_mask=False, events=None):
+        """-> leaf planes [B,26,9,9].  want_mask also copies the leaf masks / terminal flags
+        into self.leaf_mask / self.leaf_term.  events=(start, stop): torch events recorded
+        around the fused movegen+encode launch only (bench.py's roofline measurement)."""
+        mp = self.leaf_mask.data_ptr() if want_mask else 0
+        tp = self.leaf_term.data_ptr() if want_mask else 0
+        if events is None:
+            _cabi.check(self.L.qz_mcts_select(self.h, self.planes.data_ptr(), mp, tp, self._s()))
+        else:
+            _cabi.check(self.L.qz_mcts_descend(self.h, self._s()))
+            events[0].record()
+            _cabi.check(self.L.qz_mcts_leaf_inputs(self.h, self.planes.data_ptr(), mp, tp, self._s()))
+            events[1].record()
         return self.planes
 
     def select_boards(self) -> DeviceBoards:
@@ -147,8 +156,8 @@ class SelfPlayEngine:
         assert p.shape == (self.n_boards, 140) and v.numel() == self.n_boards
         _cabi.check(self.L.qz_mcts_expand_backup(self.h, p.data_ptr(), v.data_ptr(), self._s()))
 
-    def playout_step(self, evaluator):
-        p, v = evaluator(self.select())
+    def playout_step(self, evaluator, events=None):
+        p, v = evaluator(self.select(events=events))
         self.expand_backup(p, v)
 
     def capture_steps(self, evaluator, steps_per_graph=1, warmup=3):

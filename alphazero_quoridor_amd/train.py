@@ -27,7 +27,7 @@ from .quoridor import Quoridor
 
 class TrainPipeline(object):
     def __init__(self, init_model=None, n_boards=1024, device=None, seed=0, bn_mode="per_leaf",
-                 nn_dtype=torch.float32, use_graph=True):
+                 nn_dtype=torch.float32, use_graph=False):
         self.game = Quoridor()
         # the reference's hyper-parameters, same names and values (train.py:17-31)
         self.learn_rate = 2e-3
@@ -72,7 +72,7 @@ class TrainPipeline(object):
                                           device=self.policy_value_net.device)
             self._evaluator = self.policy_value_net.evaluator(self.bn_mode, self.nn_dtype)
             if self.use_graph:
-                self._engine.capture_steps(self._evaluator, 1, warmup=0)
+                self._engine.capture_steps(self._evaluator, 1, warmup=2)
         return self._engine
 
     def _extend_buffer(self, tb: TupleBatch):

@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""bench.py -- self-play games/sec on N MI355X GPUs (BASELINE.json's metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
+
+Workload (config.workload): BASELINE.json configs[3] per GPU = 4096 concurrent boards,
+n_playout=400, 9x9, reference defaults (10 walls, c_puct=5, temp=1, Dirichlet 0.3/0.25),
+random-init policy_value_net evaluated in fp32 with the reference's per-leaf BatchNorm
+statistics; weak scaling (4096 boards on every rank), finished tuples all-gathered every ply.
+
+A STEP is one ply of every board: 400 playout steps (select -> movegen+encode -> net ->
+expand/backup on the whole 4096-leaf batch) + finish_move + harvest (+ all-gather).  Nothing
+inside a step is skipped or cached.
+
+games/sec needs finished games, and a 400-playout game takes ~20 min of wall clock, so the
+boards are first DESYNCHRONISED (untimed): they play `--desync-plies` plies with
+`--desync-playouts` playouts per move so that the population is spread over all game phases
+(continuous refill).  value = games that finished inside the K timed steps / their wall
+time; plies/s, playouts/s and the mean length of the games seen are reported next to it
+(plies/s is the robust statistic: game length varies 4-10x).
+
+roofline: the fused move-generation + encoder kernel (k_movegen_encode), timed with HIP
+events around every one of its launches in the timed region on the launch stream;
+algorithmic bytes = 8,468 B/board (24 B board + 20 B mask + 26*81*4 B planes) x 4096 boards.
+cpu_baseline: the CPU oracle (oracle/, scalar C port of the reference's algorithm, one
+playout at a time, batch-1 network on the CPU like the reference) timed on this host.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+BYTES_PER_BOARD = 24 + 20 + 26 * 81 * 4
+
+
+def cpu_baseline(seconds, mean_plies_per_game, n_playout):
+    """Scalar port of the reference on one host core: playouts/s at n_playout=400 from the
+    opening, batch-1 network forward on the CPU per leaf (policy_value_net.py:145-164)."""
+    import oracle
+    from alphazero_quoridor_amd.policy_value_net import PolicyValueNet
+
+    torch.set_num_threads(1)
+    net = PolicyValueNet(use_gpu=False)
+    mod = net.policy_value_net  # train mode, batch of one: the reference's behaviour
+
+    def policy(game, legal):
+        x = torch.from_numpy(game.state().reshape(1, 26, 9, 9).astype(np.float32))
+        with torch.no_grad():
+            logp, v = mod(x)
+        p = np.exp(logp.numpy().reshape(-1))
+        return legal, p[legal], float(v.reshape(-1)[0])
+
+    g = oracle.OracleGame()
+    m = oracle.OracleMCTS(policy, c_puct=5, n_playout=n_playout)
+    for _ in range(3):
+        m.playout(g)
+    n, t0 = 0, time.time()
+    while time.time() - t0 < seconds:
+        for _ in range(10):
+            m.playout(g)
+        n += 10
+    dt = time.time() - t0
+    playouts_s = n / dt
+    games_s = playouts_s / n_playout / max(mean_plies_per_game, 1.0)
+    return {
+        "value": games_s, "unit": "games/s", "cores": 1, "kind": "port",
+        "sample": "%d playouts in %.1fs of the first ply at n_playout=%d from the opening (131 legal moves), oracle C port + "
+                  "batch-1 fp32 torch-CPU forward per leaf; games/s = playouts/s / %d / %.0f plies per game (mean of the GPU run)"
+                  % (n, dt, n_playout, n_playout, mean_plies_per_game),
+        "playouts_per_s": playouts_s,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--boards", type=int, default=4096)
+    ap.add_argument("--playouts", type=int, default=400)
+    ap.add_argument("--bn", default="per_leaf", choices=["per_leaf", "eval", "batch"])
+    ap.add_argument("--nn-dtype", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--channels-last", type=int, default=0)
+    ap.add_argument("--desync-plies", type=int, default=700)
+    ap.add_argument("--desync-playouts", type=int, default=4)
+    ap.add_argument("--seed", type=int, default=2026)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from alphazero_quoridor_amd import dist as qdist
+    from alphazero_quoridor_amd.engine import SelfPlayEngine
+    from alphazero_quoridor_amd.policy_value_net import PolicyValueNet
+
+    rank, local, world = qdist.init_from_env("cuda")
+    assert world == args.gpus or world == 1, "WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU path)"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    torch.backends.cudnn.benchmark = True
+    torch.manual_seed(args.seed)  # identical random-init weights on every rank
+    net = PolicyValueNet(use_gpu=True, device=dev)
+    dt = torch.float32 if args.nn_dtype == "fp32" else torch.bfloat16
+    ev = net.evaluator(args.bn, dt, bool(args.channels_last))
+    eng = SelfPlayEngine(args.boards, n_playout=args.playouts, c_puct=5, temp=1.0, is_selfplay=1,
+                         seed=qdist.shard_seed(args.seed, rank), device=dev)
+    is_dist = world > 1
+
+    def barrier():
+        if is_dist:
+            torch.distributed.barrier()
+        torch.cuda.synchronize(dev)
+
+    lengths = []
+
+    def end_of_ply():
+        eng.finish_move()
+        tb = eng.harvest()
+        n_games = 0
+        if tb is not None:
+            n_games = tb.n_games
+            g = tb.game.cpu().numpy()
+            lengths.extend(np.bincount(g).tolist())
+        if is_dist:  # the path's only exchange: finished tuples -> every rank's replay buffer
+            if tb is not None:
+                buf = qdist.pack_tuples(tb.boards.hbits, tb.boards.vbits, tb.boards.meta, tb.pi, tb.z)
+            else:
+                buf = torch.zeros((0, qdist.TUPLE_BYTES), dtype=torch.uint8, device=dev)
+            qdist.allgather_tuples(buf)
+        return n_games
+
+    # ---- desynchronise the games (untimed)
+    t0 = time.time()
+    for _ in range(args.desync_plies):
+        eng.run_playouts(ev, args.desync_playouts)
+        end_of_ply()
+    desync_s = time.time() - t0
+    desync_games = len(lengths)
+
+    # ---- warmup steps at the full playout count (untimed)
+    for _ in range(args.warmup):
+        eng.run_playouts(ev)
+        end_of_ply()
+
+    # ---- timed region
+    n_launch = args.steps * args.playouts
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_launch)]
+    st0 = eng.stats()
+    barrier()
+    t0 = time.perf_counter()
+    games = 0
+    k = 0
+    for _ in range(args.steps):
+        for _ in range(args.playouts):
+            eng.playout_step(ev, events=evs[k])
+            k += 1
+        games += end_of_ply()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    st1 = eng.stats()
+
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    tot = torch.tensor([games, st1["plies_played"] - st0["plies_played"], st1["playouts"] - st0["playouts"],
+                        st1["leaf_terminal"] - st0["leaf_terminal"]], dtype=torch.float64, device=dev)
+    if is_dist:
+        torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
+        torch.distributed.all_reduce(tot, op=torch.distributed.ReduceOp.SUM)
+    elapsed = float(el.item())
+    games_all, plies_all, playouts_all, term_all = (float(x) for x in tot.tolist())
+
+    kern_ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
+    achieved = args.boards * BYTES_PER_BOARD / (kern_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        mean_len = float(np.mean(lengths)) if lengths else float("nan")
+        out = {
+            "metric": "self-play games/sec (9x9, n_playout=%d)" % args.playouts,
+            "value": games_all / elapsed,
+            "unit": "games/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u64 bitboards + f64 PUCT (rules/tree kernels); %s policy-value net" % args.nn_dtype,
+            "data": "synthetic (random-init policy_value_net, seed %d; self-generated games)" % args.seed,
+            "config": {
+                "workload": "BASELINE configs[3] per GPU: %d concurrent boards/GPU, n_playout=%d, 9x9, 10 walls/player, "
+                            "c_puct=5, temp=1.0, leaf batch=%d, finished tuples all-gathered every ply"
+                            % (args.boards, args.playouts, args.boards),
+                "boards_per_gpu": args.boards, "n_playout": args.playouts, "bn_mode": args.bn,
+                "nn_dtype": args.nn_dtype, "channels_last": bool(args.channels_last),
+                "step": "one ply of every board (n_playout playout steps + finish_move + harvest)",
+                "desync": "%d untimed plies at %d playouts/move (%.0fs, %d games finished)"
+                          % (args.desync_plies, args.desync_playouts, desync_s, desync_games),
+            },
+            "games_in_timed_region": games_all,
+            "plies_per_s": plies_all / elapsed,
+            "playouts_per_s": playouts_all / elapsed,
+            "leaf_evals_per_s": playouts_all / elapsed,
+            "terminal_leaf_frac": term_all / max(playouts_all, 1.0),
+            "mean_plies_per_game": mean_len,
+            "games_per_s_from_plies": (plies_all / elapsed) / mean_len if lengths else None,
+            "roofline": {
+                "kernel": "k_movegen_encode<mask,planes> (fused Quoridor.actions() + state() on the leaf batch)",
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "avg_launch_us": kern_ms * 1e3, "launches": len(evs),
+                "algorithmic_bytes_per_launch": args.boards * BYTES_PER_BOARD,
+            },
+            "engine_stats": {k: st1[k] for k in ("node_overflow", "games_aborted", "arena_bytes")},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, mean_len if lengths else 600.0, args.playouts)
+        print(json.dumps(out))
+    eng.close()
+    if is_dist:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -130,6 +130,12 @@ int qz_engine_set_temp(qz_engine* e, float temp);
  *   leaf_terminal[n]         <- 1 if the leaf is a finished game (may be NULL) */
 int qz_mcts_select(qz_engine* e, float* leaf_planes /*[dev]*/, uint32_t* leaf_mask5 /*[dev]*/,
                    uint8_t* leaf_terminal /*[dev]*/, void* stream);
+/* the two halves of qz_mcts_select as separate launches (bench.py brackets the second one
+ * with HIP events): descend = the PUCT walk only; leaf_inputs = actions() + state() of the
+ * leaves found by the last descend (the fused move-generation + encoder kernel). */
+int qz_mcts_descend(qz_engine* e, void* stream);
+int qz_mcts_leaf_inputs(qz_engine* e, float* leaf_planes /*[dev]*/, uint32_t* leaf_mask5 /*[dev]*/,
+                        uint8_t* leaf_terminal /*[dev]*/, void* stream);
 /* same, but hands back the leaf boards instead of the planes (for host-side policy
  * callbacks: the `game` passed to policy_value_function, mcts.py:117) */
 int qz_mcts_select_boards(qz_engine* e, const qz_boards* leaf_out, uint32_t* leaf_mask5 /*[dev]*/,
