@@ -152,8 +152,11 @@ int qz_engine_create(const qz_config* cfg, qz_engine** out) {
     if (!e) return fail(QZ_E_OOM, "host allocation failed");
     e->cfg = *cfg;
     qz_config& c = e->cfg;
-    if (c.node_cap <= 0) c.node_cap = 2 * c.n_playout + 256;
-    if (c.edge_cap <= 0) c.edge_cap = 131 * c.n_playout + 40 * c.node_cap;
+    // nodes are 16 B, edges 21 B.  Early game: <= n_playout new nodes x <= 131 edges per ply.
+    // Late game (no walls left, 2-5 legal moves) trees get narrow and deep and most of the
+    // tree survives a re-root, so the node pool is sized generously and separately.
+    if (c.node_cap <= 0) c.node_cap = 16 * c.n_playout + 256;
+    if (c.edge_cap <= 0) c.edge_cap = 131 * c.n_playout + 40 * (2 * c.n_playout + 256);
     c.edge_cap = (c.edge_cap + 63) & ~63;
     if (c.max_plies <= 0) c.max_plies = 2048;
     if (c.dirichlet_alpha <= 0.f) c.dirichlet_alpha = 0.3f;

@@ -85,7 +85,7 @@ def cpu_baseline(seconds, mean_plies_per_game, n_playout):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--boards", type=int, default=4096)
     ap.add_argument("--playouts", type=int, default=400)
