@@ -77,7 +77,7 @@ class qz_stats(C.Structure):
 
 def build(force: bool = False) -> str:
     """Compile libqzero_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("qz_kernels.hip", "qz_abi.hip", "qz_rules.h", "qz_device.h")] + [HEADER]
+    srcs = [os.path.join(CSRC, f) for f in ("qz_kernels.hip", "qz_abi.hip", "qz_nn.hip", "qz_rules.h", "qz_movegen_pool.h", "qz_device.h")] + [HEADER]
     stale = force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if stale:
         subprocess.check_call(["make", "-C", CSRC, "-s"])
@@ -111,7 +111,9 @@ _SIGNATURES = {
     "qz_harvest_counts": (C.c_int, [_P, C.POINTER(C.c_int64 * 2), _P]),
     "qz_harvest": (C.c_int, [_P, C.POINTER(qz_boards), _P, _P, _P, C.c_int64, _P]),
     "qz_engine_stats": (C.c_int, [_P, C.POINTER(qz_stats), _P]),
+    "qz_nn_instnorm_act": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_float, _P]),
     "qz_selftest_sqrt": (C.c_int, [_P, C.c_int, _P]),
+    "qz_debug_set_movegen_variant": (C.c_int, [C.c_int]),
 }
 
 _lib = None

@@ -26,6 +26,8 @@ hipError_t finish_move(const EngineDev&, const uint8_t*, float*, uint8_t*, hipSt
 hipError_t reset(const EngineDev&, int, hipStream_t);
 hipError_t harvest(const EngineDev&, uint64_t*, uint64_t*, uint64_t*, float*, float*, int32_t*, long long, hipStream_t);
 hipError_t sqrt_table(double*, int, hipStream_t);
+void set_movegen_variant(int);
+hipError_t instnorm_act(const float*, const float*, const float*, const float*, float*, long long, int, int, float, hipStream_t);
 }  // namespace qzl
 
 static thread_local char g_err[512] = "";
@@ -156,9 +158,9 @@ int qz_engine_create(const qz_config* cfg, qz_engine** out) {
     // Late game (no walls left, 2-5 legal moves) trees get narrow and deep and most of the
     // tree survives a re-root, so the node pool is sized generously and separately.
     if (c.node_cap <= 0) c.node_cap = 16 * c.n_playout + 256;
-    if (c.edge_cap <= 0) c.edge_cap = 131 * c.n_playout + 40 * (2 * c.n_playout + 256);
+    if (c.edge_cap <= 0) c.edge_cap = 131 * c.n_playout + 80 * (2 * c.n_playout + 256);
     c.edge_cap = (c.edge_cap + 63) & ~63;
-    if (c.max_plies <= 0) c.max_plies = 2048;
+    if (c.max_plies <= 0) c.max_plies = 4096;  // reference-faithful random-net games run to thousands of plies
     if (c.dirichlet_alpha <= 0.f) c.dirichlet_alpha = 0.3f;
     EngineDev& d = e->dev;
     memset(&d, 0, sizeof(d));
@@ -387,6 +389,25 @@ int qz_engine_stats(qz_engine* e, qz_stats* out, void* stream) {
     out->pending_games = (int64_t)h[QZ_C_PENDING_GAMES];
     out->pending_plies = (int64_t)h[QZ_C_PENDING_PLIES];
     out->arena_bytes = e->bytes;
+    return 0;
+}
+
+// Leaf-evaluator glue: per-(sample, channel) normalisation + affine (+ residual) (+ ReLU) of an
+// NCHW float32 tensor with 9x9 planes, in one pass (see qz_nn.hip).
+int qz_nn_instnorm_act(const float* x, const float* gamma, const float* beta, const float* residual, float* out,
+                       int64_t n_planes, int channels, int relu, float eps, void* stream) {
+    int r;
+    if ((r = device_check())) return r;
+    if (n_planes < 0 || channels <= 0) return fail(QZ_E_INVALID, "bad n_planes/channels");
+    if (n_planes > 0 && (!x || !gamma || !beta || !out)) return fail(QZ_E_INVALID, "null tensor");
+    HIP_TRY(qzl::instnorm_act(x, gamma, beta, residual, out, (long long)n_planes, channels, relu, eps, (hipStream_t)stream));
+    return 0;
+}
+
+// A/B hook: 0 = pooled move-generation kernel (default), 1 = wave-per-board kernel,
+// 8/16/32 = pooled kernel with that many boards per workgroup
+int qz_debug_set_movegen_variant(int variant) {
+    qzl::set_movegen_variant(variant);
     return 0;
 }
 

@@ -13,6 +13,7 @@
 #include <stdint.h>
 
 #include "qz_rules.h"
+#include "qz_movegen_pool.h"
 #include "qz_device.h"
 
 using namespace qz;
@@ -166,6 +167,105 @@ __global__ __launch_bounds__(TPB) void k_movegen_encode(const uint64_t* __restri
         store_mask(mask5, b, lane, pawn, lh, lv);
     }
     if (DO_PLANES) wave_encode(bd, planes, b, lane, term);
+}
+
+// ---------------------------------------------------------------------------- pooled kernel
+// k_movegen_encode_pool: one 256-thread workgroup per TILE of NB boards; every phase maps
+// lanes to the unit it has many of (see qz_movegen_pool.h).  LDS holds the tile context, the
+// ordered base paths, the BFS layers of phase 1 and (reusing that space) the pooled work list.
+template <int NB>
+struct PoolShared {
+    PoolBoard ctx[NB];
+    uint8_t tiles[2 * NB][POOL_PATH_CAP];
+    uint8_t kinds[2 * NB][POOL_PATH_CAP];
+    union {
+        BB layers[(POOL_MAX_LAYERS + 1) * 2 * NB];  // P1: layer i of task l at [i * 2NB + l]
+        uint16_t items[NB * 256];                   // P2/P3: every (slot, orientation, player) at worst
+    } u;
+    uint32_t n_items;
+};
+
+template <int NB, bool DO_MASK, bool DO_PLANES>
+__global__ __launch_bounds__(256) void k_movegen_encode_pool(const uint64_t* __restrict__ hb, const uint64_t* __restrict__ vb,
+                                                             const uint64_t* __restrict__ meta, int n,
+                                                             uint32_t* __restrict__ mask5, float* __restrict__ planes,
+                                                             const uint8_t* __restrict__ terminal) {
+    __shared__ PoolShared<NB> sm;
+    const int tid = (int)threadIdx.x, lane = tid & 63;
+    const int b0 = (int)blockIdx.x * NB;
+    const int nb = (n - b0) < NB ? (n - b0) : NB;
+    if (tid == 0) sm.n_items = 0u;
+    // P0: lane = board
+    if (tid < nb) {
+        Board bd = unpack(hb[b0 + tid], vb[b0 + tid], meta[b0 + tid]);
+        bool term = terminal ? (terminal[b0 + tid] != 0) : false;
+        pool_p0(sm.ctx[tid], bd, term, DO_MASK);
+    }
+    __syncthreads();
+    if (DO_MASK) {
+        // P1: lane = (board, player)
+        if (tid < 2 * nb) pool_p1(sm.ctx[tid >> 1], (tid & 1) + 1, &sm.u.layers[tid], 2 * NB, sm.tiles[tid], sm.kinds[tid], 1);
+        __syncthreads();
+        // P2: lane = (board, slot); 64 consecutive lanes share a board
+        for (int base = 0; base < nb * 64; base += 256) {
+            int task = base + tid;
+            int bd = task >> 6, ix = task & 63;
+            uint32_t m = (task < nb * 64) ? pool_p2(sm.ctx[bd], ix) : 0u;
+#pragma unroll
+            for (int bit = 0; bit < 4; bit++) {
+                bool need = (m >> bit) & 1u;
+                uint64_t bal = __ballot(need);
+                if (bal != 0ull) {  // wave-uniform
+                    uint32_t pos = 0u;
+                    if (lane == 0) pos = atomicAdd(&sm.n_items, (uint32_t)__popcll(bal));
+                    pos = rfl(pos);
+                    if (need) sm.u.items[pos + (uint32_t)rank_below(bal)] = (uint16_t)pool_item(bd, ix, bit < 2, (bit & 1) + 1);
+                }
+            }
+        }
+        __syncthreads();
+        // P3: lane = work item
+        const uint32_t ni = sm.n_items;
+        for (uint32_t it = (uint32_t)tid; it < ni; it += 256u) {
+            uint32_t item = sm.u.items[it];
+            int bd = (int)(item >> 8), ix = (int)(item & 63u), t = 2 * bd + ((item & 0x80u) ? 1 : 0);
+            bool ok = pool_p3(sm.ctx[bd], item, sm.tiles[t], sm.kinds[t], 1);
+            if (!ok) atomicOr(&sm.ctx[bd].blocked[((item & 0x40u) ? 0 : 2) + (ix >> 5)], 1u << (ix & 31));
+        }
+        __syncthreads();
+        // P4: legal sets -> 140-bit masks
+        if (tid < nb) {
+            uint32_t m5[5];
+            pool_p4(sm.ctx[tid], m5);
+#pragma unroll
+            for (int w = 0; w < 5; w++) mask5[(size_t)(b0 + tid) * 5 + w] = m5[w];
+        }
+    }
+    if (DO_PLANES) {
+        // P5: lane = 16 bytes of output.  b0 is a multiple of NB (even), so the tile's planes
+        // start 16-byte aligned; boards are 2,106 floats, so a chunk may straddle two boards.
+        float* out = planes + (size_t)b0 * QZ_PLANES_N;
+        const int nf = nb * QZ_PLANES_N, nq = nf >> 2;
+        for (int q = tid; q < nq; q += 256) {
+            int f = q << 2;
+            int bl = f / QZ_PLANES_N, idx = f - bl * QZ_PLANES_N;
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                int i2 = idx + j, b2 = bl;
+                if (i2 >= QZ_PLANES_N) {
+                    i2 -= QZ_PLANES_N;
+                    b2 += 1;
+                }
+                v[j] = pool_plane_value(sm.ctx[b2], i2);
+            }
+            reinterpret_cast<float4*>(out)[q] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        if ((nf & 3) && tid == 0) {  // odd number of boards in the last tile: 2 floats left
+            out[nf - 2] = pool_plane_value(sm.ctx[nb - 1], QZ_PLANES_N - 2);
+            out[nf - 1] = pool_plane_value(sm.ctx[nb - 1], QZ_PLANES_N - 1);
+        }
+    }
 }
 
 // Quoridor.step() + has_a_winner(): one thread per board, fully coalesced SoA traffic
@@ -798,15 +898,37 @@ namespace qzl {
 
 static inline dim3 wave_grid(int n) { return dim3((unsigned)((n + WPB - 1) / WPB)); }
 
+int g_movegen_variant = 0;  // 0 = pooled kernel (default), 1 = wave-per-board kernel (A/B only)
+
+template <int NB>
+static void launch_pool(const uint64_t* hb, const uint64_t* vb, const uint64_t* meta, int n, uint32_t* mask5, float* planes,
+                        const uint8_t* terminal, hipStream_t s) {
+    dim3 grid((unsigned)((n + NB - 1) / NB));
+    if (mask5 && planes)
+        hipLaunchKernelGGL((k_movegen_encode_pool<NB, true, true>), grid, dim3(256), 0, s, hb, vb, meta, n, mask5, planes, terminal);
+    else if (mask5)
+        hipLaunchKernelGGL((k_movegen_encode_pool<NB, true, false>), grid, dim3(256), 0, s, hb, vb, meta, n, mask5, planes, terminal);
+    else
+        hipLaunchKernelGGL((k_movegen_encode_pool<NB, false, true>), grid, dim3(256), 0, s, hb, vb, meta, n, mask5, planes, terminal);
+}
+
 hipError_t movegen_encode(const uint64_t* hb, const uint64_t* vb, const uint64_t* meta, int n, uint32_t* mask5,
                           float* planes, const uint8_t* terminal, hipStream_t s) {
     if (n <= 0) return hipSuccess;
-    if (mask5 && planes)
-        hipLaunchKernelGGL((k_movegen_encode<true, true>), wave_grid(n), dim3(TPB), 0, s, hb, vb, meta, n, mask5, planes, terminal);
-    else if (mask5)
-        hipLaunchKernelGGL((k_movegen_encode<true, false>), wave_grid(n), dim3(TPB), 0, s, hb, vb, meta, n, mask5, planes, terminal);
-    else
-        hipLaunchKernelGGL((k_movegen_encode<false, true>), wave_grid(n), dim3(TPB), 0, s, hb, vb, meta, n, mask5, planes, terminal);
+    if (g_movegen_variant == 1) {
+        if (mask5 && planes)
+            hipLaunchKernelGGL((k_movegen_encode<true, true>), wave_grid(n), dim3(TPB), 0, s, hb, vb, meta, n, mask5, planes, terminal);
+        else if (mask5)
+            hipLaunchKernelGGL((k_movegen_encode<true, false>), wave_grid(n), dim3(TPB), 0, s, hb, vb, meta, n, mask5, planes, terminal);
+        else
+            hipLaunchKernelGGL((k_movegen_encode<false, true>), wave_grid(n), dim3(TPB), 0, s, hb, vb, meta, n, mask5, planes, terminal);
+        return hipGetLastError();
+    }
+    // tile size: enough workgroups to cover the 256 CUs a few times over, else smaller tiles
+    int nbt = g_movegen_variant >= 8 ? g_movegen_variant : (n >= 16384 ? 32 : (n >= 4096 ? 16 : 8));
+    if (nbt >= 32) launch_pool<32>(hb, vb, meta, n, mask5, planes, terminal, s);
+    else if (nbt >= 16) launch_pool<16>(hb, vb, meta, n, mask5, planes, terminal, s);
+    else launch_pool<8>(hb, vb, meta, n, mask5, planes, terminal, s);
     return hipGetLastError();
 }
 hipError_t step(uint64_t* hb, uint64_t* vb, uint64_t* meta, const uint8_t* action, int n, uint8_t* done, uint8_t* winner,
@@ -849,6 +971,7 @@ hipError_t harvest(const EngineDev& E, uint64_t* t_hb, uint64_t* t_vb, uint64_t*
     hipLaunchKernelGGL(k_harvest_copy, wave_grid(E.n_boards), dim3(TPB), 0, s, E, t_hb, t_vb, t_meta, t_pi, t_z, t_game, cap);
     return hipGetLastError();
 }
+void set_movegen_variant(int v) { g_movegen_variant = v; }
 hipError_t sqrt_table(double* out, int n, hipStream_t s) {
     hipLaunchKernelGGL(k_sqrt_table, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out, n);
     return hipGetLastError();

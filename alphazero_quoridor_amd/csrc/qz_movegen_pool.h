@@ -1,0 +1,161 @@
+// qz_movegen_pool.h -- the pooled formulation of Quoridor.actions() + state() for a TILE of
+// boards (one 256-thread workgroup = NB boards).  Instead of giving every board a whole
+// wavefront for every phase, each phase maps lanes to whatever it has many of:
+//
+//   P0  lane = board              context: blocked sets, static slot tests, pawn moves,
+//                                 jump plans, encoder bitmap                      (NB lanes)
+//   P1  lane = (board, player)    one concrete path per player, ORDERED           (2*NB lanes)
+//   P2  lane = (board, slot)      which (candidate wall, player) pairs need a
+//                                 reachability re-check -> pooled work list       (64*NB tasks)
+//   P3  lane = work item          flood with the candidate wall, early exit on the
+//                                 goal row OR on the intact tail of the base path  (~20*NB items)
+//   P4  lane = board              legal sets = static & ~blocked -> 140-bit mask
+//   P5  lane = 16 B of output     26x9x9 planes, 16-byte coalesced stores
+//
+// The phase bodies below are plain per-lane functions over a "tile context" living in LDS on
+// the device and in ordinary memory in tests/hostcheck (which runs the very same functions
+// lane by lane on the CPU to check them against the oracle).
+#pragma once
+#include "qz_rules.h"
+
+namespace qz {
+
+constexpr int POOL_MAX_LAYERS = 40;   // BFS layers kept per (board, player); longer paths fall back
+constexpr int POOL_PATH_CAP = 42;     // tiles of an ordered path (<= POOL_MAX_LAYERS + 1)
+
+struct PoolBoard {          // per board, written in P0/P1, read by P2..P5
+    Board b;
+    Blk base;
+    uint64_t sh, sv;
+    uint32_t pawn;
+    uint32_t flags;         // bit0 mover has walls, bit1 terminal (skip), bit2 both players connected
+    JumpPlan plan[2];       // plan[p-1]: jumps around player p's opponent
+    PathEdges pe[2];
+    int len[2];
+    uint32_t blocked[4];    // H lo, H hi, V lo, V hi: slots whose wall would cut somebody off
+    uint32_t enc[13];       // planes 0..4 of state() as a 405-bit string
+    uint32_t hot;           // the (up to) three all-ones planes among 5..25, one per byte
+};
+
+// ---- P0 ---------------------------------------------------------------------------------
+QZ_HD void enc_build(const Board& b, uint32_t* enc, uint32_t& hot) {
+    int pm = b.cur == 1 ? b.p1 : b.p2, po = b.cur == 1 ? b.p2 : b.p1;
+    if (pm < 0) pm += 81;
+    if (po < 0) po += 81;
+    BB pl[5] = {spread8(~(b.hb | b.vb)), spread8(b.vb), spread8(b.hb), dest_bit(pm), dest_bit(po)};
+    for (int i = 0; i < 13; i++) enc[i] = 0u;
+    for (int k = 0; k < 5; k++) {
+        int pos = 81 * k, w = pos >> 5, off = pos & 31;
+        uint32_t a0 = pl[k].w0, a1 = pl[k].w1, a2 = pl[k].w2;  // 81 bits
+        enc[w] |= a0 << off;
+        if (off) {
+            enc[w + 1] |= (a0 >> (32 - off)) | (a1 << off);
+            enc[w + 2] |= (a1 >> (32 - off)) | (a2 << off);
+            if (w + 3 < 13) enc[w + 3] |= a2 >> (32 - off);
+        } else {
+            enc[w + 1] |= a1;
+            enc[w + 2] |= a2;
+        }
+    }
+    int wm = b.cur == 1 ? b.w1 : b.w2, wo = b.cur == 1 ? b.w2 : b.w1;
+    int im = wm - 1, io = wo - 1;  // Python index -1 -> last plane (quoridor.py:79-80)
+    if (im < 0) im += 10;
+    if (io < 0) io += 10;
+    hot = (uint32_t)(5 + im) | ((uint32_t)(15 + io) << 8) | ((uint32_t)(b.cur == 2 ? 25 : 255) << 16);
+}
+
+QZ_HD void pool_p0(PoolBoard& c, const Board& b, bool terminal, bool want_moves) {
+    c.b = b;
+    c.flags = terminal ? 2u : 0u;
+    for (int i = 0; i < 4; i++) c.blocked[i] = 0u;
+    c.len[0] = c.len[1] = 0;
+    enc_build(b, c.enc, c.hot);
+    c.pawn = 0u;
+    c.sh = c.sv = 0ull;
+    c.pe[0].found = c.pe[1].found = false;
+    if (terminal || !want_moves) return;
+    c.base = blk_or(blocked_from(spread8(b.hb), spread8(b.vb)), blocked_borders());
+    c.sh = static_ok_h(b.hb, b.vb);
+    c.sv = static_ok_v(b.hb, b.vb);
+    int loc = b.cur == 1 ? b.p1 : b.p2, opp = b.cur == 1 ? b.p2 : b.p1;
+    c.pawn = pawn_actions(b.hb, b.vb, loc, opp, b.cur);
+    if ((b.cur == 1 ? b.w1 : b.w2) > 0) c.flags |= 1u;  // quoridor.py:149-150
+    c.plan[0] = make_jump_plan(b.hb, b.vb, b.p2);  // player 1's opponent
+    c.plan[1] = make_jump_plan(b.hb, b.vb, b.p1);
+}
+
+// ---- P1 ---------------------------------------------------------------------------------
+QZ_HD void pool_p1(PoolBoard& c, int p, BB* layers, int lstride, uint8_t* tiles, uint8_t* kinds, int tstride) {
+    if ((c.flags & 3u) != 1u) return;  // only live boards whose mover has walls need paths
+    Graph g = make_graph_plan(c.base, c.plan[p - 1], -1, false);
+    OrderedPath op = find_path_ordered(g, side_start(c.b, p), side_goal(p), layers, lstride, POOL_MAX_LAYERS, tiles,
+                                       kinds, tstride);
+    c.pe[p - 1] = op.e;
+    c.len[p - 1] = op.len;
+}
+
+// ---- P2 ---------------------------------------------------------------------------------
+// returns a 4-bit need mask for slot ix: bit0 (H,p1) bit1 (H,p2) bit2 (V,p1) bit3 (V,p2)
+QZ_HD uint32_t pool_p2(const PoolBoard& c, int ix) {
+    if ((c.flags & 3u) != 1u) return 0u;
+    if (!(c.pe[0].found && c.pe[1].found)) return 0u;  // handled in P4: nothing is legal
+    bool stH = (c.sh >> ix) & 1ull, stV = (c.sv >> ix) & 1ull;
+    uint32_t m = 0;
+    bool n1 = near_opp(ix, c.b.p2), n2 = near_opp(ix, c.b.p1);
+    if (stH) {
+        Blk d = candidate_delta_fast(ix, true);
+        if (cuts(d, c.pe[0]) || (c.pe[0].jump && n1)) m |= 1u;
+        if (cuts(d, c.pe[1]) || (c.pe[1].jump && n2)) m |= 2u;
+    }
+    if (stV) {
+        Blk d = candidate_delta_fast(ix, false);
+        if (cuts(d, c.pe[0]) || (c.pe[0].jump && n1)) m |= 4u;
+        if (cuts(d, c.pe[1]) || (c.pe[1].jump && n2)) m |= 8u;
+    }
+    return m;
+}
+QZ_HD uint32_t pool_item(int board, int ix, bool horizontal, int p) {
+    return ((uint32_t)board << 8) | (uint32_t)ix | (horizontal ? 0x40u : 0u) | (p == 2 ? 0x80u : 0u);
+}
+
+// ---- P3 ---------------------------------------------------------------------------------
+// true if player p can still reach its goal with the candidate wall added
+QZ_HD bool pool_p3(const PoolBoard& c, uint32_t item, const uint8_t* tiles, const uint8_t* kinds, int tstride) {
+    int ix = (int)(item & 63u);
+    bool hz = (item & 0x40u) != 0u;
+    int p = (item & 0x80u) ? 2 : 1;
+    Blk d = candidate_delta_fast(ix, hz);
+    BB target = side_goal(p);
+    int len = c.len[p - 1];
+    if (len > 0) target = bb_or(target, safe_suffix(tiles, kinds, tstride, len, d, near_opp(ix, side_opp(c.b, p))));
+    Graph g = make_graph_plan(blk_or(c.base, d), c.plan[p - 1], ix, hz);
+    return flood_to(g, side_start(c.b, p), target);
+}
+
+// ---- P4 ---------------------------------------------------------------------------------
+QZ_HD void pool_p4(const PoolBoard& c, uint32_t mask5[5]) {
+    uint64_t lh = 0, lv = 0;
+    if ((c.flags & 3u) == 1u && c.pe[0].found && c.pe[1].found) {
+        uint64_t bh = (uint64_t)c.blocked[0] | ((uint64_t)c.blocked[1] << 32);
+        uint64_t bv = (uint64_t)c.blocked[2] | ((uint64_t)c.blocked[3] << 32);
+        lh = c.sh & ~bh;
+        lv = c.sv & ~bv;
+    }
+    mask5[0] = c.pawn | (uint32_t)(lh << 12);
+    mask5[1] = (uint32_t)(lh >> 20);
+    mask5[2] = (uint32_t)(lh >> 52) | (uint32_t)(lv << 12);
+    mask5[3] = (uint32_t)(lv >> 20);
+    mask5[4] = (uint32_t)(lv >> 52);
+}
+
+// ---- P5 ---------------------------------------------------------------------------------
+QZ_HD float pool_plane_value(const PoolBoard& c, int idx) {
+    if (c.flags & 2u) return 0.0f;  // terminal leaf: the network input is ignored, keep it defined
+    if (idx < 405) return (float)((c.enc[idx >> 5] >> (idx & 31)) & 1u);
+    uint32_t plane = (uint32_t)idx / 81u;
+    uint32_t h = c.hot;
+    bool on = plane == (h & 0xFFu) || plane == ((h >> 8) & 0xFFu) || plane == ((h >> 16) & 0xFFu);
+    return on ? 1.0f : 0.0f;
+}
+
+}  // namespace qz

@@ -547,6 +547,273 @@ QZ_HD bool candidate_reaches(const MoveCtx& c, int p, int ix, bool horizontal, c
     return flood(g, side_start(c.b, p), side_goal(p));
 }
 
+// ----------------------------------------------------------------------------- v2 building blocks
+// (used by the pooled kernel: lane = board / (board,player) / (board,slot) / work item)
+
+// A corner of a tile as a REFERENCE: 0..63 = intersection index, 64 = constant +1, 65 = constant -1
+// (same case analysis as corner(); quoridor.py:356-418)
+QZ_HD int corner_ref(int t, int which) {
+    int r = t / 9, c = t - 9 * r;
+    switch (which) {
+        case 0:
+            if (c == 0) return 65;
+            if (r == 8) return 64;
+            return 8 * r + c - 1;
+        case 1:
+            if (r == 8) return 64;
+            if (r == 0) return c == 0 ? 0 : c - 1;
+            if (c == 8) return 65;
+            return 8 * r + c;
+        case 2:
+            if (c == 8) return 65;
+            if (r == 0) return 64;
+            return 8 * (r - 1) + c;
+        default:
+            if (r == 0) return 64;
+            if (c == 0) return 65;
+            return 8 * (r - 1) + c - 1;
+    }
+}
+QZ_HD int ref_value(uint64_t hb, uint64_t vb, int ref) {
+    if (ref >= 64) return ref == 64 ? 1 : -1;
+    return (int)((hb >> ref) & 1ull) - (int)((vb >> ref) & 1ull);
+}
+// Everything about the jumps around opponent tile O that does not depend on a candidate wall:
+// the 12 corners the jump rules read (as references + their values on the current walls).
+//   0..3  O.NW O.NE O.SE O.SW | 4,5 A0.NW A0.NE | 6,7 A1.SE A1.SW | 8,9 A2.SE A2.NE | 10,11 A3.SW A3.NW
+// with A0 = O-9, A1 = O+9, A2 = O-1, A3 = O+1 (quoridor.py:301-351)
+struct JumpPlan {
+    int O;
+    int8_t ref[12];
+    int8_t val[12];
+};
+QZ_HD JumpPlan make_jump_plan(uint64_t hb, uint64_t vb, int O) {
+    JumpPlan p;
+    p.O = O;
+    const int tile[12] = {O, O, O, O, O - 9, O - 9, O + 9, O + 9, O - 1, O - 1, O + 1, O + 1};
+    const int which[12] = {0, 1, 2, 3, 0, 1, 2, 3, 2, 1, 3, 0};
+    for (int i = 0; i < 12; i++) {
+        int t = tile[i];
+        bool ok = t >= 0 && t <= 80;
+        int rf = ok ? corner_ref(t, which[i]) : 64;
+        p.ref[i] = (int8_t)rf;
+        p.val[i] = (int8_t)ref_value(hb, vb, rf);
+    }
+    return p;
+}
+// jump_dests() for the current walls plus an optional candidate wall (cix < 0: none).  A
+// candidate only changes corners that refer to its own (empty) slot.
+QZ_HD Jumps plan_jumps(const JumpPlan& p, int cix, bool horizontal) {
+    const int H = 1, V = -1;
+    int cv[12];
+    int cval = horizontal ? 1 : -1;
+    for (int i = 0; i < 12; i++) cv[i] = (cix >= 0 && p.ref[i] == cix) ? cval : p.val[i];
+    const int O = p.O;
+    Jumps j;
+    for (int k = 0; k < 4; k++) {
+        j.a[k] = -1;
+        j.d[k] = bb_zero();
+    }
+    int onw = cv[0], one = cv[1], ose = cv[2], osw = cv[3];
+    if (O - 9 >= 0 && cv[5] != H && cv[4] != H) {  // :301-314  (A0: xnw = cv[4], xne = cv[5])
+        j.a[0] = O - 9;
+        BB d = bb_zero();
+        if (onw != H && one != H) d = bb_or(d, dest_bit(O + 9));
+        if (one != V && cv[5] != V) d = bb_or(d, dest_bit(O + 1));
+        if (onw != V && cv[4] != V) d = bb_or(d, dest_bit(O - 1));
+        j.d[0] = d;
+    }
+    if (O + 9 <= 80 && cv[6] != H && cv[7] != H) {  // :317-327  (A1: xse = cv[6], xsw = cv[7])
+        j.a[1] = O + 9;
+        BB d = bb_zero();
+        if (osw != H && ose != H) d = bb_or(d, dest_bit(O - 9));
+        if (ose != V && cv[6] != V) d = bb_or(d, dest_bit(O + 1));
+        if (osw != V && cv[7] != V) d = bb_or(d, dest_bit(O - 1));
+        j.d[1] = d;
+    }
+    if (O - 1 >= 0 && cv[8] != V && cv[9] != V) {  // :330-339  (A2: xse = cv[8], xne = cv[9])
+        j.a[2] = O - 1;
+        BB d = bb_zero();
+        if (ose != V && one != V) d = bb_or(d, dest_bit(O + 1));
+        if (one != H) d = bb_or(d, dest_bit(O + 9));
+        if (ose != H) d = bb_or(d, dest_bit(O - 9));
+        j.d[2] = d;
+    }
+    if (O + 1 <= 80 && cv[10] != V && cv[11] != V) {  // :342-351  (A3: xsw = cv[10], xnw = cv[11])
+        j.a[3] = O + 1;
+        BB d = bb_zero();
+        if (onw != V && osw != V) d = bb_or(d, dest_bit(O - 1));
+        if (onw != H) d = bb_or(d, dest_bit(O + 9));
+        if (osw != H) d = bb_or(d, dest_bit(O - 9));
+        j.d[3] = d;
+    }
+    return j;
+}
+QZ_HD Graph make_graph_plan(Blk blocked, const JumpPlan& plan, int cix, bool horizontal) {
+    Graph g;
+    g.cn = bb_not(blocked.n);
+    g.cs = bb_not(blocked.s);
+    g.ce = bb_not(blocked.e);
+    g.cw = bb_not(blocked.w);
+    g.notO = bb_not(dest_bit(plan.O));
+    g.j = plan_jumps(plan, cix, horizontal);
+    return g;
+}
+// what a candidate wall adds to the blocked sets, written out bit by bit (== candidate_delta)
+QZ_HD Blk candidate_delta_fast(int ix, bool horizontal) {
+    int r = ix >> 3, c = ix & 7, b = 9 * r + c;
+    Blk k;
+    k.n = k.s = k.e = k.w = bb_zero();
+    if (horizontal) {
+        // N blocked from (r,c) and (r,c+1); on row 0 only from (0,c+1), plus tile 0 for slot 0
+        if (r > 0) k.n = bb_or(bb_bit(b), bb_bit(b + 1));
+        else k.n = bb_or(bb_bit(b + 1), c == 0 ? bb_bit(0) : bb_zero());
+        k.s = bb_or(bb_bit(b + 9), bb_bit(b + 10));
+    } else {
+        // E blocked from (r,c) and (r+1,c); on row 0: tile (0,c+1) for c<=6 instead of (0,c), tile 0 for slot 0
+        if (r > 0) k.e = bb_or(bb_bit(b), bb_bit(b + 9));
+        else k.e = bb_or(bb_bit(b + 9), bb_or(c <= 6 ? bb_bit(b + 1) : bb_zero(), c == 0 ? bb_bit(0) : bb_zero()));
+        k.w = bb_or(bb_bit(b + 1), bb_bit(b + 10));
+    }
+    return k;
+}
+// the flood with two extra early exits:
+//  * `also`: tiles from which the goal is known to stay reachable whatever this candidate
+//    does (the part of the player's base path behind the last edge the candidate removes);
+//  * jump sources are tested only when the reached set touches one of them.
+QZ_HD bool flood_to(const Graph& g, int start, BB goal_or_safe) {
+    BB R = bb_bit(start);
+    if (bb_any(bb_and(R, goal_or_safe))) return true;
+    BB jsrc = bb_zero();
+    for (int k = 0; k < 4; k++)
+        if (g.j.a[k] >= 0) jsrc = bb_or(jsrc, bb_bit(g.j.a[k]));
+    for (int it = 0; it < 96; it++) {
+        BB nx = bb_shl<9>(bb_and(R, g.cn));
+        nx = bb_or(nx, bb_shr<9>(bb_and(R, g.cs)));
+        nx = bb_or(nx, bb_shl<1>(bb_and(R, g.ce)));
+        nx = bb_or(nx, bb_shr<1>(bb_and(R, g.cw)));
+        nx = bb_and(nx, g.notO);
+        if (bb_any(bb_and(R, jsrc))) {
+            for (int k = 0; k < 4; k++)
+                if (g.j.a[k] >= 0 && bb_test(R, g.j.a[k])) nx = bb_or(nx, g.j.d[k]);
+        }
+        if (bb_any(bb_and(nx, goal_or_safe))) return true;
+        BB R2 = bb_or(R, nx);
+        if (bb_eq(R2, R)) return false;
+        R = R2;
+    }
+    return false;
+}
+
+// One concrete start->goal path WITH its order, for the pooled kernel.
+//   layers: caller storage, entry i at layers[i*stride], at least max_layers+1 entries
+//   tiles[0..len]: the path's tiles (tiles[0] = start), kinds[i]: move from tiles[i] to
+//   tiles[i+1]: 0 N, 1 S, 2 E, 3 W, 4 jump.
+// If the goal is further than max_layers the path is reported as found with len = -1 and the
+// caller must treat every candidate as cutting it (exact, just slower).
+struct OrderedPath {
+    PathEdges e;
+    int len;  // number of edges, 0 if !found, -1 if found but longer than the layer store
+};
+QZ_HD OrderedPath find_path_ordered(const Graph& g, int start, BB goal, BB* layers, int stride, int max_layers,
+                                    uint8_t* tiles, uint8_t* kinds, int tstride) {
+    OrderedPath p;
+    p.e.pn = p.e.ps = p.e.pe = p.e.pw = bb_zero();
+    p.e.jump = false;
+    p.e.found = false;
+    p.len = 0;
+    BB R = bb_bit(start);
+    layers[0] = R;
+    int L = 0;
+    BB hit = bb_zero();
+    for (int it = 0; it < 81; it++) {
+        BB nx = expand(g, R);
+        hit = bb_and(nx, goal);
+        BB R2 = bb_or(R, nx);
+        if (bb_any(hit)) {
+            L = it + 1;
+            p.e.found = true;
+            break;
+        }
+        if (bb_eq(R2, R)) return p;
+        R = R2;
+        if (it + 1 <= max_layers) layers[(it + 1) * stride] = R;
+    }
+    if (!p.e.found) return p;
+    if (L > max_layers) {  // layers beyond the store were not kept: conservative answer
+        p.e.pn = p.e.ps = p.e.pe = p.e.pw = bb_not(bb_zero());
+        p.e.jump = true;
+        p.len = -1;
+        return p;
+    }
+    // walk back; fill tiles/kinds from the end
+    int t = bb_lowest(hit);
+    int n = 0;  // edges found so far (stored reversed at the tail, compacted below)
+    int pos = L;
+    tiles[pos * tstride] = (uint8_t)t;
+    for (int i = L; i >= 1; i--) {
+        BB prev = layers[(i - 1) * stride];
+        if (bb_test(prev, t)) continue;
+        int s, kind;
+        if (t >= 9 && bb_test(prev, t - 9) && bb_test(g.cn, t - 9)) {
+            s = t - 9;
+            kind = 0;
+            p.e.pn = bb_or(p.e.pn, bb_bit(s));
+        } else if (t <= 71 && bb_test(prev, t + 9) && bb_test(g.cs, t + 9)) {
+            s = t + 9;
+            kind = 1;
+            p.e.ps = bb_or(p.e.ps, bb_bit(s));
+        } else if (t >= 1 && bb_test(prev, t - 1) && bb_test(g.ce, t - 1)) {
+            s = t - 1;
+            kind = 2;
+            p.e.pe = bb_or(p.e.pe, bb_bit(s));
+        } else if (t <= 79 && bb_test(prev, t + 1) && bb_test(g.cw, t + 1)) {
+            s = t + 1;
+            kind = 3;
+            p.e.pw = bb_or(p.e.pw, bb_bit(s));
+        } else {
+            s = -1;
+            for (int k = 0; k < 4; k++)
+                if (s < 0 && g.j.a[k] >= 0 && bb_test(prev, g.j.a[k]) && bb_test(g.j.d[k], t)) s = g.j.a[k];
+            kind = 4;
+            p.e.jump = true;
+            if (s < 0) {
+                p.e.pn = p.e.ps = p.e.pe = p.e.pw = bb_not(bb_zero());
+                p.len = -1;
+                return p;
+            }
+        }
+        pos--;
+        tiles[pos * tstride] = (uint8_t)s;
+        kinds[pos * tstride] = (uint8_t)kind;
+        n++;
+        t = s;
+    }
+    // the path occupies tiles[pos..L], kinds[pos..L-1]; shift it to index 0
+    for (int i = 0; i <= n; i++) tiles[i * tstride] = tiles[(pos + i) * tstride];
+    for (int i = 0; i < n; i++) kinds[i * tstride] = kinds[(pos + i) * tstride];
+    p.len = n;
+    return p;
+}
+// Tiles of the base path from which the goal stays reachable whatever candidate (ix, horizontal)
+// does: everything behind the LAST edge it may remove.  `delta` = candidate_delta(ix, horizontal).
+QZ_HD BB safe_suffix(const uint8_t* tiles, const uint8_t* kinds, int tstride, int len, const Blk& delta,
+                     bool near_o) {
+    BB safe = bb_zero();
+    for (int i = len - 1; i >= 0; i--) {
+        int s = tiles[i * tstride], kind = kinds[i * tstride];
+        bool cut;
+        if (kind == 0) cut = bb_test(delta.n, s);
+        else if (kind == 1) cut = bb_test(delta.s, s);
+        else if (kind == 2) cut = bb_test(delta.e, s);
+        else if (kind == 3) cut = bb_test(delta.w, s);
+        else cut = near_o;
+        safe = bb_or(safe, bb_bit(tiles[(i + 1) * tstride]));
+        if (cut) return safe;
+    }
+    return bb_not(bb_zero());  // nothing cut (the caller does not flood in that case)
+}
+
 // ----------------------------------------------------------------------------- encoder
 // quoridor.py:58-131: value of element idx (= plane*81 + row*9 + col) of state()
 QZ_HD float plane_value(const Board& b, int idx) {

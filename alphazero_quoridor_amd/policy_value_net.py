@@ -93,8 +93,9 @@ class LeafEvaluator:
     legal moves: the expand kernel gathers it at the legal actions, policy_value_net.py:162).
     """
 
-    def __init__(self, net: nn.Module, bn_mode="per_leaf", dtype=torch.float32, channels_last=False):
+    def __init__(self, net: nn.Module, bn_mode="per_leaf", dtype=torch.float32, channels_last=False, fused_norm=True):
         assert bn_mode in ("per_leaf", "batch", "eval")
+        self.fused_norm = fused_norm  # per_leaf on the GPU: use the one-pass HIP normalisation kernel
         self.net = net
         self.bn_mode = bn_mode
         self.dtype = dtype
@@ -138,6 +139,15 @@ class LeafEvaluator:
     def _cbn(self, x, i, relu=True, residual=None):
         w, bias, gamma, beta = self._layers[i]
         y = F.conv2d(x, w, bias, 1, 1)
+        if self.bn_mode == "per_leaf" and self.fused_norm and y.is_cuda and y.dtype == torch.float32 \
+                and y.is_contiguous() and (residual is None or residual.is_contiguous()):
+            # one HIP pass: per-plane statistics + affine (+ residual) + ReLU (csrc/qz_nn.hip)
+            from . import _cabi
+            _cabi.check(_cabi.load().qz_nn_instnorm_act(
+                y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), residual.data_ptr() if residual is not None else 0,
+                y.data_ptr(), y.shape[0] * y.shape[1], y.shape[1], int(relu), BN_EPS,
+                torch.cuda.current_stream(y.device).cuda_stream))
+            return y
         if self.bn_mode == "per_leaf":
             # BatchNorm2d in training mode on a batch of one == per-sample statistics over
             # the 81 positions (biased variance), then the affine transform

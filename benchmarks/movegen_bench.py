@@ -90,7 +90,10 @@ def main():
     ap.add_argument("--boards", type=int, default=32768)
     ap.add_argument("--launches", type=int, default=60)
     ap.add_argument("--only", default="S-open,S-mid,S-dense")
+    ap.add_argument("--variant", type=int, default=0, help="qz_debug_set_movegen_variant: 0 pooled (default), 1 wave-per-board, 8/16/32 tile size")
     args = ap.parse_args()
+    from alphazero_quoridor_amd import _cabi
+    _cabi.load().qz_debug_set_movegen_variant(args.variant)
     dev = torch.device("cuda:0")
     n = args.boards
     mask = torch.empty((n, 5), dtype=torch.int32, device=dev)
@@ -111,7 +114,7 @@ def main():
         meta = db.meta
         placed = (20 - ((meta >> 16) & 0xFF) - ((meta >> 24) & 0xFF)).float()
         gbs = n * BYTES / us / 1e3
-        print(json.dumps({"set": name, "boards": n, "launches": args.launches, "avg_launch_us": us,
+        print(json.dumps({"set": name, "variant": args.variant, "boards": n, "launches": args.launches, "avg_launch_us": us,
                           "algorithmic_GBps": gbs, "frac_of_8TBps": gbs / 8000.0, "boards_per_s": n / us * 1e6,
                           "mean_legal_actions": float(legal.mean()), "mean_walls_placed": float(placed.mean())}))
 

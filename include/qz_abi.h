@@ -179,10 +179,24 @@ int qz_harvest(qz_engine* e, const qz_boards* t_boards, float* t_pi /*[dev]*/, f
 
 int qz_engine_stats(qz_engine* e, qz_stats* out /*[host]*/, void* stream); /* SYNC */
 
+/* ------------------------------------------------------------- leaf-evaluator glue
+ * The network stays in PyTorch-ROCm; this is the one normalisation the reference's leaf
+ * evaluation needs that stock PyTorch does badly: BatchNorm2d in TRAINING mode on a batch of
+ * ONE (policy_value_net.py:154 -- the module is never put in eval mode), i.e. every
+ * (sample, channel) 9x9 plane uses its own mean / biased variance:
+ *   out = act(gamma[c]*(x - mean_plane)/sqrt(var_plane + eps) + beta[c] [+ residual])
+ * x/out/residual: float32 NCHW [n_planes/channels, channels, 9, 9] contiguous; out may alias x. */
+int qz_nn_instnorm_act(const float* x /*[dev]*/, const float* gamma /*[dev][channels]*/,
+                       const float* beta /*[dev][channels]*/, const float* residual /*[dev] or NULL*/,
+                       float* out /*[dev]*/, int64_t n_planes, int channels, int relu, float eps, void* stream);
+
 /* self-test hook for the GPU tests: out[i] <- device sqrt((double)i), i < n.  The PUCT term
  * uses np.sqrt(parent visits) in float64 (mcts.py:69); the test checks the device result is
  * correctly rounded. */
 int qz_selftest_sqrt(double* out /*[dev]*/, int n, void* stream);
+/* A/B hook for benchmarks: 0 = pooled move-generation kernel (default), 1 = the first
+ * wave-per-board kernel, 8 | 16 | 32 = pooled kernel forced to that many boards per workgroup */
+int qz_debug_set_movegen_variant(int variant);
 
 #ifdef __cplusplus
 }

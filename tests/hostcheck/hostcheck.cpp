@@ -8,6 +8,8 @@
 #include <cstring>
 
 #include "../../alphazero_quoridor_amd/csrc/qz_rules.h"
+#include "../../alphazero_quoridor_amd/csrc/qz_movegen_pool.h"
+#include <vector>
 
 using namespace qz;
 
@@ -115,4 +117,48 @@ int hc_ordered(const uint32_t* mask5, int* out) {
     }
     return n;
 }
+}
+
+// ---- the pooled kernel's phases (qz_movegen_pool.h), executed lane by lane for tiles of nb boards
+static void pool_tile(const Board* boards, int nb, uint32_t* mask5, float* planes, int64_t* floods, int64_t* flood_iters) {
+    std::vector<PoolBoard> ctx(nb);
+    std::vector<uint8_t> tiles((size_t)nb * 2 * POOL_PATH_CAP), kinds((size_t)nb * 2 * POOL_PATH_CAP);
+    BB layers[POOL_MAX_LAYERS + 2];
+    for (int i = 0; i < nb; i++) pool_p0(ctx[i], boards[i], false, true);
+    for (int i = 0; i < nb; i++)
+        for (int p = 1; p <= 2; p++)
+            pool_p1(ctx[i], p, layers, 1, &tiles[((size_t)i * 2 + p - 1) * POOL_PATH_CAP], &kinds[((size_t)i * 2 + p - 1) * POOL_PATH_CAP], 1);
+    std::vector<uint32_t> items;
+    for (int i = 0; i < nb; i++)
+        for (int ix = 0; ix < 64; ix++) {
+            uint32_t m = pool_p2(ctx[i], ix);
+            if (m & 1u) items.push_back(pool_item(i, ix, true, 1));
+            if (m & 2u) items.push_back(pool_item(i, ix, true, 2));
+            if (m & 4u) items.push_back(pool_item(i, ix, false, 1));
+            if (m & 8u) items.push_back(pool_item(i, ix, false, 2));
+        }
+    for (uint32_t it : items) {
+        int bd = (int)(it >> 8), ix = (int)(it & 63u), p = (it & 0x80u) ? 2 : 1;
+        bool hz = (it & 0x40u) != 0u;
+        size_t o = ((size_t)bd * 2 + p - 1) * POOL_PATH_CAP;
+        bool ok = pool_p3(ctx[bd], it, &tiles[o], &kinds[o], 1);
+        if (floods) (*floods)++;
+        if (!ok) ctx[bd].blocked[(hz ? 0 : 2) + (ix >> 5)] |= 1u << (ix & 31);
+    }
+    (void)flood_iters;
+    for (int i = 0; i < nb; i++) pool_p4(ctx[i], mask5 + 5 * (long)i);
+    if (planes)
+        for (int i = 0; i < nb; i++)
+            for (int k = 0; k < 2106; k++) planes[(long)i * 2106 + k] = pool_plane_value(ctx[i], k);
+}
+
+extern "C" void hc_movegen_pool(const uint64_t* hb, const uint64_t* vb, const uint64_t* meta, int n, int nb_tile, uint32_t* mask5,
+                                float* planes, int64_t* floods) {
+    if (floods) *floods = 0;
+    std::vector<Board> bs(nb_tile);
+    for (int b0 = 0; b0 < n; b0 += nb_tile) {
+        int nb = n - b0 < nb_tile ? n - b0 : nb_tile;
+        for (int i = 0; i < nb; i++) bs[i] = unpack(hb[b0 + i], vb[b0 + i], meta[b0 + i]);
+        pool_tile(bs.data(), nb, mask5 + 5 * (long)b0, planes ? planes + (long)b0 * 2106 : nullptr, floods, nullptr);
+    }
 }

@@ -178,3 +178,40 @@ def test_train_pipeline_collects_reference_shaped_tuples(gpu_device):
     assert s.reshape(26, 81).sum(axis=1).tolist() == [64, 0, 0, 1, 1] + [0] * 9 + [81] + [0] * 9 + [81, 0]
     st = tp.engine().stats()
     assert st["games_finished"] >= 1 and st["node_overflow"] == 0
+
+
+def test_fused_per_leaf_normalisation_kernel(gpu_device):
+    """qz_nn_instnorm_act == BatchNorm2d(training) on a batch of one, for every sample
+    (+ residual, + ReLU), incl. tiles that are not a multiple of 64 planes."""
+    import torch.nn.functional as F
+    from alphazero_quoridor_amd import _cabi
+
+    L = _cabi.load()
+    g = torch.Generator(device="cpu").manual_seed(3)
+    for B, C in ((1, 64), (3, 2), (5, 4), (37, 64), (256, 64)):
+        x = torch.randn((B, C, 9, 9), generator=g).to(gpu_device) * 3 + 1
+        res = torch.randn((B, C, 9, 9), generator=g).to(gpu_device)
+        gamma = (torch.rand(C, generator=g) + 0.5).to(gpu_device)
+        beta = torch.randn(C, generator=g).to(gpu_device)
+        for use_res in (False, True):
+            for relu in (0, 1):
+                ref = torch.stack([F.batch_norm(x[i:i + 1], None, None, gamma, beta, True, 0.0, 1e-5)[0] for i in range(B)])
+                if use_res:
+                    ref = ref + res
+                if relu:
+                    ref = F.relu(ref)
+                out = torch.empty_like(x)
+                _cabi.check(L.qz_nn_instnorm_act(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), res.data_ptr() if use_res else 0,
+                                                 out.data_ptr(), B * C, C, relu, 1e-5, torch.cuda.current_stream().cuda_stream))
+                assert (out - ref).abs().max().item() < 2e-5, (B, C, use_res, relu)
+                inplace = x.clone()  # out may alias x
+                _cabi.check(L.qz_nn_instnorm_act(inplace.data_ptr(), gamma.data_ptr(), beta.data_ptr(), res.data_ptr() if use_res else 0,
+                                                 inplace.data_ptr(), B * C, C, relu, 1e-5, torch.cuda.current_stream().cuda_stream))
+                assert torch.equal(inplace, out)
+    # the evaluator with and without the fused kernel agrees
+    pvn = _fixture_net(gpu_device)
+    from alphazero_quoridor_amd.policy_value_net import LeafEvaluator
+    xs = (torch.rand((130, 26, 9, 9), generator=g) > 0.8).float().to(gpu_device)
+    p1, v1 = LeafEvaluator(pvn.policy_value_net, "per_leaf", fused_norm=True)(xs)
+    p2, v2 = LeafEvaluator(pvn.policy_value_net, "per_leaf", fused_norm=False)(xs)
+    assert (p1 - p2).abs().max().item() < 1e-5 and (v1 - v2).abs().max().item() < 1e-5

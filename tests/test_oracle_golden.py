@@ -116,7 +116,8 @@ def hostcheck():
     src = os.path.join(HERE, "hostcheck", "hostcheck.cpp")
     so = os.path.join(HERE, "hostcheck", "libqz_hostcheck.so")
     hdr = os.path.join(HERE, "..", "alphazero_quoridor_amd", "csrc", "qz_rules.h")
-    if not os.path.exists(so) or max(os.path.getmtime(src), os.path.getmtime(hdr)) > os.path.getmtime(so):
+    hdr2 = os.path.join(HERE, "..", "alphazero_quoridor_amd", "csrc", "qz_movegen_pool.h")
+    if not os.path.exists(so) or max(os.path.getmtime(src), os.path.getmtime(hdr), os.path.getmtime(hdr2)) > os.path.getmtime(so):
         subprocess.check_call(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-o", so, src])
     return C.CDLL(so)
 
@@ -142,6 +143,17 @@ def test_bitboard_movegen_equals_oracle(hostcheck, positions):
         hostcheck.hc_movegen(hb.ctypes.data_as(C.c_void_p), vb.ctypes.data_as(C.c_void_p), meta.ctypes.data_as(C.c_void_p),
                              n, m.ctypes.data_as(C.c_void_p), mode, C.byref(floods))
         assert np.array_equal(m, omask), "mode %d" % mode
+    # the pooled kernel's phase functions (qz_movegen_pool.h), tiles of 32 / 16 / 7 boards
+    ref_planes = oracle.encode_batch(boards).reshape(n, 2106)
+    for tile in (32, 16, 7):
+        m = np.zeros((n, 5), dtype=np.uint32)
+        pl = np.zeros((n, 2106), dtype=np.float32)
+        floods = C.c_int64(0)
+        hostcheck.hc_movegen_pool(hb.ctypes.data_as(C.c_void_p), vb.ctypes.data_as(C.c_void_p), meta.ctypes.data_as(C.c_void_p),
+                                  n, tile, m.ctypes.data_as(C.c_void_p), pl.ctypes.data_as(C.c_void_p), C.byref(floods))
+        assert np.array_equal(m, omask), "pool tile %d" % tile
+        assert np.array_equal(pl, ref_planes), "pool planes tile %d" % tile
+        assert floods.value < 40 * n  # path-cut pruning keeps the floods far below 256 per board
     # ordered list from the mask through order_index (the expand kernel's slot rule)
     out = (C.c_int * 140)()
     for i in range(0, n, 53):
