@@ -15,7 +15,8 @@
 #include "qz_device.h"
 
 namespace qzl {
-hipError_t movegen_encode(const uint64_t*, const uint64_t*, const uint64_t*, int, uint32_t*, float*, const uint8_t*, hipStream_t);
+hipError_t movegen_encode(const uint64_t*, const uint64_t*, const uint64_t*, int, uint32_t*, float*, const uint8_t*, void*, hipStream_t);
+size_t movegen_scratch_bytes(int);
 hipError_t step(uint64_t*, uint64_t*, uint64_t*, const uint8_t*, int, uint8_t*, uint8_t*, hipStream_t);
 hipError_t select(const EngineDev&, hipStream_t);
 hipError_t expand_backup(const EngineDev&, const float*, const float*, hipStream_t);
@@ -45,9 +46,41 @@ static int fail(int code, const char* fmt, ...) {
         if (_e != hipSuccess) return fail(QZ_E_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
     } while (0)
 
+#include <mutex>
+// Scratch for the stateless rules entry points (board records + path tables of the pooled
+// move-generation kernels): one cached allocation per device, grown on demand.  Growing
+// calls hipMalloc, so the first call of a given size must happen outside graph capture.
+static std::mutex g_scratch_mu;
+static void* g_scratch[64] = {nullptr};
+static size_t g_scratch_bytes[64] = {0};
+static int get_scratch(int n, void** out) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return fail(QZ_E_INVALID, "device ordinal %d unsupported", dev);
+    size_t need = qzl::movegen_scratch_bytes(n);
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (g_scratch_bytes[dev] < need) {
+        if (g_scratch[dev]) {
+            HIP_TRY(hipDeviceSynchronize());
+            (void)hipFree(g_scratch[dev]);
+            g_scratch[dev] = nullptr;
+            g_scratch_bytes[dev] = 0;
+        }
+        hipError_t e = hipMalloc(&g_scratch[dev], need);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(QZ_E_OOM, "hipMalloc(%zu) for move-generation scratch failed: %s", need, hipGetErrorString(e));
+        }
+        g_scratch_bytes[dev] = need;
+    }
+    *out = g_scratch[dev];
+    return 0;
+}
+
 struct qz_engine {
     qz_config cfg;
     EngineDev dev;
+    void* scratch = nullptr;
     std::vector<void*> allocs;
     int64_t bytes = 0;
 };
@@ -103,7 +136,9 @@ int qz_movegen(const qz_boards* boards, int n, uint32_t* mask5, void* stream) {
     if ((r = device_check()) || (r = check_boards(boards, n))) return r;
     if (n > 0 && !mask5) return fail(QZ_E_INVALID, "mask5 is null");
     if (n == 0) return 0;
-    HIP_TRY(qzl::movegen_encode(boards->hbits, boards->vbits, boards->meta, n, mask5, nullptr, nullptr, (hipStream_t)stream));
+    void* scratch = nullptr;
+    if ((r = get_scratch(n, &scratch))) return r;
+    HIP_TRY(qzl::movegen_encode(boards->hbits, boards->vbits, boards->meta, n, mask5, nullptr, nullptr, scratch, (hipStream_t)stream));
     return 0;
 }
 int qz_encode(const qz_boards* boards, int n, float* planes, void* stream) {
@@ -111,7 +146,9 @@ int qz_encode(const qz_boards* boards, int n, float* planes, void* stream) {
     if ((r = device_check()) || (r = check_boards(boards, n))) return r;
     if (n > 0 && !planes) return fail(QZ_E_INVALID, "planes is null");
     if (n == 0) return 0;
-    HIP_TRY(qzl::movegen_encode(boards->hbits, boards->vbits, boards->meta, n, nullptr, planes, nullptr, (hipStream_t)stream));
+    void* scratch = nullptr;
+    if ((r = get_scratch(n, &scratch))) return r;
+    HIP_TRY(qzl::movegen_encode(boards->hbits, boards->vbits, boards->meta, n, nullptr, planes, nullptr, scratch, (hipStream_t)stream));
     return 0;
 }
 int qz_movegen_encode(const qz_boards* boards, int n, uint32_t* mask5, float* planes, void* stream) {
@@ -119,7 +156,9 @@ int qz_movegen_encode(const qz_boards* boards, int n, uint32_t* mask5, float* pl
     if ((r = device_check()) || (r = check_boards(boards, n))) return r;
     if (n > 0 && (!mask5 || !planes)) return fail(QZ_E_INVALID, "mask5/planes is null");
     if (n == 0) return 0;
-    HIP_TRY(qzl::movegen_encode(boards->hbits, boards->vbits, boards->meta, n, mask5, planes, nullptr, (hipStream_t)stream));
+    void* scratch = nullptr;
+    if ((r = get_scratch(n, &scratch))) return r;
+    HIP_TRY(qzl::movegen_encode(boards->hbits, boards->vbits, boards->meta, n, mask5, planes, nullptr, scratch, (hipStream_t)stream));
     return 0;
 }
 int qz_step(qz_boards* boards, const uint8_t* action, int n, uint8_t* done, uint8_t* winner, void* stream) {
@@ -209,6 +248,11 @@ int qz_engine_create(const qz_config* cfg, qz_engine** out) {
     ALLOC(traj_pi, B * MP * QZ_N_ACT);
     ALLOC(counters, (size_t)QZ_C_COUNT);
 #undef ALLOC
+    if (!rc) {
+        uint8_t* sc = nullptr;
+        rc = dev_alloc(e, &sc, qzl::movegen_scratch_bytes(c.n_boards));
+        e->scratch = sc;
+    }
     if (rc) {
         qz_engine_destroy(e);
         return rc;
@@ -284,7 +328,7 @@ int qz_mcts_leaf_inputs(qz_engine* e, float* leaf_planes, uint32_t* leaf_mask5, 
     if (!leaf_planes) return fail(QZ_E_INVALID, "leaf_planes is null");
     hipStream_t s = (hipStream_t)stream;
     const EngineDev& d = e->dev;
-    HIP_TRY(qzl::movegen_encode(d.leaf_hb, d.leaf_vb, d.leaf_meta, d.n_boards, d.leaf_mask, leaf_planes, d.leaf_term, s));
+    HIP_TRY(qzl::movegen_encode(d.leaf_hb, d.leaf_vb, d.leaf_meta, d.n_boards, d.leaf_mask, leaf_planes, d.leaf_term, e->scratch, s));
     if (leaf_mask5)
         HIP_TRY(hipMemcpyAsync(leaf_mask5, d.leaf_mask, (size_t)d.n_boards * 5 * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
     if (leaf_terminal) HIP_TRY(hipMemcpyAsync(leaf_terminal, d.leaf_term, (size_t)d.n_boards, hipMemcpyDeviceToDevice, s));
@@ -304,7 +348,7 @@ int qz_mcts_select_boards(qz_engine* e, const qz_boards* leaf_out, uint32_t* lea
     hipStream_t s = (hipStream_t)stream;
     const EngineDev& d = e->dev;
     HIP_TRY(qzl::select(d, s));
-    HIP_TRY(qzl::movegen_encode(d.leaf_hb, d.leaf_vb, d.leaf_meta, d.n_boards, d.leaf_mask, nullptr, d.leaf_term, s));
+    HIP_TRY(qzl::movegen_encode(d.leaf_hb, d.leaf_vb, d.leaf_meta, d.n_boards, d.leaf_mask, nullptr, d.leaf_term, e->scratch, s));
     size_t nb = (size_t)d.n_boards * sizeof(uint64_t);
     HIP_TRY(hipMemcpyAsync(leaf_out->hbits, d.leaf_hb, nb, hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipMemcpyAsync(leaf_out->vbits, d.leaf_vb, nb, hipMemcpyDeviceToDevice, s));

@@ -1,12 +1,13 @@
 // qz_kernels.hip -- CDNA4 (gfx950) kernels of the Quoridor self-play engine.
 //
-// Execution shape: ONE 64-lane wavefront per board, 4 boards per 256-thread workgroup.
-// Board scalars are wave-uniform (they live in SGPRs); the 64 lanes are
-//   - the 64 wall slots of one orientation in move generation (two rounds: H, V),
-//   - the <=131 edges of a tree node in select / expand / pi (three rounds),
-//   - the 2,106 elements of the 26x9x9 state tensor in the encoder (8-byte stores).
-// Cross-lane traffic is ballots, mbcnt ranks, DPP/bpermute reductions and a small LDS
-// work list; no MFMA anywhere (integer / indexing work).
+// Tree kernels (select / expand / backup / finish_move / harvest): ONE 64-lane wavefront per
+// board, 4 boards per 256-thread workgroup; board scalars are wave-uniform (SGPRs), the lanes
+// are the <=131 edges of a tree node (three rounds).  Cross-lane traffic is ballots, mbcnt
+// ranks and shuffle reductions.
+// Rules kernels (actions() + state()): the pooled pipeline k_pool_stage1 + k_pool_masks, where
+// every phase maps lanes to the unit it has many of (qz_movegen_pool.h).  The first
+// wave-per-board kernel (k_movegen_encode) is kept for A/B runs (qz_debug_set_movegen_variant).
+// No MFMA anywhere: integer / indexing work.
 //
 // Reference semantics: see qz_rules.h (rules) and the per-kernel comments (mcts.py).
 #include <hip/hip_runtime.h>
@@ -169,102 +170,124 @@ __global__ __launch_bounds__(TPB) void k_movegen_encode(const uint64_t* __restri
     if (DO_PLANES) wave_encode(bd, planes, b, lane, term);
 }
 
-// ---------------------------------------------------------------------------- pooled kernel
-// k_movegen_encode_pool: one 256-thread workgroup per TILE of NB boards; every phase maps
-// lanes to the unit it has many of (see qz_movegen_pool.h).  LDS holds the tile context, the
-// ordered base paths, the BFS layers of phase 1 and (reusing that space) the pooled work list.
+// ---------------------------------------------------------------------------- pooled kernels
+// Quoridor.actions() + state() as two launches over an HBM scratch area (qz_movegen_pool.h):
+//   k_pool_stage1  two kinds of workgroups in ONE launch so that they overlap on the CUs:
+//                  * path groups (first in the grid): lane = (board, player): board context +
+//                    one ordered base path per player -> scratch.  Long dependent chains,
+//                    one wave each: latency-bound, almost no issue bandwidth.
+//                  * encoder groups: a tile of NBE boards -> 2,106-bit bitmaps in LDS ->
+//                    26x9x9 planes with 16-byte stores.  HBM-bound.
+//   k_pool_masks   one workgroup per tile of NB boards: slot tests -> pooled work list ->
+//                  floods -> 140-bit masks.  Issue-bound.
+template <int NBE>
+struct EncShared {
+    EncCtx ec[NBE];
+    uint32_t bm[(NBE + 1) * POOL_BM_WORDS];  // +1 zero pad board for the straddling chunk
+};
+
+template <int NBE>
+__global__ __launch_bounds__(256) void k_pool_stage1(const uint64_t* __restrict__ hb, const uint64_t* __restrict__ vb,
+                                                     const uint64_t* __restrict__ meta, int n, const uint8_t* __restrict__ terminal,
+                                                     PoolBoard* __restrict__ recs, PathTab* __restrict__ tabs,
+                                                     float* __restrict__ planes, int n_path_groups) {
+    __shared__ EncShared<NBE> sm;
+    const int tid = (int)threadIdx.x;
+    if ((int)blockIdx.x < n_path_groups) {
+        // 256 (board, player) tasks per path group, no LDS: ~1 wave per SIMD chip-wide, which
+        // leaves the other wave slots to the encoder groups that follow in the grid
+        const int task = (int)blockIdx.x * 256 + tid;
+        const int b = task >> 1, p = (task & 1) + 1;
+        if (b >= n) return;
+        Board bd = unpack(hb[b], vb[b], meta[b]);
+        bool term = terminal ? (terminal[b] != 0) : false;
+        pool_k1(bd, term, true, p, recs[b], tabs[(size_t)b * 2 + (p - 1)]);
+        return;
+    }
+    // encoder group: tile of NBE boards; b0 is even, so the tile's planes start 16-byte aligned
+    const int b0 = ((int)blockIdx.x - n_path_groups) * NBE;
+    const int nb = (n - b0) < NBE ? (n - b0) : NBE;
+    if (tid < nb) {
+        Board bd = unpack(hb[b0 + tid], vb[b0 + tid], meta[b0 + tid]);
+        enc_ctx_build(sm.ec[tid], bd, terminal ? (terminal[b0 + tid] != 0) : false);
+    }
+    __syncthreads();
+    for (int w = tid; w < (nb + 1) * POOL_BM_WORDS; w += 256) {  // lane = one 32-bit word of a bitmap
+        int bd = w / POOL_BM_WORDS, k = w - bd * POOL_BM_WORDS;
+        sm.bm[w] = bd < nb ? pool_bitmap_word(sm.ec[bd], k) : 0u;
+    }
+    __syncthreads();
+    float* out = planes + (size_t)b0 * QZ_PLANES_N;
+    const int nf = nb * QZ_PLANES_N, nq = nf >> 2;
+    for (int q = tid; q < nq; q += 256) {  // lane = 16 bytes of output: 4 bits -> 4 floats
+        int f = q << 2;
+        int bl = f / QZ_PLANES_N, idx = f - bl * QZ_PLANES_N;
+        uint32_t nib = pool_bitmap_nibble(&sm.bm[bl * POOL_BM_WORDS], sm.bm[(bl + 1) * POOL_BM_WORDS], idx);
+        reinterpret_cast<float4*>(out)[q] = make_float4((float)(nib & 1u), (float)((nib >> 1) & 1u), (float)((nib >> 2) & 1u),
+                                                        (float)((nib >> 3) & 1u));
+    }
+    if ((nf & 3) && tid == 0) {  // odd number of boards in the last tile: 2 floats left
+        uint32_t nib = pool_bitmap_nibble(&sm.bm[(nb - 1) * POOL_BM_WORDS], 0u, QZ_PLANES_N - 2);
+        out[nf - 2] = (float)(nib & 1u);
+        out[nf - 1] = (float)((nib >> 1) & 1u);
+    }
+}
+
 template <int NB>
-struct PoolShared {
+struct MasksShared {
     PoolBoard ctx[NB];
-    uint8_t tiles[2 * NB][POOL_PATH_CAP];
-    uint8_t kinds[2 * NB][POOL_PATH_CAP];
-    union {
-        BB layers[(POOL_MAX_LAYERS + 1) * 2 * NB];  // P1: layer i of task l at [i * 2NB + l]
-        uint16_t items[NB * 256];                   // P2/P3: every (slot, orientation, player) at worst
-    } u;
+    uint16_t items[NB * 256];  // every (slot, orientation, player) of every board at worst
     uint32_t n_items;
 };
 
-template <int NB, bool DO_MASK, bool DO_PLANES>
-__global__ __launch_bounds__(256) void k_movegen_encode_pool(const uint64_t* __restrict__ hb, const uint64_t* __restrict__ vb,
-                                                             const uint64_t* __restrict__ meta, int n,
-                                                             uint32_t* __restrict__ mask5, float* __restrict__ planes,
-                                                             const uint8_t* __restrict__ terminal) {
-    __shared__ PoolShared<NB> sm;
+template <int NB>
+__global__ __launch_bounds__(256) void k_pool_masks(const PoolBoard* __restrict__ recs, const PathTab* __restrict__ tabs, int n,
+                                                    uint32_t* __restrict__ mask5) {
+    __shared__ MasksShared<NB> sm;
     const int tid = (int)threadIdx.x, lane = tid & 63;
     const int b0 = (int)blockIdx.x * NB;
     const int nb = (n - b0) < NB ? (n - b0) : NB;
     if (tid == 0) sm.n_items = 0u;
-    // P0: lane = board
-    if (tid < nb) {
-        Board bd = unpack(hb[b0 + tid], vb[b0 + tid], meta[b0 + tid]);
-        bool term = terminal ? (terminal[b0 + tid] != 0) : false;
-        pool_p0(sm.ctx[tid], bd, term, DO_MASK);
+    {  // stage the tile's board records in LDS (coalesced dword copy)
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(recs + b0);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(sm.ctx);
+        const int nw = nb * (int)(sizeof(PoolBoard) / 4);
+        for (int i = tid; i < nw; i += 256) dst[i] = src[i];
     }
     __syncthreads();
-    if (DO_MASK) {
-        // P1: lane = (board, player)
-        if (tid < 2 * nb) pool_p1(sm.ctx[tid >> 1], (tid & 1) + 1, &sm.u.layers[tid], 2 * NB, sm.tiles[tid], sm.kinds[tid], 1);
-        __syncthreads();
-        // P2: lane = (board, slot); 64 consecutive lanes share a board
-        for (int base = 0; base < nb * 64; base += 256) {
-            int task = base + tid;
-            int bd = task >> 6, ix = task & 63;
-            uint32_t m = (task < nb * 64) ? pool_p2(sm.ctx[bd], ix) : 0u;
+    // P2: lane = (board, slot); the 64 lanes of a wave share a board
+    for (int base = 0; base < nb * 64; base += 256) {
+        int task = base + tid;
+        int bd = task >> 6, ix = task & 63;
+        uint32_t m = (task < nb * 64) ? pool_p2(sm.ctx[bd], ix) : 0u;
 #pragma unroll
-            for (int bit = 0; bit < 4; bit++) {
-                bool need = (m >> bit) & 1u;
-                uint64_t bal = __ballot(need);
-                if (bal != 0ull) {  // wave-uniform
-                    uint32_t pos = 0u;
-                    if (lane == 0) pos = atomicAdd(&sm.n_items, (uint32_t)__popcll(bal));
-                    pos = rfl(pos);
-                    if (need) sm.u.items[pos + (uint32_t)rank_below(bal)] = (uint16_t)pool_item(bd, ix, bit < 2, (bit & 1) + 1);
-                }
+        for (int bit = 0; bit < 4; bit++) {
+            bool need = (m >> bit) & 1u;
+            uint64_t bal = __ballot(need);
+            if (bal != 0ull) {  // wave-uniform
+                uint32_t pos = 0u;
+                if (lane == 0) pos = atomicAdd(&sm.n_items, (uint32_t)__popcll(bal));
+                pos = rfl(pos);
+                if (need) sm.items[pos + (uint32_t)rank_below(bal)] = (uint16_t)pool_item(bd, ix, bit < 2, (bit & 1) + 1);
             }
-        }
-        __syncthreads();
-        // P3: lane = work item
-        const uint32_t ni = sm.n_items;
-        for (uint32_t it = (uint32_t)tid; it < ni; it += 256u) {
-            uint32_t item = sm.u.items[it];
-            int bd = (int)(item >> 8), ix = (int)(item & 63u), t = 2 * bd + ((item & 0x80u) ? 1 : 0);
-            bool ok = pool_p3(sm.ctx[bd], item, sm.tiles[t], sm.kinds[t], 1);
-            if (!ok) atomicOr(&sm.ctx[bd].blocked[((item & 0x40u) ? 0 : 2) + (ix >> 5)], 1u << (ix & 31));
-        }
-        __syncthreads();
-        // P4: legal sets -> 140-bit masks
-        if (tid < nb) {
-            uint32_t m5[5];
-            pool_p4(sm.ctx[tid], m5);
-#pragma unroll
-            for (int w = 0; w < 5; w++) mask5[(size_t)(b0 + tid) * 5 + w] = m5[w];
         }
     }
-    if (DO_PLANES) {
-        // P5: lane = 16 bytes of output.  b0 is a multiple of NB (even), so the tile's planes
-        // start 16-byte aligned; boards are 2,106 floats, so a chunk may straddle two boards.
-        float* out = planes + (size_t)b0 * QZ_PLANES_N;
-        const int nf = nb * QZ_PLANES_N, nq = nf >> 2;
-        for (int q = tid; q < nq; q += 256) {
-            int f = q << 2;
-            int bl = f / QZ_PLANES_N, idx = f - bl * QZ_PLANES_N;
-            float v[4];
+    __syncthreads();
+    // P3: lane = work item
+    const uint32_t ni = sm.n_items;
+    for (uint32_t it = (uint32_t)tid; it < ni; it += 256u) {
+        uint32_t item = sm.items[it];
+        int bd = (int)(item >> 8), ix = (int)(item & 63u);
+        bool ok = pool_p3(sm.ctx[bd], item, tabs[(size_t)(b0 + bd) * 2 + ((item & 0x80u) ? 1 : 0)]);
+        if (!ok) atomicOr(&sm.ctx[bd].blocked[((item & 0x40u) ? 0 : 2) + (ix >> 5)], 1u << (ix & 31));
+    }
+    __syncthreads();
+    // P4: legal sets -> 140-bit masks
+    if (tid < nb) {
+        uint32_t m5[5];
+        pool_p4(sm.ctx[tid], m5);
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                int i2 = idx + j, b2 = bl;
-                if (i2 >= QZ_PLANES_N) {
-                    i2 -= QZ_PLANES_N;
-                    b2 += 1;
-                }
-                v[j] = pool_plane_value(sm.ctx[b2], i2);
-            }
-            reinterpret_cast<float4*>(out)[q] = make_float4(v[0], v[1], v[2], v[3]);
-        }
-        if ((nf & 3) && tid == 0) {  // odd number of boards in the last tile: 2 floats left
-            out[nf - 2] = pool_plane_value(sm.ctx[nb - 1], QZ_PLANES_N - 2);
-            out[nf - 1] = pool_plane_value(sm.ctx[nb - 1], QZ_PLANES_N - 1);
-        }
+        for (int w = 0; w < 5; w++) mask5[(size_t)(b0 + tid) * 5 + w] = m5[w];
     }
 }
 
@@ -898,22 +921,19 @@ namespace qzl {
 
 static inline dim3 wave_grid(int n) { return dim3((unsigned)((n + WPB - 1) / WPB)); }
 
-int g_movegen_variant = 0;  // 0 = pooled kernel (default), 1 = wave-per-board kernel (A/B only)
+int g_movegen_variant = 0;  // 0 = pooled kernels (default), 1 = wave-per-board kernel (A/B only), 8..32 = forced mask tile
+
+constexpr int NBE = 16;  // boards per encoder group
 
 template <int NB>
-static void launch_pool(const uint64_t* hb, const uint64_t* vb, const uint64_t* meta, int n, uint32_t* mask5, float* planes,
-                        const uint8_t* terminal, hipStream_t s) {
-    dim3 grid((unsigned)((n + NB - 1) / NB));
-    if (mask5 && planes)
-        hipLaunchKernelGGL((k_movegen_encode_pool<NB, true, true>), grid, dim3(256), 0, s, hb, vb, meta, n, mask5, planes, terminal);
-    else if (mask5)
-        hipLaunchKernelGGL((k_movegen_encode_pool<NB, true, false>), grid, dim3(256), 0, s, hb, vb, meta, n, mask5, planes, terminal);
-    else
-        hipLaunchKernelGGL((k_movegen_encode_pool<NB, false, true>), grid, dim3(256), 0, s, hb, vb, meta, n, mask5, planes, terminal);
+static void launch_masks(const PoolBoard* recs, const PathTab* tabs, int n, uint32_t* mask5, hipStream_t s) {
+    hipLaunchKernelGGL((k_pool_masks<NB>), dim3((unsigned)((n + NB - 1) / NB)), dim3(256), 0, s, recs, tabs, n, mask5);
 }
 
+size_t movegen_scratch_bytes(int n) { return (size_t)n * (sizeof(PoolBoard) + 2 * sizeof(PathTab)); }
+
 hipError_t movegen_encode(const uint64_t* hb, const uint64_t* vb, const uint64_t* meta, int n, uint32_t* mask5,
-                          float* planes, const uint8_t* terminal, hipStream_t s) {
+                          float* planes, const uint8_t* terminal, void* scratch, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     if (g_movegen_variant == 1) {
         if (mask5 && planes)
@@ -924,11 +944,20 @@ hipError_t movegen_encode(const uint64_t* hb, const uint64_t* vb, const uint64_t
             hipLaunchKernelGGL((k_movegen_encode<false, true>), wave_grid(n), dim3(TPB), 0, s, hb, vb, meta, n, mask5, planes, terminal);
         return hipGetLastError();
     }
-    // tile size: enough workgroups to cover the 256 CUs a few times over, else smaller tiles
-    int nbt = g_movegen_variant >= 8 ? g_movegen_variant : (n >= 16384 ? 32 : (n >= 4096 ? 16 : 8));
-    if (nbt >= 32) launch_pool<32>(hb, vb, meta, n, mask5, planes, terminal, s);
-    else if (nbt >= 16) launch_pool<16>(hb, vb, meta, n, mask5, planes, terminal, s);
-    else launch_pool<8>(hb, vb, meta, n, mask5, planes, terminal, s);
+    PoolBoard* recs = reinterpret_cast<PoolBoard*>(scratch);
+    PathTab* tabs = reinterpret_cast<PathTab*>(recs + n);
+    const int n_path_groups = mask5 ? (2 * n + 255) / 256 : 0;
+    const int n_enc_groups = planes ? (n + NBE - 1) / NBE : 0;
+    hipLaunchKernelGGL((k_pool_stage1<NBE>), dim3((unsigned)(n_path_groups + n_enc_groups)), dim3(256), 0, s, hb, vb, meta, n,
+                       terminal, recs, tabs, planes, n_path_groups);
+    if (mask5) {
+        int nbt = g_movegen_variant >= 8 ? g_movegen_variant : (n >= 16384 ? 24 : (n >= 8192 ? 16 : 8));
+        if (nbt >= 32) launch_masks<32>(recs, tabs, n, mask5, s);
+        else if (nbt >= 24) launch_masks<24>(recs, tabs, n, mask5, s);
+        else if (nbt >= 16) launch_masks<16>(recs, tabs, n, mask5, s);
+        else if (nbt >= 12) launch_masks<12>(recs, tabs, n, mask5, s);
+        else launch_masks<8>(recs, tabs, n, mask5, s);
+    }
     return hipGetLastError();
 }
 hipError_t step(uint64_t* hb, uint64_t* vb, uint64_t* meta, const uint8_t* action, int n, uint8_t* done, uint8_t* winner,

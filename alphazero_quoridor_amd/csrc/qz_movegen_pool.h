@@ -12,16 +12,18 @@
 //   P4  lane = board              legal sets = static & ~blocked -> 140-bit mask
 //   P5  lane = 16 B of output     26x9x9 planes, 16-byte coalesced stores
 //
-// The phase bodies below are plain per-lane functions over a "tile context" living in LDS on
-// the device and in ordinary memory in tests/hostcheck (which runs the very same functions
-// lane by lane on the CPU to check them against the oracle).
+// On the device P0+P1 are one launch (k_pool_paths, lane = (board, player), every lane busy)
+// that leaves a PoolBoard + two PathTab records per board in an HBM scratch area, and P2..P5
+// are a second launch (k_pool_tiles, one workgroup per tile of boards).  The phase bodies
+// below are plain per-lane functions over those records; tests/hostcheck runs the very same
+// functions lane by lane on the CPU to check them against the oracle.
 #pragma once
 #include "qz_rules.h"
 
 namespace qz {
 
-constexpr int POOL_MAX_LAYERS = 40;   // BFS layers kept per (board, player); longer paths fall back
-constexpr int POOL_PATH_CAP = 42;     // tiles of an ordered path (<= POOL_MAX_LAYERS + 1)
+constexpr int POOL_MAX_LAYERS = 40;   // edges of a base path the tables can hold; longer paths fall back
+constexpr int POOL_PATH_CAP = 30;     // tiles of an ordered path (>= POOL_MAX_LAYERS + 1)
 
 struct PoolBoard {          // per board, written in P0/P1, read by P2..P5
     Board b;
@@ -32,9 +34,19 @@ struct PoolBoard {          // per board, written in P0/P1, read by P2..P5
     JumpPlan plan[2];       // plan[p-1]: jumps around player p's opponent
     PathEdges pe[2];
     int len[2];
+    int lastjump[2];        // reverse position of the jump edge closest to the goal, -1 if none
     uint32_t blocked[4];    // H lo, H hi, V lo, V hi: slots whose wall would cut somebody off
-    uint32_t enc[13];       // planes 0..4 of state() as a 405-bit string
-    uint32_t hot;           // the (up to) three all-ones planes among 5..25, one per byte
+};
+
+// What P3 needs to know about a player's base path to stop a flood early (positions count
+// edges from the GOAL end, see find_path_tables()):
+//   srcpos[t] = k  if the path's k-th edge from the end leaves tile t (255 otherwise; a shortest
+//                  path visits a tile once, so this is well defined)
+//   suffix[k]      = tiles behind that edge: from any of them the goal stays reachable as long
+//                    as no edge closer to the goal is removed
+struct PathTab {
+    uint8_t srcpos[84];
+    BB suffix[POOL_MAX_LAYERS + 1];
 };
 
 // ---- P0 ---------------------------------------------------------------------------------
@@ -69,7 +81,6 @@ QZ_HD void pool_p0(PoolBoard& c, const Board& b, bool terminal, bool want_moves)
     c.flags = terminal ? 2u : 0u;
     for (int i = 0; i < 4; i++) c.blocked[i] = 0u;
     c.len[0] = c.len[1] = 0;
-    enc_build(b, c.enc, c.hot);
     c.pawn = 0u;
     c.sh = c.sv = 0ull;
     c.pe[0].found = c.pe[1].found = false;
@@ -78,20 +89,50 @@ QZ_HD void pool_p0(PoolBoard& c, const Board& b, bool terminal, bool want_moves)
     c.sh = static_ok_h(b.hb, b.vb);
     c.sv = static_ok_v(b.hb, b.vb);
     int loc = b.cur == 1 ? b.p1 : b.p2, opp = b.cur == 1 ? b.p2 : b.p1;
-    c.pawn = pawn_actions(b.hb, b.vb, loc, opp, b.cur);
+    c.pawn = pawn_actions_tab(b.hb, b.vb, loc, opp, b.cur);
     if ((b.cur == 1 ? b.w1 : b.w2) > 0) c.flags |= 1u;  // quoridor.py:149-150
     c.plan[0] = make_jump_plan(b.hb, b.vb, b.p2);  // player 1's opponent
     c.plan[1] = make_jump_plan(b.hb, b.vb, b.p1);
 }
 
-// ---- P1 ---------------------------------------------------------------------------------
-QZ_HD void pool_p1(PoolBoard& c, int p, BB* layers, int lstride, uint8_t* tiles, uint8_t* kinds, int tstride) {
-    if ((c.flags & 3u) != 1u) return;  // only live boards whose mover has walls need paths
-    Graph g = make_graph_plan(c.base, c.plan[p - 1], -1, false);
-    OrderedPath op = find_path_ordered(g, side_start(c.b, p), side_goal(p), layers, lstride, POOL_MAX_LAYERS, tiles,
-                                       kinds, tstride);
-    c.pe[p - 1] = op.e;
-    c.len[p - 1] = op.len;
+// ---- P0 + P1 as ONE lane task (device launch 1: lane = (board, player)) -------------------
+// Both lanes of a board derive the board context redundantly (cheap, and it keeps every lane
+// busy); lane p == 1 stores the shared part of the record, each lane stores its own path.
+QZ_HD void pool_k1(const Board& b, bool terminal, bool want_moves, int p, PoolBoard& out, PathTab& tab) {
+    const bool live = !terminal && want_moves;
+    const bool walls = live && ((b.cur == 1 ? b.w1 : b.w2) > 0);
+    Blk base;
+    base.n = base.s = base.e = base.w = bb_zero();
+    if (live) base = blk_or(blocked_from(spread8(b.hb), spread8(b.vb)), blocked_borders());
+    if (p == 1) {
+        out.b = b;
+        out.flags = (terminal ? 2u : 0u) | (walls ? 1u : 0u);
+        for (int i = 0; i < 4; i++) out.blocked[i] = 0u;
+        out.base = base;
+        out.sh = live ? static_ok_h(b.hb, b.vb) : 0ull;
+        out.sv = live ? static_ok_v(b.hb, b.vb) : 0ull;
+        int loc = b.cur == 1 ? b.p1 : b.p2, opp = b.cur == 1 ? b.p2 : b.p1;
+        out.pawn = live ? pawn_actions_tab(b.hb, b.vb, loc, opp, b.cur) : 0u;
+    }
+    PathEdges none;
+    none.pn = none.ps = none.pe = none.pw = bb_zero();
+    none.jump = false;
+    none.found = false;
+    int len = 0, lj = -1;
+    PathEdges pe = none;
+    if (live) {
+        JumpPlan plan = make_jump_plan(b.hb, b.vb, side_opp(b, p));
+        out.plan[p - 1] = plan;
+        if (walls) {
+            Graph g = make_graph_plan(base, plan, -1, false);
+            OrderedPath op = find_path_tables(g, side_start(b, p), side_goal(p), POOL_MAX_LAYERS + 1, tab, lj);
+            pe = op.e;
+            len = op.len;
+        }
+    }
+    out.pe[p - 1] = pe;
+    out.len[p - 1] = len;
+    out.lastjump[p - 1] = lj;
 }
 
 // ---- P2 ---------------------------------------------------------------------------------
@@ -120,14 +161,27 @@ QZ_HD uint32_t pool_item(int board, int ix, bool horizontal, int p) {
 
 // ---- P3 ---------------------------------------------------------------------------------
 // true if player p can still reach its goal with the candidate wall added
-QZ_HD bool pool_p3(const PoolBoard& c, uint32_t item, const uint8_t* tiles, const uint8_t* kinds, int tstride) {
+QZ_HD bool pool_p3(const PoolBoard& c, uint32_t item, const PathTab& tab) {
     int ix = (int)(item & 63u);
     bool hz = (item & 0x40u) != 0u;
     int p = (item & 0x80u) ? 2 : 1;
     Blk d = candidate_delta_fast(ix, hz);
     BB target = side_goal(p);
-    int len = c.len[p - 1];
-    if (len > 0) target = bb_or(target, safe_suffix(tiles, kinds, tstride, len, d, near_opp(ix, side_opp(c.b, p))));
+    if (c.len[p - 1] > 0) {
+        const PathEdges& e = c.pe[p - 1];
+        // source tiles of the path edges this candidate removes, and the last of them
+        BB hit = bb_or(bb_or(bb_and(d.n, e.pn), bb_and(d.s, e.ps)), bb_or(bb_and(d.e, e.pe), bb_and(d.w, e.pw)));
+        // the removed edge closest to the goal: everything behind it is still connected to the goal
+        int best = (e.jump && near_opp(ix, side_opp(c.b, p)) && c.lastjump[p - 1] >= 0) ? c.lastjump[p - 1] : 255;
+        for (int guard = 0; guard < 8 && bb_any(hit); guard++) {
+            int t = bb_lowest(hit);
+            hit = bb_andn(hit, bb_bit(t));
+            int pos = tab.srcpos[t];
+            best = pos < best ? pos : best;
+        }
+        if (best == 255) return true;  // nothing on the path is touched
+        target = bb_or(target, tab.suffix[best]);
+    }
     Graph g = make_graph_plan(blk_or(c.base, d), c.plan[p - 1], ix, hz);
     return flood_to(g, side_start(c.b, p), target);
 }
@@ -148,9 +202,48 @@ QZ_HD void pool_p4(const PoolBoard& c, uint32_t mask5[5]) {
     mask5[4] = (uint32_t)(lv >> 52);
 }
 
-// ---- P5 ---------------------------------------------------------------------------------
-QZ_HD float pool_plane_value(const PoolBoard& c, int idx) {
-    if (c.flags & 2u) return 0.0f;  // terminal leaf: the network input is ignored, keep it defined
+// ---- P5 prologue: word k (bits 32k..32k+31) of the board's 2,106-bit state() bitmap ----------
+constexpr int POOL_BM_WORDS = 66;
+struct EncCtx {          // what the encoder needs to know about one board
+    uint32_t enc[13];    // planes 0..4 as a 405-bit string
+    uint32_t hot;        // all-ones planes among 5..25, one per byte (255 = none)
+    uint32_t terminal;   // terminal leaf: all-zero planes
+};
+QZ_HD void enc_ctx_build(EncCtx& c, const Board& b, bool terminal) {
+    enc_build(b, c.enc, c.hot);
+    c.terminal = terminal ? 1u : 0u;
+}
+QZ_HD uint32_t pool_bitmap_word(const EncCtx& c, int k) {
+    if (c.terminal) return 0u;  // terminal leaf: all-zero planes
+    uint32_t val = k < 13 ? c.enc[k] : 0u;
+    const int lo_w = 32 * k, hi_w = lo_w + 32;
+    for (int j = 0; j < 3; j++) {
+        int h = (int)((c.hot >> (8 * j)) & 0xFFu);
+        if (h > 25) continue;
+        int lo = 81 * h, hi = lo + 81;
+        lo = lo > lo_w ? lo : lo_w;
+        hi = hi < hi_w ? hi : hi_w;
+        if (hi > lo) {
+            int n = hi - lo;
+            uint32_t m = n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u);
+            val |= m << (lo - lo_w);
+        }
+    }
+    return val;
+}
+// the four output floats starting at element idx (even, <= 2104) of a board, as a 4-bit value;
+// `bm` = this board's bitmap, `next0` = word 0 of the next board's bitmap (for idx == 2104)
+QZ_HD uint32_t pool_bitmap_nibble(const uint32_t* bm, uint32_t next0, int idx) {
+    int w = idx >> 5, sh = idx & 31;
+    uint64_t two = (uint64_t)bm[w] | ((uint64_t)(w + 1 < POOL_BM_WORDS ? bm[w + 1] : 0u) << 32);
+    uint32_t nib = (uint32_t)(two >> sh) & 15u;
+    if (idx == 2104) nib = (nib & 3u) | ((next0 & 3u) << 2);
+    return nib;
+}
+
+// ---- P5 (reference form, one element) ---------------------------------------------------
+QZ_HD float pool_plane_value(const EncCtx& c, int idx) {
+    if (c.terminal) return 0.0f;
     if (idx < 405) return (float)((c.enc[idx >> 5] >> (idx & 31)) & 1u);
     uint32_t plane = (uint32_t)idx / 81u;
     uint32_t h = c.hot;

@@ -23,6 +23,15 @@
 #define QZ_HD inline
 #endif
 
+// "does any lane of my wavefront see x?" -- lets per-lane loops run with ONE wave-uniform exit
+// instead of per-lane divergent breaks (which cost dozens of exec-mask scalar instructions per
+// trip on CDNA).  On the host build a "wave" is the single lane being emulated.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define QZ_WAVE_ANY(x) (__ballot((x)) != 0ull)
+#else
+#define QZ_WAVE_ANY(x) (x)
+#endif
+
 namespace qz {
 
 // ----------------------------------------------------------------------------- boards
@@ -198,6 +207,62 @@ QZ_HD int corner(uint64_t hb, uint64_t vb, int t, int which) {
     }
 }
 
+// corner_ref() for all 81 tiles x 4 corners as a constant table (generated from corner_ref();
+// tests/hostcheck verifies the two agree).  Index 4*t + which.
+#if defined(__HIPCC__)
+#define QZ_TABLE_QUAL __device__ __constant__
+#else
+#define QZ_TABLE_QUAL static const
+#endif
+#if defined(__HIPCC__)
+QZ_TABLE_QUAL uint8_t g_corner_ref_dev[324] = {
+    65, 0, 64, 64, 0, 0, 64, 64, 1, 1, 64, 64, 2, 2, 64, 64, 3, 3, 64, 64, 4, 4, 64, 64,
+    5, 5, 64, 64, 6, 6, 64, 64, 7, 7, 65, 64, 65, 8, 0, 65, 8, 9, 1, 0, 9, 10, 2, 1,
+    10, 11, 3, 2, 11, 12, 4, 3, 12, 13, 5, 4, 13, 14, 6, 5, 14, 15, 7, 6, 15, 65, 65, 7,
+    65, 16, 8, 65, 16, 17, 9, 8, 17, 18, 10, 9, 18, 19, 11, 10, 19, 20, 12, 11, 20, 21, 13, 12,
+    21, 22, 14, 13, 22, 23, 15, 14, 23, 65, 65, 15, 65, 24, 16, 65, 24, 25, 17, 16, 25, 26, 18, 17,
+    26, 27, 19, 18, 27, 28, 20, 19, 28, 29, 21, 20, 29, 30, 22, 21, 30, 31, 23, 22, 31, 65, 65, 23,
+    65, 32, 24, 65, 32, 33, 25, 24, 33, 34, 26, 25, 34, 35, 27, 26, 35, 36, 28, 27, 36, 37, 29, 28,
+    37, 38, 30, 29, 38, 39, 31, 30, 39, 65, 65, 31, 65, 40, 32, 65, 40, 41, 33, 32, 41, 42, 34, 33,
+    42, 43, 35, 34, 43, 44, 36, 35, 44, 45, 37, 36, 45, 46, 38, 37, 46, 47, 39, 38, 47, 65, 65, 39,
+    65, 48, 40, 65, 48, 49, 41, 40, 49, 50, 42, 41, 50, 51, 43, 42, 51, 52, 44, 43, 52, 53, 45, 44,
+    53, 54, 46, 45, 54, 55, 47, 46, 55, 65, 65, 47, 65, 56, 48, 65, 56, 57, 49, 48, 57, 58, 50, 49,
+    58, 59, 51, 50, 59, 60, 52, 51, 60, 61, 53, 52, 61, 62, 54, 53, 62, 63, 55, 54, 63, 65, 65, 55,
+    65, 64, 56, 65, 64, 64, 57, 56, 64, 64, 58, 57, 64, 64, 59, 58, 64, 64, 60, 59, 64, 64, 61, 60,
+    64, 64, 62, 61, 64, 64, 63, 62, 64, 64, 65, 63,
+};
+#endif
+static const uint8_t g_corner_ref_host[324] = {
+    65, 0, 64, 64, 0, 0, 64, 64, 1, 1, 64, 64, 2, 2, 64, 64, 3, 3, 64, 64, 4, 4, 64, 64,
+    5, 5, 64, 64, 6, 6, 64, 64, 7, 7, 65, 64, 65, 8, 0, 65, 8, 9, 1, 0, 9, 10, 2, 1,
+    10, 11, 3, 2, 11, 12, 4, 3, 12, 13, 5, 4, 13, 14, 6, 5, 14, 15, 7, 6, 15, 65, 65, 7,
+    65, 16, 8, 65, 16, 17, 9, 8, 17, 18, 10, 9, 18, 19, 11, 10, 19, 20, 12, 11, 20, 21, 13, 12,
+    21, 22, 14, 13, 22, 23, 15, 14, 23, 65, 65, 15, 65, 24, 16, 65, 24, 25, 17, 16, 25, 26, 18, 17,
+    26, 27, 19, 18, 27, 28, 20, 19, 28, 29, 21, 20, 29, 30, 22, 21, 30, 31, 23, 22, 31, 65, 65, 23,
+    65, 32, 24, 65, 32, 33, 25, 24, 33, 34, 26, 25, 34, 35, 27, 26, 35, 36, 28, 27, 36, 37, 29, 28,
+    37, 38, 30, 29, 38, 39, 31, 30, 39, 65, 65, 31, 65, 40, 32, 65, 40, 41, 33, 32, 41, 42, 34, 33,
+    42, 43, 35, 34, 43, 44, 36, 35, 44, 45, 37, 36, 45, 46, 38, 37, 46, 47, 39, 38, 47, 65, 65, 39,
+    65, 48, 40, 65, 48, 49, 41, 40, 49, 50, 42, 41, 50, 51, 43, 42, 51, 52, 44, 43, 52, 53, 45, 44,
+    53, 54, 46, 45, 54, 55, 47, 46, 55, 65, 65, 47, 65, 56, 48, 65, 56, 57, 49, 48, 57, 58, 50, 49,
+    58, 59, 51, 50, 59, 60, 52, 51, 60, 61, 53, 52, 61, 62, 54, 53, 62, 63, 55, 54, 63, 65, 65, 55,
+    65, 64, 56, 65, 64, 64, 57, 56, 64, 64, 58, 57, 64, 64, 59, 58, 64, 64, 60, 59, 64, 64, 61, 60,
+    64, 64, 62, 61, 64, 64, 63, 62, 64, 64, 65, 63,
+};
+QZ_HD int corner_ref_tab(int t, int which) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return g_corner_ref_dev[4 * t + which];
+#else
+    return g_corner_ref_host[4 * t + which];
+#endif
+}
+// branch-free ref_value
+QZ_HD int ref_value_fast(uint64_t hb, uint64_t vb, int ref) {
+    int sh = ref & 63;
+    int h = (int)((hb >> sh) & 1ull), v = (int)((vb >> sh) & 1ull);
+    return ref < 64 ? h - v : (ref == 64 ? 1 : -1);
+}
+QZ_HD int corner_tab(uint64_t hb, uint64_t vb, int t, int which) { return ref_value_fast(hb, vb, corner_ref_tab(t, which)); }
+
 // ----------------------------------------------------------------------------- move sets
 // blocked-by-wall sets for the four simple moves, for all tiles at once.  Linear (OR of
 // shifts) in the spread wall sets, so a candidate wall contributes an additive delta.
@@ -345,6 +410,45 @@ QZ_HD uint32_t pawn_actions(uint64_t hb, uint64_t vb, int loc, int opp, int play
     return m;
 }
 
+QZ_HD uint32_t pawn_actions_tab(uint64_t hb, uint64_t vb, int loc, int opp, int player) {
+    const int H = 1, V = -1;
+    int xnw = corner_tab(hb, vb, loc, 0), xne = corner_tab(hb, vb, loc, 1), xse = corner_tab(hb, vb, loc, 2),
+        xsw = corner_tab(hb, vb, loc, 3);
+    bool on = loc == opp - 9, os = loc == opp + 9, oe = loc == opp - 1, ow = loc == opp + 1;
+    int row = loc / 9;
+    uint32_t m = 0;
+    bool n = xnw != H && xne != H && !on;
+    bool s = xsw != H && xse != H && !os;
+    bool e = xne != V && xse != V && !oe;
+    bool w = xnw != V && xsw != V && !ow;
+    if (n || (player == 1 && row == 8)) m |= 1u << 0;
+    if (s || (player == 2 && row == 0)) m |= 1u << 1;
+    if (e) m |= 1u << 2;
+    if (w) m |= 1u << 3;
+    if (on && xne != H && xnw != H) {
+        int onw = corner_tab(hb, vb, opp, 0), one = corner_tab(hb, vb, opp, 1);
+        if ((onw != H && one != H) || (row == 7 && player == 1)) m |= 1u << 4;
+        if (one != V && xne != V) m |= 1u << 8;
+        if (onw != V && xnw != V) m |= 1u << 9;
+    } else if (os && xse != H && xsw != H) {
+        int ose = corner_tab(hb, vb, opp, 2), osw = corner_tab(hb, vb, opp, 3);
+        if ((osw != H && ose != H) || (row == 1 && player == 2)) m |= 1u << 5;
+        if (ose != V && xse != V) m |= 1u << 10;
+        if (osw != V && xsw != V) m |= 1u << 11;
+    } else if (oe && xse != V && xne != V) {
+        int one = corner_tab(hb, vb, opp, 1), ose = corner_tab(hb, vb, opp, 2);
+        if (ose != V && one != V) m |= 1u << 6;
+        if (one != H) m |= 1u << 8;
+        if (ose != H) m |= 1u << 10;
+    } else if (ow && xsw != V && xnw != V) {
+        int onw = corner_tab(hb, vb, opp, 0), osw = corner_tab(hb, vb, opp, 3);
+        if (onw != V && osw != V) m |= 1u << 7;
+        if (onw != H) m |= 1u << 9;
+        if (osw != H) m |= 1u << 11;
+    }
+    return m;
+}
+
 // ----------------------------------------------------------------------------- reachability
 struct Graph {
     BB cn, cs, ce, cw;  // tiles from which N/S/E/W passes the wall test
@@ -372,6 +476,25 @@ QZ_HD BB expand(const Graph& g, BB R) {
         if (g.j.a[k] >= 0 && bb_test(R, g.j.a[k])) nx = bb_or(nx, g.j.d[k]);
     }
     return nx;
+}
+// same, with the four jump sources pre-merged into `jsrc` (tested once per layer)
+QZ_HD BB expand_j(const Graph& g, BB jsrc, BB R) {
+    BB nx = bb_shl<9>(bb_and(R, g.cn));
+    nx = bb_or(nx, bb_shr<9>(bb_and(R, g.cs)));
+    nx = bb_or(nx, bb_shl<1>(bb_and(R, g.ce)));
+    nx = bb_or(nx, bb_shr<1>(bb_and(R, g.cw)));
+    nx = bb_and(nx, g.notO);
+    if (bb_any(bb_and(R, jsrc))) {
+        for (int k = 0; k < 4; k++)
+            if (g.j.a[k] >= 0 && bb_test(R, g.j.a[k])) nx = bb_or(nx, g.j.d[k]);
+    }
+    return nx;
+}
+QZ_HD BB jump_sources(const Graph& g) {
+    BB jsrc = bb_zero();
+    for (int k = 0; k < 4; k++)
+        if (g.j.a[k] >= 0) jsrc = bb_or(jsrc, bb_bit(g.j.a[k]));
+    return jsrc;
 }
 // quoridor.py:479-528: can `start` reach any tile of `goal`?  (goal test on generation;
 // FIFO order is unobservable, so a layered flood gives the same answer)
@@ -595,9 +718,9 @@ QZ_HD JumpPlan make_jump_plan(uint64_t hb, uint64_t vb, int O) {
     for (int i = 0; i < 12; i++) {
         int t = tile[i];
         bool ok = t >= 0 && t <= 80;
-        int rf = ok ? corner_ref(t, which[i]) : 64;
+        int rf = ok ? corner_ref_tab(t, which[i]) : 64;
         p.ref[i] = (int8_t)rf;
-        p.val[i] = (int8_t)ref_value(hb, vb, rf);
+        p.val[i] = (int8_t)ref_value_fast(hb, vb, rf);
     }
     return p;
 }
@@ -684,19 +807,9 @@ QZ_HD Blk candidate_delta_fast(int ix, bool horizontal) {
 QZ_HD bool flood_to(const Graph& g, int start, BB goal_or_safe) {
     BB R = bb_bit(start);
     if (bb_any(bb_and(R, goal_or_safe))) return true;
-    BB jsrc = bb_zero();
-    for (int k = 0; k < 4; k++)
-        if (g.j.a[k] >= 0) jsrc = bb_or(jsrc, bb_bit(g.j.a[k]));
+    const BB jsrc = jump_sources(g);
     for (int it = 0; it < 96; it++) {
-        BB nx = bb_shl<9>(bb_and(R, g.cn));
-        nx = bb_or(nx, bb_shr<9>(bb_and(R, g.cs)));
-        nx = bb_or(nx, bb_shl<1>(bb_and(R, g.ce)));
-        nx = bb_or(nx, bb_shr<1>(bb_and(R, g.cw)));
-        nx = bb_and(nx, g.notO);
-        if (bb_any(bb_and(R, jsrc))) {
-            for (int k = 0; k < 4; k++)
-                if (g.j.a[k] >= 0 && bb_test(R, g.j.a[k])) nx = bb_or(nx, g.j.d[k]);
-        }
+        BB nx = expand_j(g, jsrc, R);
         if (bb_any(bb_and(nx, goal_or_safe))) return true;
         BB R2 = bb_or(R, nx);
         if (bb_eq(R2, R)) return false;
@@ -726,8 +839,9 @@ QZ_HD OrderedPath find_path_ordered(const Graph& g, int start, BB goal, BB* laye
     layers[0] = R;
     int L = 0;
     BB hit = bb_zero();
+    const BB jsrc = jump_sources(g);
     for (int it = 0; it < 81; it++) {
-        BB nx = expand(g, R);
+        BB nx = expand_j(g, jsrc, R);
         hit = bb_and(nx, goal);
         BB R2 = bb_or(R, nx);
         if (bb_any(hit)) {
@@ -795,6 +909,107 @@ QZ_HD OrderedPath find_path_ordered(const Graph& g, int start, BB goal, BB* laye
     p.len = n;
     return p;
 }
+// One concrete shortest start->goal path and the two lookup tables P3 needs, with NO layer
+// store: the flood remembers, per tile, which KIND of move discovered it first ("came-from"
+// sets, one per move kind, fixed priority N,S,E,W,jump0..3), so the walk back from the goal
+// is a chain of set-membership tests.  Tables are indexed by REVERSE position (edge 0 = the
+// edge that enters the goal row, edge 1 the one before it, ...):
+//   tab.srcpos[t] = k   if the path's k-th edge from the end leaves tile t (255 otherwise)
+//   tab.suffix[k]       = tiles behind that edge (its destination and everything after it)
+// first_jump_r = reverse position of the jump edge closest to the goal (-1: none).
+// len = number of edges (0 if !found).  tab.suffix must hold max_edges entries; a longer path
+// is reported with len = -1 and all-ones path sets (every candidate then gets re-checked).
+template <typename Tab>
+QZ_HD OrderedPath find_path_tables(const Graph& g, int start, BB goal, int max_edges, Tab& tab, int& first_jump_r) {
+    OrderedPath p;
+    p.e.pn = p.e.ps = p.e.pe = p.e.pw = bb_zero();
+    p.e.jump = false;
+    p.e.found = false;
+    p.len = 0;
+    first_jump_r = -1;
+    BB R = bb_bit(start);
+    BB fN = bb_zero(), fS = bb_zero(), fE = bb_zero(), fW = bb_zero();
+    BB fJ[4] = {bb_zero(), bb_zero(), bb_zero(), bb_zero()};
+    const BB jsrc = jump_sources(g);
+    BB hit = bb_zero();
+    for (int it = 0; it < 81; it++) {
+        BB aN = bb_and(bb_shl<9>(bb_and(R, g.cn)), g.notO);
+        BB aS = bb_and(bb_shr<9>(bb_and(R, g.cs)), g.notO);
+        BB aE = bb_and(bb_shl<1>(bb_and(R, g.ce)), g.notO);
+        BB aW = bb_and(bb_shr<1>(bb_and(R, g.cw)), g.notO);
+        BB nx = bb_or(bb_or(aN, aS), bb_or(aE, aW));
+        BB fresh = bb_andn(nx, R);  // first reached by a simple move in this layer
+        fN = bb_or(fN, bb_and(aN, fresh));
+        fresh = bb_andn(fresh, aN);
+        fS = bb_or(fS, bb_and(aS, fresh));
+        fresh = bb_andn(fresh, aS);
+        fE = bb_or(fE, bb_and(aE, fresh));
+        fresh = bb_andn(fresh, aE);
+        fW = bb_or(fW, bb_and(aW, fresh));
+        if (bb_any(bb_and(R, jsrc))) {
+            BB seen = bb_or(R, nx);
+            for (int k = 0; k < 4; k++) {
+                if (g.j.a[k] >= 0 && bb_test(R, g.j.a[k])) {
+                    BB nj = bb_andn(g.j.d[k], seen);
+                    fJ[k] = bb_or(fJ[k], nj);
+                    seen = bb_or(seen, nj);
+                    nx = bb_or(nx, g.j.d[k]);
+                }
+            }
+        }
+        hit = bb_and(nx, goal);
+        if (bb_any(hit)) {
+            p.e.found = true;
+            break;
+        }
+        BB R2 = bb_or(R, nx);
+        if (bb_eq(R2, R)) return p;
+        R = R2;
+    }
+    if (!p.e.found) return p;
+    for (int i = 0; i < 21; i++) reinterpret_cast<uint32_t*>(tab.srcpos)[i] = 0xFFFFFFFFu;
+    int t = bb_lowest(hit);
+    BB acc = bb_zero();
+    int k = 0;
+    for (int guard = 0; guard < 82 && t != start; guard++) {
+        int s;
+        bool jump = false;
+        if (bb_test(fN, t)) {
+            s = t - 9;
+            p.e.pn = bb_or(p.e.pn, bb_bit(s));
+        } else if (bb_test(fS, t)) {
+            s = t + 9;
+            p.e.ps = bb_or(p.e.ps, bb_bit(s));
+        } else if (bb_test(fE, t)) {
+            s = t - 1;
+            p.e.pe = bb_or(p.e.pe, bb_bit(s));
+        } else if (bb_test(fW, t)) {
+            s = t + 1;
+            p.e.pw = bb_or(p.e.pw, bb_bit(s));
+        } else {
+            s = -1;
+            for (int q = 0; q < 4; q++)
+                if (s < 0 && bb_test(fJ[q], t)) s = g.j.a[q];
+            jump = true;
+            p.e.jump = true;
+        }
+        if (s < 0 || k >= max_edges) {  // cannot happen / path longer than the tables: conservative answer
+            p.e.pn = p.e.ps = p.e.pe = p.e.pw = bb_not(bb_zero());
+            p.e.jump = true;
+            p.len = -1;
+            return p;
+        }
+        acc = bb_or(acc, bb_bit(t));  // t and everything behind it
+        tab.suffix[k] = acc;
+        tab.srcpos[s] = (uint8_t)k;
+        if (jump && first_jump_r < 0) first_jump_r = k;
+        k++;
+        t = s;
+    }
+    p.len = k;
+    return p;
+}
+
 // Tiles of the base path from which the goal stays reachable whatever candidate (ix, horizontal)
 // does: everything behind the LAST edge it may remove.  `delta` = candidate_delta(ix, horizontal).
 QZ_HD BB safe_suffix(const uint8_t* tiles, const uint8_t* kinds, int tstride, int len, const Blk& delta,

@@ -20,9 +20,12 @@ boards are first DESYNCHRONISED (untimed): they play `--desync-plies` plies with
 time; plies/s, playouts/s and the mean length of the games seen are reported next to it
 (plies/s is the robust statistic: game length varies 4-10x).
 
-roofline: the fused move-generation + encoder kernel (k_movegen_encode), timed with HIP
-events around every one of its launches in the timed region on the launch stream;
-algorithmic bytes = 8,468 B/board (24 B board + 20 B mask + 26*81*4 B planes) x 4096 boards.
+roofline: the move-generation + encoder op of every playout step (qz_mcts_leaf_inputs =
+k_pool_stage1 [base paths || 26x9x9 encoder] + k_pool_masks), timed with HIP events around
+every one of its invocations in the timed region on the launch stream; algorithmic bytes =
+8,468 B/board (24 B board + 20 B mask + 26*81*4 B planes) x 4096 boards.  `traffic` is the
+PMC-measured HBM traffic of the same op at the same size (profiles/round1/pmc_traffic.json,
+collected with rocprofv3 --pmc in separate passes), or null if that file is absent.
 cpu_baseline: the CPU oracle (oracle/, scalar C port of the reference's algorithm, one
 playout at a time, batch-1 network on the CPU like the reference) timed on this host.
 """
@@ -181,6 +184,14 @@ def main():
 
     kern_ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
     achieved = args.boards * BYTES_PER_BOARD / (kern_ms * 1e-3) / 1e9
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "round1", "pmc_traffic.json")) as f:
+            t = json.load(f)
+        if int(t.get("boards", -1)) == args.boards:
+            traffic = t["traffic_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
 
     if rank == 0:
         mean_len = float(np.mean(lengths)) if lengths else float("nan")
@@ -215,9 +226,9 @@ def main():
             "mean_plies_per_game": mean_len,
             "games_per_s_from_plies": (plies_all / elapsed) / mean_len if lengths else None,
             "roofline": {
-                "kernel": "k_movegen_encode<mask,planes> (fused Quoridor.actions() + state() on the leaf batch)",
+                "kernel": "k_pool_stage1 + k_pool_masks (Quoridor.actions() + state() of the leaf batch, two launches)",
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "avg_launch_us": kern_ms * 1e3, "launches": len(evs),
                 "algorithmic_bytes_per_launch": args.boards * BYTES_PER_BOARD,
             },

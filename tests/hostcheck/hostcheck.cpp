@@ -15,10 +15,15 @@ using namespace qz;
 
 extern "C" {
 
-int hc_corner(uint64_t hb, uint64_t vb, int t, int which) { return corner(hb, vb, t, which); }
+int hc_corner(uint64_t hb, uint64_t vb, int t, int which) {
+    int a = corner(hb, vb, t, which), b = corner_tab(hb, vb, t, which);  // closed form == constant table
+    if (a != b || corner_ref(t, which) != corner_ref_tab(t, which)) return -99;
+    return a;
+}
 
 uint32_t hc_pawn_actions(uint64_t hb, uint64_t vb, int loc, int opp, int player) {
-    return pawn_actions(hb, vb, loc, opp, player);
+    uint32_t a = pawn_actions(hb, vb, loc, opp, player), b = pawn_actions_tab(hb, vb, loc, opp, player);
+    return a == b ? a : 0xFFFFFFFFu;
 }
 
 // reachability of player p (1|2) with pawns at p1/p2 on walls hb/vb
@@ -122,12 +127,9 @@ int hc_ordered(const uint32_t* mask5, int* out) {
 // ---- the pooled kernel's phases (qz_movegen_pool.h), executed lane by lane for tiles of nb boards
 static void pool_tile(const Board* boards, int nb, uint32_t* mask5, float* planes, int64_t* floods, int64_t* flood_iters) {
     std::vector<PoolBoard> ctx(nb);
-    std::vector<uint8_t> tiles((size_t)nb * 2 * POOL_PATH_CAP), kinds((size_t)nb * 2 * POOL_PATH_CAP);
-    BB layers[POOL_MAX_LAYERS + 2];
-    for (int i = 0; i < nb; i++) pool_p0(ctx[i], boards[i], false, true);
-    for (int i = 0; i < nb; i++)
-        for (int p = 1; p <= 2; p++)
-            pool_p1(ctx[i], p, layers, 1, &tiles[((size_t)i * 2 + p - 1) * POOL_PATH_CAP], &kinds[((size_t)i * 2 + p - 1) * POOL_PATH_CAP], 1);
+    std::vector<PathTab> tabs((size_t)nb * 2);
+    for (int i = 0; i < nb; i++)  // launch 1: lane = (board, player)
+        for (int p = 2; p >= 1; p--) pool_k1(boards[i], false, true, p, ctx[i], tabs[(size_t)i * 2 + p - 1]);
     std::vector<uint32_t> items;
     for (int i = 0; i < nb; i++)
         for (int ix = 0; ix < 64; ix++) {
@@ -140,16 +142,32 @@ static void pool_tile(const Board* boards, int nb, uint32_t* mask5, float* plane
     for (uint32_t it : items) {
         int bd = (int)(it >> 8), ix = (int)(it & 63u), p = (it & 0x80u) ? 2 : 1;
         bool hz = (it & 0x40u) != 0u;
-        size_t o = ((size_t)bd * 2 + p - 1) * POOL_PATH_CAP;
-        bool ok = pool_p3(ctx[bd], it, &tiles[o], &kinds[o], 1);
+        bool ok = pool_p3(ctx[bd], it, tabs[(size_t)bd * 2 + p - 1]);
         if (floods) (*floods)++;
         if (!ok) ctx[bd].blocked[(hz ? 0 : 2) + (ix >> 5)] |= 1u << (ix & 31);
     }
     (void)flood_iters;
     for (int i = 0; i < nb; i++) pool_p4(ctx[i], mask5 + 5 * (long)i);
-    if (planes)
-        for (int i = 0; i < nb; i++)
-            for (int k = 0; k < 2106; k++) planes[(long)i * 2106 + k] = pool_plane_value(ctx[i], k);
+    if (planes) {  // P5 through the per-board bitmap, 16 bytes (4 floats) at a time like the kernel
+        std::vector<uint32_t> bm((size_t)(nb + 1) * POOL_BM_WORDS, 0u);
+        for (int i = 0; i < nb; i++) {
+            EncCtx ec;
+            enc_ctx_build(ec, boards[i], false);
+            for (int k = 0; k < POOL_BM_WORDS; k++) bm[(size_t)i * POOL_BM_WORDS + k] = pool_bitmap_word(ec, k);
+        }
+        int nf = nb * 2106;
+        for (int f = 0; f + 3 < nf || f < (nf & ~3); f += 4) {
+            int bl = f / 2106, idx = f - bl * 2106;
+            uint32_t nib = pool_bitmap_nibble(&bm[(size_t)bl * POOL_BM_WORDS], bm[(size_t)(bl + 1) * POOL_BM_WORDS], idx);
+            for (int j = 0; j < 4; j++) planes[f + j] = (float)((nib >> j) & 1u);
+        }
+        if (nf & 3) {
+            EncCtx ec;
+            enc_ctx_build(ec, boards[nb - 1], false);
+            planes[nf - 2] = pool_plane_value(ec, 2104);
+            planes[nf - 1] = pool_plane_value(ec, 2105);
+        }
+    }
 }
 
 extern "C" void hc_movegen_pool(const uint64_t* hb, const uint64_t* vb, const uint64_t* meta, int n, int nb_tile, uint32_t* mask5,

@@ -128,7 +128,7 @@ e = qd.allgather_tuples(qd.pack_tuples(hb[:0], vb[:0], meta[:0], pi[:0], z[:0]) 
 assert e.shape[0] == 11
 assert qd.shard_seed(7, 0) != qd.shard_seed(7, 1)
 dist.destroy_process_group()
-print("RANK_OK", rank)
+open(os.path.join(sys.argv[2], "ok_%d" % rank), "w").write("ok")
 '''
 
 
@@ -138,10 +138,10 @@ def test_allgather_of_finished_tuples_gloo_world2(tmp_path):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     r = subprocess.run(
         [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-         "--master-port", "29517", str(script), ROOT],
+         "--master-port", "29517", str(script), ROOT, str(tmp_path)],
         env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "RANK_OK 0" in r.stdout and "RANK_OK 1" in r.stdout
+    assert (tmp_path / "ok_0").exists() and (tmp_path / "ok_1").exists(), r.stdout + r.stderr
 
 
 def test_network_mirror_matches_reference_fixture_cpu():
