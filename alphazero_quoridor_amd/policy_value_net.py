@@ -127,6 +127,11 @@ class LeafEvaluator:
                 layers.append([w, bias, None, None])
             else:
                 layers.append([conv_w(conv.weight), None, b.weight.detach().to(dt).clone(), b.bias.detach().to(dt).clone()])
+        # the two head convolutions (64->4 value, 64->2 policy) read the same trunk output: run
+        # them as ONE 64->6 convolution + one normalisation pass and split afterwards
+        hv, hp = layers[-2], layers[-1]
+        layers.append([torch.cat([hv[0], hp[0]], 0).contiguous(memory_format=mf)] +
+                      [None if a is None else torch.cat([a, b], 0) for a, b in zip(hv[1:], hp[1:])])
         fc = [[m.weight.detach().to(dt).clone(), m.bias.detach().to(dt).clone()] for m in (n.fc1, n.fc2, n.fc3)]
         if getattr(self, "_layers", None) is None:
             self._layers, self._fc = layers, fc
@@ -170,8 +175,9 @@ class LeafEvaluator:
             x = self._cbn(y, li + 1, relu=True, residual=x)
             li += 2
         B = x.shape[0]
-        v = self._cbn(x, li).reshape(B, 4 * 81)
-        p = self._cbn(x, li + 1).reshape(B, 2 * 81)
+        h = self._cbn(x, li + 2)  # merged value+policy head convolution (all norm modes are per channel)
+        v = h[:, :4].reshape(B, 4 * 81)
+        p = h[:, 4:].reshape(B, 2 * 81)
         (w1, b1), (w2, b2), (w3, b3) = self._fc
         v = torch.tanh(F.linear(F.linear(v, w1, b1), w2, b2)).reshape(B)
         p = torch.exp(F.log_softmax(F.linear(p, w3, b3).float(), dim=1))

@@ -124,3 +124,30 @@ def test_device_sqrt_is_correctly_rounded(gpu_device):
     out = torch.empty(n, dtype=torch.float64, device=gpu_device)
     _cabi.check(_cabi.load().qz_selftest_sqrt(out.data_ptr(), n, torch.cuda.current_stream().cuda_stream))
     assert np.array_equal(out.cpu().numpy(), np.sqrt(np.arange(n, dtype=np.float64)))
+
+
+@pytest.mark.parametrize("variant", [1, 8, 12, 16, 24, 32])
+def test_every_movegen_kernel_variant_matches_the_oracle(gpu_device, golden_dir, variant):
+    """The library picks the wave-per-board kernel for small batches and the pooled pipeline
+    (tile sizes 8..32) for large ones; force each on the same inputs (odd batch size, terminal
+    flags exercised through the engine tests)."""
+    import oracle
+    from alphazero_quoridor_amd import _cabi, rules
+    from alphazero_quoridor_amd.boards import DeviceBoards
+    from synth import synth_positions
+
+    d = np.load(golden_dir + "/rules_positions.npz")
+    boards = np.concatenate([d["board"][::3], synth_positions(3001, seed=31337)])
+    omask, status = oracle.movegen_batch(boards)
+    oplanes = oracle.encode_batch(boards)
+    L = _cabi.load()
+    try:
+        L.qz_debug_set_movegen_variant(variant)
+        db = DeviceBoards.from_packed(boards, gpu_device)
+        mask, planes = rules.movegen_encode(db)
+        assert np.array_equal(mask.cpu().numpy().view(np.uint32), omask)
+        assert np.array_equal(planes.cpu().numpy(), oplanes)
+        assert np.array_equal(rules.movegen(db).cpu().numpy().view(np.uint32), omask)
+        assert np.array_equal(rules.encode(db).cpu().numpy(), oplanes)
+    finally:
+        L.qz_debug_set_movegen_variant(0)
