@@ -448,8 +448,7 @@ int qz_nn_instnorm_act(const float* x, const float* gamma, const float* beta, co
     return 0;
 }
 
-// A/B hook: 0 = pooled move-generation kernel (default), 1 = wave-per-board kernel,
-// 8/16/32 = pooled kernel with that many boards per workgroup
+// A/B hook: see include/qz_abi.h
 int qz_debug_set_movegen_variant(int variant) {
     qzl::set_movegen_variant(variant);
     return 0;

@@ -233,6 +233,93 @@ __global__ __launch_bounds__(256) void k_pool_stage1(const uint64_t* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------- small batches
+// k_wave_rules: for batches too small to saturate the chip the critical path matters, not the
+// instruction count: ONE launch, no hand-off through HBM.  Move-generation groups give every
+// board a wavefront that runs the same phase functions as the pooled pipeline on LDS-resident
+// records (lanes 0/1: base paths; lane = slot: cut tests; lane = work item: floods); encoder
+// groups (as in k_pool_stage1) run beside them in the same grid.
+struct WaveBoardShared {
+    PoolBoard ctx;
+    PathTab tab[2];
+    uint16_t items[256];
+};
+template <int NBE>
+union WaveRulesShared {
+    WaveBoardShared w[WPB];
+    EncShared<NBE> enc;
+};
+
+template <int NBE>
+__global__ __launch_bounds__(256) void k_wave_rules(const uint64_t* __restrict__ hb, const uint64_t* __restrict__ vb,
+                                                    const uint64_t* __restrict__ meta, int n, const uint8_t* __restrict__ terminal,
+                                                    uint32_t* __restrict__ mask5, float* __restrict__ planes, int n_mg_groups) {
+    __shared__ WaveRulesShared<NBE> sm;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if ((int)blockIdx.x < n_mg_groups) {
+        const int b = (int)blockIdx.x * WPB + wave;
+        if (b >= n) return;  // whole wave leaves; only wave-level synchronisation below
+        WaveBoardShared& ws = sm.w[wave];
+        Board bd = load_board(hb, vb, meta, b);
+        const bool term = terminal ? (rfl(terminal[b]) != 0u) : false;
+        if (lane < 2) pool_k1(bd, term, true, lane + 1, ws.ctx, ws.tab[lane]);
+        wave_sync();
+        const uint32_t m = pool_p2(ws.ctx, lane);
+        const bool n0 = m & 1u, n1 = m & 2u, n2 = m & 4u, n3 = m & 8u;
+        const uint64_t b0 = __ballot(n0), b1 = __ballot(n1), b2 = __ballot(n2), b3 = __ballot(n3);
+        const int o1 = __popcll(b0), o2 = o1 + __popcll(b1), o3 = o2 + __popcll(b2), total = o3 + __popcll(b3);
+        if (n0) ws.items[rank_below(b0)] = (uint16_t)pool_item(0, lane, true, 1);
+        if (n1) ws.items[o1 + rank_below(b1)] = (uint16_t)pool_item(0, lane, true, 2);
+        if (n2) ws.items[o2 + rank_below(b2)] = (uint16_t)pool_item(0, lane, false, 1);
+        if (n3) ws.items[o3 + rank_below(b3)] = (uint16_t)pool_item(0, lane, false, 2);
+        wave_sync();
+        for (int base = 0; base < total; base += 64) {  // wave-uniform trip count
+            const int j = base + lane;
+            if (j < total) {
+                const uint32_t item = ws.items[j];
+                const int ix = (int)(item & 63u);
+                const bool ok = pool_p3(ws.ctx, item, ws.tab[(item & 0x80u) ? 1 : 0]);
+                if (!ok) atomicOr(&ws.ctx.blocked[((item & 0x40u) ? 0 : 2) + (ix >> 5)], 1u << (ix & 31));
+            }
+        }
+        wave_sync();
+        if (lane == 0) {
+            uint32_t m5[5];
+            pool_p4(ws.ctx, m5);
+#pragma unroll
+            for (int w = 0; w < 5; w++) mask5[(size_t)b * 5 + w] = m5[w];
+        }
+        return;
+    }
+    // encoder group: identical to k_pool_stage1's
+    const int b0 = ((int)blockIdx.x - n_mg_groups) * NBE;
+    const int nb = (n - b0) < NBE ? (n - b0) : NBE;
+    if (tid < nb) {
+        Board bd = unpack(hb[b0 + tid], vb[b0 + tid], meta[b0 + tid]);
+        enc_ctx_build(sm.enc.ec[tid], bd, terminal ? (terminal[b0 + tid] != 0) : false);
+    }
+    __syncthreads();
+    for (int w = tid; w < (nb + 1) * POOL_BM_WORDS; w += 256) {
+        int bd = w / POOL_BM_WORDS, k = w - bd * POOL_BM_WORDS;
+        sm.enc.bm[w] = bd < nb ? pool_bitmap_word(sm.enc.ec[bd], k) : 0u;
+    }
+    __syncthreads();
+    float* out = planes + (size_t)b0 * QZ_PLANES_N;
+    const int nf = nb * QZ_PLANES_N, nq = nf >> 2;
+    for (int q = tid; q < nq; q += 256) {
+        int f = q << 2;
+        int bl = f / QZ_PLANES_N, idx = f - bl * QZ_PLANES_N;
+        uint32_t nib = pool_bitmap_nibble(&sm.enc.bm[bl * POOL_BM_WORDS], sm.enc.bm[(bl + 1) * POOL_BM_WORDS], idx);
+        reinterpret_cast<float4*>(out)[q] = make_float4((float)(nib & 1u), (float)((nib >> 1) & 1u), (float)((nib >> 2) & 1u),
+                                                        (float)((nib >> 3) & 1u));
+    }
+    if ((nf & 3) && tid == 0) {
+        uint32_t nib = pool_bitmap_nibble(&sm.enc.bm[(nb - 1) * POOL_BM_WORDS], 0u, QZ_PLANES_N - 2);
+        out[nf - 2] = (float)(nib & 1u);
+        out[nf - 1] = (float)((nib >> 1) & 1u);
+    }
+}
+
 template <int NB>
 struct MasksShared {
     PoolBoard ctx[NB];
@@ -921,7 +1008,7 @@ namespace qzl {
 
 static inline dim3 wave_grid(int n) { return dim3((unsigned)((n + WPB - 1) / WPB)); }
 
-int g_movegen_variant = 0;  // 0 = pooled kernels (default), 1 = wave-per-board kernel (A/B only), 8..32 = forced mask tile
+int g_movegen_variant = 0;  // 0 = by batch size; 1 = first wave-per-board kernel (A/B); 2 = k_wave_rules; 8..32 = pooled, forced tile
 
 constexpr int NBE = 16;  // boards per encoder group
 
@@ -935,12 +1022,17 @@ size_t movegen_scratch_bytes(int n) { return (size_t)n * (sizeof(PoolBoard) + 2 
 hipError_t movegen_encode(const uint64_t* hb, const uint64_t* vb, const uint64_t* meta, int n, uint32_t* mask5,
                           float* planes, const uint8_t* terminal, void* scratch, hipStream_t s) {
     if (n <= 0) return hipSuccess;
-    // Small batches are latency-bound: the wave-per-board kernel has the shortest critical path
-    // (one launch, no hand-off through HBM).  From ~8k boards on the chip is saturated and the
-    // pooled pipeline, which issues ~3x fewer instructions per board, wins (measured on MI355X:
-    // 4,096 leaf boards in the engine 35 vs 44 us; 32,768 mid-game boards 214 vs 122 us).
-    const bool wave_per_board = g_movegen_variant == 1 || (g_movegen_variant == 0 && n < 8192);
-    if (wave_per_board) {
+    // Small batches are latency-bound: one launch, a wavefront per board, no hand-off through
+    // HBM (k_wave_rules).  From ~8k boards on the chip is saturated and the pooled two-launch
+    // pipeline, which packs lanes better, wins.
+    if (g_movegen_variant == 2 || (g_movegen_variant == 0 && n < 8192)) {
+        const int n_mg_groups = mask5 ? (n + WPB - 1) / WPB : 0;
+        const int n_enc_groups = planes ? (n + NBE - 1) / NBE : 0;
+        hipLaunchKernelGGL((k_wave_rules<NBE>), dim3((unsigned)(n_mg_groups + n_enc_groups)), dim3(256), 0, s, hb, vb, meta, n,
+                           terminal, mask5, planes, n_mg_groups);
+        return hipGetLastError();
+    }
+    if (g_movegen_variant == 1) {  // the first kernel of this repo, kept for A/B runs
         if (mask5 && planes)
             hipLaunchKernelGGL((k_movegen_encode<true, true>), wave_grid(n), dim3(TPB), 0, s, hb, vb, meta, n, mask5, planes, terminal);
         else if (mask5)

@@ -39,14 +39,20 @@ def init_from_env(device_type="cuda"):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hooks: QZ_DIST_BACKEND=gloo + QZ_SHARE_DEVICE=1 let two ranks share ONE GPU (RCCL
+    # refuses that), so the N>1 code path of bench.py can be exercised on a 1-GPU box
+    backend = os.environ.get("QZ_DIST_BACKEND", "nccl" if device_type == "cuda" else "gloo")
+    if os.environ.get("QZ_SHARE_DEVICE") == "1":
+        local = 0
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if device_type == "cuda":
             torch.cuda.set_device(local)
+        if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, local, world
 
 

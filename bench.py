@@ -21,8 +21,8 @@ time; plies/s, playouts/s and the mean length of the games seen are reported nex
 (plies/s is the robust statistic: game length varies 4-10x).
 
 roofline: the move-generation + encoder op of every playout step (qz_mcts_leaf_inputs: the
-wave-per-board kernel k_movegen_encode below 8,192 boards, the pooled pipeline k_pool_stage1 +
-k_pool_masks from there on), timed with HIP events around every one of its invocations in
+single-launch k_wave_rules below 8,192 boards, the pooled pipeline k_pool_stage1 + k_pool_masks
+from there on), timed with HIP events around every one of its invocations in
 the timed region on the launch stream; algorithmic bytes =
 8,468 B/board (24 B board + 20 B mask + 26*81*4 B planes) x 4096 boards.  `traffic` is the
 PMC-measured HBM traffic of the same op at the same size (profiles/round1/pmc_traffic.json,
@@ -227,7 +227,7 @@ def main():
             "mean_plies_per_game": mean_len,
             "games_per_s_from_plies": (plies_all / elapsed) / mean_len if lengths else None,
             "roofline": {
-                "kernel": ("k_movegen_encode<mask,planes> (fused Quoridor.actions() + state() of the leaf batch, one wave per board)"
+                "kernel": ("k_wave_rules (fused Quoridor.actions() + state() of the leaf batch: one wave per board + encoder groups, one launch)"
                            if args.boards < 8192 else
                            "k_pool_stage1 + k_pool_masks (Quoridor.actions() + state() of the leaf batch, pooled, two launches)"),
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

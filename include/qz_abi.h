@@ -194,8 +194,9 @@ int qz_nn_instnorm_act(const float* x /*[dev]*/, const float* gamma /*[dev][chan
  * uses np.sqrt(parent visits) in float64 (mcts.py:69); the test checks the device result is
  * correctly rounded. */
 int qz_selftest_sqrt(double* out /*[dev]*/, int n, void* stream);
-/* A/B hook for benchmarks: 0 = pooled move-generation kernel (default), 1 = the first
- * wave-per-board kernel, 8 | 16 | 32 = pooled kernel forced to that many boards per workgroup */
+/* A/B hook for benchmarks and tests: 0 = pick by batch size (default: k_wave_rules below 8,192
+ * boards, pooled pipeline above), 1 = the first wave-per-board kernel, 2 = k_wave_rules,
+ * 8 | 12 | 16 | 24 | 32 = pooled pipeline with that many boards per mask workgroup */
 int qz_debug_set_movegen_variant(int variant);
 
 #ifdef __cplusplus
