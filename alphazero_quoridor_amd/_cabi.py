@@ -71,7 +71,8 @@ class qz_stats(C.Structure):
         ("pending_games", C.c_int64),
         ("pending_plies", C.c_int64),
         ("arena_bytes", C.c_int64),
-        ("reserved", C.c_int64 * 3),
+        ("descent_levels", C.c_int64),
+        ("reserved", C.c_int64 * 2),
     ]
 
 

@@ -229,11 +229,9 @@ int qz_engine_create(const qz_config* cfg, qz_engine** out) {
     ALLOC(leaf_pedge, B);
     ALLOC(leaf_term, B);
     ALLOC(nodes, 2 * B * NC);
-    ALLOC(eN, 2 * B * EC);
-    ALLOC(eQ, 2 * B * EC);
-    ALLOC(eP, 2 * B * EC);
-    ALLOC(eChild, 2 * B * EC);
-    ALLOC(eAct, 2 * B * EC);
+    ALLOC(edges, 2 * B * EC);
+    ALLOC(path_edges, B * (size_t)QZ_PATH_CAP);
+    ALLOC(path_len, B);
     ALLOC(tree_half, B);
     ALLOC(n_nodes, B);
     ALLOC(n_edges, B);
@@ -247,6 +245,10 @@ int qz_engine_create(const qz_config* cfg, qz_engine** out) {
     ALLOC(traj_board, B * MP * 3);
     ALLOC(traj_pi, B * MP * QZ_N_ACT);
     ALLOC(counters, (size_t)QZ_C_COUNT);
+    ALLOC(bc_playouts, B);
+    ALLOC(bc_terminal, B);
+    ALLOC(bc_overflow, B);
+    ALLOC(bc_levels, B);
 #undef ALLOC
     if (!rc) {
         uint8_t* sc = nullptr;
@@ -261,6 +263,11 @@ int qz_engine_create(const qz_config* cfg, qz_engine** out) {
     if (he == hipSuccess) he = hipMemset(d.game_serial, 0, B * sizeof(uint32_t));
     if (he == hipSuccess) he = hipMemset(d.counters, 0, QZ_C_COUNT * sizeof(unsigned long long));
     if (he == hipSuccess) he = hipMemset(d.leaf_term, 0, B);
+    if (he == hipSuccess) he = hipMemset(d.path_len, 0, B * sizeof(uint32_t));
+    if (he == hipSuccess) he = hipMemset(d.bc_playouts, 0, B * sizeof(uint32_t));
+    if (he == hipSuccess) he = hipMemset(d.bc_terminal, 0, B * sizeof(uint32_t));
+    if (he == hipSuccess) he = hipMemset(d.bc_overflow, 0, B * sizeof(uint32_t));
+    if (he == hipSuccess) he = hipMemset(d.bc_levels, 0, B * sizeof(unsigned long long));
     if (he == hipSuccess) he = hipMemset(d.leaf_mask, 0, B * 5 * sizeof(uint32_t));
     if (he == hipSuccess) he = qzl::reset(d, 1, nullptr);
     if (he == hipSuccess) he = hipDeviceSynchronize();
@@ -421,17 +428,33 @@ int qz_engine_stats(qz_engine* e, qz_stats* out, void* stream) {
     if (!out) return fail(QZ_E_INVALID, "out is null");
     unsigned long long h[QZ_C_COUNT];
     hipStream_t s = (hipStream_t)stream;
+    const size_t B = (size_t)e->cfg.n_boards;
+    std::vector<uint32_t> bp(B), bt(B), bo(B);
+    std::vector<unsigned long long> bl(B);
     HIP_TRY(hipMemcpyAsync(h, e->dev.counters, sizeof(h), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(bp.data(), e->dev.bc_playouts, B * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(bt.data(), e->dev.bc_terminal, B * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(bo.data(), e->dev.bc_overflow, B * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(bl.data(), e->dev.bc_levels, B * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    // per-board counters wrap at 2^32 playouts per board (years); sums are 64-bit
+    unsigned long long sp = 0, st = 0, so = 0, sl = 0;
+    for (size_t i = 0; i < B; i++) {
+        sp += bp[i];
+        st += bt[i];
+        so += bo[i];
+        sl += bl[i];
+    }
     memset(out, 0, sizeof(*out));
     out->games_finished = (int64_t)h[QZ_C_GAMES];
     out->plies_played = (int64_t)h[QZ_C_PLIES];
-    out->playouts = (int64_t)h[QZ_C_PLAYOUTS];
-    out->leaf_terminal = (int64_t)h[QZ_C_LEAF_TERMINAL];
-    out->node_overflow = (int64_t)h[QZ_C_OVERFLOW];
+    out->playouts = (int64_t)sp;
+    out->leaf_terminal = (int64_t)st;
+    out->node_overflow = (int64_t)so;
     out->games_aborted = (int64_t)h[QZ_C_ABORTED];
     out->pending_games = (int64_t)h[QZ_C_PENDING_GAMES];
     out->pending_plies = (int64_t)h[QZ_C_PENDING_PLIES];
+    out->descent_levels = (int64_t)sl;
     out->arena_bytes = e->bytes;
     return 0;
 }

@@ -6,12 +6,15 @@
 //   leaf_mask[B][5], leaf_{pnode,pedge}[B], leaf_term[B]
 //   tree arenas, double buffered (half h in {0,1}), slot = h*B + b:
 //     nodes [2][B][node_cap]  16 B   {edge_off, n_edges, parent_node, parent_edge}
-//     eN    [2][B][edge_cap]  u32    visit count of the child TreeNode     (mcts.py:22)
-//     eQ    [2][B][edge_cap]  f64    its Q                                  (mcts.py:23)
-//     eP    [2][B][edge_cap]  f32    its prior                              (mcts.py:25)
-//     eChild[2][B][edge_cap]  u32    node id of the child once expanded, 0 = leaf
-//     eAct  [2][B][edge_cap]  u8     action id; a node's edges are stored in the
-//                                    reference's actions() order (dict insertion order)
+//     edges [2][B][edge_cap]  32 B   one record per child TreeNode of the reference:
+//        Q f64 (_Q, mcts.py:23) | N u32 (_n_visits, :22) | P f32 (_P, :25) | child u32 (node id
+//        once expanded, 0 = leaf) | coff u32 + cne u8 (edge offset / count of the child's own
+//        edges, so the descent needs ONE dependent HBM round trip per level) | act u8
+//     A node's edges are consecutive and in the reference's actions() order (dict insertion
+//     order).  Records rather than one array per field: a level of the descent then touches one
+//     2-4 KB span of one page instead of seven arrays megabytes apart (the first layout was
+//     bound by page-table walks: 126 us per select at depth 10).
+//   path_edges[B][QZ_PATH_CAP] u32: the edges of the last descent, root first (parallel backup)
 //   traj_board[B][max_plies][3] u64, traj_pi[B][max_plies][140] f32
 #pragma once
 #include <stdint.h>
@@ -20,6 +23,7 @@
 #define QZ_PLANES_N 2106
 #define QZ_NONE 0xFFFFFFFFu
 #define QZ_NO_MOVE_U8 255
+#define QZ_PATH_CAP 256
 
 enum { QZ_PLAYING = 0, QZ_FINISHED = 1 };
 enum {
@@ -37,6 +41,17 @@ enum {
 struct Node {
     uint32_t edge_off, n_edges, parent_node, parent_edge;
 };
+struct Edge {
+    double Q;
+    uint32_t N;
+    float P;
+    uint32_t child;
+    uint32_t coff;
+    uint8_t act, cne;
+    uint16_t pad16;
+    uint32_t pad32;
+};
+static_assert(sizeof(Edge) == 32, "edge record must be 32 bytes");
 
 struct EngineDev {
     int n_boards, node_cap, edge_cap, max_plies;
@@ -51,11 +66,8 @@ struct EngineDev {
     uint8_t* leaf_term;
     // trees
     Node* nodes;
-    uint32_t* eN;
-    double* eQ;
-    float* eP;
-    uint32_t* eChild;
-    uint8_t* eAct;
+    Edge* edges;
+    uint32_t *path_edges, *path_len;
     uint8_t* tree_half;
     uint32_t *n_nodes, *n_edges, *root_N;
     // games
@@ -63,16 +75,16 @@ struct EngineDev {
     uint8_t *status, *winner;
     uint64_t* traj_board;
     float* traj_pi;
-    unsigned long long* counters;  // QZ_C_COUNT
+    unsigned long long* counters;  // QZ_C_COUNT (touched once per ply / harvest)
+    // per-board counters for the per-playout statistics: a shared atomic would serialise all
+    // boards of a step on one address (~88 atomics/us on MI355X); summed by qz_engine_stats
+    uint32_t *bc_playouts, *bc_terminal, *bc_overflow;
+    unsigned long long* bc_levels;
 };
 
 struct TreeView {
     Node* nodes;
-    uint32_t* eN;
-    double* eQ;
-    float* eP;
-    uint32_t* eChild;
-    uint8_t* eAct;
+    Edge* e;
 };
 
 #if defined(__HIPCC__)
@@ -80,12 +92,7 @@ __device__ __forceinline__ TreeView tree_view(const EngineDev& E, int b, uint32_
     size_t slot = (size_t)half * (size_t)E.n_boards + (size_t)b;
     TreeView t;
     t.nodes = E.nodes + slot * (size_t)E.node_cap;
-    size_t eo = slot * (size_t)E.edge_cap;
-    t.eN = E.eN + eo;
-    t.eQ = E.eQ + eo;
-    t.eP = E.eP + eo;
-    t.eChild = E.eChild + eo;
-    t.eAct = E.eAct + eo;
+    t.e = E.edges + slot * (size_t)E.edge_cap;
     return t;
 }
 #endif

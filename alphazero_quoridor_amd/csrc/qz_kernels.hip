@@ -440,37 +440,55 @@ __global__ __launch_bounds__(TPB) void k_select(EngineDev E) {
     uint32_t parentN = rfl(E.root_N[b]);
     bool done = false;
     bool live = rfl(E.status[b]) == QZ_PLAYING;
+    uint32_t plen = 0u;
     if (live && n_nodes > 0) {
         uint32_t node = 0;
+        Node root = T.nodes[0];
+        uint32_t eoff = rfl(root.edge_off);
+        int ne = (int)rfl(root.n_edges);
+        uint32_t* path = E.path_edges + (size_t)b * QZ_PATH_CAP;
         for (int depth = 0; depth < 100000; depth++) {
-            Node nd = T.nodes[node];
-            uint32_t eoff = rfl(nd.edge_off);
-            int ne = (int)rfl(nd.n_edges);
             double sq = sqrt((double)parentN);  // np.sqrt(self._parent._n_visits), float64
             double best = -__builtin_inf();
             int bestk = 0x7fffffff;
+            // everything the descent needs about the winning edge rides along with the
+            // candidates, so the next level costs one dependent round trip, not three
+            uint32_t mN = 0u, mChild = 0u, mCOff = 0u, mMisc = 0u;
             for (int k = lane; k < ne; k += 64) {
-                uint32_t e = eoff + (uint32_t)k;
-                uint32_t N = T.eN[e];
-                float cp = E.c_puct * T.eP[e];                      // c_puct * self._P in float32
+                const Edge ed = T.e[eoff + (uint32_t)k];           // one 32-byte record per lane
+                uint32_t N = ed.N;
+                float cp = E.c_puct * ed.P;                         // c_puct * self._P in float32
                 double u = (double)cp * sq / (double)(1u + N);      // mcts.py:69
-                double val = T.eQ[e] + u;                           // mcts.py:70
+                double val = ed.Q + u;                              // mcts.py:70
+                uint32_t ch = ed.child, co = ed.coff;
+                uint32_t misc = (uint32_t)ed.act | ((uint32_t)ed.cne << 8);
                 if (val > best) {
                     best = val;
                     bestk = k;
+                    mN = N;
+                    mChild = ch;
+                    mCOff = co;
+                    mMisc = misc;
                 }
             }
             wave_argmax(best, bestk);
-            uint32_t e = eoff + (uint32_t)rfl((uint32_t)bestk);
-            int a = (int)rfl(T.eAct[e]);
-            uint32_t child = rfl(T.eChild[e]);
-            uint32_t childN = rfl(T.eN[e]);
+            const int kk = (int)rfl((uint32_t)bestk);
+            const int wl = kk & 63;  // the winning edge is the winning lane's own best candidate
+            uint32_t e = eoff + (uint32_t)kk;
+            uint32_t misc = rdl(mMisc, wl);
+            int a = (int)(misc & 0xFFu);
+            uint32_t child = rdl(mChild, wl);
+            uint32_t childN = rdl(mN, wl);
             done = apply_action(bd, a);  // game.step(action), mcts.py:113
             pnode = node;
             pedge = e;
+            if (lane == 0 && plen < (uint32_t)QZ_PATH_CAP) path[plen] = e;
+            plen++;
             if (child == 0u) break;  // TreeNode.is_leaf(): never expanded (or terminal)
             node = child;
             parentN = childN;
+            eoff = rdl(mCOff, wl);
+            ne = (int)((misc >> 8) & 0xFFu);
         }
     }
     if (lane == 0) {
@@ -479,6 +497,7 @@ __global__ __launch_bounds__(TPB) void k_select(EngineDev E) {
         E.leaf_meta[b] = pack_meta(bd);
         E.leaf_pnode[b] = pnode;
         E.leaf_pedge[b] = pedge;
+        E.path_len[b] = plen;
         // 0 live leaf; 1 terminal & winner == current_player; 2 terminal & winner != current_player;
         // 3 board not playing (finished, waiting for harvest): ignored by expand_backup
         uint8_t t = 0;
@@ -514,11 +533,17 @@ __global__ __launch_bounds__(TPB) void k_expand_backup(EngineDev E, const float*
                     uint32_t w = a < 32 ? m0 : (a < 64 ? m1 : (a < 96 ? m2 : (a < 128 ? m3 : m4)));
                     if ((w >> (a & 31)) & 1u) {
                         uint32_t e = neu + (uint32_t)order_index(pawn, lh, lv, a);
-                        T.eN[e] = 0u;
-                        T.eQ[e] = 0.0;
-                        T.eP[e] = p[(size_t)b * QZ_N_ACT + a];
-                        T.eChild[e] = 0u;
-                        T.eAct[e] = (uint8_t)a;
+                        Edge ed;
+                        ed.Q = 0.0;
+                        ed.N = 0u;
+                        ed.P = p[(size_t)b * QZ_N_ACT + a];
+                        ed.child = 0u;
+                        ed.coff = 0u;
+                        ed.act = (uint8_t)a;
+                        ed.cne = 0;
+                        ed.pad16 = 0;
+                        ed.pad32 = 0u;
+                        T.e[e] = ed;
                     }
                 }
                 if (lane == 0) {
@@ -528,12 +553,16 @@ __global__ __launch_bounds__(TPB) void k_expand_backup(EngineDev E, const float*
                     nd.parent_node = pnode;
                     nd.parent_edge = pedge;
                     T.nodes[nn] = nd;
-                    if (pnode != QZ_NONE) T.eChild[pedge] = nn;
+                    if (pnode != QZ_NONE) {
+                        T.e[pedge].child = nn;
+                        T.e[pedge].coff = neu;
+                        T.e[pedge].cne = (uint8_t)k;
+                    }
                     E.n_nodes[b] = nn + 1u;
                     E.n_edges[b] = neu + (uint32_t)k;
                 }
             } else if (lane == 0) {
-                atomicAdd((unsigned long long*)&E.counters[QZ_C_OVERFLOW], 1ull);
+                E.bc_overflow[b] += 1u;
             }
         }
     } else {
@@ -542,23 +571,42 @@ __global__ __launch_bounds__(TPB) void k_expand_backup(EngineDev E, const float*
         leaf_value = (term == 1u) ? 1.0 : -1.0;
         if (E.fix_terminal_sign) leaf_value = -leaf_value;
     }
-    if (lane == 0) {
-        double val = -leaf_value;  // node.update_recursive(-leaf_value), mcts.py:127
+    // node.update_recursive(-leaf_value) (mcts.py:44-62, 127): the leaf edge gets -leaf_value, its
+    // parent +leaf_value, ... up to the root.  The descent recorded its edges, so all levels are
+    // updated in parallel (lane = level); a path longer than the record falls back to walking
+    // the parent pointers.
+    const uint32_t plen = rfl(E.path_len[b]);
+    if (plen <= (uint32_t)QZ_PATH_CAP) {
+        const uint32_t* path = E.path_edges + (size_t)b * QZ_PATH_CAP;
+        for (uint32_t i = (uint32_t)lane; i < plen; i += 64u) {
+            uint32_t pe = path[i];
+            double val = ((plen - 1u - i) & 1u) ? leaf_value : -leaf_value;
+            uint32_t N = T.e[pe].N + 1u;  // mcts.py:51
+            double Q = T.e[pe].Q;
+            Q += 1.0 * (val - Q) / (double)N;  // mcts.py:53
+            T.e[pe].N = N;
+            T.e[pe].Q = Q;
+        }
+    } else if (lane == 0) {
+        double val = -leaf_value;
         uint32_t pn = pnode, pe = pedge;
         while (pn != QZ_NONE) {
-            uint32_t N = T.eN[pe] + 1u;  // mcts.py:51
-            double Q = T.eQ[pe];
-            Q += 1.0 * (val - Q) / (double)N;  // mcts.py:53
-            T.eN[pe] = N;
-            T.eQ[pe] = Q;
+            uint32_t N = T.e[pe].N + 1u;
+            double Q = T.e[pe].Q;
+            Q += 1.0 * (val - Q) / (double)N;
+            T.e[pe].N = N;
+            T.e[pe].Q = Q;
             val = -val;  // mcts.py:61
             Node nd = T.nodes[pn];
             pe = nd.parent_edge;
             pn = nd.parent_node;
         }
+    }
+    if (lane == 0) {
         E.root_N[b] = E.root_N[b] + 1u;  // the root is updated too
-        atomicAdd((unsigned long long*)&E.counters[QZ_C_PLAYOUTS], 1ull);
-        if (term != 0u) atomicAdd((unsigned long long*)&E.counters[QZ_C_LEAF_TERMINAL], 1ull);
+        E.bc_playouts[b] += 1u;
+        E.bc_levels[b] += (unsigned long long)plen;
+        if (term != 0u) E.bc_terminal[b] += 1u;
     }
 }
 
@@ -573,7 +621,7 @@ __device__ __forceinline__ void root_pi(const TreeView& T, const Node& root, dou
         int k = lane + 64 * r;
         x[r] = -__builtin_inf();
         if (k < ne) {
-            x[r] = inv_temp * log((double)T.eN[root.edge_off + k] + 1e-10);
+            x[r] = inv_temp * log((double)T.e[root.edge_off + k].N + 1e-10);
             mx = fmax(mx, x[r]);
         }
     }
@@ -608,9 +656,9 @@ __global__ __launch_bounds__(TPB) void k_root_pi(EngineDev E, double* __restrict
     for (int r = 0; r < 3; r++) {
         int k = lane + 64 * r;
         if (k < (int)root.n_edges) {
-            int a = T.eAct[root.edge_off + k];
+            int a = T.e[root.edge_off + k].act;
             if (pi) pi[(size_t)b * QZ_N_ACT + a] = pr[r];
-            if (visits) visits[(size_t)b * QZ_N_ACT + a] = (int32_t)T.eN[root.edge_off + k];
+            if (visits) visits[(size_t)b * QZ_N_ACT + a] = (int32_t)T.e[root.edge_off + k].N;
         }
     }
 }
@@ -631,10 +679,10 @@ __global__ __launch_bounds__(TPB) void k_root_children(EngineDev E, int32_t* vis
     wave_sync();
     for (int k = lane; k < (int)root.n_edges; k += 64) {
         uint32_t e = root.edge_off + k;
-        int a = T.eAct[e];
-        if (visits) visits[(size_t)b * QZ_N_ACT + a] = (int32_t)T.eN[e];
-        if (q) q[(size_t)b * QZ_N_ACT + a] = T.eQ[e];
-        if (prior) prior[(size_t)b * QZ_N_ACT + a] = T.eP[e];
+        int a = T.e[e].act;
+        if (visits) visits[(size_t)b * QZ_N_ACT + a] = (int32_t)T.e[e].N;
+        if (q) q[(size_t)b * QZ_N_ACT + a] = T.e[e].Q;
+        if (prior) prior[(size_t)b * QZ_N_ACT + a] = T.e[e].P;
     }
 }
 
@@ -646,8 +694,8 @@ __device__ __forceinline__ void wave_reroot(EngineDev& E, int b, int lane, uint3
     TreeView S = tree_view(E, b, half);
     uint32_t child = 0u, childN = 0u;
     if (edge != QZ_NONE) {
-        child = rfl(S.eChild[edge]);
-        childN = rfl(S.eN[edge]);
+        child = rfl(S.e[edge].child);
+        childN = rfl(S.e[edge].N);
     }
     uint32_t new_nodes = 0u, new_edges = 0u;
     if (child != 0u) {
@@ -672,16 +720,16 @@ __device__ __forceinline__ void wave_reroot(EngineDev& E, int b, int lane, uint3
                 int k = base + lane;
                 bool act = k < ne;
                 uint32_t c = 0u;
-                if (act) c = S.eChild[soff + k];
+                if (act) c = S.e[soff + k].child;
                 bool has = act && c != 0u;
                 uint64_t m = __ballot(has);
                 uint32_t nid = new_nodes + (uint32_t)rank_below(m);
                 if (act) {
-                    D.eN[doff + k] = S.eN[soff + k];
-                    D.eQ[doff + k] = S.eQ[soff + k];
-                    D.eP[doff + k] = S.eP[soff + k];
-                    D.eAct[doff + k] = S.eAct[soff + k];
-                    D.eChild[doff + k] = has ? nid : 0u;
+                    Edge ed = S.e[soff + k];
+                    ed.child = has ? nid : 0u;
+                    ed.coff = 0u;  // fixed up when the child itself is copied
+                    ed.cne = 0;
+                    D.e[doff + k] = ed;
                     if (has) {
                         Node cn;
                         cn.edge_off = c;  // source id, fixed up when the node is visited
@@ -693,7 +741,14 @@ __device__ __forceinline__ void wave_reroot(EngineDev& E, int b, int lane, uint3
                 }
                 new_nodes += (uint32_t)__popcll(m);
             }
-            if (lane == 0) D.nodes[i].edge_off = doff;
+            if (lane == 0) {
+                D.nodes[i].edge_off = doff;
+                if (i > 0u) {
+                    uint32_t pe = D.nodes[i].parent_edge;
+                    D.e[pe].coff = doff;
+                    D.e[pe].cne = (uint8_t)ne;
+                }
+            }
             new_edges += (uint32_t)ne;
             wave_sync();
         }
@@ -743,7 +798,7 @@ __global__ __launch_bounds__(TPB) void k_update_with_move(EngineDev E, const uin
         Node root = T.nodes[0];
         for (int base = 0; base < (int)root.n_edges; base += 64) {
             int k = base + lane;
-            bool hit = k < (int)root.n_edges && T.eAct[root.edge_off + k] == mv;
+            bool hit = k < (int)root.n_edges && T.e[root.edge_off + k].act == mv;
             uint64_t m = __ballot(hit);
             if (m) edge = root.edge_off + (uint32_t)base + (uint32_t)(__ffsll((unsigned long long)m) - 1);
         }
@@ -837,7 +892,7 @@ __global__ __launch_bounds__(TPB) void k_finish_move(EngineDev E, const uint8_t*
         int k = lane + 64 * r;
         act[r] = -1;
         if (k < ne) {
-            act[r] = T.eAct[eoff + k];
+            act[r] = T.e[eoff + k].act;
             tp[act[r]] = (float)pr[r];
             if (pi_out) pi_out[(size_t)b * QZ_N_ACT + act[r]] = (float)pr[r];
         }
@@ -897,7 +952,7 @@ __global__ __launch_bounds__(TPB) void k_finish_move(EngineDev E, const uint8_t*
         chosen_k = cnt < ne ? cnt : ne - 1;
     }
     uint32_t edge = eoff + (uint32_t)chosen_k;
-    int mv = (int)rfl(T.eAct[edge]);
+    int mv = (int)rfl(T.e[edge].act);
     if (move_out && lane == 0) move_out[b] = (uint8_t)mv;
 
     // update_with_move(move) in self-play, update_with_move(-1) otherwise (mcts.py:182,187)

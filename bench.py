@@ -225,6 +225,7 @@ def main():
             "leaf_evals_per_s": playouts_all / elapsed,
             "terminal_leaf_frac": term_all / max(playouts_all, 1.0),
             "mean_plies_per_game": mean_len,
+            "mean_descent_depth": (st1["descent_levels"] - st0["descent_levels"]) / max(st1["playouts"] - st0["playouts"], 1),
             "games_per_s_from_plies": (plies_all / elapsed) / mean_len if lengths else None,
             "roofline": {
                 "kernel": ("k_wave_rules (fused Quoridor.actions() + state() of the leaf batch: one wave per board + encoder groups, one launch)"

@@ -106,7 +106,8 @@ typedef struct {
     int64_t pending_games;     /* finished, not yet harvested                          */
     int64_t pending_plies;
     int64_t arena_bytes;       /* device bytes owned by the engine                     */
-    int64_t reserved[3];
+    int64_t descent_levels;    /* tree levels walked by all playouts (mean depth = / playouts) */
+    int64_t reserved[2];
 } qz_stats;
 
 /* MCTSPlayer.__init__ / MCTS.__init__ (mcts.py:89-100, 159-161) for n_boards trees +
