@@ -4,7 +4,7 @@
 // board, 4 boards per 256-thread workgroup; board scalars are wave-uniform (SGPRs), the lanes
 // are the <=131 edges of a tree node (three rounds).  Cross-lane traffic is ballots, mbcnt
 // ranks and shuffle reductions.
-// Rules kernels (actions() + state()): the pooled pipeline k_pool_stage1 + k_pool_masks, where
+// Rules kernels (actions() + state()): the pooled pipeline k_pool_paths + k_pool_masks_enc, where
 // every phase maps lanes to the unit it has many of (qz_movegen_pool.h).  The first
 // wave-per-board kernel (k_movegen_encode) is kept for A/B runs (qz_debug_set_movegen_variant).
 // No MFMA anywhere: integer / indexing work.
@@ -172,40 +172,26 @@ __global__ __launch_bounds__(TPB) void k_movegen_encode(const uint64_t* __restri
 
 // ---------------------------------------------------------------------------- pooled kernels
 // Quoridor.actions() + state() as two launches over an HBM scratch area (qz_movegen_pool.h):
-//   k_pool_stage1  two kinds of workgroups in ONE launch so that they overlap on the CUs:
-//                  * path groups (first in the grid): lane = (board, player): board context +
-//                    one ordered base path per player -> scratch.  Long dependent chains,
-//                    one wave each: latency-bound, almost no issue bandwidth.
-//                  * encoder groups: a tile of NBE boards -> 2,106-bit bitmaps in LDS ->
-//                    26x9x9 planes with 16-byte stores.  HBM-bound.
-//   k_pool_masks   one workgroup per tile of NB boards: slot tests -> pooled work list ->
-//                  floods -> 140-bit masks.  Issue-bound.
+//   k_pool_paths_enc  path groups (lane = (board, player): board context + one shortest base
+//                     path per player -> scratch; long dependent chains, no LDS: latency-bound)
+//                     + ~35 % of the encoder groups
+//   k_pool_masks_enc  two kinds of workgroups in ONE grid so that they overlap on the CUs:
+//                     * mask groups: a tile of NB boards: slot tests -> pooled work list ->
+//                       floods -> 140-bit masks.  Issue-bound.
+//                     * encoder groups: a tile of NBE boards -> 2,106-bit bitmaps in LDS ->
+//                       26x9x9 planes with 16-byte stores.  HBM-bound, independent of the masks.
 template <int NBE>
 struct EncShared {
     EncCtx ec[NBE];
     uint32_t bm[(NBE + 1) * POOL_BM_WORDS];  // +1 zero pad board for the straddling chunk
 };
 
+// encoder group body shared by k_pool_masks_enc and k_wave_rules: a tile of NBE boards ->
+// 2,106-bit state() bitmaps in LDS -> 26x9x9 planes with 16-byte stores (b0 even => aligned)
 template <int NBE>
-__global__ __launch_bounds__(256) void k_pool_stage1(const uint64_t* __restrict__ hb, const uint64_t* __restrict__ vb,
-                                                     const uint64_t* __restrict__ meta, int n, const uint8_t* __restrict__ terminal,
-                                                     PoolBoard* __restrict__ recs, PathTab* __restrict__ tabs,
-                                                     float* __restrict__ planes, int n_path_groups) {
-    __shared__ EncShared<NBE> sm;
-    const int tid = (int)threadIdx.x;
-    if ((int)blockIdx.x < n_path_groups) {
-        // 256 (board, player) tasks per path group, no LDS: ~1 wave per SIMD chip-wide, which
-        // leaves the other wave slots to the encoder groups that follow in the grid
-        const int task = (int)blockIdx.x * 256 + tid;
-        const int b = task >> 1, p = (task & 1) + 1;
-        if (b >= n) return;
-        Board bd = unpack(hb[b], vb[b], meta[b]);
-        bool term = terminal ? (terminal[b] != 0) : false;
-        pool_k1(bd, term, true, p, recs[b], tabs[(size_t)b * 2 + (p - 1)]);
-        return;
-    }
-    // encoder group: tile of NBE boards; b0 is even, so the tile's planes start 16-byte aligned
-    const int b0 = ((int)blockIdx.x - n_path_groups) * NBE;
+__device__ __forceinline__ void encoder_group(EncShared<NBE>& sm, const uint64_t* __restrict__ hb, const uint64_t* __restrict__ vb,
+                                              const uint64_t* __restrict__ meta, int n, const uint8_t* __restrict__ terminal,
+                                              float* __restrict__ planes, int b0, int tid) {
     const int nb = (n - b0) < NBE ? (n - b0) : NBE;
     if (tid < nb) {
         Board bd = unpack(hb[b0 + tid], vb[b0 + tid], meta[b0 + tid]);
@@ -233,12 +219,35 @@ __global__ __launch_bounds__(256) void k_pool_stage1(const uint64_t* __restrict_
     }
 }
 
+// First launch of the pooled pipeline: path groups, plus a share of the encoder groups so the
+// HBM-bound stores overlap the latency-bound path search as well.
+template <int NBE>
+__global__ __launch_bounds__(256) void k_pool_paths_enc(const uint64_t* __restrict__ hb, const uint64_t* __restrict__ vb,
+                                                        const uint64_t* __restrict__ meta, int n, const uint8_t* __restrict__ terminal,
+                                                        PoolBoard* __restrict__ recs, PathTab* __restrict__ tabs, int n_path_groups,
+                                                        float* __restrict__ planes) {
+    __shared__ EncShared<NBE> sm;
+    const int tid = (int)threadIdx.x;
+    if ((int)blockIdx.x < n_path_groups) {
+        // lane = (board, player): board context + one shortest base path per player -> scratch.
+        // Long dependent chains, no LDS: latency-bound, ~1 wave per SIMD chip-wide.
+        const int task = (int)blockIdx.x * 256 + tid;
+        const int b = task >> 1, p = (task & 1) + 1;
+        if (b >= n) return;
+        Board bd = unpack(hb[b], vb[b], meta[b]);
+        bool term = terminal ? (terminal[b] != 0) : false;
+        pool_k1(bd, term, true, p, recs[b], tabs[(size_t)b * 2 + (p - 1)]);
+        return;
+    }
+    encoder_group<NBE>(sm, hb, vb, meta, n, terminal, planes, ((int)blockIdx.x - n_path_groups) * NBE, tid);
+}
+
 // ---------------------------------------------------------------------------- small batches
 // k_wave_rules: for batches too small to saturate the chip the critical path matters, not the
 // instruction count: ONE launch, no hand-off through HBM.  Move-generation groups give every
 // board a wavefront that runs the same phase functions as the pooled pipeline on LDS-resident
 // records (lanes 0/1: base paths; lane = slot: cut tests; lane = work item: floods); encoder
-// groups (as in k_pool_stage1) run beside them in the same grid.
+// groups (encoder_group) run beside them in the same grid.
 struct WaveBoardShared {
     PoolBoard ctx;
     PathTab tab[2];
@@ -291,33 +300,7 @@ __global__ __launch_bounds__(256) void k_wave_rules(const uint64_t* __restrict__
         }
         return;
     }
-    // encoder group: identical to k_pool_stage1's
-    const int b0 = ((int)blockIdx.x - n_mg_groups) * NBE;
-    const int nb = (n - b0) < NBE ? (n - b0) : NBE;
-    if (tid < nb) {
-        Board bd = unpack(hb[b0 + tid], vb[b0 + tid], meta[b0 + tid]);
-        enc_ctx_build(sm.enc.ec[tid], bd, terminal ? (terminal[b0 + tid] != 0) : false);
-    }
-    __syncthreads();
-    for (int w = tid; w < (nb + 1) * POOL_BM_WORDS; w += 256) {
-        int bd = w / POOL_BM_WORDS, k = w - bd * POOL_BM_WORDS;
-        sm.enc.bm[w] = bd < nb ? pool_bitmap_word(sm.enc.ec[bd], k) : 0u;
-    }
-    __syncthreads();
-    float* out = planes + (size_t)b0 * QZ_PLANES_N;
-    const int nf = nb * QZ_PLANES_N, nq = nf >> 2;
-    for (int q = tid; q < nq; q += 256) {
-        int f = q << 2;
-        int bl = f / QZ_PLANES_N, idx = f - bl * QZ_PLANES_N;
-        uint32_t nib = pool_bitmap_nibble(&sm.enc.bm[bl * POOL_BM_WORDS], sm.enc.bm[(bl + 1) * POOL_BM_WORDS], idx);
-        reinterpret_cast<float4*>(out)[q] = make_float4((float)(nib & 1u), (float)((nib >> 1) & 1u), (float)((nib >> 2) & 1u),
-                                                        (float)((nib >> 3) & 1u));
-    }
-    if ((nf & 3) && tid == 0) {
-        uint32_t nib = pool_bitmap_nibble(&sm.enc.bm[(nb - 1) * POOL_BM_WORDS], 0u, QZ_PLANES_N - 2);
-        out[nf - 2] = (float)(nib & 1u);
-        out[nf - 1] = (float)((nib >> 1) & 1u);
-    }
+    encoder_group<NBE>(sm.enc, hb, vb, meta, n, terminal, planes, ((int)blockIdx.x - n_mg_groups) * NBE, tid);
 }
 
 template <int NB>
@@ -326,12 +309,28 @@ struct MasksShared {
     uint16_t items[NB * 256];  // every (slot, orientation, player) of every board at worst
     uint32_t n_items;
 };
+template <int NB, int NBE>
+union MasksEncShared {
+    MasksShared<NB> m;
+    EncShared<NBE> enc;
+};
 
-template <int NB>
-__global__ __launch_bounds__(256) void k_pool_masks(const PoolBoard* __restrict__ recs, const PathTab* __restrict__ tabs, int n,
-                                                    uint32_t* __restrict__ mask5) {
-    __shared__ MasksShared<NB> sm;
+// Second launch of the pooled pipeline: mask groups (issue-bound: slot tests, floods) and
+// encoder groups (HBM-bound) are independent of each other, so they share one grid and
+// overlap on the CUs.
+template <int NB, int NBE>
+__global__ __launch_bounds__(256) void k_pool_masks_enc(const PoolBoard* __restrict__ recs, const PathTab* __restrict__ tabs, int n,
+                                                        uint32_t* __restrict__ mask5, int n_mask_groups, int enc_tile0,
+                                                        const uint64_t* __restrict__ hb, const uint64_t* __restrict__ vb,
+                                                        const uint64_t* __restrict__ meta, const uint8_t* __restrict__ terminal,
+                                                        float* __restrict__ planes) {
+    __shared__ MasksEncShared<NB, NBE> smu;
     const int tid = (int)threadIdx.x, lane = tid & 63;
+    if ((int)blockIdx.x >= n_mask_groups) {
+        encoder_group<NBE>(smu.enc, hb, vb, meta, n, terminal, planes, (enc_tile0 + (int)blockIdx.x - n_mask_groups) * NBE, tid);
+        return;
+    }
+    MasksShared<NB>& sm = smu.m;
     const int b0 = (int)blockIdx.x * NB;
     const int nb = (n - b0) < NB ? (n - b0) : NB;
     if (tid == 0) sm.n_items = 0u;
@@ -1068,8 +1067,13 @@ int g_movegen_variant = 0;  // 0 = by batch size; 1 = first wave-per-board kerne
 constexpr int NBE = 16;  // boards per encoder group
 
 template <int NB>
-static void launch_masks(const PoolBoard* recs, const PathTab* tabs, int n, uint32_t* mask5, hipStream_t s) {
-    hipLaunchKernelGGL((k_pool_masks<NB>), dim3((unsigned)((n + NB - 1) / NB)), dim3(256), 0, s, recs, tabs, n, mask5);
+static void launch_masks_enc(const PoolBoard* recs, const PathTab* tabs, int n, uint32_t* mask5, const uint64_t* hb,
+                             const uint64_t* vb, const uint64_t* meta, const uint8_t* terminal, float* planes, int enc_tile0,
+                             int n_enc_groups, hipStream_t s) {
+    const int n_mask_groups = mask5 ? (n + NB - 1) / NB : 0;
+    if (n_mask_groups + n_enc_groups == 0) return;
+    hipLaunchKernelGGL((k_pool_masks_enc<NB, NBE>), dim3((unsigned)(n_mask_groups + n_enc_groups)), dim3(256), 0, s, recs, tabs, n,
+                       mask5, n_mask_groups, enc_tile0, hb, vb, meta, terminal, planes);
 }
 
 size_t movegen_scratch_bytes(int n) { return (size_t)n * (sizeof(PoolBoard) + 2 * sizeof(PathTab)); }
@@ -1098,18 +1102,22 @@ hipError_t movegen_encode(const uint64_t* hb, const uint64_t* vb, const uint64_t
     }
     PoolBoard* recs = reinterpret_cast<PoolBoard*>(scratch);
     PathTab* tabs = reinterpret_cast<PathTab*>(recs + n);
-    const int n_path_groups = mask5 ? (2 * n + 255) / 256 : 0;
-    const int n_enc_groups = planes ? (n + NBE - 1) / NBE : 0;
-    hipLaunchKernelGGL((k_pool_stage1<NBE>), dim3((unsigned)(n_path_groups + n_enc_groups)), dim3(256), 0, s, hb, vb, meta, n,
-                       terminal, recs, tabs, planes, n_path_groups);
+    // encoder tiles are split over the two launches: ~35 % ride beside the path search, the
+    // rest beside the mask groups
+    const int enc_total = planes ? (n + NBE - 1) / NBE : 0;
+    const int enc_a = mask5 ? (enc_total * 35) / 100 : 0;
     if (mask5) {
-        int nbt = g_movegen_variant >= 8 ? g_movegen_variant : (n >= 16384 ? 24 : (n >= 8192 ? 16 : 8));
-        if (nbt >= 32) launch_masks<32>(recs, tabs, n, mask5, s);
-        else if (nbt >= 24) launch_masks<24>(recs, tabs, n, mask5, s);
-        else if (nbt >= 16) launch_masks<16>(recs, tabs, n, mask5, s);
-        else if (nbt >= 12) launch_masks<12>(recs, tabs, n, mask5, s);
-        else launch_masks<8>(recs, tabs, n, mask5, s);
+        const int n_path_groups = (2 * n + 255) / 256;
+        hipLaunchKernelGGL((k_pool_paths_enc<NBE>), dim3((unsigned)(n_path_groups + enc_a)), dim3(256), 0, s, hb, vb, meta, n,
+                           terminal, recs, tabs, n_path_groups, planes);
     }
+    int nbt = g_movegen_variant >= 8 ? g_movegen_variant : (n >= 16384 ? 24 : (n >= 8192 ? 16 : 8));
+    const int enc_b = enc_total - enc_a;
+    if (nbt >= 32) launch_masks_enc<32>(recs, tabs, n, mask5, hb, vb, meta, terminal, planes, enc_a, enc_b, s);
+    else if (nbt >= 24) launch_masks_enc<24>(recs, tabs, n, mask5, hb, vb, meta, terminal, planes, enc_a, enc_b, s);
+    else if (nbt >= 16) launch_masks_enc<16>(recs, tabs, n, mask5, hb, vb, meta, terminal, planes, enc_a, enc_b, s);
+    else if (nbt >= 12) launch_masks_enc<12>(recs, tabs, n, mask5, hb, vb, meta, terminal, planes, enc_a, enc_b, s);
+    else launch_masks_enc<8>(recs, tabs, n, mask5, hb, vb, meta, terminal, planes, enc_a, enc_b, s);
     return hipGetLastError();
 }
 hipError_t step(uint64_t* hb, uint64_t* vb, uint64_t* meta, const uint8_t* action, int n, uint8_t* done, uint8_t* winner,
