@@ -306,7 +306,8 @@ __global__ __launch_bounds__(256) void k_wave_rules(const uint64_t* __restrict__
 template <int NB>
 struct MasksShared {
     PoolBoard ctx[NB];
-    uint16_t items[NB * 256];  // every (slot, orientation, player) of every board at worst
+    uint32_t srcpos[NB * 2][21];  // PathTab.srcpos of both players (84 B each), staged from scratch
+    uint16_t items[NB * 256];     // every (slot, orientation, player) of every board at worst
     uint32_t n_items;
 };
 template <int NB, int NBE>
@@ -339,6 +340,10 @@ __global__ __launch_bounds__(256) void k_pool_masks_enc(const PoolBoard* __restr
         uint32_t* dst = reinterpret_cast<uint32_t*>(sm.ctx);
         const int nw = nb * (int)(sizeof(PoolBoard) / 4);
         for (int i = tid; i < nw; i += 256) dst[i] = src[i];
+        for (int i = tid; i < nb * 2 * 21; i += 256) {
+            int t = i / 21, k = i - t * 21;
+            sm.srcpos[t][k] = reinterpret_cast<const uint32_t*>(tabs[(size_t)b0 * 2 + t].srcpos)[k];
+        }
     }
     __syncthreads();
     // P2: lane = (board, slot); the 64 lanes of a wave share a board

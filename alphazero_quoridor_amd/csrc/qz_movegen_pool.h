@@ -36,6 +36,7 @@ struct PoolBoard {          // per board, written in P0/P1, read by P2..P5
     int len[2];
     int lastjump[2];        // reverse position of the jump edge closest to the goal, -1 if none
     uint32_t blocked[4];    // H lo, H hi, V lo, V hi: slots whose wall would cut somebody off
+    uint64_t need[4];       // slots whose wall touches a base path: (H,p1) (H,p2) (V,p1) (V,p2)
 };
 
 // What P3 needs to know about a player's base path to stop a flood early (positions count
@@ -133,11 +134,22 @@ QZ_HD void pool_k1(const Board& b, bool terminal, bool want_moves, int p, PoolBo
     out.pe[p - 1] = pe;
     out.len[p - 1] = len;
     out.lastjump[p - 1] = lj;
+    // candidates that remove an edge of this path (or, if the path jumps, that sit next to the
+    // opponent): only those need a flood for player p
+    uint64_t nh = 0, nv = 0;
+    if (pe.found) {
+        CutMasks cm = path_cut_masks(pe);
+        uint64_t near = pe.jump ? near_opp_mask(side_opp(b, p)) : 0ull;
+        nh = static_ok_h(b.hb, b.vb) & (cm.h | near);
+        nv = static_ok_v(b.hb, b.vb) & (cm.v | near);
+    }
+    out.need[p - 1] = nh;
+    out.need[2 + p - 1] = nv;
 }
 
 // ---- P2 ---------------------------------------------------------------------------------
 // returns a 4-bit need mask for slot ix: bit0 (H,p1) bit1 (H,p2) bit2 (V,p1) bit3 (V,p2)
-QZ_HD uint32_t pool_p2(const PoolBoard& c, int ix) {
+QZ_HD uint32_t pool_p2_ref(const PoolBoard& c, int ix) {
     if ((c.flags & 3u) != 1u) return 0u;
     if (!(c.pe[0].found && c.pe[1].found)) return 0u;  // handled in P4: nothing is legal
     bool stH = (c.sh >> ix) & 1ull, stV = (c.sv >> ix) & 1ull;
@@ -155,13 +167,20 @@ QZ_HD uint32_t pool_p2(const PoolBoard& c, int ix) {
     }
     return m;
 }
+// the same answer from the per-board need masks the path lanes left behind
+QZ_HD uint32_t pool_p2(const PoolBoard& c, int ix) {
+    if ((c.flags & 3u) != 1u) return 0u;
+    if (!(c.pe[0].found && c.pe[1].found)) return 0u;  // handled in P4: nothing is legal
+    return (uint32_t)((c.need[0] >> ix) & 1ull) | ((uint32_t)((c.need[1] >> ix) & 1ull) << 1) |
+           ((uint32_t)((c.need[2] >> ix) & 1ull) << 2) | ((uint32_t)((c.need[3] >> ix) & 1ull) << 3);
+}
 QZ_HD uint32_t pool_item(int board, int ix, bool horizontal, int p) {
     return ((uint32_t)board << 8) | (uint32_t)ix | (horizontal ? 0x40u : 0u) | (p == 2 ? 0x80u : 0u);
 }
 
 // ---- P3 ---------------------------------------------------------------------------------
 // true if player p can still reach its goal with the candidate wall added
-QZ_HD bool pool_p3(const PoolBoard& c, uint32_t item, const PathTab& tab) {
+QZ_HD bool pool_p3(const PoolBoard& c, uint32_t item, const uint8_t* srcpos, const BB* suffix) {
     int ix = (int)(item & 63u);
     bool hz = (item & 0x40u) != 0u;
     int p = (item & 0x80u) ? 2 : 1;
@@ -176,15 +195,17 @@ QZ_HD bool pool_p3(const PoolBoard& c, uint32_t item, const PathTab& tab) {
         for (int guard = 0; guard < 8 && bb_any(hit); guard++) {
             int t = bb_lowest(hit);
             hit = bb_andn(hit, bb_bit(t));
-            int pos = tab.srcpos[t];
+            int pos = srcpos[t];
             best = pos < best ? pos : best;
         }
         if (best == 255) return true;  // nothing on the path is touched
-        target = bb_or(target, tab.suffix[best]);
+        target = bb_or(target, suffix[best]);
     }
     Graph g = make_graph_plan(blk_or(c.base, d), c.plan[p - 1], ix, hz);
     return flood_to(g, side_start(c.b, p), target);
 }
+
+QZ_HD bool pool_p3(const PoolBoard& c, uint32_t item, const PathTab& tab) { return pool_p3(c, item, tab.srcpos, tab.suffix); }
 
 // ---- P4 ---------------------------------------------------------------------------------
 QZ_HD void pool_p4(const PoolBoard& c, uint32_t mask5[5]) {

@@ -602,6 +602,51 @@ QZ_HD bool near_opp(int ix, int O) {
     return ir >= r - 2 && ir <= r + 1 && ic >= c - 2 && ic <= c + 1;
 }
 
+// 81-bit tile set -> 64-bit slot set: bit (8r+c) <- tile (r,c) for r,c < 8 (row 8 / column 8 dropped)
+QZ_HD uint64_t compress8(BB t) {
+    uint64_t out = 0;
+    const uint32_t w[4] = {t.w0, t.w1, t.w2, 0u};
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int r = 0; r < 8; r++) {
+        int pos = 9 * r, i = pos >> 5, off = pos & 31;
+        uint32_t v = w[i] >> off;
+        if (off > 24) v |= w[i + 1] << (32 - off);
+        out |= (uint64_t)(v & 0xFFu) << (8 * r);
+    }
+    return out;
+}
+// All wall slots whose wall removes at least one edge of a path, per orientation: the inverse
+// image of candidate_delta_fast() over the path's edge sets (== cuts() for all 128 candidates).
+struct CutMasks {
+    uint64_t h, v;
+};
+QZ_HD CutMasks path_cut_masks(const PathEdges& e) {
+    const uint64_t ROW0 = 0xFFull;
+    CutMasks m;
+    uint64_t a = compress8(e.pn), b = compress8(bb_shr<1>(e.pn));
+    uint64_t cn = ((a | b) & ~ROW0) | ((b | (a & 1ull)) & ROW0);
+    uint64_t cs = compress8(bb_shr<9>(e.ps)) | compress8(bb_shr<10>(e.ps));
+    m.h = cn | cs;
+    uint64_t e0 = compress8(e.pe), e1 = compress8(bb_shr<1>(e.pe)), e9 = compress8(bb_shr<9>(e.pe));
+    uint64_t ce = ((e0 | e9) & ~ROW0) | ((e9 | (e1 & 0x7Full) | (e0 & 1ull)) & ROW0);
+    uint64_t cw = compress8(bb_shr<1>(e.pw)) | compress8(bb_shr<10>(e.pw));
+    m.v = ce | cw;
+    return m;
+}
+// near_opp() for all 64 slots at once
+QZ_HD uint64_t near_opp_mask(int O) {
+    int r = O / 9, c = O - 9 * r;
+    int c0 = c - 2 < 0 ? 0 : c - 2, c1 = c + 1 > 7 ? 7 : c + 1;
+    int r0 = r - 2 < 0 ? 0 : r - 2, r1 = r + 1 > 7 ? 7 : r + 1;
+    if (c0 > c1 || r0 > r1) return 0ull;
+    uint64_t cols = ((1ull << (c1 - c0 + 1)) - 1ull) << c0;
+    uint64_t m = 0;
+    for (int rr = r0; rr <= r1; rr++) m |= cols << (8 * rr);
+    return m;
+}
+
 // position of an action inside the reference's ordered actions() list, given the legal
 // sets (pawn12, legalH, legalV): quoridor.py:146-157 + 423-428 (pawn codes ascending, then
 // walls interleaved h(ix), v(ix))
@@ -808,10 +853,14 @@ QZ_HD bool flood_to(const Graph& g, int start, BB goal_or_safe) {
     BB R = bb_bit(start);
     if (bb_any(bb_and(R, goal_or_safe))) return true;
     const BB jsrc = jump_sources(g);
-    for (int it = 0; it < 96; it++) {
-        BB nx = expand_j(g, jsrc, R);
-        if (bb_any(bb_and(nx, goal_or_safe))) return true;
-        BB R2 = bb_or(R, nx);
+    // two layers per trip: the exit tests (and, on the GPU, the exec-mask bookkeeping of a
+    // divergent loop) cost about as much as a layer, so test every other layer
+    for (int it = 0; it < 48; it++) {
+        BB n1 = expand_j(g, jsrc, R);
+        BB R1 = bb_or(R, n1);
+        BB n2 = expand_j(g, jsrc, R1);
+        BB R2 = bb_or(R1, n2);
+        if (bb_any(bb_and(bb_or(n1, n2), goal_or_safe))) return true;
         if (bb_eq(R2, R)) return false;
         R = R2;
     }

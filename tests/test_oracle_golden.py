@@ -154,6 +154,8 @@ def test_bitboard_movegen_equals_oracle(hostcheck, positions):
         assert np.array_equal(m, omask), "pool tile %d" % tile
         assert np.array_equal(pl, ref_planes), "pool planes tile %d" % tile
         assert floods.value < 40 * n  # path-cut pruning keeps the floods far below 256 per board
+    hostcheck.hc_p2_mismatches.restype = C.c_long
+    assert hostcheck.hc_p2_mismatches() == 0  # per-board need masks == per-slot cut tests
     # ordered list from the mask through order_index (the expand kernel's slot rule)
     out = (C.c_int * 140)()
     for i in range(0, n, 53):
