@@ -29,6 +29,7 @@ hipError_t harvest(const EngineDev&, uint64_t*, uint64_t*, uint64_t*, float*, fl
 hipError_t sqrt_table(double*, int, hipStream_t);
 void set_movegen_variant(int);
 hipError_t instnorm_act(const float*, const float*, const float*, const float*, float*, long long, int, int, float, hipStream_t);
+hipError_t instnorm_act_nhwc(const float*, const float*, const float*, const float*, float*, long long, int, int, float, hipStream_t);
 }  // namespace qzl
 
 static thread_local char g_err[512] = "";
@@ -468,6 +469,17 @@ int qz_nn_instnorm_act(const float* x, const float* gamma, const float* beta, co
     if (n_planes < 0 || channels <= 0) return fail(QZ_E_INVALID, "bad n_planes/channels");
     if (n_planes > 0 && (!x || !gamma || !beta || !out)) return fail(QZ_E_INVALID, "null tensor");
     HIP_TRY(qzl::instnorm_act(x, gamma, beta, residual, out, (long long)n_planes, channels, relu, eps, (hipStream_t)stream));
+    return 0;
+}
+
+// the same for channels-last memory ([B][81][C]); channels <= 64
+int qz_nn_instnorm_act_nhwc(const float* x, const float* gamma, const float* beta, const float* residual, float* out,
+                            int64_t n_samples, int channels, int relu, float eps, void* stream) {
+    int r;
+    if ((r = device_check())) return r;
+    if (n_samples < 0 || channels <= 0 || channels > 64) return fail(QZ_E_INVALID, "bad n_samples/channels (1..64)");
+    if (n_samples > 0 && (!x || !gamma || !beta || !out)) return fail(QZ_E_INVALID, "null tensor");
+    HIP_TRY(qzl::instnorm_act_nhwc(x, gamma, beta, residual, out, (long long)n_samples, channels, relu, eps, (hipStream_t)stream));
     return 0;
 }
 

@@ -95,7 +95,7 @@ def main():
     ap.add_argument("--playouts", type=int, default=400)
     ap.add_argument("--bn", default="per_leaf", choices=["per_leaf", "eval", "batch"])
     ap.add_argument("--nn-dtype", default="fp32", choices=["fp32", "bf16"])
-    ap.add_argument("--channels-last", type=int, default=0)
+    ap.add_argument("--channels-last", type=int, default=1)
     ap.add_argument("--desync-plies", type=int, default=700)
     ap.add_argument("--desync-playouts", type=int, default=4)
     ap.add_argument("--seed", type=int, default=2026)

@@ -63,7 +63,7 @@ def main():
     print("== engine step pieces, B=4096, n_playout=400 config")
     B = 4096
     eng = SelfPlayEngine(B, n_playout=400, device=dev, seed=1)
-    ev = net.evaluator("per_leaf", torch.float32, False)
+    ev = net.evaluator("per_leaf", torch.float32, True)
     for _ in range(50):
         eng.playout_step(ev)
     p, v = ev(eng.planes)

@@ -191,6 +191,12 @@ int qz_nn_instnorm_act(const float* x /*[dev]*/, const float* gamma /*[dev][chan
                        const float* beta /*[dev][channels]*/, const float* residual /*[dev] or NULL*/,
                        float* out /*[dev]*/, int64_t n_planes, int channels, int relu, float eps, void* stream);
 
+/* the same on channels-last memory: x/out/residual are the NHWC storage [n_samples][81][channels]
+ * of a logical [n_samples, channels, 9, 9] tensor; channels <= 64 */
+int qz_nn_instnorm_act_nhwc(const float* x /*[dev]*/, const float* gamma /*[dev]*/, const float* beta /*[dev]*/,
+                            const float* residual /*[dev] or NULL*/, float* out /*[dev]*/, int64_t n_samples,
+                            int channels, int relu, float eps, void* stream);
+
 /* self-test hook for the GPU tests: out[i] <- device sqrt((double)i), i < n.  The PUCT term
  * uses np.sqrt(parent visits) in float64 (mcts.py:69); the test checks the device result is
  * correctly rounded. */

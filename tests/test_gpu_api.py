@@ -120,7 +120,9 @@ def test_network_outputs_match_reference_fixture(gpu_device, golden_dir):
     assert np.abs(v.cpu().numpy() - d["eval_v"].reshape(-1)).max() < TOL
     p, v = pvn.evaluator("batch")(planes)
     assert np.abs(p.cpu().numpy() - d["train_p"]).max() < TOL and np.abs(v.cpu().numpy() - d["train_v"].reshape(-1)).max() < TOL
-    p, v = pvn.evaluator("per_leaf")(planes[:16])
+    pc, vc = pvn.evaluator("per_leaf", torch.float32, True)(planes[:16])  # channels-last route
+    p, v = pvn.evaluator("per_leaf", torch.float32, False)(planes[:16])  # NCHW route
+    assert (pc - p).abs().max().item() < TOL and (vc - v).abs().max().item() < TOL
     p, v = p.cpu().numpy(), v.cpu().numpy()
     for i in range(16):
         acts = d["leaf_acts"][i]
@@ -208,6 +210,25 @@ def test_fused_per_leaf_normalisation_kernel(gpu_device):
                 _cabi.check(L.qz_nn_instnorm_act(inplace.data_ptr(), gamma.data_ptr(), beta.data_ptr(), res.data_ptr() if use_res else 0,
                                                  inplace.data_ptr(), B * C, C, relu, 1e-5, torch.cuda.current_stream().cuda_stream))
                 assert torch.equal(inplace, out)
+    # channels-last variant: same maths on NHWC memory
+    for B, C in ((1, 64), (3, 6), (11, 6), (37, 64), (130, 64), (5, 2)):
+        x = (torch.randn((B, C, 9, 9), generator=g) * 2 - 0.5).to(gpu_device).contiguous(memory_format=torch.channels_last)
+        res = torch.randn((B, C, 9, 9), generator=g).to(gpu_device).contiguous(memory_format=torch.channels_last)
+        gamma = (torch.rand(C, generator=g) + 0.5).to(gpu_device)
+        beta = torch.randn(C, generator=g).to(gpu_device)
+        for use_res in (False, True):
+            for relu in (0, 1):
+                xn = x.contiguous()  # reference on plain NCHW copies
+                ref = torch.stack([F.batch_norm(xn[i:i + 1], None, None, gamma, beta, True, 0.0, 1e-5)[0] for i in range(B)])
+                if use_res:
+                    ref = ref + res.contiguous()
+                if relu:
+                    ref = F.relu(ref)
+                out = x.clone(memory_format=torch.preserve_format)
+                assert out.is_contiguous(memory_format=torch.channels_last)
+                _cabi.check(L.qz_nn_instnorm_act_nhwc(out.data_ptr(), gamma.data_ptr(), beta.data_ptr(), res.data_ptr() if use_res else 0,
+                                                      out.data_ptr(), B, C, relu, 1e-5, torch.cuda.current_stream().cuda_stream))
+                assert (out - ref).abs().max().item() < 2e-5, ("nhwc", B, C, use_res, relu)
     # the evaluator with and without the fused kernel agrees
     pvn = _fixture_net(gpu_device)
     from alphazero_quoridor_amd.policy_value_net import LeafEvaluator
@@ -215,3 +236,5 @@ def test_fused_per_leaf_normalisation_kernel(gpu_device):
     p1, v1 = LeafEvaluator(pvn.policy_value_net, "per_leaf", fused_norm=True)(xs)
     p2, v2 = LeafEvaluator(pvn.policy_value_net, "per_leaf", fused_norm=False)(xs)
     assert (p1 - p2).abs().max().item() < 1e-5 and (v1 - v2).abs().max().item() < 1e-5
+    p3, v3 = LeafEvaluator(pvn.policy_value_net, "per_leaf", channels_last=True)(xs)  # NHWC end to end
+    assert (p3 - p2).abs().max().item() < 1e-5 and (v3 - v2).abs().max().item() < 1e-5
