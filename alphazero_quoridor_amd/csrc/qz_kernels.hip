@@ -248,55 +248,66 @@ __global__ __launch_bounds__(256) void k_pool_paths_enc(const uint64_t* __restri
 // board a wavefront that runs the same phase functions as the pooled pipeline on LDS-resident
 // records (lanes 0/1: base paths; lane = slot: cut tests; lane = work item: floods); encoder
 // groups (encoder_group) run beside them in the same grid.
+template <int G>
 struct WaveBoardShared {
-    PoolBoard ctx;
-    PathTab tab[2];
-    uint16_t items[256];
+    PoolBoard ctx[G];
+    PathTab tab[G][2];
+    uint16_t items[G * 256];
 };
-template <int NBE>
+template <int NBE, int G>
 union WaveRulesShared {
-    WaveBoardShared w[WPB];
+    WaveBoardShared<G> w[WPB];
     EncShared<NBE> enc;
 };
 
-template <int NBE>
+// G boards per wavefront: the 2G base-path searches of a wave run side by side on 2G lanes (the
+// search is one long dependent chain, so it costs a wave the same whether 2 or 8 lanes are
+// live), and the work items of the G boards share the flood passes.
+template <int NBE, int G>
 __global__ __launch_bounds__(256) void k_wave_rules(const uint64_t* __restrict__ hb, const uint64_t* __restrict__ vb,
                                                     const uint64_t* __restrict__ meta, int n, const uint8_t* __restrict__ terminal,
                                                     uint32_t* __restrict__ mask5, float* __restrict__ planes, int n_mg_groups) {
-    __shared__ WaveRulesShared<NBE> sm;
+    __shared__ WaveRulesShared<NBE, G> sm;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if ((int)blockIdx.x < n_mg_groups) {
-        const int b = (int)blockIdx.x * WPB + wave;
-        if (b >= n) return;  // whole wave leaves; only wave-level synchronisation below
-        WaveBoardShared& ws = sm.w[wave];
-        Board bd = load_board(hb, vb, meta, b);
-        const bool term = terminal ? (rfl(terminal[b]) != 0u) : false;
-        if (lane < 2) pool_k1(bd, term, true, lane + 1, ws.ctx, ws.tab[lane]);
+        const int bw = ((int)blockIdx.x * WPB + wave) * G;  // first board of this wave
+        if (bw >= n) return;  // whole wave leaves; only wave-level synchronisation below
+        const int ng = (n - bw) < G ? (n - bw) : G;
+        WaveBoardShared<G>& ws = sm.w[wave];
+        if (lane < 2 * ng) {
+            const int g = lane >> 1, b = bw + g;
+            Board bd = unpack(hb[b], vb[b], meta[b]);
+            const bool term = terminal ? (terminal[b] != 0) : false;
+            pool_k1(bd, term, true, (lane & 1) + 1, ws.ctx[g], ws.tab[g][lane & 1]);
+        }
         wave_sync();
-        const uint32_t m = pool_p2(ws.ctx, lane);
-        const bool n0 = m & 1u, n1 = m & 2u, n2 = m & 4u, n3 = m & 8u;
-        const uint64_t b0 = __ballot(n0), b1 = __ballot(n1), b2 = __ballot(n2), b3 = __ballot(n3);
-        const int o1 = __popcll(b0), o2 = o1 + __popcll(b1), o3 = o2 + __popcll(b2), total = o3 + __popcll(b3);
-        if (n0) ws.items[rank_below(b0)] = (uint16_t)pool_item(0, lane, true, 1);
-        if (n1) ws.items[o1 + rank_below(b1)] = (uint16_t)pool_item(0, lane, true, 2);
-        if (n2) ws.items[o2 + rank_below(b2)] = (uint16_t)pool_item(0, lane, false, 1);
-        if (n3) ws.items[o3 + rank_below(b3)] = (uint16_t)pool_item(0, lane, false, 2);
+        int total = 0;
+        for (int g = 0; g < ng; g++) {  // wave-uniform
+            const uint32_t m = pool_p2(ws.ctx[g], lane);
+#pragma unroll
+            for (int bit = 0; bit < 4; bit++) {
+                const bool need = (m >> bit) & 1u;
+                const uint64_t bal = __ballot(need);
+                if (need) ws.items[total + rank_below(bal)] = (uint16_t)pool_item(g, lane, bit < 2, (bit & 1) + 1);
+                total += __popcll(bal);
+            }
+        }
         wave_sync();
         for (int base = 0; base < total; base += 64) {  // wave-uniform trip count
             const int j = base + lane;
             if (j < total) {
                 const uint32_t item = ws.items[j];
-                const int ix = (int)(item & 63u);
-                const bool ok = pool_p3(ws.ctx, item, ws.tab[(item & 0x80u) ? 1 : 0]);
-                if (!ok) atomicOr(&ws.ctx.blocked[((item & 0x40u) ? 0 : 2) + (ix >> 5)], 1u << (ix & 31));
+                const int g = (int)(item >> 8), ix = (int)(item & 63u);
+                const bool ok = pool_p3(ws.ctx[g], item, ws.tab[g][(item & 0x80u) ? 1 : 0]);
+                if (!ok) atomicOr(&ws.ctx[g].blocked[((item & 0x40u) ? 0 : 2) + (ix >> 5)], 1u << (ix & 31));
             }
         }
         wave_sync();
-        if (lane == 0) {
+        if (lane < ng) {
             uint32_t m5[5];
-            pool_p4(ws.ctx, m5);
+            pool_p4(ws.ctx[lane], m5);
 #pragma unroll
-            for (int w = 0; w < 5; w++) mask5[(size_t)b * 5 + w] = m5[w];
+            for (int w = 0; w < 5; w++) mask5[(size_t)(bw + lane) * 5 + w] = m5[w];
         }
         return;
     }
@@ -1067,7 +1078,7 @@ namespace qzl {
 
 static inline dim3 wave_grid(int n) { return dim3((unsigned)((n + WPB - 1) / WPB)); }
 
-int g_movegen_variant = 0;  // 0 = by batch size; 1 = first wave-per-board kernel (A/B); 2 = k_wave_rules; 8..32 = pooled, forced tile
+int g_movegen_variant = 0;  // 0 = by batch size; 1 = first wave-per-board kernel (A/B); 2/3/4 = k_wave_rules with 2/1/4 boards per wave; 8..32 = pooled, forced tile
 
 constexpr int NBE = 16;  // boards per encoder group
 
@@ -1089,11 +1100,14 @@ hipError_t movegen_encode(const uint64_t* hb, const uint64_t* vb, const uint64_t
     // Small batches are latency-bound: one launch, a wavefront per board, no hand-off through
     // HBM (k_wave_rules).  From ~8k boards on the chip is saturated and the pooled two-launch
     // pipeline, which packs lanes better, wins.
-    if (g_movegen_variant == 2 || (g_movegen_variant == 0 && n < 8192)) {
-        const int n_mg_groups = mask5 ? (n + WPB - 1) / WPB : 0;
+    if (g_movegen_variant == 2 || g_movegen_variant == 3 || g_movegen_variant == 4 || (g_movegen_variant == 0 && n < 8192)) {
         const int n_enc_groups = planes ? (n + NBE - 1) / NBE : 0;
-        hipLaunchKernelGGL((k_wave_rules<NBE>), dim3((unsigned)(n_mg_groups + n_enc_groups)), dim3(256), 0, s, hb, vb, meta, n,
-                           terminal, mask5, planes, n_mg_groups);
+        const int G = g_movegen_variant == 3 ? 1 : (g_movegen_variant == 4 ? 4 : 2);
+        const int n_mg_groups = mask5 ? (n + WPB * G - 1) / (WPB * G) : 0;
+        dim3 grid((unsigned)(n_mg_groups + n_enc_groups));
+        if (G == 1) hipLaunchKernelGGL((k_wave_rules<NBE, 1>), grid, dim3(256), 0, s, hb, vb, meta, n, terminal, mask5, planes, n_mg_groups);
+        else if (G == 4) hipLaunchKernelGGL((k_wave_rules<NBE, 4>), grid, dim3(256), 0, s, hb, vb, meta, n, terminal, mask5, planes, n_mg_groups);
+        else hipLaunchKernelGGL((k_wave_rules<NBE, 2>), grid, dim3(256), 0, s, hb, vb, meta, n, terminal, mask5, planes, n_mg_groups);
         return hipGetLastError();
     }
     if (g_movegen_variant == 1) {  // the first kernel of this repo, kept for A/B runs

@@ -202,8 +202,9 @@ int qz_nn_instnorm_act_nhwc(const float* x /*[dev]*/, const float* gamma /*[dev]
  * correctly rounded. */
 int qz_selftest_sqrt(double* out /*[dev]*/, int n, void* stream);
 /* A/B hook for benchmarks and tests: 0 = pick by batch size (default: k_wave_rules below 8,192
- * boards, pooled pipeline above), 1 = the first wave-per-board kernel, 2 = k_wave_rules,
- * 8 | 12 | 16 | 24 | 32 = pooled pipeline with that many boards per mask workgroup */
+ * boards, pooled pipeline above), 1 = the first wave-per-board kernel, 2 | 3 | 4 = k_wave_rules
+ * with 2 | 1 | 4 boards per wavefront, 8 | 12 | 16 | 24 | 32 = pooled pipeline with that many
+ * boards per mask workgroup */
 int qz_debug_set_movegen_variant(int variant);
 
 #ifdef __cplusplus

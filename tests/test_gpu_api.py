@@ -238,3 +238,60 @@ def test_fused_per_leaf_normalisation_kernel(gpu_device):
     assert (p1 - p2).abs().max().item() < 1e-5 and (v1 - v2).abs().max().item() < 1e-5
     p3, v3 = LeafEvaluator(pvn.policy_value_net, "per_leaf", channels_last=True)(xs)  # NHWC end to end
     assert (p3 - p2).abs().max().item() < 1e-5 and (v3 - v2).abs().max().item() < 1e-5
+
+
+def test_bench_multi_rank_path_on_one_gpu(gpu_device):
+    """bench.py's N>1 path (one engine per rank, per-ply all-gather of finished tuples, MAX /
+    SUM reductions, one JSON line from rank 0) with two ranks sharing this GPU over gloo
+    (RCCL refuses two ranks on one device; the driver's real runs use nccl)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, QZ_DIST_BACKEND="gloo", QZ_SHARE_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+         "--master-port", "29541", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+         "--boards", "256", "--playouts", "16", "--desync-plies", "200", "--no-cpu-baseline"],
+        env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 2
+    assert d["playouts_per_s"] > 0 and d["roofline"]["achieved"] > 0
+    # both ranks' work is in the aggregate: 2 ranks x 256 boards x 2 plies
+    assert abs(d["plies_per_s"] * d["ms_per_step"] * 2 / 1e3 - 2 * 256 * 2) < 2 * 256 * 2 * 0.05
+
+
+def test_selfplay_then_policy_update_closes_the_loop(gpu_device):
+    """collect_selfplay_data -> policy_update (train.py:65-92) -> the engine's cached evaluator
+    weights follow the optimiser step (refreshed in place) -> self-play continues."""
+    from alphazero_quoridor_amd.train import TrainPipeline
+
+    torch.manual_seed(1)
+    tp = TrainPipeline(n_boards=128, seed=9)
+    tp.n_playout = 2
+    tp.batch_size = 32
+    tp.epochs = 2
+    with quiet():
+        tp.collect_selfplay_data(2)
+    assert len(tp.data_buffer) > tp.batch_size
+    ev = tp._evaluator
+    x = (torch.rand((8, 26, 9, 9), device=gpu_device) > 0.8).float()
+    before = ev(x)[0].clone()
+    with quiet():
+        loss, entropy = tp.policy_update()
+    assert np.isfinite(loss) and np.isfinite(entropy) and 0.1 <= tp.lr_multiplier <= 10
+    after = ev(x)[0]
+    assert not torch.equal(before, after), "the evaluator must see the updated weights"
+    # module forward (train-mode BN on a batch of one per sample) == evaluator, after the update
+    with torch.no_grad():
+        ref = torch.cat([torch.exp(tp.policy_value_net.policy_value_net(x[i:i + 1])[0]) for i in range(8)])
+    assert (ref - after).abs().max().item() < 1e-5
+    n0 = len(tp.data_buffer)
+    with quiet():
+        tp.collect_selfplay_data(1)
+    assert len(tp.data_buffer) > n0 or len(tp.data_buffer) == tp.buffer_size

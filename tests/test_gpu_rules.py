@@ -126,7 +126,7 @@ def test_device_sqrt_is_correctly_rounded(gpu_device):
     assert np.array_equal(out.cpu().numpy(), np.sqrt(np.arange(n, dtype=np.float64)))
 
 
-@pytest.mark.parametrize("variant", [1, 2, 8, 12, 16, 24, 32])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 8, 12, 16, 24, 32])
 def test_every_movegen_kernel_variant_matches_the_oracle(gpu_device, golden_dir, variant):
     """The library picks k_wave_rules (2) for small batches and the pooled pipeline (tile sizes
     8..32) for large ones; 1 is the first kernel, kept for A/B.  Force each on the same inputs
