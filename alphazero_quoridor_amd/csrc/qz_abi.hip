@@ -47,34 +47,42 @@ static int fail(int code, const char* fmt, ...) {
         if (_e != hipSuccess) return fail(QZ_E_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
     } while (0)
 
+#include <map>
 #include <mutex>
+#include <utility>
 // Scratch for the stateless rules entry points (board records + path tables of the pooled
 // move-generation kernels): one cached allocation per device, grown on demand.  Growing
 // calls hipMalloc, so the first call of a given size must happen outside graph capture.
+// Scratch of the stateless rules entry points (the pooled pipeline hands path records from its
+// first to its second launch through HBM): one buffer per (device, stream), so calls issued on
+// different streams never share it.  Engines own theirs.
 static std::mutex g_scratch_mu;
-static void* g_scratch[64] = {nullptr};
-static size_t g_scratch_bytes[64] = {0};
-static int get_scratch(int n, void** out) {
+struct ScratchBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+static std::map<std::pair<int, void*>, ScratchBuf> g_scratch;
+static int get_scratch(int n, void* stream, void** out) {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64) return fail(QZ_E_INVALID, "device ordinal %d unsupported", dev);
     size_t need = qzl::movegen_scratch_bytes(n);
     std::lock_guard<std::mutex> lk(g_scratch_mu);
-    if (g_scratch_bytes[dev] < need) {
-        if (g_scratch[dev]) {
+    ScratchBuf& sb = g_scratch[std::make_pair(dev, stream)];
+    if (sb.bytes < need) {
+        if (sb.p) {
             HIP_TRY(hipDeviceSynchronize());
-            (void)hipFree(g_scratch[dev]);
-            g_scratch[dev] = nullptr;
-            g_scratch_bytes[dev] = 0;
+            (void)hipFree(sb.p);
+            sb = ScratchBuf();
         }
-        hipError_t e = hipMalloc(&g_scratch[dev], need);
+        hipError_t e = hipMalloc(&sb.p, need);
         if (e != hipSuccess) {
             (void)hipGetLastError();
+            sb = ScratchBuf();
             return fail(QZ_E_OOM, "hipMalloc(%zu) for move-generation scratch failed: %s", need, hipGetErrorString(e));
         }
-        g_scratch_bytes[dev] = need;
+        sb.bytes = need;
     }
-    *out = g_scratch[dev];
+    *out = sb.p;
     return 0;
 }
 
@@ -138,7 +146,7 @@ int qz_movegen(const qz_boards* boards, int n, uint32_t* mask5, void* stream) {
     if (n > 0 && !mask5) return fail(QZ_E_INVALID, "mask5 is null");
     if (n == 0) return 0;
     void* scratch = nullptr;
-    if ((r = get_scratch(n, &scratch))) return r;
+    if ((r = get_scratch(n, stream, &scratch))) return r;
     HIP_TRY(qzl::movegen_encode(boards->hbits, boards->vbits, boards->meta, n, mask5, nullptr, nullptr, scratch, (hipStream_t)stream));
     return 0;
 }
@@ -148,7 +156,7 @@ int qz_encode(const qz_boards* boards, int n, float* planes, void* stream) {
     if (n > 0 && !planes) return fail(QZ_E_INVALID, "planes is null");
     if (n == 0) return 0;
     void* scratch = nullptr;
-    if ((r = get_scratch(n, &scratch))) return r;
+    if ((r = get_scratch(n, stream, &scratch))) return r;
     HIP_TRY(qzl::movegen_encode(boards->hbits, boards->vbits, boards->meta, n, nullptr, planes, nullptr, scratch, (hipStream_t)stream));
     return 0;
 }
@@ -158,7 +166,7 @@ int qz_movegen_encode(const qz_boards* boards, int n, uint32_t* mask5, float* pl
     if (n > 0 && (!mask5 || !planes)) return fail(QZ_E_INVALID, "mask5/planes is null");
     if (n == 0) return 0;
     void* scratch = nullptr;
-    if ((r = get_scratch(n, &scratch))) return r;
+    if ((r = get_scratch(n, stream, &scratch))) return r;
     HIP_TRY(qzl::movegen_encode(boards->hbits, boards->vbits, boards->meta, n, mask5, planes, nullptr, scratch, (hipStream_t)stream));
     return 0;
 }

@@ -1102,7 +1102,10 @@ hipError_t movegen_encode(const uint64_t* hb, const uint64_t* vb, const uint64_t
     // pipeline, which packs lanes better, wins.
     if (g_movegen_variant == 2 || g_movegen_variant == 3 || g_movegen_variant == 4 || (g_movegen_variant == 0 && n < 8192)) {
         const int n_enc_groups = planes ? (n + NBE - 1) / NBE : 0;
-        const int G = g_movegen_variant == 3 ? 1 : (g_movegen_variant == 4 ? 4 : 2);
+        // boards per wavefront: on bench trees (late-game boards, many without walls left) one board per
+        // wavefront measured 29.1 us vs 33.0 (two) / 34.6 (four) at 4,096 boards; on the synthetic
+        // S-mid set two were slightly ahead (40.4 vs 42.9 us).  The in-situ number decides.
+        const int G = g_movegen_variant == 2 ? 2 : (g_movegen_variant == 4 ? 4 : 1);
         const int n_mg_groups = mask5 ? (n + WPB * G - 1) / (WPB * G) : 0;
         dim3 grid((unsigned)(n_mg_groups + n_enc_groups));
         if (G == 1) hipLaunchKernelGGL((k_wave_rules<NBE, 1>), grid, dim3(256), 0, s, hb, vb, meta, n, terminal, mask5, planes, n_mg_groups);

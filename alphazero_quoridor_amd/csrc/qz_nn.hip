@@ -182,6 +182,77 @@ __global__ __launch_bounds__(256) void k_instnorm_act_nhwc(const float* __restri
     }
 }
 
+// C = 64 (every trunk layer: 11 of the 12 normalisations of a forward pass), one sample per
+// workgroup, no LDS tile: float4 q = tid + 256 k of the 81 x 64 sample always holds channels
+// 4 (tid & 15) .. +3, so a thread keeps its 5-6 float4 in registers, sums them, meets the other
+// 15 threads of its channel quad through two lane shuffles (xor 16, 32) and one 1 KB LDS exchange
+// between the four wavefronts; the centred second pass costs no memory traffic.
+__device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 quad_reduce(float4 s, float (*red)[64], int wave, int lane, int cq) {
+    s.x += __shfl_xor(s.x, 16); s.y += __shfl_xor(s.y, 16); s.z += __shfl_xor(s.z, 16); s.w += __shfl_xor(s.w, 16);
+    s.x += __shfl_xor(s.x, 32); s.y += __shfl_xor(s.y, 32); s.z += __shfl_xor(s.z, 32); s.w += __shfl_xor(s.w, 32);
+    if (lane < 16) reinterpret_cast<float4*>(red[wave])[lane] = s;
+    __syncthreads();
+    float4 t = reinterpret_cast<const float4*>(red[0])[cq];
+    t = f4_add(t, reinterpret_cast<const float4*>(red[1])[cq]);
+    t = f4_add(t, reinterpret_cast<const float4*>(red[2])[cq]);
+    t = f4_add(t, reinterpret_cast<const float4*>(red[3])[cq]);
+    return t;
+}
+template <bool HAS_RES, bool RELU>
+__global__ __launch_bounds__(256) void k_instnorm_act_nhwc64(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const float* __restrict__ res,
+                                                             float* __restrict__ out, float eps) {
+    __shared__ __attribute__((aligned(16))) float s_a[4][64];
+    __shared__ __attribute__((aligned(16))) float s_b[4][64];
+    const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63, cq = tid & 15;
+    const size_t base = (size_t)blockIdx.x * (PL * 64);
+    const float4* x4 = reinterpret_cast<const float4*>(x + base);
+    const bool tail = tid < 16;  // 1296 float4 per sample = 5 * 256 + 16
+    float4 v[6];
+#pragma unroll
+    for (int k = 0; k < 5; k++) v[k] = x4[tid + 256 * k];
+    v[5] = tail ? x4[tid + 1280] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 r[6];
+    if (HAS_RES) {
+        const float4* r4 = reinterpret_cast<const float4*>(res + base);
+#pragma unroll
+        for (int k = 0; k < 5; k++) r[k] = r4[tid + 256 * k];
+        r[5] = tail ? r4[tid + 1280] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float4 s = v[0];
+#pragma unroll
+    for (int k = 1; k < 6; k++) s = f4_add(s, v[k]);
+    s = quad_reduce(s, s_a, wave, lane, cq);
+    const float4 mean = make_float4(s.x * (1.0f / PL), s.y * (1.0f / PL), s.z * (1.0f / PL), s.w * (1.0f / PL));
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        if (k < 5 || tail) {
+            const float dx = v[k].x - mean.x, dy = v[k].y - mean.y, dz = v[k].z - mean.z, dw = v[k].w - mean.w;
+            q.x += dx * dx; q.y += dy * dy; q.z += dz * dz; q.w += dw * dw;
+        }
+    }
+    q = quad_reduce(q, s_b, wave, lane, cq);
+    const float4 g4 = reinterpret_cast<const float4*>(gamma)[cq], b4 = reinterpret_cast<const float4*>(beta)[cq];
+    float4 sc, sh;
+    sc.x = g4.x / sqrtf(q.x * (1.0f / PL) + eps); sh.x = b4.x - mean.x * sc.x;
+    sc.y = g4.y / sqrtf(q.y * (1.0f / PL) + eps); sh.y = b4.y - mean.y * sc.y;
+    sc.z = g4.z / sqrtf(q.z * (1.0f / PL) + eps); sh.z = b4.z - mean.z * sc.z;
+    sc.w = g4.w / sqrtf(q.w * (1.0f / PL) + eps); sh.w = b4.w - mean.w * sc.w;
+    float4* o4 = reinterpret_cast<float4*>(out + base);
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        if (k < 5 || tail) {
+            float4 y;
+            y.x = v[k].x * sc.x + sh.x; y.y = v[k].y * sc.y + sh.y; y.z = v[k].z * sc.z + sh.z; y.w = v[k].w * sc.w + sh.w;
+            if (HAS_RES) { y.x += r[k].x; y.y += r[k].y; y.z += r[k].z; y.w += r[k].w; }
+            if (RELU) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
+            o4[tid + 256 * k] = y;
+        }
+    }
+}
+
 }  // namespace
 
 namespace qzl {
@@ -199,6 +270,15 @@ hipError_t instnorm_act_nhwc(const float* x, const float* gamma, const float* be
                              long long n_samples, int C, int relu, float eps, hipStream_t s) {
     if (n_samples <= 0) return hipSuccess;
     if (C < 1 || C > 64) return hipErrorInvalidValue;
+    const bool aligned16 = (((uintptr_t)x | (uintptr_t)out | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)res) & 15) == 0;
+    if (C == 64 && aligned16) {
+        dim3 grid((unsigned)n_samples), block(256);
+        if (res && relu) hipLaunchKernelGGL((k_instnorm_act_nhwc64<true, true>), grid, block, 0, s, x, gamma, beta, res, out, eps);
+        else if (res) hipLaunchKernelGGL((k_instnorm_act_nhwc64<true, false>), grid, block, 0, s, x, gamma, beta, res, out, eps);
+        else if (relu) hipLaunchKernelGGL((k_instnorm_act_nhwc64<false, true>), grid, block, 0, s, x, gamma, beta, res, out, eps);
+        else hipLaunchKernelGGL((k_instnorm_act_nhwc64<false, false>), grid, block, 0, s, x, gamma, beta, res, out, eps);
+        return hipGetLastError();
+    }
     int S = NF / (PL * C);
     if (S < 1) S = 1;
     if (S * C > 64) S = 64 / C;

@@ -56,26 +56,31 @@ def init_from_env(device_type="cuda"):
     return rank, local, world
 
 
-def allgather_tuples(buf: torch.Tensor, group=None) -> torch.Tensor:
+def allgather_tuples(buf: torch.Tensor, group=None, n_games=None):
     """Every rank contributes uint8 [n_r, 588]; every rank gets the concatenation in rank
-    order, uint8 [sum n_r, 588]."""
+    order, uint8 [sum n_r, 588].  With `n_games` (this rank's finished games) the call returns
+    (tuples, games summed over ranks) -- the same number on every rank, so loops that run
+    "until N games" stay in lockstep and issue the same sequence of collectives."""
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return buf
+        return buf if n_games is None else (buf, int(n_games))
     world = dist.get_world_size(group)
     dev = buf.device
-    count = torch.tensor([buf.shape[0]], dtype=torch.int64, device=dev)
-    counts = torch.zeros(world, dtype=torch.int64, device=dev)
+    count = torch.tensor([buf.shape[0], int(n_games or 0)], dtype=torch.int64, device=dev)
+    counts = torch.zeros(2 * world, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(counts, count, group=group)
-    counts = counts.cpu().tolist()
+    counts = counts.cpu().reshape(world, 2)
+    games = int(counts[:, 1].sum())
+    counts = counts[:, 0].tolist()
     mx = max(counts)
     if mx == 0:
-        return buf
+        return buf if n_games is None else (buf, games)
     padded = torch.zeros((mx, TUPLE_BYTES), dtype=torch.uint8, device=dev)
     padded[: buf.shape[0]] = buf
     out = torch.empty((world * mx, TUPLE_BYTES), dtype=torch.uint8, device=dev)
     dist.all_gather_into_tensor(out, padded, group=group)
     out = out.reshape(world, mx, TUPLE_BYTES)
-    return torch.cat([out[r, : counts[r]] for r in range(world)], dim=0)
+    out = torch.cat([out[r, : counts[r]] for r in range(world)], dim=0)
+    return out if n_games is None else (out, games)
 
 
 def shard_seed(seed: int, rank: int) -> int:

@@ -259,3 +259,112 @@ class SelfPlayEngine:
             if max_plies is not None and plies >= max_plies:
                 break
         return out
+
+
+class BoardGroups:
+    """The boards of one GPU split into `n_groups` independent ``SelfPlayEngine``s, each on its
+    own HIP stream with its own leaf evaluator.  A playout step is select -> rules -> net ->
+    expand/backup, strictly dependent inside one group; with two groups the tree kernels of one
+    (their duration is the deepest descent / longest path search of the group: latency, not
+    bandwidth) run underneath the other's convolutions.  Measured on MI355X, 400 playouts,
+    per-leaf BN fp32: 1x4096 boards 1.32 M playouts/s, 2x2048 1.39 M, 2x4096 1.48 M
+    (benchmarks/two_group_overlap.py).
+
+    Groups never exchange anything; every board keeps its own Philox stream
+    (seed -> group seed -> board), so results do not depend on how the streams interleave."""
+
+    def __init__(self, n_boards, n_groups, make_evaluator, seed=0, device="cuda:0", **engine_kw):
+        n_boards, n_groups = int(n_boards), int(n_groups)
+        if n_groups < 1 or n_boards % n_groups:
+            raise ValueError("n_boards=%d is not a multiple of n_groups=%d" % (n_boards, n_groups))
+        self.device = torch.device(device)
+        self.n_boards, self.n_groups = n_boards, n_groups
+        self.engines = [SelfPlayEngine(n_boards // n_groups, seed=self.group_seed(seed, g), device=self.device, **engine_kw)
+                        for g in range(n_groups)]
+        self.evaluators = [make_evaluator() for _ in range(n_groups)]
+        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(n_groups)]
+        main = torch.cuda.current_stream(self.device)
+        for s in self.streams:
+            s.wait_stream(main)
+        self.n_playout = self.engines[0].n_playout
+
+    @staticmethod
+    def group_seed(seed, g):
+        # additive, with a different constant than dist.shard_seed's xor, so (rank, group) pairs
+        # never collide; group 0 keeps the seed (one group == a plain SelfPlayEngine)
+        return (int(seed) + 0xD1B54A32D192ED03 * g) & 0xFFFFFFFFFFFFFFFF
+
+    def _each(self):
+        for g in range(self.n_groups):
+            with torch.cuda.stream(self.streams[g]):
+                yield g, self.engines[g], self.evaluators[g]
+
+    def playout_step(self, events=None):
+        """One playout of every board; `events` = one (start, end) pair per group around the
+        group's rules-op launch."""
+        for g, eng, ev in self._each():
+            eng.playout_step(ev, events=None if events is None else events[g])
+
+    def run_playouts(self, n=None):
+        n = self.n_playout if n is None else int(n)
+        if self.n_groups == 1:  # may replay a captured HIP graph
+            for _, eng, ev in self._each():
+                eng.run_playouts(ev, n)
+            return
+        for _ in range(n):
+            self.playout_step()
+
+    # Results handed to the caller were produced on a group stream: the caller's stream is made to
+    # wait for it, and the tensors are marked as used there, before anything is returned.
+    def _publish(self, g, tensors):
+        main = torch.cuda.current_stream(self.device)
+        main.wait_stream(self.streams[g])
+        for t in tensors:
+            if t is not None and t.is_cuda:
+                t.record_stream(main)
+
+    def finish_move(self):
+        out = []
+        for g, eng, _ in self._each():
+            out.append(eng.finish_move())
+        for g, (moves, pi) in enumerate(out):
+            self._publish(g, (moves, pi))
+        return out
+
+    def harvest(self):
+        """-> list[TupleBatch] (one per group that had finished games)"""
+        out = []
+        for g, eng, _ in self._each():
+            tb = eng.harvest()
+            if tb is not None:
+                out.append((g, tb))
+        for g, tb in out:
+            self._publish(g, (tb.boards.hbits, tb.boards.vbits, tb.boards.meta, tb.pi, tb.z, tb.game))
+        return [tb for _, tb in out]
+
+    def play_ply(self, n_playout=None):
+        self.run_playouts(n_playout)
+        return self.finish_move()
+
+    def stats(self) -> dict:
+        tot = {}
+        for _, eng, _ in self._each():
+            for k, v in eng.stats().items():
+                tot[k] = tot.get(k, 0) + v
+        return tot
+
+    def synchronize(self):
+        for s in self.streams:
+            s.synchronize()
+
+    def join_main(self):
+        """Order the group streams after the caller's stream (e.g. after a training step changed
+        the weights the evaluators read)."""
+        main = torch.cuda.current_stream(self.device)
+        for s in self.streams:
+            s.wait_stream(main)
+
+    def close(self):
+        self.synchronize()
+        for eng in self.engines:
+            eng.close()

@@ -19,7 +19,7 @@ import torch
 
 from . import dist as qdist
 from .boards import DeviceBoards
-from .engine import SelfPlayEngine, TupleBatch
+from .engine import BoardGroups, TupleBatch
 from .mcts import MCTSPlayer
 from .policy_value_net import PolicyValueNet
 from .quoridor import Quoridor
@@ -27,7 +27,7 @@ from .quoridor import Quoridor
 
 class TrainPipeline(object):
     def __init__(self, init_model=None, n_boards=1024, device=None, seed=0, bn_mode="per_leaf",
-                 nn_dtype=torch.float32, use_graph=False):
+                 nn_dtype=torch.float32, use_graph=False, n_groups=1):
         self.game = Quoridor()
         # the reference's hyper-parameters, same names and values (train.py:17-31)
         self.learn_rate = 2e-3
@@ -53,6 +53,7 @@ class TrainPipeline(object):
         self.bn_mode = bn_mode
         self.nn_dtype = nn_dtype
         self.use_graph = use_graph
+        self.n_groups = n_groups  # board groups on separate HIP streams (engine.BoardGroups)
         self.episode_len = 0
         self._engine = None
 
@@ -64,39 +65,55 @@ class TrainPipeline(object):
                                            n_playout=self.n_playout, is_selfplay=1)
         return self._mcts_player
 
-    def engine(self) -> SelfPlayEngine:
+    def engine(self) -> BoardGroups:
         if self._engine is None:
             rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
-            self._engine = SelfPlayEngine(self.n_boards, n_playout=self.n_playout, c_puct=self.c_puct, temp=self.temp,
-                                          is_selfplay=1, seed=qdist.shard_seed(self.seed, rank),
-                                          device=self.policy_value_net.device)
-            self._evaluator = self.policy_value_net.evaluator(self.bn_mode, self.nn_dtype)
-            if self.use_graph:
-                self._engine.capture_steps(self._evaluator, 1, warmup=2)
+            net = self.policy_value_net
+            self._engine = BoardGroups(self.n_boards, self.n_groups, lambda: net.evaluator(self.bn_mode, self.nn_dtype),
+                                       seed=qdist.shard_seed(self.seed, rank), device=net.device,
+                                       n_playout=self.n_playout, c_puct=self.c_puct, temp=self.temp, is_selfplay=1)
+            if self.use_graph and self.n_groups == 1:
+                with torch.cuda.stream(self._engine.streams[0]):
+                    self._engine.engines[0].capture_steps(self._engine.evaluators[0], 1, warmup=2)
         return self._engine
 
-    def _extend_buffer(self, tb: TupleBatch):
-        if torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
-            buf = qdist.allgather_tuples(qdist.pack_tuples(tb.boards.hbits, tb.boards.vbits, tb.boards.meta, tb.pi, tb.z))
+    def _is_dist(self):
+        return torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+
+    def _extend_buffer(self, tbs):
+        """Finished tuples of this ply -> replay buffer; returns the number of games they hold.
+        Multi-GPU: ONE all-gather per ply on every rank, whether or not this rank finished a
+        game, and the game count is the sum over ranks (identical everywhere), so all ranks
+        leave collect_selfplay_data after the same ply."""
+        n_games = sum(tb.n_games for tb in tbs)
+        if self._is_dist():
+            dev = self.policy_value_net.device
+            bufs = [qdist.pack_tuples(tb.boards.hbits, tb.boards.vbits, tb.boards.meta, tb.pi, tb.z) for tb in tbs]
+            bufs.append(torch.zeros((0, qdist.TUPLE_BYTES), dtype=torch.uint8, device=dev))
+            buf, n_games = qdist.allgather_tuples(torch.cat(bufs), n_games=n_games)
+            if buf.shape[0] == 0:
+                return n_games
             hb, vb, meta, pi, z = qdist.unpack_tuples(buf)
             boards = DeviceBoards(len(hb), hb.device)
             boards.hbits, boards.vbits, boards.meta = hb, vb, meta
-            tb = TupleBatch(boards, pi, z, tb.game, tb.n_games)
-        self.data_buffer.extend(tb.to_reference_tuples())
+            tbs = [TupleBatch(boards, pi, z, None, n_games)]
+        for tb in tbs:
+            self.data_buffer.extend(tb.to_reference_tuples())
+        return n_games
 
     def collect_selfplay_data(self, n_games=1):
         """Generate self-play data until `n_games` more games are complete (train.py:55-63)."""
         eng = self.engine()
+        eng.join_main()  # self-play streams start after whatever updated the weights
         got = 0
         while got < n_games:
-            eng.play_ply(self._evaluator)
-            tb = eng.harvest()
-            if tb is None:
-                continue
-            got += tb.n_games
-            last = int(tb.game.max().item())
-            self.episode_len = int((tb.game == last).sum().item())
-            self._extend_buffer(tb)
+            eng.play_ply()
+            tbs = eng.harvest()
+            for tb in tbs:
+                last = int(tb.game.max().item())
+                self.episode_len = int((tb.game == last).sum().item())
+            eng.synchronize()
+            got += self._extend_buffer(tbs)
 
     def policy_update(self):
         """KL-adaptive policy/value update (train.py:65-92)."""

@@ -93,6 +93,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--boards", type=int, default=4096)
     ap.add_argument("--playouts", type=int, default=400)
+    ap.add_argument("--groups", type=int, default=1,
+                    help="split the boards of a GPU into this many independent groups on their own HIP streams")
     ap.add_argument("--bn", default="per_leaf", choices=["per_leaf", "eval", "batch"])
     ap.add_argument("--nn-dtype", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--channels-last", type=int, default=1)
@@ -104,7 +106,7 @@ def main():
     args = ap.parse_args()
 
     from alphazero_quoridor_amd import dist as qdist
-    from alphazero_quoridor_amd.engine import SelfPlayEngine
+    from alphazero_quoridor_amd.engine import BoardGroups
     from alphazero_quoridor_amd.policy_value_net import PolicyValueNet
 
     rank, local, world = qdist.init_from_env("cuda")
@@ -116,9 +118,10 @@ def main():
     torch.manual_seed(args.seed)  # identical random-init weights on every rank
     net = PolicyValueNet(use_gpu=True, device=dev)
     dt = torch.float32 if args.nn_dtype == "fp32" else torch.bfloat16
-    ev = net.evaluator(args.bn, dt, bool(args.channels_last))
-    eng = SelfPlayEngine(args.boards, n_playout=args.playouts, c_puct=5, temp=1.0, is_selfplay=1,
-                         seed=qdist.shard_seed(args.seed, rank), device=dev)
+    eng = BoardGroups(args.boards, args.groups, lambda: net.evaluator(args.bn, dt, bool(args.channels_last)),
+                      seed=qdist.shard_seed(args.seed, rank), device=dev,
+                      n_playout=args.playouts, c_puct=5, temp=1.0, is_selfplay=1)
+    group_boards = args.boards // args.groups
     is_dist = world > 1
 
     def barrier():
@@ -130,36 +133,37 @@ def main():
 
     def end_of_ply():
         eng.finish_move()
-        tb = eng.harvest()
+        tbs = eng.harvest()
         n_games = 0
-        if tb is not None:
-            n_games = tb.n_games
-            g = tb.game.cpu().numpy()
-            lengths.extend(np.bincount(g).tolist())
+        for tb in tbs:
+            n_games += tb.n_games
+            gid = tb.game.cpu().numpy()
+            assert gid.size and 0 <= int(gid.min()) and int(gid.max()) < tb.n_games, "corrupt game ids in a harvest"
+            lengths.extend(np.bincount(gid, minlength=tb.n_games).tolist())
         if is_dist:  # the path's only exchange: finished tuples -> every rank's replay buffer
-            if tb is not None:
-                buf = qdist.pack_tuples(tb.boards.hbits, tb.boards.vbits, tb.boards.meta, tb.pi, tb.z)
-            else:
-                buf = torch.zeros((0, qdist.TUPLE_BYTES), dtype=torch.uint8, device=dev)
-            qdist.allgather_tuples(buf)
+            eng.synchronize()
+            bufs = [qdist.pack_tuples(tb.boards.hbits, tb.boards.vbits, tb.boards.meta, tb.pi, tb.z) for tb in tbs]
+            bufs.append(torch.zeros((0, qdist.TUPLE_BYTES), dtype=torch.uint8, device=dev))
+            qdist.allgather_tuples(torch.cat(bufs))
         return n_games
 
     # ---- desynchronise the games (untimed)
     t0 = time.time()
     for _ in range(args.desync_plies):
-        eng.run_playouts(ev, args.desync_playouts)
+        eng.run_playouts(args.desync_playouts)
         end_of_ply()
     desync_s = time.time() - t0
     desync_games = len(lengths)
 
     # ---- warmup steps at the full playout count (untimed)
     for _ in range(args.warmup):
-        eng.run_playouts(ev)
+        eng.run_playouts()
         end_of_ply()
 
     # ---- timed region
     n_launch = args.steps * args.playouts
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_launch)]
+    evs = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.groups)]
+           for _ in range(n_launch)]
     st0 = eng.stats()
     barrier()
     t0 = time.perf_counter()
@@ -167,7 +171,7 @@ def main():
     k = 0
     for _ in range(args.steps):
         for _ in range(args.playouts):
-            eng.playout_step(ev, events=evs[k])
+            eng.playout_step(events=evs[k])
             k += 1
         games += end_of_ply()
     barrier()
@@ -183,13 +187,14 @@ def main():
     elapsed = float(el.item())
     games_all, plies_all, playouts_all, term_all = (float(x) for x in tot.tolist())
 
-    kern_ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
-    achieved = args.boards * BYTES_PER_BOARD / (kern_ms * 1e-3) / 1e9
+    n_evs = len(evs) * args.groups
+    kern_ms = sum(a.elapsed_time(b) for row in evs for a, b in row) / n_evs
+    achieved = group_boards * BYTES_PER_BOARD / (kern_ms * 1e-3) / 1e9
     traffic = None
     try:
         with open(os.path.join(ROOT, "profiles", "round1", "pmc_traffic.json")) as f:
             t = json.load(f)
-        if int(t.get("boards", -1)) == args.boards:
+        if int(t.get("boards", -1)) == group_boards:
             traffic = t["traffic_bytes_per_launch"]
     except (OSError, ValueError, KeyError):
         pass
@@ -213,7 +218,7 @@ def main():
                 "workload": "BASELINE configs[3] per GPU: %d concurrent boards/GPU, n_playout=%d, 9x9, 10 walls/player, "
                             "c_puct=5, temp=1.0, leaf batch=%d, finished tuples all-gathered every ply"
                             % (args.boards, args.playouts, args.boards),
-                "boards_per_gpu": args.boards, "n_playout": args.playouts, "bn_mode": args.bn,
+                "boards_per_gpu": args.boards, "board_groups": args.groups, "n_playout": args.playouts, "bn_mode": args.bn,
                 "nn_dtype": args.nn_dtype, "channels_last": bool(args.channels_last),
                 "step": "one ply of every board (n_playout playout steps + finish_move + harvest)",
                 "desync": "%d untimed plies at %d playouts/move (%.0fs, %d games finished)"
@@ -229,12 +234,12 @@ def main():
             "games_per_s_from_plies": (plies_all / elapsed) / mean_len if lengths else None,
             "roofline": {
                 "kernel": ("k_wave_rules (fused Quoridor.actions() + state() of the leaf batch: one wave per board + encoder groups, one launch)"
-                           if args.boards < 8192 else
+                           if group_boards < 8192 else
                            "k_pool_stage1 + k_pool_masks (Quoridor.actions() + state() of the leaf batch, pooled, two launches)"),
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "avg_launch_us": kern_ms * 1e3, "launches": len(evs),
-                "algorithmic_bytes_per_launch": args.boards * BYTES_PER_BOARD,
+                "avg_launch_us": kern_ms * 1e3, "launches": n_evs,
+                "algorithmic_bytes_per_launch": group_boards * BYTES_PER_BOARD,
             },
             "engine_stats": {k: st1[k] for k in ("node_overflow", "games_aborted", "arena_bytes")},
         }

@@ -1,0 +1,18 @@
+import os, sys, torch
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+from alphazero_quoridor_amd import _cabi
+from alphazero_quoridor_amd.engine import SelfPlayEngine
+from alphazero_quoridor_amd.policy_value_net import PolicyValueNet
+dev = torch.device("cuda:0"); torch.manual_seed(2026); torch.backends.cudnn.benchmark = True
+net = PolicyValueNet(use_gpu=True); ev = net.evaluator("per_leaf")
+eng = SelfPlayEngine(4096, n_playout=400, seed=1, device=dev)
+for _ in range(300):
+    eng.run_playouts(ev, 4); eng.finish_move(); eng.harvest()
+L = _cabi.load()
+for variant in (0, 3, 4, 0):
+    L.qz_debug_set_movegen_variant(variant)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(200)]
+    for i in range(200): eng.playout_step(ev, events=evs[i])
+    torch.cuda.synchronize()
+    print("variant", variant, "avg rules-op us", sum(a.elapsed_time(b) for a, b in evs) / 200 * 1e3)
+L.qz_debug_set_movegen_variant(0)

@@ -272,14 +272,14 @@ def test_selfplay_then_policy_update_closes_the_loop(gpu_device):
     from alphazero_quoridor_amd.train import TrainPipeline
 
     torch.manual_seed(1)
-    tp = TrainPipeline(n_boards=128, seed=9)
+    tp = TrainPipeline(n_boards=128, seed=9, n_groups=2)  # two board groups on two HIP streams
     tp.n_playout = 2
     tp.batch_size = 32
     tp.epochs = 2
     with quiet():
         tp.collect_selfplay_data(2)
     assert len(tp.data_buffer) > tp.batch_size
-    ev = tp._evaluator
+    ev = tp.engine().evaluators[0]
     x = (torch.rand((8, 26, 9, 9), device=gpu_device) > 0.8).float()
     before = ev(x)[0].clone()
     with quiet():

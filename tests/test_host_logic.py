@@ -126,6 +126,12 @@ assert both[0].item() == both[1].item()
 # an empty contribution from one rank must not hang or break the gather
 e = qd.allgather_tuples(qd.pack_tuples(hb[:0], vb[:0], meta[:0], pi[:0], z[:0]) if rank == 0 else qd.pack_tuples(hb, vb, meta, pi, z))
 assert e.shape[0] == 11
+# the "until N games" loop of TrainPipeline: game counts are summed over ranks, identical
+# everywhere, also when nobody has tuples (both ranks must still meet in the collective)
+e2, games = qd.allgather_tuples(qd.pack_tuples(hb, vb, meta, pi, z), n_games=rank + 1)
+assert e2.shape[0] == 16 and games == 3
+e3, games = qd.allgather_tuples(qd.pack_tuples(hb[:0], vb[:0], meta[:0], pi[:0], z[:0]), n_games=0)
+assert e3.shape[0] == 0 and games == 0
 assert qd.shard_seed(7, 0) != qd.shard_seed(7, 1)
 dist.destroy_process_group()
 open(os.path.join(sys.argv[2], "ok_%d" % rank), "w").write("ok")
