@@ -380,7 +380,9 @@ __global__ __launch_bounds__(256) void k_pool_masks_enc(const PoolBoard* __restr
     for (uint32_t it = (uint32_t)tid; it < ni; it += 256u) {
         uint32_t item = sm.items[it];
         int bd = (int)(item >> 8), ix = (int)(item & 63u);
-        bool ok = pool_p3(sm.ctx[bd], item, tabs[(size_t)(b0 + bd) * 2 + ((item & 0x80u) ? 1 : 0)]);
+        const int side = (item & 0x80u) ? 1 : 0;
+        bool ok = pool_p3(sm.ctx[bd], item, reinterpret_cast<const uint8_t*>(sm.srcpos[bd * 2 + side]),
+                          tabs[(size_t)(b0 + bd) * 2 + side].suffix);
         if (!ok) atomicOr(&sm.ctx[bd].blocked[((item & 0x40u) ? 0 : 2) + (ix >> 5)], 1u << (ix & 31));
     }
     __syncthreads();

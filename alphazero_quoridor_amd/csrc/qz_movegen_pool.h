@@ -35,6 +35,8 @@ struct PoolBoard {          // per board, written in P0/P1, read by P2..P5
     PathEdges pe[2];
     int len[2];
     int lastjump[2];        // reverse position of the jump edge closest to the goal, -1 if none
+    int farjump[2];         // ... of the jump edge closest to the start, -1 if none
+    BB tiles[2];            // every tile of the base path, the pawn's included
     uint32_t blocked[4];    // H lo, H hi, V lo, V hi: slots whose wall would cut somebody off
     uint64_t need[4];       // slots whose wall touches a base path: (H,p1) (H,p2) (V,p1) (V,p2)
 };
@@ -119,14 +121,14 @@ QZ_HD void pool_k1(const Board& b, bool terminal, bool want_moves, int p, PoolBo
     none.pn = none.ps = none.pe = none.pw = bb_zero();
     none.jump = false;
     none.found = false;
-    int len = 0, lj = -1;
+    int len = 0, lj = -1, fj = -1;
     PathEdges pe = none;
     if (live) {
         JumpPlan plan = make_jump_plan(b.hb, b.vb, side_opp(b, p));
         out.plan[p - 1] = plan;
         if (walls) {
             Graph g = make_graph_plan(base, plan, -1, false);
-            OrderedPath op = find_path_tables(g, side_start(b, p), side_goal(p), POOL_MAX_LAYERS + 1, tab, lj);
+            OrderedPath op = find_path_tables(g, side_start(b, p), side_goal(p), POOL_MAX_LAYERS + 1, tab, lj, fj);
             pe = op.e;
             len = op.len;
         }
@@ -134,6 +136,8 @@ QZ_HD void pool_k1(const Board& b, bool terminal, bool want_moves, int p, PoolBo
     out.pe[p - 1] = pe;
     out.len[p - 1] = len;
     out.lastjump[p - 1] = lj;
+    out.farjump[p - 1] = fj;
+    out.tiles[p - 1] = len > 0 ? bb_or(tab.suffix[len - 1], bb_bit(side_start(b, p))) : bb_zero();
     // candidates that remove an edge of this path (or, if the path jumps, that sit next to the
     // opponent): only those need a flood for player p
     uint64_t nh = 0, nv = 0;
@@ -186,23 +190,36 @@ QZ_HD bool pool_p3(const PoolBoard& c, uint32_t item, const uint8_t* srcpos, con
     int p = (item & 0x80u) ? 2 : 1;
     Blk d = candidate_delta_fast(ix, hz);
     BB target = side_goal(p);
+    BB from = bb_bit(side_start(c.b, p));
     if (c.len[p - 1] > 0) {
         const PathEdges& e = c.pe[p - 1];
-        // source tiles of the path edges this candidate removes, and the last of them
+        // source tiles of the path edges this candidate removes
         BB hit = bb_or(bb_or(bb_and(d.n, e.pn), bb_and(d.s, e.ps)), bb_or(bb_and(d.e, e.pe), bb_and(d.w, e.pw)));
-        // the removed edge closest to the goal: everything behind it is still connected to the goal
-        int best = (e.jump && near_opp(ix, side_opp(c.b, p)) && c.lastjump[p - 1] >= 0) ? c.lastjump[p - 1] : 255;
+        // `best`: the removed edge closest to the goal -- everything behind it is still connected to
+        // the goal.  `worst`: the removed edge closest to the pawn -- everything in front of it is
+        // still connected to the pawn.  A wall next to the opponent may also change the jump
+        // edges, so those count as removed.  The flood then runs from the front part to the back
+        // part of the path: a detour around the wall instead of the whole way from the pawn.
+        const bool jumps = e.jump && near_opp(ix, side_opp(c.b, p)) && c.lastjump[p - 1] >= 0;
+        int best = jumps ? c.lastjump[p - 1] : 255;
+        int worst = jumps ? c.farjump[p - 1] : -1;
         for (int guard = 0; guard < 8 && bb_any(hit); guard++) {
             int t = bb_lowest(hit);
             hit = bb_andn(hit, bb_bit(t));
             int pos = srcpos[t];
             best = pos < best ? pos : best;
+            worst = pos > worst ? pos : worst;
         }
         if (best == 255) return true;  // nothing on the path is touched
-        target = bb_or(target, suffix[best]);
+        const BB behind_best = suffix[best];
+        target = bb_or(target, behind_best);
+        // tiles of the path in front of edge `worst` = all path tiles minus (its destination and
+        // everything behind it); one removed edge is the common case: no second table read
+        const BB behind_worst = worst == best ? behind_best : suffix[worst];
+        from = bb_andn(c.tiles[p - 1], behind_worst);
     }
     Graph g = make_graph_plan(blk_or(c.base, d), c.plan[p - 1], ix, hz);
-    return flood_to(g, side_start(c.b, p), target);
+    return flood_to(g, from, target);
 }
 
 QZ_HD bool pool_p3(const PoolBoard& c, uint32_t item, const PathTab& tab) { return pool_p3(c, item, tab.srcpos, tab.suffix); }

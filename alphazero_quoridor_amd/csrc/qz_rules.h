@@ -849,8 +849,11 @@ QZ_HD Blk candidate_delta_fast(int ix, bool horizontal) {
 //  * `also`: tiles from which the goal is known to stay reachable whatever this candidate
 //    does (the part of the player's base path behind the last edge the candidate removes);
 //  * jump sources are tested only when the reached set touches one of them.
-QZ_HD bool flood_to(const Graph& g, int start, BB goal_or_safe) {
-    BB R = bb_bit(start);
+//  * `from`: any set of tiles known to be connected to the player's pawn under this candidate
+//    (the pawn tile itself, or the part of the base path in front of the first edge the
+//    candidate removes): the flood then only has to find a way AROUND the wall.
+QZ_HD bool flood_to(const Graph& g, BB from, BB goal_or_safe) {
+    BB R = from;
     if (bb_any(bb_and(R, goal_or_safe))) return true;
     const BB jsrc = jump_sources(g);
     // two layers per trip: the exit tests (and, on the GPU, the exec-mask bookkeeping of a
@@ -866,6 +869,7 @@ QZ_HD bool flood_to(const Graph& g, int start, BB goal_or_safe) {
     }
     return false;
 }
+QZ_HD bool flood_to(const Graph& g, int start, BB goal_or_safe) { return flood_to(g, bb_bit(start), goal_or_safe); }
 
 // One concrete start->goal path WITH its order, for the pooled kernel.
 //   layers: caller storage, entry i at layers[i*stride], at least max_layers+1 entries
@@ -969,13 +973,15 @@ QZ_HD OrderedPath find_path_ordered(const Graph& g, int start, BB goal, BB* laye
 // len = number of edges (0 if !found).  tab.suffix must hold max_edges entries; a longer path
 // is reported with len = -1 and all-ones path sets (every candidate then gets re-checked).
 template <typename Tab>
-QZ_HD OrderedPath find_path_tables(const Graph& g, int start, BB goal, int max_edges, Tab& tab, int& first_jump_r) {
+QZ_HD OrderedPath find_path_tables(const Graph& g, int start, BB goal, int max_edges, Tab& tab, int& first_jump_r,
+                                   int& far_jump_r) {
     OrderedPath p;
     p.e.pn = p.e.ps = p.e.pe = p.e.pw = bb_zero();
     p.e.jump = false;
     p.e.found = false;
     p.len = 0;
     first_jump_r = -1;
+    far_jump_r = -1;  // reverse position of the jump edge closest to the START
     BB R = bb_bit(start);
     BB fN = bb_zero(), fS = bb_zero(), fE = bb_zero(), fW = bb_zero();
     BB fJ[4] = {bb_zero(), bb_zero(), bb_zero(), bb_zero()};
@@ -1052,6 +1058,7 @@ QZ_HD OrderedPath find_path_tables(const Graph& g, int start, BB goal, int max_e
         tab.suffix[k] = acc;
         tab.srcpos[s] = (uint8_t)k;
         if (jump && first_jump_r < 0) first_jump_r = k;
+        if (jump) far_jump_r = k;
         k++;
         t = s;
     }
