@@ -183,11 +183,10 @@ __global__ __launch_bounds__(TPB) void k_movegen_encode(const uint64_t* __restri
 template <int NBE>
 struct EncShared {
     EncCtx ec[NBE];
-    uint32_t bm[(NBE + 1) * POOL_BM_WORDS];  // +1 zero pad board for the straddling chunk
+    uint32_t bm[(NBE + 1) * POOL_BM_WORDS];      // word-aligned bitmaps, +1 all-zero pad board
+    uint32_t st[POOL_STREAM_WORDS(NBE) + 1];      // the tile as one bit stream (2,106 bits per board)
+    __attribute__((aligned(16))) float tbl[16][4];  // nibble -> four floats
 };
-
-// encoder group body shared by k_pool_masks_enc and k_wave_rules: a tile of NBE boards ->
-// 2,106-bit state() bitmaps in LDS -> 26x9x9 planes with 16-byte stores (b0 even => aligned)
 template <int NBE>
 __device__ __forceinline__ void encoder_group(EncShared<NBE>& sm, const uint64_t* __restrict__ hb, const uint64_t* __restrict__ vb,
                                               const uint64_t* __restrict__ meta, int n, const uint8_t* __restrict__ terminal,
@@ -197,30 +196,35 @@ __device__ __forceinline__ void encoder_group(EncShared<NBE>& sm, const uint64_t
         Board bd = unpack(hb[b0 + tid], vb[b0 + tid], meta[b0 + tid]);
         enc_ctx_build(sm.ec[tid], bd, terminal ? (terminal[b0 + tid] != 0) : false);
     }
+    if (tid >= 64 && tid < 128) {  // a 256 B table: entry e lives in banks 4e..4e+3, so the b128 reads below never conflict
+        const int e = (tid - 64) >> 2, j = tid & 3;
+        sm.tbl[e][j] = (float)((e >> j) & 1);
+    }
     __syncthreads();
     for (int w = tid; w < (nb + 1) * POOL_BM_WORDS; w += 256) {  // lane = one 32-bit word of a bitmap
         int bd = w / POOL_BM_WORDS, k = w - bd * POOL_BM_WORDS;
         sm.bm[w] = bd < nb ? pool_bitmap_word(sm.ec[bd], k) : 0u;
     }
     __syncthreads();
-    float* out = planes + (size_t)b0 * QZ_PLANES_N;
+    const int nsw = POOL_STREAM_WORDS(nb);
+    for (int w = tid; w < nsw; w += 256) sm.st[w] = pool_stream_word(sm.bm, w);
+    __syncthreads();
+    // lane = 16 bytes of output.  q advances by 256, so the nibble's shift is lane-invariant and
+    // its word index advances by 32: per store one LDS word read, one bit-field extract, one
+    // b128 table read.
+    float4* out = reinterpret_cast<float4*>(planes + (size_t)b0 * QZ_PLANES_N);
     const int nf = nb * QZ_PLANES_N, nq = nf >> 2;
-    for (int q = tid; q < nq; q += 256) {  // lane = 16 bytes of output: 4 bits -> 4 floats
-        int f = q << 2;
-        int bl = f / QZ_PLANES_N, idx = f - bl * QZ_PLANES_N;
-        uint32_t nib = pool_bitmap_nibble(&sm.bm[bl * POOL_BM_WORDS], sm.bm[(bl + 1) * POOL_BM_WORDS], idx);
-        reinterpret_cast<float4*>(out)[q] = make_float4((float)(nib & 1u), (float)((nib >> 1) & 1u), (float)((nib >> 2) & 1u),
-                                                        (float)((nib >> 3) & 1u));
-    }
+    const uint32_t sh = (uint32_t)(tid & 7) << 2;
+    const float4* tbl = reinterpret_cast<const float4*>(sm.tbl);
+#pragma unroll 4
+    for (int q = tid; q < nq; q += 256) out[q] = tbl[(sm.st[q >> 3] >> sh) & 15u];
     if ((nf & 3) && tid == 0) {  // odd number of boards in the last tile: 2 floats left
-        uint32_t nib = pool_bitmap_nibble(&sm.bm[(nb - 1) * POOL_BM_WORDS], 0u, QZ_PLANES_N - 2);
-        out[nf - 2] = (float)(nib & 1u);
-        out[nf - 1] = (float)((nib >> 1) & 1u);
+        const int bit = nf - 2;
+        const uint32_t two = (sm.st[bit >> 5] >> (bit & 31)) & 3u;
+        planes[(size_t)b0 * QZ_PLANES_N + nf - 2] = (float)(two & 1u);
+        planes[(size_t)b0 * QZ_PLANES_N + nf - 1] = (float)(two >> 1);
     }
 }
-
-// First launch of the pooled pipeline: path groups, plus a share of the encoder groups so the
-// HBM-bound stores overlap the latency-bound path search as well.
 template <int NBE>
 __global__ __launch_bounds__(256) void k_pool_paths_enc(const uint64_t* __restrict__ hb, const uint64_t* __restrict__ vb,
                                                         const uint64_t* __restrict__ meta, int n, const uint8_t* __restrict__ terminal,
@@ -1080,6 +1084,7 @@ namespace qzl {
 
 static inline dim3 wave_grid(int n) { return dim3((unsigned)((n + WPB - 1) / WPB)); }
 
+int g_enc_split_pct = 35;
 int g_movegen_variant = 0;  // 0 = by batch size; 1 = first wave-per-board kernel (A/B); 2/3/4 = k_wave_rules with 2/1/4 boards per wave; 8..32 = pooled, forced tile
 
 constexpr int NBE = 16;  // boards per encoder group
@@ -1129,7 +1134,7 @@ hipError_t movegen_encode(const uint64_t* hb, const uint64_t* vb, const uint64_t
     // encoder tiles are split over the two launches: ~35 % ride beside the path search, the
     // rest beside the mask groups
     const int enc_total = planes ? (n + NBE - 1) / NBE : 0;
-    const int enc_a = mask5 ? (enc_total * 35) / 100 : 0;
+    const int enc_a = mask5 ? (enc_total * g_enc_split_pct) / 100 : 0;
     if (mask5) {
         const int n_path_groups = (2 * n + 255) / 256;
         hipLaunchKernelGGL((k_pool_paths_enc<NBE>), dim3((unsigned)(n_path_groups + enc_a)), dim3(256), 0, s, hb, vb, meta, n,
@@ -1184,7 +1189,13 @@ hipError_t harvest(const EngineDev& E, uint64_t* t_hb, uint64_t* t_vb, uint64_t*
     hipLaunchKernelGGL(k_harvest_copy, wave_grid(E.n_boards), dim3(TPB), 0, s, E, t_hb, t_vb, t_meta, t_pi, t_z, t_game, cap);
     return hipGetLastError();
 }
-void set_movegen_variant(int v) { g_movegen_variant = v; }
+void set_movegen_variant(int v) {
+    if (v >= 100 && v <= 200) {  // A/B knob: share of the encoder tiles that ride beside the path search
+        g_enc_split_pct = v - 100;
+        return;
+    }
+    g_movegen_variant = v;
+}
 hipError_t sqrt_table(double* out, int n, hipStream_t s) {
     hipLaunchKernelGGL(k_sqrt_table, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out, n);
     return hipGetLastError();

@@ -242,6 +242,8 @@ QZ_HD void pool_p4(const PoolBoard& c, uint32_t mask5[5]) {
 
 // ---- P5 prologue: word k (bits 32k..32k+31) of the board's 2,106-bit state() bitmap ----------
 constexpr int POOL_BM_WORDS = 66;
+constexpr int QZ_POOL_PLANES_N = 2106;  // 26 * 81 floats of state() per board
+constexpr int POOL_STREAM_WORDS(int nb) { return (nb * QZ_POOL_PLANES_N + 31) / 32; }
 struct EncCtx {          // what the encoder needs to know about one board
     uint32_t enc[13];    // planes 0..4 as a 405-bit string
     uint32_t hot;        // all-ones planes among 5..25, one per byte (255 = none)
@@ -278,6 +280,24 @@ QZ_HD uint32_t pool_bitmap_nibble(const uint32_t* bm, uint32_t next0, int idx) {
     if (idx == 2104) nib = (nib & 3u) | ((next0 & 3u) << 2);
     return nib;
 }
+
+// The encoder groups write a tile of boards as ONE bit stream (2,106 bits per board, boards back
+// to back, no padding): output float4 q of the tile is then bits 4q..4q+3 of the stream -- a
+// nibble that never straddles a word, at a lane-invariant shift when q advances by 256.
+// word w of that stream, from the tile's word-aligned bitmaps (`bm`, POOL_BM_WORDS per board,
+// followed by one all-zero pad board; bits past 2,106 of a board's last word are zero)
+QZ_HD uint32_t pool_stream_word(const uint32_t* bm, int w) {
+    const int bit0 = 32 * w;
+    const int bd = bit0 / QZ_POOL_PLANES_N, o = bit0 - bd * QZ_POOL_PLANES_N;
+    const int k = o >> 5, sh = o & 31;
+    const uint32_t* b = bm + bd * POOL_BM_WORDS;
+    const uint32_t lo = b[k], hi = (k + 1 < POOL_BM_WORDS) ? b[k + 1] : 0u;
+    uint32_t v = (uint32_t)((((uint64_t)hi << 32) | (uint64_t)lo) >> sh);
+    const int rem = QZ_POOL_PLANES_N - o;  // bits this board still has from `o` on (>= 1)
+    if (rem < 32) v |= b[POOL_BM_WORDS] << rem;  // the rest comes from word 0 of the next board
+    return v;
+}
+QZ_HD uint32_t pool_stream_nibble(const uint32_t* st, int q) { return (st[q >> 3] >> ((q & 7) << 2)) & 15u; }
 
 // ---- P5 (reference form, one element) ---------------------------------------------------
 QZ_HD float pool_plane_value(const EncCtx& c, int idx) {

@@ -159,10 +159,11 @@ static void pool_tile(const Board* boards, int nb, uint32_t* mask5, float* plane
             for (int k = 0; k < POOL_BM_WORDS; k++) bm[(size_t)i * POOL_BM_WORDS + k] = pool_bitmap_word(ec, k);
         }
         int nf = nb * 2106;
-        for (int f = 0; f + 3 < nf || f < (nf & ~3); f += 4) {
-            int bl = f / 2106, idx = f - bl * 2106;
-            uint32_t nib = pool_bitmap_nibble(&bm[(size_t)bl * POOL_BM_WORDS], bm[(size_t)(bl + 1) * POOL_BM_WORDS], idx);
-            for (int j = 0; j < 4; j++) planes[f + j] = (float)((nib >> j) & 1u);
+        std::vector<uint32_t> st((size_t)POOL_STREAM_WORDS(nb) + 1, 0u);
+        for (int w = 0; w < POOL_STREAM_WORDS(nb); w++) st[w] = pool_stream_word(bm.data(), w);
+        for (int q = 0; q < (nf >> 2); q++) {
+            uint32_t nib = pool_stream_nibble(st.data(), q);
+            for (int j = 0; j < 4; j++) planes[4 * q + j] = (float)((nib >> j) & 1u);
         }
         if (nf & 3) {
             EncCtx ec;
