@@ -229,7 +229,7 @@ template <int NBE>
 __global__ __launch_bounds__(256) void k_pool_paths_enc(const uint64_t* __restrict__ hb, const uint64_t* __restrict__ vb,
                                                         const uint64_t* __restrict__ meta, int n, const uint8_t* __restrict__ terminal,
                                                         PoolBoard* __restrict__ recs, PathTab* __restrict__ tabs, int n_path_groups,
-                                                        float* __restrict__ planes) {
+                                                        float* __restrict__ planes, int detour_mode) {
     __shared__ EncShared<NBE> sm;
     const int tid = (int)threadIdx.x;
     if ((int)blockIdx.x < n_path_groups) {
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void k_pool_paths_enc(const uint64_t* __restri
         if (b >= n) return;
         Board bd = unpack(hb[b], vb[b], meta[b]);
         bool term = terminal ? (terminal[b] != 0) : false;
-        pool_k1(bd, term, true, p, recs[b], tabs[(size_t)b * 2 + (p - 1)]);
+        pool_k1(bd, term, true, p, recs[b], tabs[(size_t)b * 2 + (p - 1)], detour_mode);
         return;
     }
     encoder_group<NBE>(sm, hb, vb, meta, n, terminal, planes, ((int)blockIdx.x - n_path_groups) * NBE, tid);
@@ -270,7 +270,8 @@ union WaveRulesShared {
 template <int NBE, int G>
 __global__ __launch_bounds__(256) void k_wave_rules(const uint64_t* __restrict__ hb, const uint64_t* __restrict__ vb,
                                                     const uint64_t* __restrict__ meta, int n, const uint8_t* __restrict__ terminal,
-                                                    uint32_t* __restrict__ mask5, float* __restrict__ planes, int n_mg_groups) {
+                                                    uint32_t* __restrict__ mask5, float* __restrict__ planes, int n_mg_groups,
+                                                    int detour_mode) {
     __shared__ WaveRulesShared<NBE, G> sm;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if ((int)blockIdx.x < n_mg_groups) {
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(256) void k_wave_rules(const uint64_t* __restrict__
             const int g = lane >> 1, b = bw + g;
             Board bd = unpack(hb[b], vb[b], meta[b]);
             const bool term = terminal ? (terminal[b] != 0) : false;
-            pool_k1(bd, term, true, (lane & 1) + 1, ws.ctx[g], ws.tab[g][lane & 1]);
+            pool_k1(bd, term, true, (lane & 1) + 1, ws.ctx[g], ws.tab[g][lane & 1], detour_mode);
         }
         wave_sync();
         int total = 0;
@@ -1084,7 +1085,8 @@ namespace qzl {
 
 static inline dim3 wave_grid(int n) { return dim3((unsigned)((n + WPB - 1) / WPB)); }
 
-int g_enc_split_pct = 35;
+int g_enc_split_pct = 70;
+int g_detour_pooled = 1, g_detour_wave = 0;  // pool_k1's detour_mode per kernel family
 int g_movegen_variant = 0;  // 0 = by batch size; 1 = first wave-per-board kernel (A/B); 2/3/4 = k_wave_rules with 2/1/4 boards per wave; 8..32 = pooled, forced tile
 
 constexpr int NBE = 16;  // boards per encoder group
@@ -1115,9 +1117,9 @@ hipError_t movegen_encode(const uint64_t* hb, const uint64_t* vb, const uint64_t
         const int G = g_movegen_variant == 2 ? 2 : (g_movegen_variant == 4 ? 4 : 1);
         const int n_mg_groups = mask5 ? (n + WPB * G - 1) / (WPB * G) : 0;
         dim3 grid((unsigned)(n_mg_groups + n_enc_groups));
-        if (G == 1) hipLaunchKernelGGL((k_wave_rules<NBE, 1>), grid, dim3(256), 0, s, hb, vb, meta, n, terminal, mask5, planes, n_mg_groups);
-        else if (G == 4) hipLaunchKernelGGL((k_wave_rules<NBE, 4>), grid, dim3(256), 0, s, hb, vb, meta, n, terminal, mask5, planes, n_mg_groups);
-        else hipLaunchKernelGGL((k_wave_rules<NBE, 2>), grid, dim3(256), 0, s, hb, vb, meta, n, terminal, mask5, planes, n_mg_groups);
+        if (G == 1) hipLaunchKernelGGL((k_wave_rules<NBE, 1>), grid, dim3(256), 0, s, hb, vb, meta, n, terminal, mask5, planes, n_mg_groups, g_detour_wave);
+        else if (G == 4) hipLaunchKernelGGL((k_wave_rules<NBE, 4>), grid, dim3(256), 0, s, hb, vb, meta, n, terminal, mask5, planes, n_mg_groups, g_detour_wave);
+        else hipLaunchKernelGGL((k_wave_rules<NBE, 2>), grid, dim3(256), 0, s, hb, vb, meta, n, terminal, mask5, planes, n_mg_groups, g_detour_wave);
         return hipGetLastError();
     }
     if (g_movegen_variant == 1) {  // the first kernel of this repo, kept for A/B runs
@@ -1131,14 +1133,16 @@ hipError_t movegen_encode(const uint64_t* hb, const uint64_t* vb, const uint64_t
     }
     PoolBoard* recs = reinterpret_cast<PoolBoard*>(scratch);
     PathTab* tabs = reinterpret_cast<PathTab*>(recs + n);
-    // encoder tiles are split over the two launches: ~35 % ride beside the path search, the
-    // rest beside the mask groups
+    // encoder tiles are split over the two launches: 70 % ride beside the path search (a
+    // latency-bound dependent chain of ~31 us that leaves issue slots and the memory pipe idle),
+    // the rest beside the mask groups (~22 us alone).  Sweep at 32,768 boards, S-mid: 35 % 80 us,
+    // 50 % 80, 60 % 77, 70 % 75, 80 % 78, 100 % 82.
     const int enc_total = planes ? (n + NBE - 1) / NBE : 0;
     const int enc_a = mask5 ? (enc_total * g_enc_split_pct) / 100 : 0;
     if (mask5) {
         const int n_path_groups = (2 * n + 255) / 256;
         hipLaunchKernelGGL((k_pool_paths_enc<NBE>), dim3((unsigned)(n_path_groups + enc_a)), dim3(256), 0, s, hb, vb, meta, n,
-                           terminal, recs, tabs, n_path_groups, planes);
+                           terminal, recs, tabs, n_path_groups, planes, g_detour_pooled);
     }
     int nbt = g_movegen_variant >= 8 ? g_movegen_variant : (n >= 16384 ? 24 : (n >= 8192 ? 16 : 8));
     const int enc_b = enc_total - enc_a;
@@ -1190,6 +1194,11 @@ hipError_t harvest(const EngineDev& E, uint64_t* t_hb, uint64_t* t_vb, uint64_t*
     return hipGetLastError();
 }
 void set_movegen_variant(int v) {
+    if (v >= 300 && v < 309) {  // A/B knob: detour_mode of the pooled (v % 3) and the wave-per-board kernel (v / 3)
+        g_detour_pooled = (v - 300) % 3;
+        g_detour_wave = (v - 300) / 3;
+        return;
+    }
     if (v >= 100 && v <= 200) {  // A/B knob: share of the encoder tiles that ride beside the path search
         g_enc_split_pct = v - 100;
         return;

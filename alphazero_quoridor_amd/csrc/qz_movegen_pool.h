@@ -101,7 +101,7 @@ QZ_HD void pool_p0(PoolBoard& c, const Board& b, bool terminal, bool want_moves)
 // ---- P0 + P1 as ONE lane task (device launch 1: lane = (board, player)) -------------------
 // Both lanes of a board derive the board context redundantly (cheap, and it keeps every lane
 // busy); lane p == 1 stores the shared part of the record, each lane stores its own path.
-QZ_HD void pool_k1(const Board& b, bool terminal, bool want_moves, int p, PoolBoard& out, PathTab& tab) {
+QZ_HD void pool_k1(const Board& b, bool terminal, bool want_moves, int p, PoolBoard& out, PathTab& tab, int detour_mode = 0) {
     const bool live = !terminal && want_moves;
     const bool walls = live && ((b.cur == 1 ? b.w1 : b.w2) > 0);
     Blk base;
@@ -146,6 +146,25 @@ QZ_HD void pool_k1(const Board& b, bool terminal, bool want_moves, int p, PoolBo
         uint64_t near = pe.jump ? near_opp_mask(side_opp(b, p)) : 0ull;
         nh = static_ok_h(b.hb, b.vb) & (cm.h | near);
         nv = static_ok_v(b.hb, b.vb) & (cm.v | near);
+        // One flood instead of one per candidate: take away EVERY edge that any of those candidates
+        // would remove (blocked sets are a union over walls, so this is blocked_from of the candidate
+        // set) and all jump edges.  If the goal is still reachable by simple moves, that detour
+        // survives each single candidate, so none of them can cut this player off.  If not, the
+        // horizontal and the vertical candidates are tried as two smaller groups (detour_mode 2).
+        // Floods per board on the synthetic sets: 20 -> 10 (one group) -> 4 (three groups).
+        if (detour_mode >= 1 && (nh | nv) != 0ull) {
+            const int start = side_start(b, p), opp = side_opp(b, p);
+            const BB goal = side_goal(p);
+            Graph g2 = make_graph_nojump(blk_or(base, blocked_from(spread8(nh), spread8(nv))), opp);
+            if (flood_to(g2, bb_bit(start), goal)) {
+                nh = nv = 0ull;
+            } else if (detour_mode >= 2 && nh != 0ull && nv != 0ull) {
+                g2 = make_graph_nojump(blk_or(base, blocked_from(spread8(nh), bb_zero())), opp);
+                if (flood_to(g2, bb_bit(start), goal)) nh = 0ull;
+                g2 = make_graph_nojump(blk_or(base, blocked_from(bb_zero(), spread8(nv))), opp);
+                if (flood_to(g2, bb_bit(start), goal)) nv = 0ull;
+            }
+        }
     }
     out.need[p - 1] = nh;
     out.need[2 + p - 1] = nv;

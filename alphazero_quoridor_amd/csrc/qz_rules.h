@@ -827,6 +827,20 @@ QZ_HD Graph make_graph_plan(Blk blocked, const JumpPlan& plan, int cix, bool hor
     g.j = plan_jumps(plan, cix, horizontal);
     return g;
 }
+// simple moves only (no jump edges); the opponent's tile stays an obstacle
+QZ_HD Graph make_graph_nojump(Blk blocked, int O) {
+    Graph g;
+    g.cn = bb_not(blocked.n);
+    g.cs = bb_not(blocked.s);
+    g.ce = bb_not(blocked.e);
+    g.cw = bb_not(blocked.w);
+    g.notO = bb_not(dest_bit(O));
+    for (int k = 0; k < 4; k++) {
+        g.j.a[k] = -1;
+        g.j.d[k] = bb_zero();
+    }
+    return g;
+}
 // what a candidate wall adds to the blocked sets, written out bit by bit (== candidate_delta)
 QZ_HD Blk candidate_delta_fast(int ix, bool horizontal) {
     int r = ix >> 3, c = ix & 7, b = 9 * r + c;

@@ -92,9 +92,12 @@ def main():
     ap.add_argument("--only", default="S-open,S-mid,S-dense")
     ap.add_argument("--variant", type=int, default=0, help="qz_debug_set_movegen_variant: 0 pooled (default), 1 wave-per-board, 8/16/32 tile size")
     ap.add_argument("--enc-split", type=int, default=-1, help="A/B: percent of the encoder tiles launched beside the path search")
+    ap.add_argument("--detour", type=int, default=-1, help="A/B: pool_k1 detour_mode, pooled + 3 * wave-per-board (0..8)")
     args = ap.parse_args()
     from alphazero_quoridor_amd import _cabi
     _cabi.load().qz_debug_set_movegen_variant(args.variant)
+    if args.detour >= 0:
+        _cabi.load().qz_debug_set_movegen_variant(300 + args.detour)
     if args.enc_split >= 0:
         _cabi.load().qz_debug_set_movegen_variant(100 + args.enc_split)
     dev = torch.device("cuda:0")

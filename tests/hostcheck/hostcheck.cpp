@@ -127,16 +127,18 @@ int hc_ordered(const uint32_t* mask5, int* out) {
 static long g_p2_mismatch = 0;
 extern "C" long hc_p2_mismatches() { return g_p2_mismatch; }
 // ---- the pooled kernel's phases (qz_movegen_pool.h), executed lane by lane for tiles of nb boards
+static int g_try_detour = 0;
+extern "C" void hc_set_detour(int on) { g_try_detour = on; }
 static void pool_tile(const Board* boards, int nb, uint32_t* mask5, float* planes, int64_t* floods, int64_t* flood_iters) {
     std::vector<PoolBoard> ctx(nb);
     std::vector<PathTab> tabs((size_t)nb * 2);
     for (int i = 0; i < nb; i++)  // launch 1: lane = (board, player)
-        for (int p = 2; p >= 1; p--) pool_k1(boards[i], false, true, p, ctx[i], tabs[(size_t)i * 2 + p - 1]);
+        for (int p = 2; p >= 1; p--) pool_k1(boards[i], false, true, p, ctx[i], tabs[(size_t)i * 2 + p - 1], g_try_detour);
     std::vector<uint32_t> items;
     for (int i = 0; i < nb; i++)
         for (int ix = 0; ix < 64; ix++) {
             uint32_t m = pool_p2(ctx[i], ix);
-            if (m != pool_p2_ref(ctx[i], ix)) g_p2_mismatch++;  // need masks must equal the per-slot tests
+            if (!g_try_detour && m != pool_p2_ref(ctx[i], ix)) g_p2_mismatch++;  // need masks must equal the per-slot tests
             if (m & 1u) items.push_back(pool_item(i, ix, true, 1));
             if (m & 2u) items.push_back(pool_item(i, ix, true, 2));
             if (m & 4u) items.push_back(pool_item(i, ix, false, 1));

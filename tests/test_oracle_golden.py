@@ -156,6 +156,17 @@ def test_bitboard_movegen_equals_oracle(hostcheck, positions):
         assert floods.value < 40 * n  # path-cut pruning keeps the floods far below 256 per board
     hostcheck.hc_p2_mismatches.restype = C.c_long
     assert hostcheck.hc_p2_mismatches() == 0  # per-board need masks == per-slot cut tests
+    # group detours (pool_k1 detour_mode 1 / 2): same masks, far fewer floods
+    base_floods = floods.value
+    for mode in (1, 2):
+        hostcheck.hc_set_detour(mode)
+        m = np.zeros((n, 5), dtype=np.uint32)
+        floods = C.c_int64(0)
+        hostcheck.hc_movegen_pool(hb.ctypes.data_as(C.c_void_p), vb.ctypes.data_as(C.c_void_p), meta.ctypes.data_as(C.c_void_p),
+                                  n, 24, m.ctypes.data_as(C.c_void_p), None, C.byref(floods))
+        assert np.array_equal(m, omask), "detour mode %d" % mode
+        assert floods.value < base_floods * (0.75 if mode == 1 else 0.5)
+    hostcheck.hc_set_detour(0)
     # ordered list from the mask through order_index (the expand kernel's slot rule)
     out = (C.c_int * 140)()
     for i in range(0, n, 53):
