@@ -278,6 +278,20 @@ __global__ __launch_bounds__(256) void k_wave_rules(const uint64_t* __restrict__
         const int bw = ((int)blockIdx.x * WPB + wave) * G;  // first board of this wave
         if (bw >= n) return;  // whole wave leaves; only wave-level synchronisation below
         const int ng = (n - bw) < G ? (n - bw) : G;
+        if (G == 1) {
+            // wave-uniform short cut: a terminal board has no moves, a mover without walls only pawn
+            // moves -- one lane, no records, no work list
+            const Board bd = unpack(hb[bw], vb[bw], meta[bw]);
+            const bool term = terminal ? (terminal[bw] != 0) : false;
+            if (term || (bd.cur == 1 ? bd.w1 : bd.w2) <= 0) {
+                if (lane == 0) {
+                    const int loc = bd.cur == 1 ? bd.p1 : bd.p2, opp = bd.cur == 1 ? bd.p2 : bd.p1;
+                    mask5[(size_t)bw * 5] = term ? 0u : pawn_actions_tab(bd.hb, bd.vb, loc, opp, bd.cur);
+                }
+                if (lane >= 1 && lane < 5) mask5[(size_t)bw * 5 + lane] = 0u;
+                return;
+            }
+        }
         WaveBoardShared<G>& ws = sm.w[wave];
         if (lane < 2 * ng) {
             const int g = lane >> 1, b = bw + g;

@@ -9,7 +9,7 @@ eng = SelfPlayEngine(4096, n_playout=400, seed=1, device=dev)
 for _ in range(300):
     eng.run_playouts(ev, 4); eng.finish_move(); eng.harvest()
 L = _cabi.load()
-for variant in (0, 303, 306, 300):  # detour_mode of the wave-per-board kernel: 0 (default), 1, 2, 0
+for variant in (0, 2, 4, 0):  # boards per wavefront of k_wave_rules: 1 (default), 2, 4
     L.qz_debug_set_movegen_variant(variant)
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(200)]
     for i in range(200): eng.playout_step(ev, events=evs[i])
