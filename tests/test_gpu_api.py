@@ -295,3 +295,38 @@ def test_selfplay_then_policy_update_closes_the_loop(gpu_device):
     with quiet():
         tp.collect_selfplay_data(1)
     assert len(tp.data_buffer) > n0 or len(tp.data_buffer) == tp.buffer_size
+
+
+def test_board_groups_equal_independent_engines(gpu_device):
+    """engine.BoardGroups (groups on their own HIP streams, results published to the caller's
+    stream) must produce exactly what the same engines produce one after the other on one stream:
+    moves, pi, harvested tuples."""
+    from alphazero_quoridor_amd.engine import BoardGroups, SelfPlayEngine
+
+    ev = _fixture_net(gpu_device).evaluator("per_leaf")
+    kw = dict(n_playout=6, c_puct=5, temp=1.0, is_selfplay=1)
+    grp = BoardGroups(96, 3, lambda: ev, seed=11, device=gpu_device, **kw)
+    solo = [SelfPlayEngine(32, seed=BoardGroups.group_seed(11, g), device=gpu_device, **kw) for g in range(3)]
+    assert BoardGroups.group_seed(11, 0) == 11 and len({BoardGroups.group_seed(11, g) for g in range(3)}) == 3
+    n_tuples = 0
+    for ply in range(150):
+        got = grp.play_ply()
+        tbs = grp.harvest()
+        exp_tbs = []
+        for g, eng in enumerate(solo):
+            moves, pi = eng.play_ply(ev)
+            assert torch.equal(got[g][0], moves), (ply, g)
+            assert torch.equal(got[g][1], pi), (ply, g)
+            tb = eng.harvest()
+            if tb is not None:
+                exp_tbs.append(tb)
+        assert len(tbs) == len(exp_tbs)
+        for a, b in zip(tbs, exp_tbs):
+            assert a.n_games == b.n_games and torch.equal(a.pi, b.pi) and torch.equal(a.z, b.z)
+            assert torch.equal(a.boards.meta, b.boards.meta) and torch.equal(a.game, b.game)
+            n_tuples += len(a)
+    st = grp.stats()
+    assert st["playouts"] == sum(e.stats()["playouts"] for e in solo)
+    grp.close()
+    for e in solo:
+        e.close()
