@@ -30,6 +30,8 @@ hipError_t sqrt_table(double*, int, hipStream_t);
 void set_movegen_variant(int);
 hipError_t instnorm_act(const float*, const float*, const float*, const float*, float*, long long, int, int, float, hipStream_t);
 hipError_t instnorm_act_nhwc(const float*, const float*, const float*, const float*, float*, long long, int, int, float, hipStream_t);
+hipError_t input_layer(const uint64_t*, const uint64_t*, const uint64_t*, const uint8_t*, long long, const float*, const float*,
+                       const float*, const float*, const float*, float*, float, hipStream_t);
 }  // namespace qzl
 
 static thread_local char g_err[512] = "";
@@ -488,6 +490,29 @@ int qz_nn_instnorm_act_nhwc(const float* x, const float* gamma, const float* bet
     if (n_samples < 0 || channels <= 0 || channels > 64) return fail(QZ_E_INVALID, "bad n_samples/channels (1..64)");
     if (n_samples > 0 && (!x || !gamma || !beta || !out)) return fail(QZ_E_INVALID, "null tensor");
     HIP_TRY(qzl::instnorm_act_nhwc(x, gamma, beta, residual, out, (long long)n_samples, channels, relu, eps, (hipStream_t)stream));
+    return 0;
+}
+
+int qz_nn_input_layer(const qz_boards* boards, const uint8_t* terminal, int64_t n, const float* hot9, const float* base0,
+                      const float* wd, const float* gamma, const float* beta, float* out, float eps, void* stream) {
+    int r;
+    if ((r = device_check())) return r;
+    if (n < 0 || n > 0x7fffffff) return fail(QZ_E_INVALID, "bad n");
+    if ((r = check_boards(boards, (int)n))) return r;
+    if (n > 0 && (!hot9 || !base0 || !wd || !beta || !out)) return fail(QZ_E_INVALID, "null tensor");
+    if (n == 0) return 0;
+    if ((((uintptr_t)hot9 | (uintptr_t)base0 | (uintptr_t)wd | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)out) & 15) != 0)
+        return fail(QZ_E_INVALID, "tables / out must be 16-byte aligned");
+    HIP_TRY(qzl::input_layer((const uint64_t*)boards->hbits, (const uint64_t*)boards->vbits, (const uint64_t*)boards->meta, terminal,
+                             (long long)n, hot9, base0, wd, gamma, beta, out, eps, (hipStream_t)stream));
+    return 0;
+}
+int qz_engine_leaf_boards(qz_engine* e, qz_boards* boards_out, const uint8_t** terminal_out) {
+    if (!e || !boards_out) return fail(QZ_E_INVALID, "null argument");
+    boards_out->hbits = e->dev.leaf_hb;
+    boards_out->vbits = e->dev.leaf_vb;
+    boards_out->meta = e->dev.leaf_meta;
+    if (terminal_out) *terminal_out = e->dev.leaf_term;
     return 0;
 }
 

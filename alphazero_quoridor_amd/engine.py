@@ -95,6 +95,7 @@ class SelfPlayEngine:
         self.pi = torch.zeros((B, 140), dtype=torch.float32, device=dev)
         self._graph = None
         self._graph_steps = 0
+        self._leaf_ref = None
 
     # ------------------------------------------------------------------ plumbing
     def _s(self):
@@ -156,8 +157,23 @@ class SelfPlayEngine:
         assert p.shape == (self.n_boards, 140) and v.numel() == self.n_boards
         _cabi.check(self.L.qz_mcts_expand_backup(self.h, p.data_ptr(), v.data_ptr(), self._s()))
 
+    def leaf_ref(self):
+        """(qz_boards struct, terminal-flag pointer, n) of the engine's current leaf boards: what a
+        LeafEvaluator needs to compute its first layer straight from the boards
+        (qz_nn_input_layer) instead of from the float planes."""
+        if self._leaf_ref is None:
+            st = _cabi.qz_boards()
+            term = C.c_void_p()
+            _cabi.check(self.L.qz_engine_leaf_boards(self.h, C.byref(st), C.byref(term)))
+            self._leaf_ref = (st, term.value, self.n_boards)
+        return self._leaf_ref
+
     def playout_step(self, evaluator, events=None):
-        p, v = evaluator(self.select(events=events))
+        planes = self.select(events=events)
+        if getattr(evaluator, "accepts_leaf_boards", False):
+            p, v = evaluator(planes, leaf=self.leaf_ref())
+        else:
+            p, v = evaluator(planes)
         self.expand_backup(p, v)
 
     def capture_steps(self, evaluator, steps_per_graph=1, warmup=3):

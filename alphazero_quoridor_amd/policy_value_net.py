@@ -93,9 +93,16 @@ class LeafEvaluator:
     legal moves: the expand kernel gathers it at the legal actions, policy_value_net.py:162).
     """
 
-    def __init__(self, net: nn.Module, bn_mode="per_leaf", dtype=torch.float32, channels_last=False, fused_norm=True):
+    def __init__(self, net: nn.Module, bn_mode="per_leaf", dtype=torch.float32, channels_last=False, fused_norm=True,
+                 board_input_layer=True):
         assert bn_mode in ("per_leaf", "batch", "eval")
         self.fused_norm = fused_norm  # per_leaf on the GPU: use the one-pass HIP normalisation kernel
+        # first layer straight from the packed boards (qz_nn_input_layer) when the caller hands them
+        # over: fp32, channels-last, per-leaf or folded BatchNorm
+        self.board_input_layer = board_input_layer and bn_mode in ("per_leaf", "eval") and dtype == torch.float32 \
+            and channels_last and fused_norm
+        self.accepts_leaf_boards = self.board_input_layer
+        self._in_tables = None
         self.net = net
         self.bn_mode = bn_mode
         self.dtype = dtype
@@ -133,6 +140,13 @@ class LeafEvaluator:
         layers.append([torch.cat([hv[0], hp[0]], 0).contiguous(memory_format=mf)] +
                       [None if a is None else torch.cat([a, b], 0) for a, b in zip(hv[1:], hp[1:])])
         fc = [[m.weight.detach().to(dt).clone(), m.bias.detach().to(dt).clone()] for m in (n.fc1, n.fc2, n.fc3)]
+        if self.board_input_layer and layers[0][0].is_cuda:
+            tabs = self._input_tables(layers[0][0])
+            if self._in_tables is None:
+                self._in_tables = tabs
+            else:
+                for o, t in zip(self._in_tables, tabs):
+                    o.copy_(t)
         if getattr(self, "_layers", None) is None:
             self._layers, self._fc = layers, fc
         else:
@@ -140,6 +154,42 @@ class LeafEvaluator:
                 for o, t in zip(old, new):
                     if o is not None:
                         o.copy_(t)
+
+    @staticmethod
+    def _input_tables(w):
+        """Tables of qz_nn_input_layer (include/qz_abi.h) from the first layer's weight
+        [64,26,3,3]: the layer applied, in float64, to the few images state() is made of."""
+        W = w.detach().to(torch.float64).contiguous()
+        dev = W.device
+        img = torch.zeros((22, 26, 9, 9), dtype=torch.float64, device=dev)
+        for i in range(21):
+            img[i, 5 + i] = 1.0              # an all-ones plane 5+i
+        img[21, 0, :8, :8] = 1.0             # plane 0 with no wall on the board
+        out = F.conv2d(img, W, None, 1, 1)   # [22,64,9,9]
+        rep = torch.tensor([0, 4, 8], device=dev)
+        hot9 = out[:21][:, :, rep][:, :, :, rep]                     # [21,64,3,3]: the nine border classes
+        hot9 = hot9.permute(0, 2, 3, 1).reshape(21, 9, 64)
+        base0 = out[21].permute(1, 2, 0).reshape(81, 64)
+        kinds = torch.stack([W[:, 2] - W[:, 0], W[:, 1] - W[:, 0], W[:, 3], W[:, 4]])   # [4,64,3,3]
+        # output (y,x) sees input pixel (y+dy, x+dx) through W[.., dy+1, dx+1]
+        wd = kinds.permute(0, 2, 3, 1).reshape(4, 9, 64)
+        return [t.to(torch.float32).contiguous() for t in (hot9, base0, wd)]
+
+    def _first_layer_from_boards(self, leaf):
+        from . import _cabi
+        import ctypes as C
+        st, term_ptr, n = leaf
+        w, bias, gamma, beta = self._layers[0]
+        dev = w.device
+        out = torch.empty((n, 64, 9, 9), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
+        hot9, base0, wd = self._in_tables
+        if self.bn_mode == "eval":
+            g_ptr, b_ptr = 0, bias.data_ptr()
+        else:
+            g_ptr, b_ptr = gamma.data_ptr(), beta.data_ptr()
+        _cabi.check(_cabi.load().qz_nn_input_layer(C.byref(st), term_ptr or 0, n, hot9.data_ptr(), base0.data_ptr(), wd.data_ptr(),
+                                                   g_ptr, b_ptr, out.data_ptr(), BN_EPS, torch.cuda.current_stream(dev).cuda_stream))
+        return out
 
     def _cbn(self, x, i, relu=True, residual=None):
         w, bias, gamma, beta = self._layers[i]
@@ -172,11 +222,17 @@ class LeafEvaluator:
         return F.relu(y) if relu else y
 
     @torch.no_grad()
-    def __call__(self, planes: torch.Tensor):
-        x = planes.to(self.dtype)
-        if self.channels_last:
-            x = x.contiguous(memory_format=torch.channels_last)
-        x = self._cbn(x, 0)
+    def __call__(self, planes: torch.Tensor, leaf=None):
+        """leaf = (qz_boards struct, terminal-flag device pointer or None, n): the boards `planes`
+        was encoded from (SelfPlayEngine.leaf_ref()); with it the first layer is computed from
+        the 24-byte boards and `planes` is not read."""
+        if leaf is not None and self.board_input_layer and self._in_tables is not None:
+            x = self._first_layer_from_boards(leaf)
+        else:
+            x = planes.to(self.dtype)
+            if self.channels_last:
+                x = x.contiguous(memory_format=torch.channels_last)
+            x = self._cbn(x, 0)
         li = 1
         for _ in range(N_RES):
             y = self._cbn(x, li)

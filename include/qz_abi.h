@@ -197,6 +197,25 @@ int qz_nn_instnorm_act_nhwc(const float* x /*[dev]*/, const float* gamma /*[dev]
                             const float* residual /*[dev] or NULL*/, float* out /*[dev]*/, int64_t n_samples,
                             int channels, int relu, float eps, void* stream);
 
+/* First layer of the policy-value net straight from the boards: out = relu(norm(conv1(state(board))))
+ * without materialising state() (replaces encode + F.conv2d(conv1) + bn1 + relu of
+ * policy_value_net.py:53-60,73 on the reference's leaf evaluation; same values up to fp32 summation
+ * order).  Tables, built from conv1's weight W[64][26][3][3] by the caller (policy_value_net.py,
+ * LeafEvaluator.refresh): hot9 [21][9][64] = 3x3 convolution of an all-ones plane 5+i at the nine
+ * border classes (row class * 3 + column class, class = 0 first / 1 inner / 2 last); base0 [81][64] =
+ * convolution of plane 0 with no wall on the board; wd [4][9][64] = per-tap weights of one extra
+ * pixel: H wall (W2 - W0), V wall (W1 - W0), mover pawn (W3), other pawn (W4), tap = 3*ky + kx.
+ * gamma != NULL: per-leaf normalisation over the 81 positions with gamma / beta (BatchNorm in
+ * training mode on a batch of one); gamma == NULL: beta is a per-channel bias.  terminal[i] != 0
+ * marks a leaf whose planes are all zero (may be NULL).  out: NHWC storage [n][81][64]. */
+int qz_nn_input_layer(const qz_boards* boards /*[dev]*/, const uint8_t* terminal /*[dev] or NULL*/, int64_t n,
+                      const float* hot9 /*[dev]*/, const float* base0 /*[dev]*/, const float* wd /*[dev]*/,
+                      const float* gamma /*[dev] or NULL*/, const float* beta /*[dev]*/, float* out /*[dev]*/, float eps,
+                      void* stream);
+/* the engine's current leaf boards (what qz_mcts_select just produced) and their terminal flags,
+ * as device pointers owned by the engine: input of qz_nn_input_layer */
+int qz_engine_leaf_boards(qz_engine* e, qz_boards* boards_out, const uint8_t** terminal_out);
+
 /* self-test hook for the GPU tests: out[i] <- device sqrt((double)i), i < n.  The PUCT term
  * uses np.sqrt(parent visits) in float64 (mcts.py:69); the test checks the device result is
  * correctly rounded. */
@@ -204,7 +223,8 @@ int qz_selftest_sqrt(double* out /*[dev]*/, int n, void* stream);
 /* A/B hook for benchmarks and tests: 0 = pick by batch size (default: k_wave_rules below 8,192
  * boards, pooled pipeline above), 1 = the first wave-per-board kernel, 2 | 3 | 4 = k_wave_rules
  * with 2 | 1 | 4 boards per wavefront, 8 | 12 | 16 | 24 | 32 = pooled pipeline with that many
- * boards per mask workgroup */
+ * boards per mask workgroup; 100 + p = p percent of the encoder groups beside the path groups;
+ * 300 + a + 3 b = group-detour mode a (0 | 1 | 2) in the pooled pipeline, b in k_wave_rules */
 int qz_debug_set_movegen_variant(int variant);
 
 #ifdef __cplusplus

@@ -330,3 +330,52 @@ def test_board_groups_equal_independent_engines(gpu_device):
     grp.close()
     for e in solo:
         e.close()
+
+
+def test_input_layer_from_boards_equals_conv_of_planes(gpu_device, golden_dir):
+    """qz_nn_input_layer: relu(norm(conv1(state(board)))) computed from the 24-byte boards must
+    equal the same layer applied to the encoder's planes (fp32 summation order aside), for live
+    and terminal leaves, with per-leaf and with folded BatchNorm; end to end the evaluator's
+    (p, v) stay within the 1e-5 of the parity contract."""
+    from alphazero_quoridor_amd import rules
+    from alphazero_quoridor_amd.boards import DeviceBoards
+    from alphazero_quoridor_amd.policy_value_net import LeafEvaluator
+
+    pos = np.load(str(golden_dir) + "/rules_positions.npz")
+    packed = pos["board"][::7][:3000]
+    db = DeviceBoards.from_packed(packed, gpu_device)
+    n = db.n
+    g = torch.Generator(device="cpu").manual_seed(5)
+    term = (torch.rand(n, generator=g) < 0.05).to(torch.uint8).to(gpu_device)
+    planes = rules.encode(db)
+    planes[term.bool()] = 0.0  # a terminal leaf has all-zero planes (mcts.py:118-125 never evaluates it)
+    pvn = _fixture_net(gpu_device)
+    bn = pvn.policy_value_net.bn1  # make the folded-BN mode non-trivial
+    with torch.no_grad():
+        bn.running_mean.copy_(torch.linspace(-0.3, 0.4, 64))
+        bn.running_var.copy_(torch.linspace(0.5, 2.0, 64))
+    leaf = (db.struct(), term.data_ptr(), n)
+    for mode in ("per_leaf", "eval"):
+        ev = LeafEvaluator(pvn.policy_value_net, mode, channels_last=True)
+        assert ev.accepts_leaf_boards
+        x = planes.contiguous(memory_format=torch.channels_last)
+        ref = ev._cbn(x, 0)                       # MIOpen convolution + fused normalisation on the planes
+        got = ev._first_layer_from_boards(leaf)
+        assert got.shape == ref.shape and got.is_contiguous(memory_format=torch.channels_last)
+        err = (got - ref).abs().max().item()
+        assert err < 2e-5, (mode, err)
+        p0, v0 = ev(planes)
+        p1, v1 = ev(planes, leaf=leaf)
+        assert (p0 - p1).abs().max().item() < 1e-5 and (v0 - v1).abs().max().item() < 1e-5, mode
+    # the engine hands its leaf boards to such an evaluator by itself
+    from alphazero_quoridor_amd.engine import SelfPlayEngine
+    ev = LeafEvaluator(pvn.policy_value_net, "per_leaf", channels_last=True)
+    ev_planes = LeafEvaluator(pvn.policy_value_net, "per_leaf", channels_last=True, board_input_layer=False)
+    eng = SelfPlayEngine(64, n_playout=16, seed=4, device=gpu_device)
+    for _ in range(30):
+        eng.playout_step(ev)
+    pl = eng.select(want_mask=True)
+    pa, va = ev(pl, leaf=eng.leaf_ref())
+    pb, vb = ev_planes(pl)
+    assert (pa - pb).abs().max().item() < 1e-5 and (va - vb).abs().max().item() < 1e-5
+    eng.close()
