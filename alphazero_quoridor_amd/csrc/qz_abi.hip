@@ -32,6 +32,8 @@ hipError_t instnorm_act(const float*, const float*, const float*, const float*, 
 hipError_t instnorm_act_nhwc(const float*, const float*, const float*, const float*, float*, long long, int, int, float, hipStream_t);
 hipError_t input_layer(const uint64_t*, const uint64_t*, const uint64_t*, const uint8_t*, long long, const float*, const float*,
                        const float*, const float*, const float*, float*, float, hipStream_t);
+hipError_t head(const float*, long long, const float*, const float*, const float*, const float*, const float*, const float*, const float*,
+                const float*, const float*, float*, float*, float, hipStream_t);
 }  // namespace qzl
 
 static thread_local char g_err[512] = "";
@@ -505,6 +507,17 @@ int qz_nn_input_layer(const qz_boards* boards, const uint8_t* terminal, int64_t 
         return fail(QZ_E_INVALID, "tables / out must be 16-byte aligned");
     HIP_TRY(qzl::input_layer((const uint64_t*)boards->hbits, (const uint64_t*)boards->vbits, (const uint64_t*)boards->meta, terminal,
                              (long long)n, hot9, base0, wd, gamma, beta, out, eps, (hipStream_t)stream));
+    return 0;
+}
+int qz_nn_head(const float* t, int64_t n, const float* w6k, const float* gamma6, const float* beta6, const float* w1t, const float* b1,
+               const float* w2, const float* b2, const float* w3t, const float* b3, float* p_out, float* v_out, float eps, void* stream) {
+    int r;
+    if ((r = device_check())) return r;
+    if (n < 0) return fail(QZ_E_INVALID, "n < 0");
+    if (n == 0) return 0;
+    if (!t || !w6k || !beta6 || !w1t || !b1 || !w2 || !b2 || !w3t || !b3 || !p_out || !v_out) return fail(QZ_E_INVALID, "null tensor");
+    if (((uintptr_t)t & 15) != 0) return fail(QZ_E_INVALID, "t must be 16-byte aligned");
+    HIP_TRY(qzl::head(t, (long long)n, w6k, gamma6, beta6, w1t, b1, w2, b2, w3t, b3, p_out, v_out, eps, (hipStream_t)stream));
     return 0;
 }
 int qz_engine_leaf_boards(qz_engine* e, qz_boards* boards_out, const uint8_t** terminal_out) {

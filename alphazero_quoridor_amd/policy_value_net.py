@@ -94,7 +94,7 @@ class LeafEvaluator:
     """
 
     def __init__(self, net: nn.Module, bn_mode="per_leaf", dtype=torch.float32, channels_last=False, fused_norm=True,
-                 board_input_layer=True):
+                 board_input_layer=True, fused_head=True):
         assert bn_mode in ("per_leaf", "batch", "eval")
         self.fused_norm = fused_norm  # per_leaf on the GPU: use the one-pass HIP normalisation kernel
         # first layer straight from the packed boards (qz_nn_input_layer) when the caller hands them
@@ -103,6 +103,11 @@ class LeafEvaluator:
             and channels_last and fused_norm
         self.accepts_leaf_boards = self.board_input_layer
         self._in_tables = None
+        # both heads in one HIP kernel (qz_nn_head), same conditions: 118 us instead of 183 us for the
+        # library convolution + zero-fill + normalisation + three GEMMs + softmax/exp/tanh + copies
+        self.fused_head = fused_head and fused_norm and bn_mode in ("per_leaf", "eval") and dtype == torch.float32 \
+            and channels_last
+        self._head = None
         self.net = net
         self.bn_mode = bn_mode
         self.dtype = dtype
@@ -140,6 +145,19 @@ class LeafEvaluator:
         layers.append([torch.cat([hv[0], hp[0]], 0).contiguous(memory_format=mf)] +
                       [None if a is None else torch.cat([a, b], 0) for a, b in zip(hv[1:], hp[1:])])
         fc = [[m.weight.detach().to(dt).clone(), m.bias.detach().to(dt).clone()] for m in (n.fc1, n.fc2, n.fc3)]
+        if self.fused_head and layers[0][0].is_cuda:
+            hw, hbias, hg, hb = layers[-1]
+            head = [hw.permute(2, 3, 1, 0).reshape(9, 64, 6).contiguous(),          # [tap][cin][6]
+                    (hbias if self.bn_mode == "eval" else hb).contiguous(),
+                    fc[0][0].t().contiguous(), fc[0][1], fc[1][0].reshape(-1).contiguous(), fc[1][1],
+                    fc[2][0].t().contiguous(), fc[2][1]]
+            if self.bn_mode != "eval":
+                head.append(hg.contiguous())
+            if self._head is None:
+                self._head = head
+            else:
+                for o, t in zip(self._head, head):
+                    o.copy_(t)
         if self.board_input_layer and layers[0][0].is_cuda:
             tabs = self._input_tables(layers[0][0])
             if self._in_tables is None:
@@ -239,6 +257,16 @@ class LeafEvaluator:
             x = self._cbn(y, li + 1, relu=True, residual=x)
             li += 2
         B = x.shape[0]
+        if self.fused_head and self._head is not None and x.is_cuda and x.is_contiguous(memory_format=torch.channels_last):
+            from . import _cabi
+            hd = self._head
+            p = torch.empty((B, N_ACTIONS), dtype=torch.float32, device=x.device)
+            v = torch.empty(B, dtype=torch.float32, device=x.device)
+            _cabi.check(_cabi.load().qz_nn_head(
+                x.data_ptr(), B, hd[0].data_ptr(), hd[8].data_ptr() if len(hd) > 8 else 0, hd[1].data_ptr(), hd[2].data_ptr(),
+                hd[3].data_ptr(), hd[4].data_ptr(), hd[5].data_ptr(), hd[6].data_ptr(), hd[7].data_ptr(), p.data_ptr(), v.data_ptr(),
+                BN_EPS, torch.cuda.current_stream(x.device).cuda_stream))
+            return p, v
         h = self._cbn(x, li + 2)  # merged value+policy head convolution (all norm modes are per channel)
         v = h[:, :4].reshape(B, 4 * 81)
         p = h[:, 4:].reshape(B, 2 * 81)

@@ -212,6 +212,14 @@ int qz_nn_input_layer(const qz_boards* boards /*[dev]*/, const uint8_t* terminal
                       const float* hot9 /*[dev]*/, const float* base0 /*[dev]*/, const float* wd /*[dev]*/,
                       const float* gamma /*[dev] or NULL*/, const float* beta /*[dev]*/, float* out /*[dev]*/, float eps,
                       void* stream);
+/* Both heads of the policy-value net in one pass (policy_value_net.py:64-70,88-93,155): trunk
+ * output t (NHWC [n][81][64]) -> p [n][140] = exp(log_softmax(fc3(.))), v [n] = tanh(fc2(fc1(.))).
+ * w6k [9][64][6]: the 3x3 weights of conv2 (channels 0..3) and conv3 (4..5), tap-major; gamma6 / beta6
+ * [6]: bn2 + bn3 per-leaf normalisation (gamma6 == NULL: beta6 is a bias, folded BatchNorm);
+ * w1t [324][128], w3t [162][140]: fc1 / fc3 weights transposed; b1 [128], w2 [128], b2 [1], b3 [140]. */
+int qz_nn_head(const float* t /*[dev]*/, int64_t n, const float* w6k, const float* gamma6 /*or NULL*/, const float* beta6,
+               const float* w1t, const float* b1, const float* w2, const float* b2, const float* w3t, const float* b3,
+               float* p_out /*[dev] n*140*/, float* v_out /*[dev] n*/, float eps, void* stream);
 /* the engine's current leaf boards (what qz_mcts_select just produced) and their terminal flags,
  * as device pointers owned by the engine: input of qz_nn_input_layer */
 int qz_engine_leaf_boards(qz_engine* e, qz_boards* boards_out, const uint8_t** terminal_out);

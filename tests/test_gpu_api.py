@@ -379,3 +379,30 @@ def test_input_layer_from_boards_equals_conv_of_planes(gpu_device, golden_dir):
     pb, vb = ev_planes(pl)
     assert (pa - pb).abs().max().item() < 1e-5 and (va - vb).abs().max().item() < 1e-5
     eng.close()
+
+
+def test_fused_head_kernel_equals_library_head(gpu_device):
+    """qz_nn_head (conv2+conv3 merged, bn2/bn3 per leaf or folded, fc1/fc2/tanh, fc3/softmax) ==
+    the same head through MIOpen / rocBLAS / torch ops, for ragged batch sizes (3 leaves per
+    workgroup) and both BatchNorm modes."""
+    from alphazero_quoridor_amd.policy_value_net import LeafEvaluator
+
+    pvn = _fixture_net(gpu_device)
+    with torch.no_grad():
+        for bn in (pvn.policy_value_net.bn2, pvn.policy_value_net.bn3):
+            bn.running_mean.copy_(torch.linspace(-0.2, 0.3, bn.num_features))
+            bn.running_var.copy_(torch.linspace(0.6, 1.7, bn.num_features))
+    g = torch.Generator(device="cpu").manual_seed(9)
+    for mode in ("per_leaf", "eval"):
+        fused = LeafEvaluator(pvn.policy_value_net, mode, channels_last=True)
+        plain = LeafEvaluator(pvn.policy_value_net, mode, channels_last=True, fused_head=False)
+        assert not plain.fused_head
+        assert fused.fused_head and fused._head is not None
+        for B in (1, 2, 3, 4, 7, 256, 1000):
+            xs = (torch.rand((B, 26, 9, 9), generator=g) > 0.8).float().to(gpu_device)
+            p1, v1 = fused(xs)
+            p2, v2 = plain(xs)
+            assert p1.shape == (B, 140) and v1.shape == (B,)
+            assert (p1 - p2).abs().max().item() < 1e-5, (mode, B)
+            assert (v1 - v2).abs().max().item() < 1e-5, (mode, B)
+            assert (p1.sum(dim=1) - 1).abs().max().item() < 1e-5
