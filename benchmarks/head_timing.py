@@ -1,16 +1,29 @@
-"""Times the fused head kernel (qz_nn_head) against the library head on a 4,096-leaf batch."""
+"""Times the fused head kernel (qz_nn_head) alone and the forward pass with / without it on a
+4,096-leaf batch."""
 import os, sys, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+from alphazero_quoridor_amd import _cabi
 from alphazero_quoridor_amd.policy_value_net import PolicyValueNet, LeafEvaluator
 dev = torch.device("cuda:0"); torch.manual_seed(1); torch.backends.cudnn.benchmark = True
 net = PolicyValueNet(use_gpu=True)
-x = (torch.rand((4096, 26, 9, 9), device=dev) > 0.8).float()
-for fused in (True, False, True):
-    ev = LeafEvaluator(net.policy_value_net, "per_leaf", channels_last=True, fused_head=fused)
-    for _ in range(5): ev(x)
+ev = LeafEvaluator(net.policy_value_net, "per_leaf", channels_last=True)
+t = torch.rand((4096, 64, 9, 9), device=dev).contiguous(memory_format=torch.channels_last)
+hd, L = ev._head, _cabi.load()
+p = torch.empty((4096, 140), device=dev); v = torch.empty(4096, device=dev)
+def head():
+    _cabi.check(L.qz_nn_head(t.data_ptr(), 4096, hd[0].data_ptr(), hd[8].data_ptr(), hd[1].data_ptr(), hd[2].data_ptr(), hd[3].data_ptr(),
+                             hd[4].data_ptr(), hd[5].data_ptr(), hd[6].data_ptr(), hd[7].data_ptr(), p.data_ptr(), v.data_ptr(), 1e-5,
+                             torch.cuda.current_stream().cuda_stream))
+def timeit(f, n=50):
+    for _ in range(5): f()
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
-    for _ in range(30): ev(x)
+    for _ in range(n): f()
     b.record(); torch.cuda.synchronize()
-    print("fused_head", fused, "forward ms %.3f" % (a.elapsed_time(b) / 30))
+    return a.elapsed_time(b) / n * 1e3
+print("qz_nn_head alone: %.1f us" % timeit(head))
+x = (torch.rand((4096, 26, 9, 9), device=dev) > 0.8).float()
+for fused in (True, False):
+    e2 = LeafEvaluator(net.policy_value_net, "per_leaf", channels_last=True, fused_head=fused)
+    print("forward, fused_head=%s: %.1f us" % (fused, timeit(lambda: e2(x), 30)))
