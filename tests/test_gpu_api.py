@@ -291,6 +291,9 @@ def test_selfplay_then_policy_update_closes_the_loop(gpu_device):
     with torch.no_grad():
         ref = torch.cat([torch.exp(tp.policy_value_net.policy_value_net(x[i:i + 1])[0]) for i in range(8)])
     assert (ref - after).abs().max().item() < 1e-5
+    # the tables of the board input layer follow the weights as well (rebuilt in place)
+    fresh = ev._input_tables(ev._layers[0][0])
+    assert all(torch.equal(a, b) for a, b in zip(ev._in_tables, fresh))
     n0 = len(tp.data_buffer)
     with quiet():
         tp.collect_selfplay_data(1)
