@@ -402,7 +402,9 @@ __global__ __launch_bounds__(256) void k_input_layer(const uint64_t* __restrict_
 // positions do not collide.  fc1 runs on wavefronts 0-1 and fc3 on wavefronts 2-3 with
 // pre-transposed weights (coalesced), each weight read once for the three leaves.
 typedef float f2_t __attribute__((ext_vector_type(2)));
-constexpr int HB = 9;     // leaves per workgroup: thread = (position, group of three leaves), 243 of 256 threads
+constexpr int HB = 6;     // leaves per workgroup: thread = (position, group of three leaves), 162 of 192 threads
+constexpr int HT = 192;   // threads per workgroup; with 78 KB of LDS two workgroups share a CU, so one's
+                          // latency-bound phases (staging, fully connected layers) run under the other's convolution
 constexpr int XS = 36;    // row stride of a staged half tile (32 input channels + 4 pad), floats
 constexpr int FS = 488;   // feature stride per leaf (486 used; 16-byte aligned rows)
 struct HeadFc {           // lives in the tile memory once the convolutions are done
@@ -410,23 +412,23 @@ struct HeadFc {           // lives in the tile memory once the convolutions are 
     float logit[HB][144];
 };
 template <bool NORM>
-__global__ __launch_bounds__(256) void k_head(const float* __restrict__ t, long long n, const float* __restrict__ w6k,
+__global__ __launch_bounds__(HT) void k_head(const float* __restrict__ t, long long n, const float* __restrict__ w6k,
                                               const float* __restrict__ gamma6, const float* __restrict__ beta6,
                                               const float* __restrict__ w1t, const float* __restrict__ b1,
                                               const float* __restrict__ w2, const float* __restrict__ b2,
                                               const float* __restrict__ w3t, const float* __restrict__ b3,
                                               float* __restrict__ p_out, float* __restrict__ v_out, float eps) {
-    __shared__ __attribute__((aligned(16))) float s_x[HB * PL * XS];   // 105 KB: nine half tiles, later HeadFc
+    __shared__ __attribute__((aligned(16))) float s_x[HB * PL * XS];   // 70 KB: six half tiles; later features + HeadFc
     __shared__ __attribute__((aligned(16))) float s_w[9 * 32 * 6];     // the 3x3 weights of the current half
-    __shared__ __attribute__((aligned(16))) float s_f[HB * FS];        // normalised features, c*81+pos order
+    float* const s_f = s_x;                                            // normalised features, c*81+pos order (tiles are dead by then)
     __shared__ float s_part[HB * 6][4];
     __shared__ float s_stat[HB * 6][2];
-    static_assert(sizeof(HeadFc) <= sizeof(float) * HB * PL * XS, "fc scratch must fit in the tile memory");
+    static_assert(sizeof(HeadFc) + sizeof(float) * HB * FS <= sizeof(float) * HB * PL * XS, "features + fc scratch must fit in the tile memory");
     const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const long long s0 = (long long)blockIdx.x * HB;
     const int nb = (int)((n - s0) < HB ? (n - s0) : HB);
     const int grp = tid / PL, pos = tid - PL * grp;   // conv role: leaves 3 grp .. 3 grp + 2 at one position
-    const bool active = tid < 3 * PL;
+    const bool active = tid < (HB / 3) * PL;
     f2_t acc[3][3];
 #pragma unroll
     for (int s = 0; s < 3; s++)
@@ -436,11 +438,11 @@ __global__ __launch_bounds__(256) void k_head(const float* __restrict__ t, long 
     for (int half = 0; half < 2; half++) {
         if (half) __syncthreads();
         // float4 q = (leaf, position, channel quad of the half); eight loads in flight per thread
-        for (int q0 = tid; q0 < HB * PL * 8; q0 += 256 * 8) {
+        for (int q0 = tid; q0 < HB * PL * 8; q0 += HT * 8) {
             float4 v[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                const int q = q0 + 256 * k;
+                const int q = q0 + HT * k;
                 const int sl = q / (PL * 8), rem = q - sl * (PL * 8), p = rem >> 3, c4 = rem & 7;
                 v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (q < HB * PL * 8 && sl < nb)
@@ -448,12 +450,12 @@ __global__ __launch_bounds__(256) void k_head(const float* __restrict__ t, long 
             }
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                const int q = q0 + 256 * k;
+                const int q = q0 + HT * k;
                 const int sl = q / (PL * 8), rem = q - sl * (PL * 8), p = rem >> 3, c4 = rem & 7;
                 if (q < HB * PL * 8) *reinterpret_cast<float4*>(&s_x[(sl * PL + p) * XS + c4 * 4]) = v[k];
             }
         }
-        for (int q = tid; q < 9 * 32 * 6 / 4; q += 256) {  // [tap][32 channels of this half][6]
+        for (int q = tid; q < 9 * 32 * 6 / 4; q += HT) {  // [tap][32 channels of this half][6]
             const int tap = q / 48, r4 = q - tap * 48;
             reinterpret_cast<float4*>(s_w)[q] = reinterpret_cast<const float4*>(w6k + (tap * 64 + half * 32) * 6)[r4];
         }
@@ -495,6 +497,7 @@ __global__ __launch_bounds__(256) void k_head(const float* __restrict__ t, long 
             }
         }
     }
+    __syncthreads();  // every thread is done with the tiles: their memory becomes the feature buffer
     if (active) {
 #pragma unroll
         for (int sl = 0; sl < 3; sl++) {
@@ -556,7 +559,7 @@ __global__ __launch_bounds__(256) void k_head(const float* __restrict__ t, long 
         }
     }
     __syncthreads();
-    HeadFc& fc = *reinterpret_cast<HeadFc*>(s_x);
+    HeadFc& fc = *reinterpret_cast<HeadFc*>(s_x + HB * FS);
     if (wave < 2) {  // fc1: 324 -> 128, thread = output
         const int j = tid;
         float a1[HB];
@@ -582,18 +585,19 @@ __global__ __launch_bounds__(256) void k_head(const float* __restrict__ t, long 
         const float bb = b1[j];
 #pragma unroll
         for (int s = 0; s < HB; s++) fc.h1[s][j] = a1[s] + bb;
-    } else {  // fc3: 162 -> 140, thread = outputs j and j + 128
-        const int j = tid - 128, j2 = j + 128;
-        const bool two = j2 < 140;
-        float a3[HB], a3b[HB];
+    } else {  // fc3: 162 -> 140 on the third wavefront, thread = outputs j, j + 64, j + 128
+        const int j = tid - 128, j1 = j + 64, j2 = j + 128;
+        const bool three = j2 < 140;
+        float a3[HB], a3b[HB], a3c[HB];
 #pragma unroll
-        for (int s = 0; s < HB; s++) a3[s] = a3b[s] = 0.f;
-        for (int i = 0; i < 2 * PL; i += 6) {  // 162 = 27 * 6: up to 12 loads in flight per trip
-            float wa[6], wb[6];
+        for (int s = 0; s < HB; s++) a3[s] = a3b[s] = a3c[s] = 0.f;
+        for (int i = 0; i < 2 * PL; i += 6) {  // 162 = 27 * 6: up to 18 loads in flight per trip
+            float wa[6], wb[6], wc[6];
 #pragma unroll
             for (int k = 0; k < 6; k++) {
                 wa[k] = w3t[(i + k) * 140 + j];
-                wb[k] = two ? w3t[(i + k) * 140 + j2] : 0.f;
+                wb[k] = w3t[(i + k) * 140 + j1];
+                wc[k] = three ? w3t[(i + k) * 140 + j2] : 0.f;
             }
 #pragma unroll
             for (int s = 0; s < HB; s++) {
@@ -604,18 +608,21 @@ __global__ __launch_bounds__(256) void k_head(const float* __restrict__ t, long 
                     a3[s] = __builtin_fmaf(wa[2 * k2 + 1], f.y, a3[s]);
                     a3b[s] = __builtin_fmaf(wb[2 * k2], f.x, a3b[s]);
                     a3b[s] = __builtin_fmaf(wb[2 * k2 + 1], f.y, a3b[s]);
+                    a3c[s] = __builtin_fmaf(wc[2 * k2], f.x, a3c[s]);
+                    a3c[s] = __builtin_fmaf(wc[2 * k2 + 1], f.y, a3c[s]);
                 }
             }
         }
-        const float ba = b3[j], bb = two ? b3[j2] : 0.f;
+        const float ba = b3[j], bb = b3[j1], bc = three ? b3[j2] : 0.f;
 #pragma unroll
         for (int s = 0; s < HB; s++) {
             fc.logit[s][j] = a3[s] + ba;
-            if (two) fc.logit[s][j2] = a3b[s] + bb;
+            fc.logit[s][j1] = a3b[s] + bb;
+            if (three) fc.logit[s][j2] = a3c[s] + bc;
         }
     }
     __syncthreads();
-    for (int s = wave; s < nb; s += 4) {  // a wavefront finishes a leaf
+    for (int s = wave; s < nb; s += HT / 64) {  // a wavefront finishes a leaf
         float part = fc.h1[s][lane] * w2[lane] + fc.h1[s][lane + 64] * w2[lane + 64];
         for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
         if (lane == 0) v_out[s0 + s] = tanhf(part + b2[0]);
@@ -683,7 +690,7 @@ hipError_t input_layer(const uint64_t* hb, const uint64_t* vb, const uint64_t* m
 hipError_t head(const float* t, long long n, const float* w6k, const float* gamma6, const float* beta6, const float* w1t, const float* b1,
                 const float* w2, const float* b2, const float* w3t, const float* b3, float* p_out, float* v_out, float eps, hipStream_t s) {
     if (n <= 0) return hipSuccess;
-    dim3 grid((unsigned)((n + HB - 1) / HB)), block(256);
+    dim3 grid((unsigned)((n + HB - 1) / HB)), block(HT);
     if (gamma6) hipLaunchKernelGGL((k_head<true>), grid, block, 0, s, t, n, w6k, gamma6, beta6, w1t, b1, w2, b2, w3t, b3, p_out, v_out, eps);
     else hipLaunchKernelGGL((k_head<false>), grid, block, 0, s, t, n, w6k, gamma6, beta6, w1t, b1, w2, b2, w3t, b3, p_out, v_out, eps);
     return hipGetLastError();

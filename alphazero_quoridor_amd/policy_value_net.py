@@ -103,7 +103,7 @@ class LeafEvaluator:
             and channels_last and fused_norm
         self.accepts_leaf_boards = self.board_input_layer
         self._in_tables = None
-        # both heads in one HIP kernel (qz_nn_head), same conditions: 118 us instead of 183 us for the
+        # both heads in one HIP kernel (qz_nn_head), same conditions: 104 us instead of 183 us for the
         # library convolution + zero-fill + normalisation + three GEMMs + softmax/exp/tanh + copies
         self.fused_head = fused_head and fused_norm and bn_mode in ("per_leaf", "eval") and dtype == torch.float32 \
             and channels_last
