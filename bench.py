@@ -109,6 +109,10 @@ def main():
     from alphazero_quoridor_amd.engine import BoardGroups
     from alphazero_quoridor_amd.policy_value_net import PolicyValueNet
 
+    if os.environ.get("QZ_DEBUG_VARIANT"):  # A/B knobs of include/qz_abi.h (qz_debug_set_movegen_variant), comma separated
+        from alphazero_quoridor_amd import _cabi
+        for v in os.environ["QZ_DEBUG_VARIANT"].split(","):
+            _cabi.load().qz_debug_set_movegen_variant(int(v))
     rank, local, world = qdist.init_from_env("cuda")
     assert world == args.gpus or world == 1, "WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU path)"
