@@ -297,6 +297,14 @@ __global__ __launch_bounds__(256) void k_input_layer(const uint64_t* __restrict_
         bd.cur = (int)((m >> 32) & 0xFF);
     }
     const bool term = terminal ? (terminal[b] != 0) : false;
+    // the base rows only depend on the thread: issue their loads before anything waits on the board
+    const bool tail = tid < 16;
+    float4 base[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const int p = (tid >> 4) + 16 * k;
+        base[k] = (k < 5 || tail) ? reinterpret_cast<const float4*>(base0)[p * 16 + cq] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     for (int q = tid; q < 576; q += 256) reinterpret_cast<float4*>(s_wd)[q] = reinterpret_cast<const float4*>(wd)[q];
     {
         const int wm = bd.cur == 1 ? bd.w1 : bd.w2, wo = bd.cur == 1 ? bd.w2 : bd.w1;
@@ -326,7 +334,6 @@ __global__ __launch_bounds__(256) void k_input_layer(const uint64_t* __restrict_
         s_code[tid] = (uint8_t)code;
     }
     __syncthreads();
-    const bool tail = tid < 16;
     float4 v[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) {
@@ -335,7 +342,7 @@ __global__ __launch_bounds__(256) void k_input_layer(const uint64_t* __restrict_
         if ((k < 5 || tail) && !term) {
             const int y = p / 9, x = p - 9 * y;
             const int cls = (y == 0 ? 0 : (y == 8 ? 2 : 1)) * 3 + (x == 0 ? 0 : (x == 8 ? 2 : 1));
-            acc = f4_add(reinterpret_cast<const float4*>(s_s9)[cls * 16 + cq], reinterpret_cast<const float4*>(base0)[p * 16 + cq]);
+            acc = f4_add(reinterpret_cast<const float4*>(s_s9)[cls * 16 + cq], base[k]);
             for (int dy = -1; dy <= 1; dy++) {
                 const int ny = y + dy;
                 if (ny < 0 || ny > 8) continue;
