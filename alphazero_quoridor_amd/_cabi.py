@@ -72,7 +72,8 @@ class qz_stats(C.Structure):
         ("pending_plies", C.c_int64),
         ("arena_bytes", C.c_int64),
         ("descent_levels", C.c_int64),
-        ("reserved", C.c_int64 * 2),
+        ("max_nodes", C.c_int64),
+        ("max_edges", C.c_int64),
     ]
 
 

@@ -206,10 +206,13 @@ int qz_engine_create(const qz_config* cfg, qz_engine** out) {
     if (!e) return fail(QZ_E_OOM, "host allocation failed");
     e->cfg = *cfg;
     qz_config& c = e->cfg;
-    // nodes are 16 B, edges 21 B.  Early game: <= n_playout new nodes x <= 131 edges per ply.
-    // Late game (no walls left, 2-5 legal moves) trees get narrow and deep and most of the
-    // tree survives a re-root, so the node pool is sized generously and separately.
-    if (c.node_cap <= 0) c.node_cap = 16 * c.n_playout + 256;
+    // nodes are 16 B, edges 32 B.  Early game: <= n_playout new nodes x <= 131 edges per ply.
+    // Late game (no walls left, 2-5 legal moves) trees get narrow and deep and almost the whole
+    // tree survives a re-root: in forced lines a tree grows by ~0.9 n_playout nodes per ply.
+    // Measured peak over 80 plies x 2,048 boards at n_playout = 400: 12,798 nodes (32 per playout),
+    // 65,084 edges (benchmarks/arena_occupancy.py); 16 n + 256 nodes overflowed 2,004 times in a
+    // bench run.  Nodes are cheap (64 n + 256 of them = 0.8 MB per board, the edges 8.8 MB).
+    if (c.node_cap <= 0) c.node_cap = 64 * c.n_playout + 256;
     if (c.edge_cap <= 0) c.edge_cap = 131 * c.n_playout + 80 * (2 * c.n_playout + 256);
     c.edge_cap = (c.edge_cap + 63) & ~63;
     if (c.max_plies <= 0) c.max_plies = 4096;  // reference-faithful random-net games run to thousands of plies
@@ -442,17 +445,22 @@ int qz_engine_stats(qz_engine* e, qz_stats* out, void* stream) {
     unsigned long long h[QZ_C_COUNT];
     hipStream_t s = (hipStream_t)stream;
     const size_t B = (size_t)e->cfg.n_boards;
-    std::vector<uint32_t> bp(B), bt(B), bo(B);
+    std::vector<uint32_t> bp(B), bt(B), bo(B), nn(B), ne(B);
     std::vector<unsigned long long> bl(B);
     HIP_TRY(hipMemcpyAsync(h, e->dev.counters, sizeof(h), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(bp.data(), e->dev.bc_playouts, B * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(bt.data(), e->dev.bc_terminal, B * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(bo.data(), e->dev.bc_overflow, B * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(bl.data(), e->dev.bc_levels, B * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(nn.data(), e->dev.n_nodes, B * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(ne.data(), e->dev.n_edges, B * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     // per-board counters wrap at 2^32 playouts per board (years); sums are 64-bit
     unsigned long long sp = 0, st = 0, so = 0, sl = 0;
+    uint32_t mn = 0, me = 0;
     for (size_t i = 0; i < B; i++) {
+        mn = nn[i] > mn ? nn[i] : mn;
+        me = ne[i] > me ? ne[i] : me;
         sp += bp[i];
         st += bt[i];
         so += bo[i];
@@ -469,6 +477,8 @@ int qz_engine_stats(qz_engine* e, qz_stats* out, void* stream) {
     out->pending_plies = (int64_t)h[QZ_C_PENDING_PLIES];
     out->descent_levels = (int64_t)sl;
     out->arena_bytes = e->bytes;
+    out->max_nodes = (int64_t)mn;
+    out->max_edges = (int64_t)me;
     return 0;
 }
 

@@ -255,7 +255,7 @@ class SelfPlayEngine:
     def stats(self) -> dict:
         st = _cabi.qz_stats()
         _cabi.check(self.L.qz_engine_stats(self.h, C.byref(st), self._s()))
-        return {k: int(getattr(st, k)) for k, _ in st._fields_ if k != "reserved"}
+        return {k: int(getattr(st, k)) for k, _ in st._fields_}
 
     # ------------------------------------------------------------------ whole plies / games
     def play_ply(self, evaluator, n_playout=None, forced=None):

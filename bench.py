@@ -245,7 +245,7 @@ def main():
                 "avg_launch_us": kern_ms * 1e3, "launches": n_evs,
                 "algorithmic_bytes_per_launch": group_boards * BYTES_PER_BOARD,
             },
-            "engine_stats": {k: st1[k] for k in ("node_overflow", "games_aborted", "arena_bytes")},
+            "engine_stats": {k: st1[k] for k in ("node_overflow", "games_aborted", "arena_bytes", "max_nodes", "max_edges")},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, mean_len if lengths else 600.0, args.playouts)

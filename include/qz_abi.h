@@ -107,7 +107,8 @@ typedef struct {
     int64_t pending_plies;
     int64_t arena_bytes;       /* device bytes owned by the engine                     */
     int64_t descent_levels;    /* tree levels walked by all playouts (mean depth = / playouts) */
-    int64_t reserved[2];
+    int64_t max_nodes;         /* largest tree right now, in nodes / in edges (arena occupancy   */
+    int64_t max_edges;         /* against qz_config.node_cap / edge_cap)                         */
 } qz_stats;
 
 /* MCTSPlayer.__init__ / MCTS.__init__ (mcts.py:89-100, 159-161) for n_boards trees +
