@@ -86,6 +86,37 @@ def cpu_baseline(seconds, mean_plies_per_game, n_playout):
     }
 
 
+def c3_microbench(dev, launches=60):
+    """BASELINE configs[2] / SURVEY C3: the fused actions() + state() op on 32,768 mid-game boards
+    (random legal play from the opening, mover has a wall left), outside the timed region.
+    Reported next to `roofline` (which is the same op on the 4,096-leaf batches of the timed
+    region) because at this size the pooled pipeline runs instead of the wave-per-board kernel."""
+    sys.path.insert(0, os.path.join(ROOT, "benchmarks"))
+    from movegen_bench import position_set
+    from alphazero_quoridor_amd import rules
+
+    n = 32768
+    db = position_set("S-mid", n, dev)
+    mask = torch.empty((n, 5), dtype=torch.int32, device=dev)
+    planes = torch.empty((n, 26, 9, 9), dtype=torch.float32, device=dev)
+    for _ in range(5):
+        rules.movegen_encode(db, mask, planes)
+    torch.cuda.synchronize(dev)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(launches)]
+    for a, b in evs:
+        a.record()
+        rules.movegen_encode(db, mask, planes)
+        b.record()
+    torch.cuda.synchronize(dev)
+    us = sum(a.elapsed_time(b) for a, b in evs) / launches * 1e3
+    gbs = n * BYTES_PER_BOARD / us / 1e3
+    return {"workload": "BASELINE configs[2] microbenchmark: 32,768 boards (S-mid: 0..20 plies of random legal play, mover has a wall), "
+                        "actions() + state(), inputs resident in HBM, NOT part of the timed region",
+            "kernel": "k_pool_paths_enc + k_pool_masks_enc (pooled pipeline, two launches)",
+            "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+            "avg_launch_us": us, "launches": launches, "algorithmic_bytes_per_launch": n * BYTES_PER_BOARD}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -103,6 +134,7 @@ def main():
     ap.add_argument("--seed", type=int, default=2026)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-c3", action="store_true", help="skip the 32,768-board microbenchmark line (roofline_c3)")
     args = ap.parse_args()
 
     from alphazero_quoridor_amd import dist as qdist
@@ -247,6 +279,8 @@ def main():
             },
             "engine_stats": {k: st1[k] for k in ("node_overflow", "games_aborted", "arena_bytes", "max_nodes", "max_edges")},
         }
+        if world == 1 and not args.no_c3:
+            out["roofline_c3"] = c3_microbench(dev)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, mean_len if lengths else 600.0, args.playouts)
         print(json.dumps(out))
