@@ -55,13 +55,17 @@ class _NodeView(object):
 
 class MCTS(object):
     def __init__(self, policy_value_fn, c_puct=5, n_playout=1800, is_selfplay=1, fix_terminal_sign=False,
-                 node_cap=0, edge_cap=0):
+                 node_cap=0, edge_cap=0, use_graph=True):
         self._policy = policy_value_fn
         self._c_puct = c_puct
         self._n_playout = n_playout
         self._engine = SelfPlayEngine(1, n_playout=n_playout, c_puct=c_puct, temp=1.0, is_selfplay=is_selfplay,
                                       device=_device(), fix_terminal_sign=fix_terminal_sign, node_cap=node_cap,
                                       edge_cap=edge_cap, max_plies=8)
+        # device route only: replay the playout step (select -> rules -> net -> expand/backup, ~25
+        # launches on one board) as a HIP graph; one board is launch-bound, not GPU-bound
+        self._use_graph = bool(use_graph)
+        self._graph_tried = False
         owner = getattr(policy_value_fn, "__self__", None)
         self._evaluator = None
         if owner is not None and hasattr(owner, "evaluator") and getattr(policy_value_fn, "__name__", "") == "policy_value_fn" \
@@ -97,8 +101,18 @@ class MCTS(object):
         """n_playout simulations, then (acts, probs) over the root's children in the
         reference's insertion order (mcts.py:129-144)."""
         self._set_root_board(game)
-        for _ in range(self._n_playout):
-            self._playout_on_root()
+        if self._evaluator is not None:
+            todo = self._n_playout
+            if self._use_graph and not self._graph_tried and todo >= 16:
+                self._graph_tried = True
+                try:
+                    todo -= self._engine.capture_steps(self._evaluator, steps_per_graph=8, warmup=3)
+                except Exception:  # capture unsupported for some op on this stack: stay eager
+                    self._engine._graph = None
+            self._engine.run_playouts(self._evaluator, todo)
+        else:
+            for _ in range(self._n_playout):
+                self._playout_on_root()
         visits = self._engine.root_children()[0].cpu().numpy()[0]
         acts = tuple(a for a in rules.ACTION_ORDER if visits[a] >= 0)
         counts = np.array([visits[a] for a in acts])

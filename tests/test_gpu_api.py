@@ -163,6 +163,10 @@ def test_device_route_equals_callback_route(gpu_device):
     a1, p1 = fast.get_move_probs(g, temp=1.0)
     a2, p2 = slow.get_move_probs(g, temp=1.0)
     assert a1 == a2 and np.array_equal(p1, p2)
+    # the device route replayed its playout steps as a HIP graph (3 warm-up + 2 x 8 replayed + 5 eager)
+    assert fast._engine._graph is not None and fast._engine._graph_steps == 8
+    a3, p3 = MCTS(pvn.policy_value_fn, c_puct=5, n_playout=24, use_graph=False).get_move_probs(g, temp=1.0)
+    assert a3 == a1 and np.array_equal(p3, p1)
 
 
 def test_train_pipeline_collects_reference_shaped_tuples(gpu_device):
