@@ -1,5 +1,7 @@
 """GPU parity: HIP rules kernels (through the C ABI) vs the CPU oracle and the golden
 fixtures recorded from the real reference.  Bit-exact: integer / bit work."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -151,3 +153,47 @@ def test_every_movegen_kernel_variant_matches_the_oracle(gpu_device, golden_dir,
         assert np.array_equal(rules.encode(db).cpu().numpy(), oplanes)
     finally:
         L.qz_debug_set_movegen_variant(0)
+
+
+def test_c3_size_kernel_families_agree_and_match_oracle_sample(gpu_device):
+    """BASELINE configs[2] size: 32,768 boards reached by random legal play on the GPU.  At this
+    size the oracle is too slow for every board, so: (a) the three kernel families (pooled
+    pipeline = default here, wave-per-board, first kernel) and the three group-detour modes must
+    agree bit for bit on every mask and plane; (b) a strided sample of 2,048 boards is checked
+    against the oracle; (c) the op is idempotent."""
+    import sys
+
+    import oracle
+    from alphazero_quoridor_amd import _cabi, rules
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "benchmarks"))
+    from movegen_bench import position_set
+
+    L = _cabi.load()
+    n = 32768
+    try:
+        for name in ("S-mid", "S-dense"):
+            db = position_set(name, n, gpu_device)
+            L.qz_debug_set_movegen_variant(0)
+            L.qz_debug_set_movegen_variant(301)          # pooled pipeline, one detour group (the default)
+            mask, planes = rules.movegen_encode(db)
+            mask2, planes2 = rules.movegen_encode(db)
+            assert torch.equal(mask, mask2) and torch.equal(planes, planes2)
+            for knob in (300, 302):                       # no detours / three detour groups
+                L.qz_debug_set_movegen_variant(knob)
+                m, _ = rules.movegen_encode(db)
+                assert torch.equal(m, mask), (name, knob)
+            L.qz_debug_set_movegen_variant(301)
+            for variant in (3, 1):                        # wave-per-board kernel, first kernel of the repo
+                L.qz_debug_set_movegen_variant(variant)
+                m, p = rules.movegen_encode(db)
+                assert torch.equal(m, mask) and torch.equal(p, planes), (name, variant)
+            L.qz_debug_set_movegen_variant(0)
+            sample = db.to_packed()[::16]
+            omask, status = oracle.movegen_batch(sample)
+            assert (status >= 0).all()
+            assert np.array_equal(mask.cpu().numpy().view(np.uint32)[::16], omask), name
+            assert np.array_equal(planes.cpu().numpy()[::16], oracle.encode_batch(sample)), name
+    finally:
+        L.qz_debug_set_movegen_variant(0)
+        L.qz_debug_set_movegen_variant(301)
