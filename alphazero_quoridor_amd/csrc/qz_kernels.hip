@@ -4,9 +4,14 @@
 // board, 4 boards per 256-thread workgroup; board scalars are wave-uniform (SGPRs), the lanes
 // are the <=131 edges of a tree node (three rounds).  Cross-lane traffic is ballots, mbcnt
 // ranks and shuffle reductions.
-// Rules kernels (actions() + state()): the pooled pipeline k_pool_paths + k_pool_masks_enc, where
-// every phase maps lanes to the unit it has many of (qz_movegen_pool.h).  The first
-// wave-per-board kernel (k_movegen_encode) is kept for A/B runs (qz_debug_set_movegen_variant).
+// Rules kernels (actions() + state()), chosen by batch size in qzl::movegen_encode:
+//   k_wave_rules                          < 8,192 boards: one launch, a wavefront per board
+//   k_pool_paths_enc + k_pool_masks_enc   pooled pipeline, where every phase maps lanes to the
+//                                         unit it has many of (qz_movegen_pool.h)
+//   encoder groups                        ride in both: a tile of 16 boards -> one bit stream in
+//                                         LDS -> 16-byte stores
+// The first wave-per-board kernel (k_movegen_encode) is kept for A/B runs and as an independent
+// implementation in the parity tests (qz_debug_set_movegen_variant).
 // No MFMA anywhere: integer / indexing work.
 //
 // Reference semantics: see qz_rules.h (rules) and the per-kernel comments (mcts.py).
