@@ -134,6 +134,9 @@ def main():
     ap.add_argument("--seed", type=int, default=2026)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fix-terminal-sign", action="store_true",
+                    help="NOT the headline: back a winning move up as +1 (the reference backs it up as -1, mcts.py:125, which makes "
+                         "searches avoid winning and games run for thousands of plies)")
     ap.add_argument("--no-c3", action="store_true", help="skip the 32,768-board microbenchmark line (roofline_c3)")
     args = ap.parse_args()
 
@@ -156,7 +159,7 @@ def main():
     dt = torch.float32 if args.nn_dtype == "fp32" else torch.bfloat16
     eng = BoardGroups(args.boards, args.groups, lambda: net.evaluator(args.bn, dt, bool(args.channels_last)),
                       seed=qdist.shard_seed(args.seed, rank), device=dev,
-                      n_playout=args.playouts, c_puct=5, temp=1.0, is_selfplay=1)
+                      n_playout=args.playouts, c_puct=5, temp=1.0, is_selfplay=1, fix_terminal_sign=args.fix_terminal_sign)
     group_boards = args.boards // args.groups
     is_dist = world > 1
 
@@ -254,7 +257,7 @@ def main():
                 "workload": "BASELINE configs[3] per GPU: %d concurrent boards/GPU, n_playout=%d, 9x9, 10 walls/player, "
                             "c_puct=5, temp=1.0, leaf batch=%d, finished tuples all-gathered every ply"
                             % (args.boards, args.playouts, args.boards),
-                "boards_per_gpu": args.boards, "board_groups": args.groups, "n_playout": args.playouts, "bn_mode": args.bn,
+                "boards_per_gpu": args.boards, "board_groups": args.groups, "fix_terminal_sign": bool(args.fix_terminal_sign), "n_playout": args.playouts, "bn_mode": args.bn,
                 "nn_dtype": args.nn_dtype, "channels_last": bool(args.channels_last),
                 "step": "one ply of every board (n_playout playout steps + finish_move + harvest)",
                 "desync": "%d untimed plies at %d playouts/move (%.0fs, %d games finished)"
