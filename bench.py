@@ -110,10 +110,16 @@ def c3_microbench(dev, launches=60):
     torch.cuda.synchronize(dev)
     us = sum(a.elapsed_time(b) for a, b in evs) / launches * 1e3
     gbs = n * BYTES_PER_BOARD / us / 1e3
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "round1", "pmc_traffic_c3.json")) as f:
+            traffic = json.load(f)["traffic_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
     return {"workload": "BASELINE configs[2] microbenchmark: 32,768 boards (S-mid: 0..20 plies of random legal play, mover has a wall), "
                         "actions() + state(), inputs resident in HBM, NOT part of the timed region",
             "kernel": "k_pool_paths_enc + k_pool_masks_enc (pooled pipeline, two launches)",
-            "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+            "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
             "avg_launch_us": us, "launches": launches, "algorithmic_bytes_per_launch": n * BYTES_PER_BOARD}
 
 
