@@ -413,3 +413,34 @@ def test_fused_head_kernel_equals_library_head(gpu_device):
             assert (p1 - p2).abs().max().item() < 1e-5, (mode, B)
             assert (v1 - v2).abs().max().item() < 1e-5, (mode, B)
             assert (p1.sum(dim=1) - 1).abs().max().item() < 1e-5
+
+
+def test_bench_single_gpu_line_carries_the_contract(gpu_device):
+    """`python bench.py` (N=1, tiny workload): ONE JSON line with the driver's contract keys, the
+    roofline of the rules op in the timed region, the 32,768-board microbenchmark (roofline_c3) and
+    the CPU baseline; no expansion skipped."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--boards", "256",
+                        "--playouts", "16", "--desync-plies", "100", "--cpu-seconds", "2"],
+                       capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["unit"] == "games/s" and "workload" in d["config"] and "model" not in d["config"]
+    for rf in (d["roofline"], d["roofline_c3"]):
+        assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+        assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0 < rf["frac"] < 1
+    assert d["roofline_c3"]["algorithmic_bytes_per_launch"] == 32768 * 8468
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb
+    assert d["engine_stats"]["node_overflow"] == 0
