@@ -19,6 +19,7 @@ LIB_PATH = os.path.join(_HERE, "libqzero_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "qz_abi.h")
 
+ABI_VERSION = 2
 N_ACTIONS = 140
 PLANES = 26 * 81
 MASK_WORDS = 5
@@ -41,6 +42,10 @@ class qz_boards(C.Structure):
     _fields_ = [("hbits", C.c_void_p), ("vbits", C.c_void_p), ("meta", C.c_void_p)]
 
 
+class qz_rules_opts(C.Structure):
+    _fields_ = [("variant", C.c_int32), ("detour_pooled", C.c_int32), ("detour_wave", C.c_int32), ("enc_split_pct", C.c_int32)]
+
+
 class qz_config(C.Structure):
     _fields_ = [
         ("n_boards", C.c_int32),
@@ -56,7 +61,10 @@ class qz_config(C.Structure):
         ("node_cap", C.c_int32),
         ("edge_cap", C.c_int32),
         ("max_plies", C.c_int32),
-        ("reserved", C.c_int32 * 4),
+        ("tree_pool_pages", C.c_int32),
+        ("traj_pool_pages", C.c_int32),
+        ("traj_page_dwords", C.c_int32),
+        ("rules", qz_rules_opts),
     ]
 
 
@@ -74,6 +82,17 @@ class qz_stats(C.Structure):
         ("descent_levels", C.c_int64),
         ("max_nodes", C.c_int64),
         ("max_edges", C.c_int64),
+        ("aborted_no_move", C.c_int64),
+        ("aborted_max_plies", C.c_int64),
+        ("aborted_pool", C.c_int64),
+        ("bad_forced_moves", C.c_int64),
+        ("nonfinite_values", C.c_int64),
+        ("tree_pages_total", C.c_int64),
+        ("tree_pages_in_use", C.c_int64),
+        ("tree_pages_peak", C.c_int64),
+        ("traj_pages_total", C.c_int64),
+        ("traj_pages_in_use", C.c_int64),
+        ("traj_pages_peak", C.c_int64),
     ]
 
 
@@ -94,6 +113,7 @@ _SIGNATURES = {
     "qz_movegen": (C.c_int, [C.POINTER(qz_boards), C.c_int, _P, _P]),
     "qz_encode": (C.c_int, [C.POINTER(qz_boards), C.c_int, _P, _P]),
     "qz_movegen_encode": (C.c_int, [C.POINTER(qz_boards), C.c_int, _P, _P, _P]),
+    "qz_movegen_encode_opts": (C.c_int, [C.POINTER(qz_boards), C.c_int, _P, _P, C.POINTER(qz_rules_opts), _P]),
     "qz_step": (C.c_int, [C.POINTER(qz_boards), _P, C.c_int, _P, _P, _P]),
     "qz_engine_create": (C.c_int, [C.POINTER(qz_config), C.POINTER(_P)]),
     "qz_engine_destroy": (C.c_int, [_P]),
@@ -101,6 +121,7 @@ _SIGNATURES = {
     "qz_engine_set_boards": (C.c_int, [_P, C.POINTER(qz_boards), C.c_int, _P]),
     "qz_engine_get_boards": (C.c_int, [_P, C.POINTER(qz_boards), _P]),
     "qz_engine_set_temp": (C.c_int, [_P, C.c_float]),
+    "qz_engine_set_rules_opts": (C.c_int, [_P, C.POINTER(qz_rules_opts)]),
     "qz_mcts_select": (C.c_int, [_P, _P, _P, _P, _P]),
     "qz_mcts_descend": (C.c_int, [_P, _P]),
     "qz_mcts_leaf_inputs": (C.c_int, [_P, _P, _P, _P, _P]),
@@ -119,7 +140,6 @@ _SIGNATURES = {
     "qz_engine_leaf_boards": (C.c_int, [_P, _P, _P]),
     "qz_nn_head": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, _P]),
     "qz_selftest_sqrt": (C.c_int, [_P, C.c_int, _P]),
-    "qz_debug_set_movegen_variant": (C.c_int, [C.c_int]),
 }
 
 _lib = None
@@ -143,8 +163,8 @@ def load():
         fn = getattr(L, name)
         fn.restype = res
         fn.argtypes = args
-    if L.qz_version() != 1:
-        raise QzLibraryError("ABI version mismatch: library %d, binding 1" % L.qz_version())
+    if L.qz_version() != ABI_VERSION:
+        raise QzLibraryError("ABI version mismatch: library %d, binding %d (rebuild: make -C %s)" % (L.qz_version(), ABI_VERSION, CSRC))
     _lib = L
     return L
 

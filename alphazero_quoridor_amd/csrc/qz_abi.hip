@@ -15,7 +15,7 @@
 #include "qz_device.h"
 
 namespace qzl {
-hipError_t movegen_encode(const uint64_t*, const uint64_t*, const uint64_t*, int, uint32_t*, float*, const uint8_t*, void*, hipStream_t);
+hipError_t movegen_encode(const uint64_t*, const uint64_t*, const uint64_t*, int, uint32_t*, float*, const uint8_t*, void*, const RulesOpts&, hipStream_t);
 size_t movegen_scratch_bytes(int);
 hipError_t step(uint64_t*, uint64_t*, uint64_t*, const uint8_t*, int, uint8_t*, uint8_t*, hipStream_t);
 hipError_t select(const EngineDev&, hipStream_t);
@@ -25,9 +25,9 @@ hipError_t root_children(const EngineDev&, int32_t*, double*, float*, int32_t*, 
 hipError_t update_with_move(const EngineDev&, const uint8_t*, hipStream_t);
 hipError_t finish_move(const EngineDev&, const uint8_t*, float*, uint8_t*, hipStream_t);
 hipError_t reset(const EngineDev&, int, hipStream_t);
+hipError_t pool_init(const EngineDev&, hipStream_t);
 hipError_t harvest(const EngineDev&, uint64_t*, uint64_t*, uint64_t*, float*, float*, int32_t*, long long, hipStream_t);
 hipError_t sqrt_table(double*, int, hipStream_t);
-void set_movegen_variant(int);
 hipError_t instnorm_act(const float*, const float*, const float*, const float*, float*, long long, int, int, float, hipStream_t);
 hipError_t instnorm_act_nhwc(const float*, const float*, const float*, const float*, float*, long long, int, int, float, hipStream_t);
 hipError_t input_layer(const uint64_t*, const uint64_t*, const uint64_t*, const uint8_t*, long long, const float*, const float*,
@@ -90,9 +90,20 @@ static int get_scratch(int n, void* stream, void** out) {
     return 0;
 }
 
+static RulesOpts rules_opts(const qz_rules_opts* o) {
+    RulesOpts r;  // the defaults
+    if (!o) return r;
+    r.variant = o->variant;
+    if (o->detour_pooled > 0) r.detour_pooled = o->detour_pooled - 1;
+    if (o->detour_wave > 0) r.detour_wave = o->detour_wave - 1;
+    if (o->enc_split_pct > 0) r.enc_split_pct = o->enc_split_pct > 100 ? 100 : o->enc_split_pct;
+    return r;
+}
+
 struct qz_engine {
     qz_config cfg;
     EngineDev dev;
+    RulesOpts rules;
     void* scratch = nullptr;
     std::vector<void*> allocs;
     int64_t bytes = 0;
@@ -144,35 +155,28 @@ static int check_boards(const qz_boards* b, int n) {
     return 0;
 }
 
-int qz_movegen(const qz_boards* boards, int n, uint32_t* mask5, void* stream) {
+int qz_movegen_encode_opts(const qz_boards* boards, int n, uint32_t* mask5, float* planes, const qz_rules_opts* opts, void* stream) {
     int r;
     if ((r = device_check()) || (r = check_boards(boards, n))) return r;
-    if (n > 0 && !mask5) return fail(QZ_E_INVALID, "mask5 is null");
+    if (n > 0 && !mask5 && !planes) return fail(QZ_E_INVALID, "mask5 and planes are both null");
     if (n == 0) return 0;
     void* scratch = nullptr;
     if ((r = get_scratch(n, stream, &scratch))) return r;
-    HIP_TRY(qzl::movegen_encode(boards->hbits, boards->vbits, boards->meta, n, mask5, nullptr, nullptr, scratch, (hipStream_t)stream));
+    HIP_TRY(qzl::movegen_encode(boards->hbits, boards->vbits, boards->meta, n, mask5, planes, nullptr, scratch, rules_opts(opts),
+                                (hipStream_t)stream));
     return 0;
+}
+int qz_movegen(const qz_boards* boards, int n, uint32_t* mask5, void* stream) {
+    if (n > 0 && !mask5) return fail(QZ_E_INVALID, "mask5 is null");
+    return qz_movegen_encode_opts(boards, n, mask5, nullptr, nullptr, stream);
 }
 int qz_encode(const qz_boards* boards, int n, float* planes, void* stream) {
-    int r;
-    if ((r = device_check()) || (r = check_boards(boards, n))) return r;
     if (n > 0 && !planes) return fail(QZ_E_INVALID, "planes is null");
-    if (n == 0) return 0;
-    void* scratch = nullptr;
-    if ((r = get_scratch(n, stream, &scratch))) return r;
-    HIP_TRY(qzl::movegen_encode(boards->hbits, boards->vbits, boards->meta, n, nullptr, planes, nullptr, scratch, (hipStream_t)stream));
-    return 0;
+    return qz_movegen_encode_opts(boards, n, nullptr, planes, nullptr, stream);
 }
 int qz_movegen_encode(const qz_boards* boards, int n, uint32_t* mask5, float* planes, void* stream) {
-    int r;
-    if ((r = device_check()) || (r = check_boards(boards, n))) return r;
     if (n > 0 && (!mask5 || !planes)) return fail(QZ_E_INVALID, "mask5/planes is null");
-    if (n == 0) return 0;
-    void* scratch = nullptr;
-    if ((r = get_scratch(n, stream, &scratch))) return r;
-    HIP_TRY(qzl::movegen_encode(boards->hbits, boards->vbits, boards->meta, n, mask5, planes, nullptr, scratch, (hipStream_t)stream));
-    return 0;
+    return qz_movegen_encode_opts(boards, n, mask5, planes, nullptr, stream);
 }
 int qz_step(qz_boards* boards, const uint8_t* action, int n, uint8_t* done, uint8_t* winner, void* stream) {
     int r;
@@ -206,16 +210,34 @@ int qz_engine_create(const qz_config* cfg, qz_engine** out) {
     if (!e) return fail(QZ_E_OOM, "host allocation failed");
     e->cfg = *cfg;
     qz_config& c = e->cfg;
-    // nodes are 16 B, edges 32 B.  Early game: <= n_playout new nodes x <= 131 edges per ply.
-    // Late game (no walls left, 2-5 legal moves) trees get narrow and deep and almost the whole
-    // tree survives a re-root: in forced lines a tree grows by ~0.9 n_playout nodes per ply.
-    // Measured peak over 80 plies x 2,048 boards at n_playout = 400: 12,798 nodes (32 per playout),
-    // 65,084 edges (benchmarks/arena_occupancy.py); 16 n + 256 nodes overflowed 2,004 times in a
-    // bench run.  Nodes are cheap (64 n + 256 of them = 0.8 MB per board, the edges 8.8 MB).
-    if (c.node_cap <= 0) c.node_cap = 64 * c.n_playout + 256;
-    if (c.edge_cap <= 0) c.edge_cap = 131 * c.n_playout + 80 * (2 * c.n_playout + 256);
-    c.edge_cap = (c.edge_cap + 63) & ~63;
-    if (c.max_plies <= 0) c.max_plies = 4096;  // reference-faithful random-net games run to thousands of plies
+    // Trees: a shared pool of 64-KB pages (include/qz_abi.h, qz_device.h).  Measured on round-1
+    // runs at n_playout = 400: a tree peaks at 65 k edges early in the game (400 new nodes x <= 131
+    // edges per ply on top of the kept subtree) and holds 10-20 k in the long late game; during a
+    // re-root the old and the new tree coexist.  250 edges per playout per board on average
+    // (3.2 MB at n_playout = 400) covers the lock-step start from the opening, where every
+    // board peaks at once; qz_stats.tree_pages_peak reports what a run really used.
+    if (c.node_cap < 0) c.node_cap = 0;
+    const int edge_reach = QZ_TREE_PT * (int)QZ_PAGE_EDGES;
+    if (c.edge_cap <= 0 || c.edge_cap > edge_reach) c.edge_cap = edge_reach;
+    if (c.max_plies < 0) c.max_plies = 0;
+    if (c.tree_pool_pages <= 0) {
+        long long per = (250LL * c.n_playout + QZ_PAGE_EDGES - 1) / QZ_PAGE_EDGES;
+        if (per < 4) per = 4;
+        long long tot = per * c.n_boards;
+        // few boards share little: one tree alone may fill its whole page table, twice during a re-root
+        if (tot < 2 * QZ_TREE_PT + 8) tot = 2 * QZ_TREE_PT + 8;
+        if (tot > (1LL << 21) - 1) tot = (1LL << 21) - 1;  // physical edge indices are 32 bit
+        c.tree_pool_pages = (int)tot;
+    }
+    if (c.tree_pool_pages > (1 << 21) - 1) return (delete e, fail(QZ_E_INVALID, "tree_pool_pages > 2^21 - 1 (32-bit edge indices)"));
+    if (c.traj_pool_pages <= 0) {
+        long long tot = 16LL * c.n_boards;
+        if (tot > 0x7fffffffLL) tot = 0x7fffffffLL;
+        c.traj_pool_pages = (int)tot;
+    }
+    if (c.traj_page_dwords <= 0) c.traj_page_dwords = QZ_TPAGE_DWORDS;
+    if (c.traj_page_dwords < 256) return (delete e, fail(QZ_E_INVALID, "traj_page_dwords must be >= 256"));
+    e->rules = rules_opts(&c.rules);
     if (c.dirichlet_alpha <= 0.f) c.dirichlet_alpha = 0.3f;
     EngineDev& d = e->dev;
     memset(&d, 0, sizeof(d));
@@ -223,6 +245,9 @@ int qz_engine_create(const qz_config* cfg, qz_engine** out) {
     d.node_cap = c.node_cap;
     d.edge_cap = c.edge_cap;
     d.max_plies = c.max_plies;
+    d.tree_pool_pages = c.tree_pool_pages;
+    d.traj_pool_pages = c.traj_pool_pages;
+    d.traj_page_dwords = (uint32_t)c.traj_page_dwords;
     d.c_puct = c.c_puct;
     d.temp = c.temp;
     d.dirichlet_alpha = c.dirichlet_alpha;
@@ -230,7 +255,7 @@ int qz_engine_create(const qz_config* cfg, qz_engine** out) {
     d.seed = c.seed;
     d.is_selfplay = c.is_selfplay;
     d.fix_terminal_sign = c.fix_terminal_sign;
-    const size_t B = (size_t)c.n_boards, NC = (size_t)c.node_cap, EC = (size_t)c.edge_cap, MP = (size_t)c.max_plies;
+    const size_t B = (size_t)c.n_boards;
     int rc = 0;
 #define ALLOC(field, count) \
     if (!rc) rc = dev_alloc(e, &d.field, (count))
@@ -241,11 +266,21 @@ int qz_engine_create(const qz_config* cfg, qz_engine** out) {
     ALLOC(leaf_vb, B);
     ALLOC(leaf_meta, B);
     ALLOC(leaf_mask, B * 5);
-    ALLOC(leaf_pnode, B);
     ALLOC(leaf_pedge, B);
     ALLOC(leaf_term, B);
-    ALLOC(nodes, 2 * B * NC);
-    ALLOC(edges, 2 * B * EC);
+    ALLOC(edge_pool, (size_t)c.tree_pool_pages * QZ_PAGE_EDGES);
+    ALLOC(tree_ptab, 2 * B * QZ_TREE_PT);
+    ALLOC(tree_npages, 2 * B);
+    ALLOC(free_tree, (size_t)c.tree_pool_pages);
+    ALLOC(traj_pool, (size_t)c.traj_pool_pages * (size_t)c.traj_page_dwords);
+    ALLOC(traj_ptab, B * QZ_TRAJ_PT);
+    ALLOC(traj_npages, B);
+    ALLOC(traj_cursor, B);
+    ALLOC(free_traj, (size_t)c.traj_pool_pages);
+    ALLOC(pool_words, (size_t)QZ_P_COUNT);
+    ALLOC(release, B);
+    ALLOC(root_eoff, B);
+    ALLOC(root_ne, B);
     ALLOC(path_edges, B * (size_t)QZ_PATH_CAP);
     ALLOC(path_len, B);
     ALLOC(tree_half, B);
@@ -258,12 +293,11 @@ int qz_engine_create(const qz_config* cfg, qz_engine** out) {
     ALLOC(harvest_gid, B);
     ALLOC(status, B);
     ALLOC(winner, B);
-    ALLOC(traj_board, B * MP * 3);
-    ALLOC(traj_pi, B * MP * QZ_N_ACT);
     ALLOC(counters, (size_t)QZ_C_COUNT);
     ALLOC(bc_playouts, B);
     ALLOC(bc_terminal, B);
     ALLOC(bc_overflow, B);
+    ALLOC(bc_nonfinite, B);
     ALLOC(bc_levels, B);
 #undef ALLOC
     if (!rc) {
@@ -283,6 +317,12 @@ int qz_engine_create(const qz_config* cfg, qz_engine** out) {
     if (he == hipSuccess) he = hipMemset(d.bc_playouts, 0, B * sizeof(uint32_t));
     if (he == hipSuccess) he = hipMemset(d.bc_terminal, 0, B * sizeof(uint32_t));
     if (he == hipSuccess) he = hipMemset(d.bc_overflow, 0, B * sizeof(uint32_t));
+    if (he == hipSuccess) he = hipMemset(d.bc_nonfinite, 0, B * sizeof(uint32_t));
+    if (he == hipSuccess) he = hipMemset(d.tree_npages, 0, 2 * B * sizeof(uint32_t));
+    if (he == hipSuccess) he = hipMemset(d.traj_npages, 0, B * sizeof(uint32_t));
+    if (he == hipSuccess) he = hipMemset(d.traj_cursor, 0, B * sizeof(uint32_t));
+    if (he == hipSuccess) he = hipMemset(d.release, 0, B);
+    if (he == hipSuccess) he = qzl::pool_init(d, nullptr);
     if (he == hipSuccess) he = hipMemset(d.bc_levels, 0, B * sizeof(unsigned long long));
     if (he == hipSuccess) he = hipMemset(d.leaf_mask, 0, B * 5 * sizeof(uint32_t));
     if (he == hipSuccess) he = qzl::reset(d, 1, nullptr);
@@ -340,6 +380,14 @@ int qz_engine_set_temp(qz_engine* e, float temp) {
     return 0;
 }
 
+int qz_engine_set_rules_opts(qz_engine* e, const qz_rules_opts* opts) {
+    if (!e) return fail(QZ_E_INVALID, "null engine");
+    if (opts) e->cfg.rules = *opts;
+    else memset(&e->cfg.rules, 0, sizeof(e->cfg.rules));
+    e->rules = rules_opts(&e->cfg.rules);
+    return 0;
+}
+
 int qz_mcts_descend(qz_engine* e, void* stream) {
     ENGINE_CHECK(e);
     HIP_TRY(qzl::select(e->dev, (hipStream_t)stream));
@@ -348,10 +396,9 @@ int qz_mcts_descend(qz_engine* e, void* stream) {
 
 int qz_mcts_leaf_inputs(qz_engine* e, float* leaf_planes, uint32_t* leaf_mask5, uint8_t* leaf_terminal, void* stream) {
     ENGINE_CHECK(e);
-    if (!leaf_planes) return fail(QZ_E_INVALID, "leaf_planes is null");
     hipStream_t s = (hipStream_t)stream;
     const EngineDev& d = e->dev;
-    HIP_TRY(qzl::movegen_encode(d.leaf_hb, d.leaf_vb, d.leaf_meta, d.n_boards, d.leaf_mask, leaf_planes, d.leaf_term, e->scratch, s));
+    HIP_TRY(qzl::movegen_encode(d.leaf_hb, d.leaf_vb, d.leaf_meta, d.n_boards, d.leaf_mask, leaf_planes, d.leaf_term, e->scratch, e->rules, s));
     if (leaf_mask5)
         HIP_TRY(hipMemcpyAsync(leaf_mask5, d.leaf_mask, (size_t)d.n_boards * 5 * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
     if (leaf_terminal) HIP_TRY(hipMemcpyAsync(leaf_terminal, d.leaf_term, (size_t)d.n_boards, hipMemcpyDeviceToDevice, s));
@@ -371,7 +418,7 @@ int qz_mcts_select_boards(qz_engine* e, const qz_boards* leaf_out, uint32_t* lea
     hipStream_t s = (hipStream_t)stream;
     const EngineDev& d = e->dev;
     HIP_TRY(qzl::select(d, s));
-    HIP_TRY(qzl::movegen_encode(d.leaf_hb, d.leaf_vb, d.leaf_meta, d.n_boards, d.leaf_mask, nullptr, d.leaf_term, e->scratch, s));
+    HIP_TRY(qzl::movegen_encode(d.leaf_hb, d.leaf_vb, d.leaf_meta, d.n_boards, d.leaf_mask, nullptr, d.leaf_term, e->scratch, e->rules, s));
     size_t nb = (size_t)d.n_boards * sizeof(uint64_t);
     HIP_TRY(hipMemcpyAsync(leaf_out->hbits, d.leaf_hb, nb, hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipMemcpyAsync(leaf_out->vbits, d.leaf_vb, nb, hipMemcpyDeviceToDevice, s));
@@ -432,8 +479,6 @@ int qz_harvest(qz_engine* e, const qz_boards* t_boards, float* t_pi, float* t_z,
     if (cap < 0) return fail(QZ_E_INVALID, "cap < 0");
     if (cap > 0 && (!t_boards || !t_boards->hbits || !t_boards->vbits || !t_boards->meta || !t_pi || !t_z))
         return fail(QZ_E_INVALID, "null tuple buffers");
-    static uint64_t dummy = 0;
-    (void)dummy;
     HIP_TRY(qzl::harvest(e->dev, cap ? t_boards->hbits : nullptr, cap ? t_boards->vbits : nullptr,
                          cap ? t_boards->meta : nullptr, t_pi, t_z, t_game, (long long)cap, (hipStream_t)stream));
     return 0;
@@ -445,18 +490,21 @@ int qz_engine_stats(qz_engine* e, qz_stats* out, void* stream) {
     unsigned long long h[QZ_C_COUNT];
     hipStream_t s = (hipStream_t)stream;
     const size_t B = (size_t)e->cfg.n_boards;
-    std::vector<uint32_t> bp(B), bt(B), bo(B), nn(B), ne(B);
+    std::vector<uint32_t> bp(B), bt(B), bo(B), nn(B), ne(B), bf(B);
+    int pw[QZ_P_COUNT];
     std::vector<unsigned long long> bl(B);
     HIP_TRY(hipMemcpyAsync(h, e->dev.counters, sizeof(h), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(bp.data(), e->dev.bc_playouts, B * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(bt.data(), e->dev.bc_terminal, B * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(bo.data(), e->dev.bc_overflow, B * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(bf.data(), e->dev.bc_nonfinite, B * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(pw, e->dev.pool_words, sizeof(pw), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(bl.data(), e->dev.bc_levels, B * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(nn.data(), e->dev.n_nodes, B * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(ne.data(), e->dev.n_edges, B * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     // per-board counters wrap at 2^32 playouts per board (years); sums are 64-bit
-    unsigned long long sp = 0, st = 0, so = 0, sl = 0;
+    unsigned long long sp = 0, st = 0, so = 0, sl = 0, sf = 0;
     uint32_t mn = 0, me = 0;
     for (size_t i = 0; i < B; i++) {
         mn = nn[i] > mn ? nn[i] : mn;
@@ -464,6 +512,7 @@ int qz_engine_stats(qz_engine* e, qz_stats* out, void* stream) {
         sp += bp[i];
         st += bt[i];
         so += bo[i];
+        sf += bf[i];
         sl += bl[i];
     }
     memset(out, 0, sizeof(*out));
@@ -472,7 +521,18 @@ int qz_engine_stats(qz_engine* e, qz_stats* out, void* stream) {
     out->playouts = (int64_t)sp;
     out->leaf_terminal = (int64_t)st;
     out->node_overflow = (int64_t)so;
-    out->games_aborted = (int64_t)h[QZ_C_ABORTED];
+    out->aborted_no_move = (int64_t)h[QZ_C_ABORT_NO_MOVE];
+    out->aborted_max_plies = (int64_t)h[QZ_C_ABORT_MAX_PLIES];
+    out->aborted_pool = (int64_t)h[QZ_C_ABORT_POOL];
+    out->games_aborted = out->aborted_no_move + out->aborted_max_plies + out->aborted_pool;
+    out->bad_forced_moves = (int64_t)h[QZ_C_BAD_FORCED];
+    out->nonfinite_values = (int64_t)sf;
+    out->tree_pages_total = e->cfg.tree_pool_pages;
+    out->tree_pages_in_use = e->cfg.tree_pool_pages - pw[QZ_P_TREE_TOP];
+    out->tree_pages_peak = e->cfg.tree_pool_pages - pw[QZ_P_TREE_LOW];
+    out->traj_pages_total = e->cfg.traj_pool_pages;
+    out->traj_pages_in_use = e->cfg.traj_pool_pages - pw[QZ_P_TRAJ_TOP];
+    out->traj_pages_peak = e->cfg.traj_pool_pages - pw[QZ_P_TRAJ_LOW];
     out->pending_games = (int64_t)h[QZ_C_PENDING_GAMES];
     out->pending_plies = (int64_t)h[QZ_C_PENDING_PLIES];
     out->descent_levels = (int64_t)sl;
@@ -536,12 +596,6 @@ int qz_engine_leaf_boards(qz_engine* e, qz_boards* boards_out, const uint8_t** t
     boards_out->vbits = e->dev.leaf_vb;
     boards_out->meta = e->dev.leaf_meta;
     if (terminal_out) *terminal_out = e->dev.leaf_term;
-    return 0;
-}
-
-// A/B hook: see include/qz_abi.h
-int qz_debug_set_movegen_variant(int variant) {
-    qzl::set_movegen_variant(variant);
     return 0;
 }
 

@@ -1,21 +1,38 @@
-// qz_device.h -- device-side view of the engine: board SoA, per-board tree arenas,
+// qz_device.h -- device-side view of the engine: board SoA, paged tree storage, paged
 // trajectories.  Plain pointers + sizes, passed to kernels by value.
 //
 // HBM layout (B = n_boards; everything is allocated once by qz_engine_create):
 //   root_{hb,vb,meta}[B], leaf_{hb,vb,meta}[B]      24 B/board each, SoA (include/qz_abi.h)
-//   leaf_mask[B][5], leaf_{pnode,pedge}[B], leaf_term[B]
-//   tree arenas, double buffered (half h in {0,1}), slot = h*B + b:
-//     nodes [2][B][node_cap]  16 B   {edge_off, n_edges, parent_node, parent_edge}
-//     edges [2][B][edge_cap]  32 B   one record per child TreeNode of the reference:
-//        Q f64 (_Q, mcts.py:23) | N u32 (_n_visits, :22) | P f32 (_P, :25) | child u32 (node id
-//        once expanded, 0 = leaf) | coff u32 + cne u8 (edge offset / count of the child's own
-//        edges, so the descent needs ONE dependent HBM round trip per level) | act u8
-//     A node's edges are consecutive and in the reference's actions() order (dict insertion
-//     order).  Records rather than one array per field: a level of the descent then touches one
-//     2-4 KB span of one page instead of seven arrays megabytes apart (the first layout was
-//     bound by page-table walks: 126 us per select at depth 10).
-//   path_edges[B][QZ_PATH_CAP] u32: the edges of the last descent, root first (parallel backup)
-//   traj_board[B][max_plies][3] u64, traj_pi[B][max_plies][140] f32
+//   leaf_mask[B][5], leaf_pedge[B], leaf_term[B]
+//
+//   Trees: ONE pool of 64-KB pages (QZ_PAGE_EDGES = 2,048 edge records of 32 B) shared by all
+//   boards, handed out by a free stack.  A tree addresses its edges by a LOGICAL index
+//   0 .. n_edges-1 that its page table (tree_ptab, QZ_TREE_PT entries) maps to pool pages:
+//       physical = tree_ptab[slot][e >> 11] * 2048 + (e & 2047)
+//   so a board only owns the pages its tree really fills (round 1 reserved 2 x 136,896 edges
+//   per board = 8.8 MB and used 0.5-2 MB of them; with the pool 32,768 boards x n_playout=400
+//   fit one MI355X).  One edge record per child TreeNode of the reference:
+//        Q f64 (_Q, mcts.py:23) | N u32 (_n_visits, :22) | P f32 (_P, :25) | pedge u32 (physical
+//        index of the edge this node hangs under, QZ_NONE for the root's children: the
+//        _parent link, :20) | coff u32 + cne u8 (logical offset / count of the child's own edge
+//        block once expanded, cne == 0 <=> TreeNode.is_leaf(): the descent needs ONE dependent
+//        HBM round trip per level) | act u8
+//     A node's edges are consecutive, in the reference's actions() order (dict insertion
+//     order), and never straddle a page (the allocation cursor skips to the next page instead),
+//     so a wave translates a block's base once (wave-uniform) and lanes add their k.
+//     There is no separate node array: everything the reference keeps in a TreeNode lives in
+//     the edge that points to it, plus root_eoff/root_ne/root_N per board for the root.
+//   Subtree reuse copies the kept subtree breadth-first into FRESH pages (table half h^1), then
+//   the old half's pages go back to the stack (k_release, a push-only kernel: kernels that pop
+//   never push, so the stack needs no ABA protection).
+//   path_edges[B][QZ_PATH_CAP] u32: physical edges of the last descent, root first (parallel backup)
+//
+//   Trajectories: a second pool of 64-KB pages of dwords; one variable-length record per ply
+//       [0] ne | [1] 0 | [2..7] board (hbits, vbits, meta) | [8..8+ne) pi f32 of the root's
+//       children in actions() order | ceil(ne/4) dwords of action ids (u8 each)
+//   = 60 B for a late-game ply with 5 legal moves, 688 B at most (round 1: 584 B for every
+//   ply, 4,096 plies reserved per board, longer games dropped).  Records never straddle a
+//   page; a page that cannot take the next record ends with the marker 0xFFFFFFFF.
 #pragma once
 #include <stdint.h>
 
@@ -25,27 +42,34 @@
 #define QZ_NO_MOVE_U8 255
 #define QZ_PATH_CAP 256
 
-enum { QZ_PLAYING = 0, QZ_FINISHED = 1 };
+#define QZ_PAGE_SHIFT 11
+#define QZ_PAGE_EDGES (1u << QZ_PAGE_SHIFT)  // 2,048 x 32 B = 64 KB
+#define QZ_TREE_PT 128                       // page-table entries per tree: 262,144 logical edges
+#define QZ_TPAGE_DWORDS 16384                // default trajectory page: 64 KB (EngineDev.traj_page_dwords)
+#define QZ_TRAJ_PT 256                       // page-table entries per game: >= 24k plies, ~140k typical
+#define QZ_TRAJ_HDR 8u
+#define QZ_TRAJ_SKIP 0xFFFFFFFFu
+
+enum { QZ_PLAYING = 0, QZ_FINISHED = 1, QZ_ABORTED = 2 };
 enum {
     QZ_C_GAMES = 0,
     QZ_C_PLIES,
-    QZ_C_PLAYOUTS,
-    QZ_C_LEAF_TERMINAL,
-    QZ_C_OVERFLOW,
-    QZ_C_ABORTED,
+    QZ_C_ABORT_NO_MOVE,     // no legal move at the root
+    QZ_C_ABORT_MAX_PLIES,   // qz_config.max_plies reached / trajectory page table full
+    QZ_C_ABORT_POOL,        // trajectory pool exhausted
     QZ_C_PENDING_GAMES,
     QZ_C_PENDING_PLIES,
+    QZ_C_BAD_FORCED,        // forced moves that were not children of the root (sticky error flag)
     QZ_C_COUNT
 };
+// pool bookkeeping words (int): free-stack tops and low-water marks
+enum { QZ_P_TREE_TOP = 0, QZ_P_TREE_LOW, QZ_P_TRAJ_TOP, QZ_P_TRAJ_LOW, QZ_P_COUNT };
 
-struct Node {
-    uint32_t edge_off, n_edges, parent_node, parent_edge;
-};
 struct Edge {
     double Q;
     uint32_t N;
     float P;
-    uint32_t child;
+    uint32_t pedge;
     uint32_t coff;
     uint8_t act, cne;
     uint16_t pad16;
@@ -53,8 +77,20 @@ struct Edge {
 };
 static_assert(sizeof(Edge) == 32, "edge record must be 32 bytes");
 
+// Which formulation of the rules op (actions() + state()) a call uses: per engine / per call,
+// never process-global.  variant: 0 = by batch size (k_wave_rules below 8,192 boards, pooled
+// pipeline above), 2 | 3 | 4 = k_wave_rules with 2 | 1 | 4 boards per wavefront, 8 | 12 | 16 |
+// 24 | 32 = pooled pipeline with that many boards per mask workgroup.
+struct RulesOpts {
+    int variant = 0;
+    int detour_pooled = 1, detour_wave = 0;  // pool_k1's detour_mode per kernel family
+    int enc_split_pct = 70;                  // share of the encoder tiles beside the path groups
+};
+
 struct EngineDev {
     int n_boards, node_cap, edge_cap, max_plies;
+    int tree_pool_pages, traj_pool_pages;
+    uint32_t traj_page_dwords;
     float c_puct, temp, dirichlet_alpha, noise_frac;
     uint64_t seed;
     int is_selfplay, fix_terminal_sign;
@@ -62,37 +98,55 @@ struct EngineDev {
     uint64_t *root_hb, *root_vb, *root_meta;
     uint64_t *leaf_hb, *leaf_vb, *leaf_meta;
     uint32_t* leaf_mask;
-    uint32_t *leaf_pnode, *leaf_pedge;
+    uint32_t* leaf_pedge;
     uint8_t* leaf_term;
     // trees
-    Node* nodes;
-    Edge* edges;
+    Edge* edge_pool;          // [tree_pool_pages][QZ_PAGE_EDGES]
+    uint32_t* tree_ptab;      // [2][B][QZ_TREE_PT]
+    uint32_t* tree_npages;    // [2][B]
+    uint32_t* free_tree;      // [tree_pool_pages] stack of free pages
+    uint32_t* traj_pool;      // [traj_pool_pages][traj_page_dwords]
+    uint32_t* traj_ptab;      // [B][QZ_TRAJ_PT]
+    uint32_t *traj_npages, *traj_cursor;  // [B]
+    uint32_t* free_traj;      // [traj_pool_pages]
+    int* pool_words;          // QZ_P_COUNT
     uint32_t *path_edges, *path_len;
     uint8_t* tree_half;
-    uint32_t *n_nodes, *n_edges, *root_N;
+    uint8_t* release;         // [B] bit0: the other table half holds pages to give back
+    uint32_t *n_nodes, *n_edges, *root_N, *root_eoff, *root_ne;
     // games
     uint32_t *ply, *game_serial, *harvest_off, *harvest_gid;
     uint8_t *status, *winner;
-    uint64_t* traj_board;
-    float* traj_pi;
     unsigned long long* counters;  // QZ_C_COUNT (touched once per ply / harvest)
     // per-board counters for the per-playout statistics: a shared atomic would serialise all
     // boards of a step on one address (~88 atomics/us on MI355X); summed by qz_engine_stats
-    uint32_t *bc_playouts, *bc_terminal, *bc_overflow;
+    uint32_t *bc_playouts, *bc_terminal, *bc_overflow, *bc_nonfinite;
     unsigned long long* bc_levels;
 };
 
-struct TreeView {
-    Node* nodes;
-    Edge* e;
-};
-
 #if defined(__HIPCC__)
-__device__ __forceinline__ TreeView tree_view(const EngineDev& E, int b, uint32_t half) {
-    size_t slot = (size_t)half * (size_t)E.n_boards + (size_t)b;
+// A tree's page table, held by the wave: lane l keeps entries l and l + 64.
+struct TreeView {
+    Edge* pool;
+    uint32_t* ptab;   // this tree's table in HBM (QZ_TREE_PT entries)
+    uint32_t pt0, pt1;
+};
+__device__ __forceinline__ size_t tree_slot(const EngineDev& E, int b, uint32_t half) {
+    return (size_t)half * (size_t)E.n_boards + (size_t)b;
+}
+__device__ __forceinline__ TreeView tree_view(const EngineDev& E, int b, uint32_t half, int lane) {
     TreeView t;
-    t.nodes = E.nodes + slot * (size_t)E.node_cap;
-    t.e = E.edges + slot * (size_t)E.edge_cap;
+    t.pool = E.edge_pool;
+    t.ptab = E.tree_ptab + tree_slot(E, b, half) * QZ_TREE_PT;
+    t.pt0 = t.ptab[lane];
+    t.pt1 = t.ptab[64 + lane];
     return t;
+}
+// physical index of logical edge e; e must be wave-uniform
+__device__ __forceinline__ uint32_t tree_phys(const TreeView& t, uint32_t e) {
+    const uint32_t pg = e >> QZ_PAGE_SHIFT;
+    const int l = __builtin_amdgcn_readfirstlane((int)(pg & 63u));
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)t.pt0, l), c = (uint32_t)__builtin_amdgcn_readlane((int)t.pt1, l);
+    return ((pg < 64u ? a : c) << QZ_PAGE_SHIFT) | (e & (QZ_PAGE_EDGES - 1u));
 }
 #endif

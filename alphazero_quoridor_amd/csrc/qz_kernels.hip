@@ -10,8 +10,8 @@
 //                                         unit it has many of (qz_movegen_pool.h)
 //   encoder groups                        ride in both: a tile of 16 boards -> one bit stream in
 //                                         LDS -> 16-byte stores
-// The first wave-per-board kernel (k_movegen_encode) is kept for A/B runs and as an independent
-// implementation in the parity tests (qz_debug_set_movegen_variant).
+// (The first wave-per-board kernel of round 1 lives in tests/hip/ as a test-only second
+// implementation; it is not part of this library.)
 // No MFMA anywhere: integer / indexing work.
 //
 // Reference semantics: see qz_rules.h (rules) and the per-kernel comments (mcts.py).
@@ -40,16 +40,6 @@ __device__ __forceinline__ uint64_t rfl64(uint64_t x) {
 }
 __device__ __forceinline__ uint32_t rdl(uint32_t x, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)x, l); }
 __device__ __forceinline__ BB bb_rdl(BB a, int l) { return BB{rdl(a.w0, l), rdl(a.w1, l), rdl(a.w2, l)}; }
-__device__ __forceinline__ PathEdges path_rdl(const PathEdges& p, int l) {
-    PathEdges r;
-    r.pn = bb_rdl(p.pn, l);
-    r.ps = bb_rdl(p.ps, l);
-    r.pe = bb_rdl(p.pe, l);
-    r.pw = bb_rdl(p.pw, l);
-    r.jump = rdl(p.jump ? 1u : 0u, l) != 0u;
-    r.found = rdl(p.found ? 1u : 0u, l) != 0u;
-    return r;
-}
 // number of set bits of a ballot below this lane
 __device__ __forceinline__ int rank_below(uint64_t m) {
     return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -59,121 +49,6 @@ __device__ __forceinline__ Board load_board(const uint64_t* hb, const uint64_t* 
 }
 
 // ============================================================================ rules kernels
-
-struct MoveShared {
-    BB layers[WPB][2][84];     // BFS layers of the two base floods (lanes 0 / 1 of each wave)
-    uint8_t items[WPB][256];   // work list: ix | horizontal<<6 | (player-1)<<7
-    uint8_t res[WPB][256];     // flood results per work item
-};
-
-// Quoridor.actions() for one board per wave; returns the three legal sets.
-__device__ __forceinline__ void wave_movegen(const Board& bd, MoveShared& sm, int wave, int lane, uint32_t& pawn,
-                                             uint64_t& lh, uint64_t& lv) {
-    MoveCtx c = make_ctx(bd);
-    pawn = c.pawn;
-    lh = 0;
-    lv = 0;
-    if (!c.walls) return;  // quoridor.py:149-156: no wall actions without walls (wave-uniform)
-
-    // one concrete path per player on the current walls: lanes 0 and 1 in parallel
-    PathEdges mine;
-    mine.pn = mine.ps = mine.pe = mine.pw = bb_zero();
-    mine.jump = false;
-    mine.found = false;
-    if (lane < 2) mine = base_path(c, lane + 1, &sm.layers[wave][lane][0]);
-    PathEdges path1 = path_rdl(mine, 0), path2 = path_rdl(mine, 1);
-    if (!(path1.found && path2.found)) return;  // somebody is already cut off: every wall "blocks"
-
-    // lane = slot ix; round H then round V share the same lane
-    const int ix = lane;
-    bool stH = (c.sh >> ix) & 1ull, stV = (c.sv >> ix) & 1ull;
-    Blk dH = candidate_delta(ix, true), dV = candidate_delta(ix, false);
-    bool nH1 = stH && needs_check(c, path1, 1, ix, dH);
-    bool nH2 = stH && needs_check(c, path2, 2, ix, dH);
-    bool nV1 = stV && needs_check(c, path1, 1, ix, dV);
-    bool nV2 = stV && needs_check(c, path2, 2, ix, dV);
-    uint64_t mH1 = __ballot(nH1), mH2 = __ballot(nH2), mV1 = __ballot(nV1), mV2 = __ballot(nV2);
-    int o1 = __popcll(mH1), o2 = o1 + __popcll(mH2), o3 = o2 + __popcll(mV1), total = o3 + __popcll(mV2);
-    int sH1 = rank_below(mH1), sH2 = o1 + rank_below(mH2), sV1 = o2 + rank_below(mV1), sV2 = o3 + rank_below(mV2);
-    if (total > 0) {
-        if (nH1) sm.items[wave][sH1] = (uint8_t)(ix | 0x40);
-        if (nH2) sm.items[wave][sH2] = (uint8_t)(ix | 0x40 | 0x80);
-        if (nV1) sm.items[wave][sV1] = (uint8_t)(ix);
-        if (nV2) sm.items[wave][sV2] = (uint8_t)(ix | 0x80);
-        wave_sync();
-        for (int base = 0; base < total; base += 64) {  // wave-uniform trip count
-            int j = base + lane;
-            if (j < total) {
-                int it = sm.items[wave][j];
-                int cix = it & 63;
-                bool hz = (it & 0x40) != 0;
-                int p = (it & 0x80) ? 2 : 1;
-                Blk d = candidate_delta(cix, hz);
-                sm.res[wave][j] = candidate_reaches(c, p, cix, hz, d) ? 1 : 0;
-            }
-        }
-        wave_sync();
-    }
-    bool okH = stH, okV = stV;
-    if (nH1) okH = okH && sm.res[wave][sH1];
-    if (nH2) okH = okH && sm.res[wave][sH2];
-    if (nV1) okV = okV && sm.res[wave][sV1];
-    if (nV2) okV = okV && sm.res[wave][sV2];
-    lh = __ballot(okH);
-    lv = __ballot(okV);
-}
-
-__device__ __forceinline__ void store_mask(uint32_t* mask5, int b, int lane, uint32_t pawn, uint64_t lh, uint64_t lv) {
-    // 140 bits: [pawn 12][H 64][V 64]
-    if (lane < 5) {
-        uint32_t w;
-        switch (lane) {
-            case 0: w = pawn | (uint32_t)(lh << 12); break;
-            case 1: w = (uint32_t)(lh >> 20); break;
-            case 2: w = (uint32_t)(lh >> 52) | (uint32_t)(lv << 12); break;
-            case 3: w = (uint32_t)(lv >> 20); break;
-            default: w = (uint32_t)(lv >> 52); break;
-        }
-        mask5[(size_t)b * 5 + lane] = w;
-    }
-}
-
-// Quoridor.state(): 2,106 floats per board, written as 1,053 coalesced 8-byte stores
-__device__ __forceinline__ void wave_encode(const Board& bd, float* planes, int b, int lane, bool zero) {
-    float2* out = reinterpret_cast<float2*>(planes + (size_t)b * QZ_PLANES_N);
-#pragma unroll 1
-    for (int q = lane; q < QZ_PLANES_N / 2; q += 64) {
-        float2 v;
-        if (zero) {
-            v.x = 0.f;
-            v.y = 0.f;
-        } else {
-            v.x = plane_value(bd, 2 * q);
-            v.y = plane_value(bd, 2 * q + 1);
-        }
-        out[q] = v;
-    }
-}
-
-template <bool DO_MASK, bool DO_PLANES>
-__global__ __launch_bounds__(TPB) void k_movegen_encode(const uint64_t* __restrict__ hb, const uint64_t* __restrict__ vb,
-                                                        const uint64_t* __restrict__ meta, int n,
-                                                        uint32_t* __restrict__ mask5, float* __restrict__ planes,
-                                                        const uint8_t* __restrict__ terminal) {
-    __shared__ MoveShared sm;
-    const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
-    const int b = (int)blockIdx.x * WPB + wave;
-    if (b >= n) return;  // whole wave leaves; no workgroup barrier is used below
-    Board bd = load_board(hb, vb, meta, b);
-    bool term = terminal ? (rfl(terminal[b]) != 0u) : false;
-    if (DO_MASK) {
-        uint32_t pawn = 0;
-        uint64_t lh = 0, lv = 0;
-        if (!term) wave_movegen(bd, sm, wave, lane, pawn, lh, lv);
-        store_mask(mask5, b, lane, pawn, lh, lv);
-    }
-    if (DO_PLANES) wave_encode(bd, planes, b, lane, term);
-}
 
 // ---------------------------------------------------------------------------- pooled kernels
 // Quoridor.actions() + state() as two launches over an HBM scratch area (qz_movegen_pool.h):
@@ -469,74 +344,140 @@ __device__ __forceinline__ double wave_scan(double v, int lane) {
     return v;
 }
 
+// ---------------------------------------------------------------------------- page pools
+// Free pages live on a stack (free_list[0 .. top)).  A kernel either pops or pushes, never
+// both: pops race only with pops, pushes only with pushes, so plain atomics on `top` suffice.
+__device__ __forceinline__ uint32_t wave_pop(const uint32_t* free_list, int* top, int* low, int lane) {
+    uint32_t page = QZ_NONE;
+    if (lane == 0) {
+        int old = atomicSub(top, 1);
+        if (old <= 0) {
+            atomicAdd(top, 1);  // empty: undo
+        } else {
+            atomicMin(low, old - 1);
+            page = free_list[old - 1];
+        }
+    }
+    return rfl(page);
+}
+// push the n pages of a table (n <= 256: four per lane at most) back; push-only kernels
+__device__ __forceinline__ void wave_push(uint32_t* free_list, int* top, const uint32_t* ptab, uint32_t n, int lane) {
+    if (n == 0u) return;
+    int pos = 0;
+    if (lane == 0) pos = atomicAdd(top, (int)n);
+    pos = (int)rfl((uint32_t)pos);
+    for (uint32_t i = (uint32_t)lane; i < n; i += 64u) free_list[pos + (int)i] = ptab[i];
+}
+__device__ __forceinline__ void wave_free_tree_half(const EngineDev& E, int b, uint32_t half, int lane) {
+    const size_t slot = tree_slot(E, b, half);
+    const uint32_t n = rfl(E.tree_npages[slot]);
+    wave_push(E.free_tree, E.pool_words + QZ_P_TREE_TOP, E.tree_ptab + slot * QZ_TREE_PT, n, lane);
+    if (lane == 0) E.tree_npages[slot] = 0u;
+}
+__device__ __forceinline__ void wave_free_traj(const EngineDev& E, int b, int lane) {
+    const uint32_t n = rfl(E.traj_npages[b]);
+    wave_push(E.free_traj, E.pool_words + QZ_P_TRAJ_TOP, E.traj_ptab + (size_t)b * QZ_TRAJ_PT, n, lane);
+    if (lane == 0) {
+        E.traj_npages[b] = 0u;
+        E.traj_cursor[b] = 0u;
+    }
+}
+
+// Room for a block of k (1..131) consecutive edges at the end of tree T: logical offset, or
+// QZ_NONE when the shared pool is empty / the page table or qz_config.edge_cap is exhausted.
+// `neu` = the tree's allocation cursor, `np` = pages it maps.  A block never straddles a page;
+// `mark_hole` zeroes cne in the skipped tail so that a linear scan (wave_reroot) sees no nodes there.
+__device__ __forceinline__ uint32_t tree_alloc(const EngineDev& E, TreeView& T, uint32_t& neu, uint32_t& np, int k, int lane,
+                                               bool mark_hole) {
+    uint32_t off = neu;
+    if ((off & (QZ_PAGE_EDGES - 1u)) + (uint32_t)k > QZ_PAGE_EDGES) {
+        const uint32_t next = (off + QZ_PAGE_EDGES - 1u) & ~(QZ_PAGE_EDGES - 1u);
+        if (mark_hole) {
+            const uint32_t base = tree_phys(T, off);
+            for (uint32_t i = (uint32_t)lane; i < next - off; i += 64u) T.pool[base + i].cne = 0;
+        }
+        off = next;
+    }
+    const uint32_t pg = off >> QZ_PAGE_SHIFT;
+    if (pg >= (uint32_t)QZ_TREE_PT || off + (uint32_t)k > (uint32_t)E.edge_cap) return QZ_NONE;
+    if (pg >= np) {
+        const uint32_t page = wave_pop(E.free_tree, E.pool_words + QZ_P_TREE_TOP, E.pool_words + QZ_P_TREE_LOW, lane);
+        if (page == QZ_NONE) return QZ_NONE;
+        if (lane == 0) T.ptab[pg] = page;
+        if (lane == (int)(pg & 63u)) {
+            if (pg < 64u) T.pt0 = page;
+            else T.pt1 = page;
+        }
+        np = pg + 1u;
+    }
+    neu = off + (uint32_t)k;
+    return off;
+}
+
 // MCTS._playout descent (mcts.py:107-113) + TreeNode.select/get_value (mcts.py:37-42, 64-70)
 __global__ __launch_bounds__(TPB) void k_select(EngineDev E) {
     const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
     const int b = (int)blockIdx.x * WPB + wave;
     if (b >= E.n_boards) return;
     Board bd = load_board(E.root_hb, E.root_vb, E.root_meta, b);
-    TreeView T = tree_view(E, b, rfl(E.tree_half[b]));
-    uint32_t n_nodes = rfl(E.n_nodes[b]);
-    uint32_t pnode = QZ_NONE, pedge = QZ_NONE;
+    uint32_t pedge = QZ_NONE;
     uint32_t parentN = rfl(E.root_N[b]);
-    bool done = false;
-    bool live = rfl(E.status[b]) == QZ_PLAYING;
+    int ne = (int)rfl(E.root_ne[b]);
+    bool done = false, nonfinite = false;
+    const bool live = rfl(E.status[b]) == QZ_PLAYING;
     uint32_t plen = 0u;
-    if (live && n_nodes > 0) {
-        uint32_t node = 0;
-        Node root = T.nodes[0];
-        uint32_t eoff = rfl(root.edge_off);
-        int ne = (int)rfl(root.n_edges);
+    if (live && ne > 0) {
+        const TreeView T = tree_view(E, b, rfl(E.tree_half[b]), lane);
+        uint32_t eoff = rfl(E.root_eoff[b]);
         uint32_t* path = E.path_edges + (size_t)b * QZ_PATH_CAP;
-        for (int depth = 0; depth < 100000; depth++) {
+        for (int depth = 0; depth < 1000000; depth++) {
+            const uint32_t base = tree_phys(T, eoff);
             double sq = sqrt((double)parentN);  // np.sqrt(self._parent._n_visits), float64
             double best = -__builtin_inf();
             int bestk = 0x7fffffff;
             // everything the descent needs about the winning edge rides along with the
             // candidates, so the next level costs one dependent round trip, not three
-            uint32_t mN = 0u, mChild = 0u, mCOff = 0u, mMisc = 0u;
+            uint32_t mN = 0u, mCOff = 0u, mMisc = 0u;
             for (int k = lane; k < ne; k += 64) {
-                const Edge ed = T.e[eoff + (uint32_t)k];           // one 32-byte record per lane
+                const Edge ed = T.pool[base + (uint32_t)k];        // one 32-byte record per lane
                 uint32_t N = ed.N;
                 float cp = E.c_puct * ed.P;                         // c_puct * self._P in float32
                 double u = (double)cp * sq / (double)(1u + N);      // mcts.py:69
                 double val = ed.Q + u;                              // mcts.py:70
-                uint32_t ch = ed.child, co = ed.coff;
                 uint32_t misc = (uint32_t)ed.act | ((uint32_t)ed.cne << 8);
-                if (val > best) {
+                // a lane's first candidate is always taken: with non-finite values (a diverged
+                // network) every comparison is false and Python's max() keeps the first child
+                if (val > best || bestk == 0x7fffffff) {
                     best = val;
                     bestk = k;
                     mN = N;
-                    mChild = ch;
-                    mCOff = co;
+                    mCOff = ed.coff;
                     mMisc = misc;
                 }
             }
             wave_argmax(best, bestk);
-            const int kk = (int)rfl((uint32_t)bestk);
+            const int kk = (int)rfl((uint32_t)bestk);  // lane 0 always holds a valid pair (k = 0 is its own)
+            nonfinite = nonfinite || !(best == best);
             const int wl = kk & 63;  // the winning edge is the winning lane's own best candidate
-            uint32_t e = eoff + (uint32_t)kk;
-            uint32_t misc = rdl(mMisc, wl);
-            int a = (int)(misc & 0xFFu);
-            uint32_t child = rdl(mChild, wl);
-            uint32_t childN = rdl(mN, wl);
+            const uint32_t e = base + (uint32_t)kk;
+            const uint32_t misc = rdl(mMisc, wl);
+            const int a = (int)(misc & 0xFFu);
+            const uint32_t childN = rdl(mN, wl);
             done = apply_action(bd, a);  // game.step(action), mcts.py:113
-            pnode = node;
             pedge = e;
             if (lane == 0 && plen < (uint32_t)QZ_PATH_CAP) path[plen] = e;
             plen++;
-            if (child == 0u) break;  // TreeNode.is_leaf(): never expanded (or terminal)
-            node = child;
+            const int cne = (int)((misc >> 8) & 0xFFu);
+            if (cne == 0) break;  // TreeNode.is_leaf(): never expanded (or terminal)
             parentN = childN;
             eoff = rdl(mCOff, wl);
-            ne = (int)((misc >> 8) & 0xFFu);
+            ne = cne;
         }
     }
     if (lane == 0) {
         E.leaf_hb[b] = bd.hb;
         E.leaf_vb[b] = bd.vb;
         E.leaf_meta[b] = pack_meta(bd);
-        E.leaf_pnode[b] = pnode;
         E.leaf_pedge[b] = pedge;
         E.path_len[b] = plen;
         // 0 live leaf; 1 terminal & winner == current_player; 2 terminal & winner != current_player;
@@ -545,6 +486,7 @@ __global__ __launch_bounds__(TPB) void k_select(EngineDev E) {
         if (!live) t = 3;
         else if (done) t = (winner_of(bd) == bd.cur) ? 1 : 2;
         E.leaf_term[b] = t;
+        if (nonfinite) E.bc_nonfinite[b] += 1u;
     }
 }
 
@@ -555,8 +497,7 @@ __global__ __launch_bounds__(TPB) void k_expand_backup(EngineDev E, const float*
     if (b >= E.n_boards) return;
     uint32_t term = rfl(E.leaf_term[b]);
     if (term == 3u) return;
-    TreeView T = tree_view(E, b, rfl(E.tree_half[b]));
-    uint32_t pnode = rfl(E.leaf_pnode[b]), pedge = rfl(E.leaf_pedge[b]);
+    const uint32_t pedge = rfl(E.leaf_pedge[b]);
     double leaf_value;
     if (term == 0u) {
         leaf_value = (double)v[b];
@@ -567,43 +508,47 @@ __global__ __launch_bounds__(TPB) void k_expand_backup(EngineDev E, const float*
         uint64_t lh = ((uint64_t)m0 >> 12) | ((uint64_t)m1 << 20) | ((uint64_t)(m2 & 0xFFFu) << 52);
         uint64_t lv = ((uint64_t)m2 >> 12) | ((uint64_t)m3 << 20) | ((uint64_t)(m4 & 0xFFFu) << 52);
         int k = __popc(pawn) + __popcll(lh) + __popcll(lv);
-        uint32_t nn = rfl(E.n_nodes[b]), neu = rfl(E.n_edges[b]);
         if (k > 0) {
-            if (nn < (uint32_t)E.node_cap && neu + (uint32_t)k <= (uint32_t)E.edge_cap) {
+            const uint32_t half = rfl(E.tree_half[b]);
+            const size_t slot = tree_slot(E, b, half);
+            TreeView T = tree_view(E, b, half, lane);
+            uint32_t nn = rfl(E.n_nodes[b]), neu = rfl(E.n_edges[b]), np = rfl(E.tree_npages[slot]);
+            uint32_t off = QZ_NONE;
+            if (E.node_cap <= 0 || nn < (uint32_t)E.node_cap) off = tree_alloc(E, T, neu, np, k, lane, false);
+            if (off != QZ_NONE) {
+                const uint32_t base = tree_phys(T, off);
                 for (int a = lane; a < QZ_N_ACT; a += 64) {
                     uint32_t w = a < 32 ? m0 : (a < 64 ? m1 : (a < 96 ? m2 : (a < 128 ? m3 : m4)));
                     if ((w >> (a & 31)) & 1u) {
-                        uint32_t e = neu + (uint32_t)order_index(pawn, lh, lv, a);
+                        uint32_t e = base + (uint32_t)order_index(pawn, lh, lv, a);
                         Edge ed;
                         ed.Q = 0.0;
                         ed.N = 0u;
                         ed.P = p[(size_t)b * QZ_N_ACT + a];
-                        ed.child = 0u;
+                        ed.pedge = pedge;
                         ed.coff = 0u;
                         ed.act = (uint8_t)a;
                         ed.cne = 0;
                         ed.pad16 = 0;
                         ed.pad32 = 0u;
-                        T.e[e] = ed;
+                        T.pool[e] = ed;
                     }
                 }
                 if (lane == 0) {
-                    Node nd;
-                    nd.edge_off = neu;
-                    nd.n_edges = (uint32_t)k;
-                    nd.parent_node = pnode;
-                    nd.parent_edge = pedge;
-                    T.nodes[nn] = nd;
-                    if (pnode != QZ_NONE) {
-                        T.e[pedge].child = nn;
-                        T.e[pedge].coff = neu;
-                        T.e[pedge].cne = (uint8_t)k;
+                    if (pedge != QZ_NONE) {
+                        T.pool[pedge].coff = off;
+                        T.pool[pedge].cne = (uint8_t)k;
+                    } else {
+                        E.root_eoff[b] = off;
+                        E.root_ne[b] = (uint32_t)k;
                     }
                     E.n_nodes[b] = nn + 1u;
-                    E.n_edges[b] = neu + (uint32_t)k;
+                    E.n_edges[b] = neu;
+                    E.tree_npages[slot] = np;
                 }
             } else if (lane == 0) {
                 E.bc_overflow[b] += 1u;
+                E.tree_npages[slot] = np;
             }
         }
     } else {
@@ -615,32 +560,31 @@ __global__ __launch_bounds__(TPB) void k_expand_backup(EngineDev E, const float*
     // node.update_recursive(-leaf_value) (mcts.py:44-62, 127): the leaf edge gets -leaf_value, its
     // parent +leaf_value, ... up to the root.  The descent recorded its edges, so all levels are
     // updated in parallel (lane = level); a path longer than the record falls back to walking
-    // the parent pointers.
+    // the parent links.
+    Edge* pool = E.edge_pool;
     const uint32_t plen = rfl(E.path_len[b]);
     if (plen <= (uint32_t)QZ_PATH_CAP) {
         const uint32_t* path = E.path_edges + (size_t)b * QZ_PATH_CAP;
         for (uint32_t i = (uint32_t)lane; i < plen; i += 64u) {
             uint32_t pe = path[i];
             double val = ((plen - 1u - i) & 1u) ? leaf_value : -leaf_value;
-            uint32_t N = T.e[pe].N + 1u;  // mcts.py:51
-            double Q = T.e[pe].Q;
+            uint32_t N = pool[pe].N + 1u;  // mcts.py:51
+            double Q = pool[pe].Q;
             Q += 1.0 * (val - Q) / (double)N;  // mcts.py:53
-            T.e[pe].N = N;
-            T.e[pe].Q = Q;
+            pool[pe].N = N;
+            pool[pe].Q = Q;
         }
     } else if (lane == 0) {
         double val = -leaf_value;
-        uint32_t pn = pnode, pe = pedge;
-        while (pn != QZ_NONE) {
-            uint32_t N = T.e[pe].N + 1u;
-            double Q = T.e[pe].Q;
+        uint32_t pe = pedge;
+        while (pe != QZ_NONE) {
+            uint32_t N = pool[pe].N + 1u;
+            double Q = pool[pe].Q;
             Q += 1.0 * (val - Q) / (double)N;
-            T.e[pe].N = N;
-            T.e[pe].Q = Q;
+            pool[pe].N = N;
+            pool[pe].Q = Q;
             val = -val;  // mcts.py:61
-            Node nd = T.nodes[pn];
-            pe = nd.parent_edge;
-            pn = nd.parent_node;
+            pe = pool[pe].pedge;
         }
     }
     if (lane == 0) {
@@ -653,8 +597,7 @@ __global__ __launch_bounds__(TPB) void k_expand_backup(EngineDev E, const float*
 
 // softmax(1/temp * log(visits + 1e-10)) over the root's children (mcts.py:6-9, 141-144).
 // Returns this lane's probabilities for edges lane, lane+64, lane+128 in pr[3].
-__device__ __forceinline__ void root_pi(const TreeView& T, const Node& root, double inv_temp, int lane, double pr[3]) {
-    int ne = (int)root.n_edges;
+__device__ __forceinline__ void root_pi(const Edge* __restrict__ re, int ne, double inv_temp, int lane, double pr[3]) {
     double x[3];
     double mx = -__builtin_inf();
 #pragma unroll
@@ -662,7 +605,7 @@ __device__ __forceinline__ void root_pi(const TreeView& T, const Node& root, dou
         int k = lane + 64 * r;
         x[r] = -__builtin_inf();
         if (k < ne) {
-            x[r] = inv_temp * log((double)T.e[root.edge_off + k].N + 1e-10);
+            x[r] = inv_temp * log((double)re[k].N + 1e-10);
             mx = fmax(mx, x[r]);
         }
     }
@@ -678,6 +621,13 @@ __device__ __forceinline__ void root_pi(const TreeView& T, const Node& root, dou
 #pragma unroll
     for (int r = 0; r < 3; r++) pr[r] = pr[r] / s;
 }
+// the root's edge block of board b (NULL if the root was never expanded)
+__device__ __forceinline__ Edge* root_block(const EngineDev& E, int b, int lane, int& ne) {
+    ne = (int)rfl(E.root_ne[b]);
+    if (ne == 0) return nullptr;
+    const TreeView T = tree_view(E, b, rfl(E.tree_half[b]), lane);
+    return T.pool + tree_phys(T, rfl(E.root_eoff[b]));
+}
 
 __global__ __launch_bounds__(TPB) void k_root_pi(EngineDev E, double* __restrict__ pi, int32_t* __restrict__ visits) {
     const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
@@ -687,19 +637,19 @@ __global__ __launch_bounds__(TPB) void k_root_pi(EngineDev E, double* __restrict
         if (pi) pi[(size_t)b * QZ_N_ACT + a] = 0.0;
         if (visits) visits[(size_t)b * QZ_N_ACT + a] = -1;
     }
-    if (rfl(E.n_nodes[b]) == 0u) return;
-    TreeView T = tree_view(E, b, rfl(E.tree_half[b]));
-    Node root = T.nodes[0];
+    int ne;
+    const Edge* re = root_block(E, b, lane, ne);
+    if (!re) return;
     double pr[3];
-    root_pi(T, root, 1.0 / (double)E.temp, lane, pr);
+    root_pi(re, ne, 1.0 / (double)E.temp, lane, pr);
     wave_sync();
 #pragma unroll
     for (int r = 0; r < 3; r++) {
         int k = lane + 64 * r;
-        if (k < (int)root.n_edges) {
-            int a = T.e[root.edge_off + k].act;
+        if (k < ne) {
+            int a = re[k].act;
             if (pi) pi[(size_t)b * QZ_N_ACT + a] = pr[r];
-            if (visits) visits[(size_t)b * QZ_N_ACT + a] = (int32_t)T.e[root.edge_off + k].N;
+            if (visits) visits[(size_t)b * QZ_N_ACT + a] = (int32_t)re[k].N;
         }
     }
 }
@@ -714,95 +664,116 @@ __global__ __launch_bounds__(TPB) void k_root_children(EngineDev E, int32_t* vis
         if (prior) prior[(size_t)b * QZ_N_ACT + a] = 0.f;
     }
     if (root_visits && lane == 0) root_visits[b] = (int32_t)E.root_N[b];
-    if (rfl(E.n_nodes[b]) == 0u) return;
-    TreeView T = tree_view(E, b, rfl(E.tree_half[b]));
-    Node root = T.nodes[0];
+    int ne;
+    const Edge* re = root_block(E, b, lane, ne);
+    if (!re) return;
     wave_sync();
-    for (int k = lane; k < (int)root.n_edges; k += 64) {
-        uint32_t e = root.edge_off + k;
-        int a = T.e[e].act;
-        if (visits) visits[(size_t)b * QZ_N_ACT + a] = (int32_t)T.e[e].N;
-        if (q) q[(size_t)b * QZ_N_ACT + a] = T.e[e].Q;
-        if (prior) prior[(size_t)b * QZ_N_ACT + a] = T.e[e].P;
+    for (int k = lane; k < ne; k += 64) {
+        int a = re[k].act;
+        if (visits) visits[(size_t)b * QZ_N_ACT + a] = (int32_t)re[k].N;
+        if (q) q[(size_t)b * QZ_N_ACT + a] = re[k].Q;
+        if (prior) prior[(size_t)b * QZ_N_ACT + a] = re[k].P;
+    }
+}
+
+// copy one node's edge block (logical s_off in S) to logical d_off in D; the copies hang under
+// physical edge `pedge`.  coff / cne still name the SOURCE blocks of the children: they are
+// fixed up when wave_reroot's scan reaches them.
+__device__ __forceinline__ void copy_block(const TreeView& S, uint32_t s_off, const TreeView& D, uint32_t d_off, int ne,
+                                           uint32_t pedge, int lane) {
+    const uint32_t sb = tree_phys(S, s_off), db = tree_phys(D, d_off);
+    for (int k = lane; k < ne; k += 64) {
+        Edge ed = S.pool[sb + (uint32_t)k];
+        ed.pedge = pedge;
+        D.pool[db + (uint32_t)k] = ed;
     }
 }
 
 // MCTS.update_with_move (mcts.py:146-151): keep the chosen child's subtree by copying it,
-// breadth first, into the other arena half (new root = node 0).  `edge` is the root edge of
-// the move or QZ_NONE for a fresh root.
+// breadth first, into fresh pages mapped by the board's other page table; `edge` is the
+// physical root edge of the move or QZ_NONE for a fresh root.  The breadth-first queue is the
+// copy itself: blocks are appended in discovery order, so scanning the new tree's edges in
+// logical order and expanding every edge with cne > 0 visits the nodes breadth first.  The old
+// pages are handed back by k_release (launched right after every kernel that re-roots).
 __device__ __forceinline__ void wave_reroot(EngineDev& E, int b, int lane, uint32_t edge) {
-    uint32_t half = rfl(E.tree_half[b]);
-    TreeView S = tree_view(E, b, half);
-    uint32_t child = 0u, childN = 0u;
+    const uint32_t half = rfl(E.tree_half[b]);
+    const TreeView S = tree_view(E, b, half, lane);
+    uint32_t s_off = 0u, childN = 0u;
+    int s_ne = 0;
     if (edge != QZ_NONE) {
-        child = rfl(S.e[edge].child);
-        childN = rfl(S.e[edge].N);
+        s_ne = (int)rfl((uint32_t)S.pool[edge].cne);
+        s_off = rfl(S.pool[edge].coff);
+        childN = rfl(S.pool[edge].N);
     }
-    uint32_t new_nodes = 0u, new_edges = 0u;
-    if (child != 0u) {
-        TreeView D = tree_view(E, b, half ^ 1u);
-        if (lane == 0) {
-            Node r;
-            r.edge_off = child;  // temporarily: id of the source node
-            r.n_edges = S.nodes[child].n_edges;
-            r.parent_node = QZ_NONE;
-            r.parent_edge = QZ_NONE;
-            D.nodes[0] = r;
-        }
-        new_nodes = 1u;
-        wave_sync();
-        for (uint32_t i = 0; i < new_nodes; i++) {
-            uint32_t old = rfl(D.nodes[i].edge_off);
-            Node on = S.nodes[old];
-            uint32_t soff = rfl(on.edge_off);
-            int ne = (int)rfl(on.n_edges);
-            uint32_t doff = new_edges;
-            for (int base = 0; base < ne; base += 64) {
-                int k = base + lane;
-                bool act = k < ne;
-                uint32_t c = 0u;
-                if (act) c = S.e[soff + k].child;
-                bool has = act && c != 0u;
-                uint64_t m = __ballot(has);
-                uint32_t nid = new_nodes + (uint32_t)rank_below(m);
-                if (act) {
-                    Edge ed = S.e[soff + k];
-                    ed.child = has ? nid : 0u;
-                    ed.coff = 0u;  // fixed up when the child itself is copied
-                    ed.cne = 0;
-                    D.e[doff + k] = ed;
-                    if (has) {
-                        Node cn;
-                        cn.edge_off = c;  // source id, fixed up when the node is visited
-                        cn.n_edges = S.nodes[c].n_edges;
-                        cn.parent_node = i;
-                        cn.parent_edge = doff + (uint32_t)k;
-                        D.nodes[nid] = cn;
+    uint32_t new_nodes = 0u, new_edges = 0u, dnp = 0u, root_off = 0u, truncated = 0u;
+    int root_ne = 0;
+    bool flipped = false;
+    if (s_ne > 0) {
+        TreeView D = tree_view(E, b, half ^ 1u, lane);
+        const uint32_t off = tree_alloc(E, D, new_edges, dnp, s_ne, lane, true);
+        if (off != QZ_NONE) {
+            copy_block(S, s_off, D, off, s_ne, QZ_NONE, lane);
+            new_nodes = 1u;
+            root_off = off;
+            root_ne = s_ne;
+            flipped = true;
+            bool exhausted = false;
+            uint32_t q = 0u;
+            while (q < new_edges) {  // wave-uniform
+                wave_sync();
+                const uint32_t wbase = q & ~63u;
+                const uint32_t lim = new_edges < wbase + 64u ? new_edges : wbase + 64u;
+                const uint32_t idx = wbase + (uint32_t)lane;
+                const uint32_t pb = tree_phys(D, wbase);
+                uint32_t cne = 0u;
+                if (idx >= q && idx < lim) cne = D.pool[pb + (uint32_t)lane].cne;
+                uint64_t m = __ballot(cne > 0u);
+                while (m) {  // the nodes found in this window, in order
+                    const int l = __ffsll((unsigned long long)m) - 1;
+                    m &= m - 1ull;
+                    const uint32_t pe = pb + (uint32_t)l;
+                    const int c_ne = (int)rfl((uint32_t)D.pool[pe].cne);
+                    const uint32_t c_src = rfl(D.pool[pe].coff);
+                    uint32_t doff = QZ_NONE;
+                    if (!exhausted) doff = tree_alloc(E, D, new_edges, dnp, c_ne, lane, true);
+                    if (doff == QZ_NONE) {  // pool empty: the rest of the subtree is cut off (counted)
+                        exhausted = true;
+                        truncated++;
+                        if (lane == 0) {
+                            D.pool[pe].cne = 0;
+                            D.pool[pe].coff = 0u;
+                        }
+                    } else {
+                        copy_block(S, c_src, D, doff, c_ne, pe, lane);
+                        if (lane == 0) D.pool[pe].coff = doff;
+                        new_nodes++;
                     }
                 }
-                new_nodes += (uint32_t)__popcll(m);
+                q = lim;
             }
-            if (lane == 0) {
-                D.nodes[i].edge_off = doff;
-                if (i > 0u) {
-                    uint32_t pe = D.nodes[i].parent_edge;
-                    D.e[pe].coff = doff;
-                    D.e[pe].cne = (uint8_t)ne;
-                }
-            }
-            new_edges += (uint32_t)ne;
-            wave_sync();
+        } else {
+            truncated = 1u;
         }
-        if (lane == 0) E.tree_half[b] = (uint8_t)(half ^ 1u);
     }
     if (lane == 0) {
+        // successful copy: the old tree (now the other half) goes back to the pool; otherwise the
+        // board restarts from a fresh root and its current half is returned
+        E.release[b] = flipped ? 1 : 2;
+        if (flipped) {
+            E.tree_half[b] = (uint8_t)(half ^ 1u);
+            E.tree_npages[tree_slot(E, b, half ^ 1u)] = dnp;
+        }
         E.n_nodes[b] = new_nodes;
         E.n_edges[b] = new_edges;
         E.root_N[b] = childN;
+        E.root_eoff[b] = root_off;
+        E.root_ne[b] = (uint32_t)root_ne;
+        if (truncated) E.bc_overflow[b] += truncated;
     }
 }
 
-__device__ __forceinline__ void reset_board_state(EngineDev& E, int b) {  // lane 0 only
+// lane 0 only; pages are given back by the caller (push-only kernels)
+__device__ __forceinline__ void reset_board_state(EngineDev& E, int b) {
     Board o = opening();
     E.root_hb[b] = o.hb;
     E.root_vb[b] = o.vb;
@@ -810,22 +781,54 @@ __device__ __forceinline__ void reset_board_state(EngineDev& E, int b) {  // lan
     E.n_nodes[b] = 0u;
     E.n_edges[b] = 0u;
     E.root_N[b] = 0u;
+    E.root_ne[b] = 0u;
+    E.root_eoff[b] = 0u;
     E.ply[b] = 0u;
     E.status[b] = QZ_PLAYING;
     E.winner[b] = 0;
+    E.release[b] = 0;
     E.game_serial[b] = E.game_serial[b] + 1u;
 }
 
-__global__ __launch_bounds__(256) void k_reset(EngineDev E, int reset_boards) {
-    int b = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+// PUSH-ONLY.  reset_boards: Quoridor.reset() + fresh trees + empty trajectories; otherwise
+// only the trees are dropped (MCTSPlayer.reset_player, mcts.py:168-169).
+__global__ __launch_bounds__(TPB) void k_reset(EngineDev E, int reset_boards) {
+    const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+    const int b = (int)blockIdx.x * WPB + wave;
     if (b >= E.n_boards) return;
+    wave_free_tree_half(E, b, 0u, lane);
+    wave_free_tree_half(E, b, 1u, lane);
     if (reset_boards) {
-        reset_board_state(E, b);
-    } else {
+        wave_free_traj(E, b, lane);
+        if (lane == 0) reset_board_state(E, b);
+    } else if (lane == 0) {
         E.n_nodes[b] = 0u;
         E.n_edges[b] = 0u;
         E.root_N[b] = 0u;
+        E.root_ne[b] = 0u;
+        E.root_eoff[b] = 0u;
+        E.release[b] = 0;
     }
+}
+
+// PUSH-ONLY, launched after every kernel that re-roots (k_finish_move, k_update_with_move):
+// returns the pages of the trees that were replaced and restarts dropped games.
+__global__ __launch_bounds__(TPB) void k_release(EngineDev E) {
+    const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+    const int b = (int)blockIdx.x * WPB + wave;
+    if (b >= E.n_boards) return;
+    const uint32_t rel = rfl((uint32_t)E.release[b]);
+    const uint32_t half = rfl(E.tree_half[b]);
+    if (rfl((uint32_t)E.status[b]) == QZ_ABORTED) {
+        wave_free_tree_half(E, b, 0u, lane);
+        wave_free_tree_half(E, b, 1u, lane);
+        wave_free_traj(E, b, lane);
+        if (lane == 0) reset_board_state(E, b);
+        return;
+    }
+    if (rel & 1u) wave_free_tree_half(E, b, half ^ 1u, lane);
+    if (rel & 2u) wave_free_tree_half(E, b, half, lane);
+    if (rel && lane == 0) E.release[b] = 0;
 }
 
 __global__ __launch_bounds__(TPB) void k_update_with_move(EngineDev E, const uint8_t* __restrict__ moves) {
@@ -834,14 +837,14 @@ __global__ __launch_bounds__(TPB) void k_update_with_move(EngineDev E, const uin
     if (b >= E.n_boards) return;
     int mv = (int)rfl(moves[b]);
     uint32_t edge = QZ_NONE;
-    if (mv < QZ_N_ACT && rfl(E.n_nodes[b]) > 0u) {
-        TreeView T = tree_view(E, b, rfl(E.tree_half[b]));
-        Node root = T.nodes[0];
-        for (int base = 0; base < (int)root.n_edges; base += 64) {
+    int ne;
+    const Edge* re = root_block(E, b, lane, ne);
+    if (mv < QZ_N_ACT && re) {
+        for (int base = 0; base < ne; base += 64) {
             int k = base + lane;
-            bool hit = k < (int)root.n_edges && T.e[root.edge_off + k].act == mv;
+            bool hit = k < ne && re[k].act == mv;
             uint64_t m = __ballot(hit);
-            if (m) edge = root.edge_off + (uint32_t)base + (uint32_t)(__ffsll((unsigned long long)m) - 1);
+            if (m) edge = (uint32_t)(re - E.edge_pool) + (uint32_t)base + (uint32_t)(__ffsll((unsigned long long)m) - 1);
         }
     }
     wave_reroot(E, b, lane, edge);
@@ -893,69 +896,113 @@ __device__ double gamma_small(const Philox& ph, uint32_t c0, uint32_t c1, uint32
 }
 
 // MCTSPlayer.choose_action tail + one iteration of start_self_play (mcts.py:174-187,
-// quoridor.py:585-602)
+// quoridor.py:585-602).  POP-ONLY (trajectory page, pages of the re-rooted tree).
 __global__ __launch_bounds__(TPB) void k_finish_move(EngineDev E, const uint8_t* __restrict__ forced, float* __restrict__ pi_out,
                                                      uint8_t* __restrict__ move_out) {
     const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
     const int b = (int)blockIdx.x * WPB + wave;
     if (b >= E.n_boards) return;
     if (move_out && lane == 0) move_out[b] = QZ_NO_MOVE_U8;
+    if (pi_out)
+        for (int a = lane; a < QZ_N_ACT; a += 64) pi_out[(size_t)b * QZ_N_ACT + a] = 0.f;
     if (rfl(E.status[b]) != QZ_PLAYING) return;
     Board bd = load_board(E.root_hb, E.root_vb, E.root_meta, b);
-    uint32_t ply = rfl(E.ply[b]);
-    uint32_t n_nodes = rfl(E.n_nodes[b]);
-    if (n_nodes == 0u || ply >= (uint32_t)E.max_plies) {
-        // no legal move at the root (the reference prints "board is full" and crashes in
-        // start_self_play's unpack, mcts.py:195-196) or the trajectory is full: drop the game
+    const uint32_t ply = rfl(E.ply[b]);
+    int ne;
+    Edge* re = root_block(E, b, lane, ne);
+    // a game that cannot go on is dropped, counted by cause, and restarted by k_release:
+    //   no legal move at the root (the reference prints "board is full" and crashes in
+    //   start_self_play's unpack, mcts.py:195-196); qz_config.max_plies reached; no room left
+    //   for its trajectory (page table full / pool empty)
+    int abort_cause = -1;
+    if (!re) abort_cause = QZ_C_ABORT_NO_MOVE;
+    else if (E.max_plies > 0 && ply >= (uint32_t)E.max_plies) abort_cause = QZ_C_ABORT_MAX_PLIES;
+    // the forced move must be a child of the root: otherwise the board stays where it is and the
+    // sticky error counter goes up (qz_stats.bad_forced_moves)
+    const int fm = forced ? (int)rfl(forced[b]) : QZ_NO_MOVE_U8;
+    int act[3];
+    int chosen_k = -1;
+    if (abort_cause < 0) {
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            int k = lane + 64 * r;
+            act[r] = k < ne ? (int)re[k].act : -1;
+        }
+        if (fm < QZ_N_ACT) {
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                uint64_t m = __ballot(act[r] == fm);
+                if (m) chosen_k = 64 * r + (__ffsll((unsigned long long)m) - 1);
+            }
+            if (chosen_k < 0) {
+                if (lane == 0) atomicAdd((unsigned long long*)&E.counters[QZ_C_BAD_FORCED], 1ull);
+                return;
+            }
+        }
+    }
+    // room for this ply's record: [ne][0][board x6][pi f32 x ne][act u8 x ne, padded to 4]
+    uint32_t* rec = nullptr;
+    if (abort_cause < 0) {
+        const uint32_t need = QZ_TRAJ_HDR + (uint32_t)ne + (((uint32_t)ne + 3u) >> 2);
+        uint32_t* ptab = E.traj_ptab + (size_t)b * QZ_TRAJ_PT;
+        uint32_t npg = rfl(E.traj_npages[b]), cur = rfl(E.traj_cursor[b]);
+        if (npg == 0u || cur + need > E.traj_page_dwords) {
+            uint32_t page = QZ_NONE;
+            if (npg >= (uint32_t)QZ_TRAJ_PT) abort_cause = QZ_C_ABORT_MAX_PLIES;
+            else {
+                page = wave_pop(E.free_traj, E.pool_words + QZ_P_TRAJ_TOP, E.pool_words + QZ_P_TRAJ_LOW, lane);
+                if (page == QZ_NONE) abort_cause = QZ_C_ABORT_POOL;
+            }
+            if (abort_cause < 0) {
+                if (lane == 0) {
+                    if (npg > 0u && cur < E.traj_page_dwords) E.traj_pool[(size_t)ptab[npg - 1u] * E.traj_page_dwords + cur] = QZ_TRAJ_SKIP;
+                    ptab[npg] = page;
+                    E.traj_npages[b] = npg + 1u;
+                }
+                cur = 0u;
+                rec = E.traj_pool + (size_t)page * E.traj_page_dwords;
+            }
+        } else {
+            rec = E.traj_pool + (size_t)rfl(ptab[npg - 1u]) * E.traj_page_dwords + cur;
+        }
+        if (abort_cause < 0 && lane == 0) E.traj_cursor[b] = cur + need;
+    }
+    if (abort_cause >= 0) {
         if (lane == 0) {
-            atomicAdd((unsigned long long*)&E.counters[QZ_C_ABORTED], 1ull);
-            reset_board_state(E, b);
+            atomicAdd((unsigned long long*)&E.counters[abort_cause], 1ull);
+            E.status[b] = QZ_ABORTED;
         }
         return;
     }
-    TreeView T = tree_view(E, b, rfl(E.tree_half[b]));
-    Node root = T.nodes[0];
-    uint32_t eoff = rfl(root.edge_off);
-    int ne = (int)rfl(root.n_edges);
     double pr[3];
-    root_pi(T, root, 1.0 / (double)E.temp, lane, pr);
+    root_pi(re, ne, 1.0 / (double)E.temp, lane, pr);
 
     // record (board, pi) BEFORE the move (quoridor.py:589-591)
-    float* tp = E.traj_pi + ((size_t)b * E.max_plies + ply) * QZ_N_ACT;
-    for (int a = lane; a < QZ_N_ACT; a += 64) {
-        tp[a] = 0.f;
-        if (pi_out) pi_out[(size_t)b * QZ_N_ACT + a] = 0.f;
-    }
-    wave_sync();
-    int act[3];
+    wave_sync();  // pi_out was zero-filled by other lanes above
+    uint8_t* rec_act = reinterpret_cast<uint8_t*>(rec + QZ_TRAJ_HDR + ne);
 #pragma unroll
     for (int r = 0; r < 3; r++) {
         int k = lane + 64 * r;
-        act[r] = -1;
         if (k < ne) {
-            act[r] = T.e[eoff + k].act;
-            tp[act[r]] = (float)pr[r];
+            reinterpret_cast<float*>(rec)[QZ_TRAJ_HDR + k] = (float)pr[r];
+            rec_act[k] = (uint8_t)act[r];
             if (pi_out) pi_out[(size_t)b * QZ_N_ACT + act[r]] = (float)pr[r];
         }
     }
     if (lane == 0) {
-        uint64_t* tb = E.traj_board + ((size_t)b * E.max_plies + ply) * 3;
-        tb[0] = bd.hb;
-        tb[1] = bd.vb;
-        tb[2] = pack_meta(bd);
+        rec[0] = (uint32_t)ne;
+        rec[1] = 0u;
+        const uint64_t m = pack_meta(bd);
+        rec[2] = (uint32_t)bd.hb;
+        rec[3] = (uint32_t)(bd.hb >> 32);
+        rec[4] = (uint32_t)bd.vb;
+        rec[5] = (uint32_t)(bd.vb >> 32);
+        rec[6] = (uint32_t)m;
+        rec[7] = (uint32_t)(m >> 32);
     }
 
     // the move
-    int chosen_k = -1;
-    int fm = forced ? (int)rfl(forced[b]) : QZ_NO_MOVE_U8;
-    if (fm < QZ_N_ACT) {
-#pragma unroll
-        for (int r = 0; r < 3; r++) {
-            uint64_t m = __ballot(act[r] == fm);
-            if (m) chosen_k = 64 * r + (__ffsll((unsigned long long)m) - 1);
-        }
-        if (chosen_k < 0) chosen_k = 0;  // illegal forced move: fall back to the first child
-    } else {
+    if (fm >= QZ_N_ACT) {
         Philox ph{(uint32_t)E.seed, (uint32_t)(E.seed >> 32)};
         uint32_t serial = rfl(E.game_serial[b]);
         double w[3];
@@ -992,12 +1039,11 @@ __global__ __launch_bounds__(TPB) void k_finish_move(EngineDev E, const uint8_t*
         }
         chosen_k = cnt < ne ? cnt : ne - 1;
     }
-    uint32_t edge = eoff + (uint32_t)chosen_k;
-    int mv = (int)rfl(T.e[edge].act);
+    const int mv = (int)rfl((uint32_t)re[chosen_k].act);
     if (move_out && lane == 0) move_out[b] = (uint8_t)mv;
 
     // update_with_move(move) in self-play, update_with_move(-1) otherwise (mcts.py:182,187)
-    wave_reroot(E, b, lane, E.is_selfplay ? edge : QZ_NONE);
+    wave_reroot(E, b, lane, E.is_selfplay ? (uint32_t)(re - E.edge_pool) + (uint32_t)chosen_k : QZ_NONE);
 
     // self.step(move); has_a_winner() (quoridor.py:593-596)
     bool done = apply_action(bd, mv);
@@ -1062,7 +1108,8 @@ __global__ __launch_bounds__(1024) void k_harvest_scan(EngineDev E) {
     }
 }
 
-// quoridor.py:596-610: z = +1 where the recorded mover is the winner, else -1; then reset
+// quoridor.py:596-610: z = +1 where the recorded mover is the winner, else -1; then reset.
+// PUSH-ONLY: the finished game's tree and trajectory pages go back to the pools.
 __global__ __launch_bounds__(TPB) void k_harvest_copy(EngineDev E, uint64_t* t_hb, uint64_t* t_vb, uint64_t* t_meta,
                                                       float* __restrict__ t_pi, float* __restrict__ t_z,
                                                       int32_t* __restrict__ t_game, long long cap) {
@@ -1070,26 +1117,55 @@ __global__ __launch_bounds__(TPB) void k_harvest_copy(EngineDev E, uint64_t* t_h
     const int b = (int)blockIdx.x * WPB + wave;
     if (b >= E.n_boards) return;
     if (rfl(E.status[b]) != QZ_FINISHED) return;
-    uint32_t n = rfl(E.ply[b]), off = rfl(E.harvest_off[b]), gid = rfl(E.harvest_gid[b]);
-    int win = (int)rfl(E.winner[b]);
+    const uint32_t n = rfl(E.ply[b]), off = rfl(E.harvest_off[b]), gid = rfl(E.harvest_gid[b]);
+    const int win = (int)rfl(E.winner[b]);
+    const uint32_t* ptab = E.traj_ptab + (size_t)b * QZ_TRAJ_PT;
+    uint32_t pgi = 0u, cur = 0u;
     for (uint32_t i = 0; i < n; i++) {
-        long long o = (long long)off + i;
+        const long long o = (long long)off + i;
         if (o >= cap) break;
-        const uint64_t* tb = E.traj_board + ((size_t)b * E.max_plies + i) * 3;
-        const float* tp = E.traj_pi + ((size_t)b * E.max_plies + i) * QZ_N_ACT;
-        for (int a = lane; a < QZ_N_ACT; a += 64) t_pi[(size_t)o * QZ_N_ACT + a] = tp[a];
+        const uint32_t* page = E.traj_pool + (size_t)rfl(ptab[pgi]) * E.traj_page_dwords;
+        if (cur >= E.traj_page_dwords || rfl(page[cur]) == QZ_TRAJ_SKIP) {  // the writer moved on to the next page here
+            pgi++;
+            cur = 0u;
+            page = E.traj_pool + (size_t)rfl(ptab[pgi]) * E.traj_page_dwords;
+        }
+        const uint32_t* rec = page + cur;
+        const int ne = (int)rfl(rec[0]);
+        float* row = t_pi + (size_t)o * QZ_N_ACT;
+        for (int a = lane; a < QZ_N_ACT; a += 64) row[a] = 0.f;
+        wave_sync();
+        const uint8_t* rec_act = reinterpret_cast<const uint8_t*>(rec + QZ_TRAJ_HDR + ne);
+        for (int k = lane; k < ne; k += 64) row[rec_act[k]] = reinterpret_cast<const float*>(rec)[QZ_TRAJ_HDR + k];
         if (lane == 0) {
-            uint64_t m = tb[2];
-            t_hb[o] = tb[0];
-            t_vb[o] = tb[1];
+            const uint64_t m = (uint64_t)rec[6] | ((uint64_t)rec[7] << 32);
+            t_hb[o] = (uint64_t)rec[2] | ((uint64_t)rec[3] << 32);
+            t_vb[o] = (uint64_t)rec[4] | ((uint64_t)rec[5] << 32);
             t_meta[o] = m;
-            int mover = (int)((m >> 32) & 0xFF);
+            const int mover = (int)((m >> 32) & 0xFF);
             t_z[o] = (mover == win) ? 1.0f : -1.0f;
             if (t_game) t_game[o] = (int32_t)gid;
         }
+        cur += QZ_TRAJ_HDR + (uint32_t)ne + (((uint32_t)ne + 3u) >> 2);
     }
     wave_sync();
+    wave_free_tree_half(E, b, 0u, lane);
+    wave_free_tree_half(E, b, 1u, lane);
+    wave_free_traj(E, b, lane);
     if (lane == 0) reset_board_state(E, b);
+}
+
+// free lists <- 0..n-1 (engine creation)
+__global__ void k_pool_init(EngineDev E) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i < E.tree_pool_pages) E.free_tree[i] = (uint32_t)(E.tree_pool_pages - 1 - i);  // low pages are popped first
+    if (i < E.traj_pool_pages) E.free_traj[i] = (uint32_t)(E.traj_pool_pages - 1 - i);
+    if (i == 0) {
+        E.pool_words[QZ_P_TREE_TOP] = E.tree_pool_pages;
+        E.pool_words[QZ_P_TREE_LOW] = E.tree_pool_pages;
+        E.pool_words[QZ_P_TRAJ_TOP] = E.traj_pool_pages;
+        E.pool_words[QZ_P_TRAJ_LOW] = E.traj_pool_pages;
+    }
 }
 
 __global__ void k_sqrt_table(double* out, int n) {  // self-test helper: device sqrt(double(i))
@@ -1103,10 +1179,6 @@ __global__ void k_sqrt_table(double* out, int n) {  // self-test helper: device 
 namespace qzl {
 
 static inline dim3 wave_grid(int n) { return dim3((unsigned)((n + WPB - 1) / WPB)); }
-
-int g_enc_split_pct = 70;
-int g_detour_pooled = 1, g_detour_wave = 0;  // pool_k1's detour_mode per kernel family
-int g_movegen_variant = 0;  // 0 = by batch size; 1 = first wave-per-board kernel (A/B); 2/3/4 = k_wave_rules with 2/1/4 boards per wave; 8..32 = pooled, forced tile
 
 constexpr int NBE = 16;  // boards per encoder group
 
@@ -1123,31 +1195,22 @@ static void launch_masks_enc(const PoolBoard* recs, const PathTab* tabs, int n, 
 size_t movegen_scratch_bytes(int n) { return (size_t)n * (sizeof(PoolBoard) + 2 * sizeof(PathTab)); }
 
 hipError_t movegen_encode(const uint64_t* hb, const uint64_t* vb, const uint64_t* meta, int n, uint32_t* mask5,
-                          float* planes, const uint8_t* terminal, void* scratch, hipStream_t s) {
+                          float* planes, const uint8_t* terminal, void* scratch, const RulesOpts& ro, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     // Small batches are latency-bound: one launch, a wavefront per board, no hand-off through
     // HBM (k_wave_rules).  From ~8k boards on the chip is saturated and the pooled two-launch
     // pipeline, which packs lanes better, wins.
-    if (g_movegen_variant == 2 || g_movegen_variant == 3 || g_movegen_variant == 4 || (g_movegen_variant == 0 && n < 8192)) {
+    if (ro.variant == 2 || ro.variant == 3 || ro.variant == 4 || (ro.variant == 0 && n < 8192)) {
         const int n_enc_groups = planes ? (n + NBE - 1) / NBE : 0;
         // boards per wavefront: on bench trees (late-game boards, many without walls left) one board per
         // wavefront measured 29.1 us vs 33.0 (two) / 34.6 (four) at 4,096 boards; on the synthetic
         // S-mid set two were slightly ahead (40.4 vs 42.9 us).  The in-situ number decides.
-        const int G = g_movegen_variant == 2 ? 2 : (g_movegen_variant == 4 ? 4 : 1);
+        const int G = ro.variant == 2 ? 2 : (ro.variant == 4 ? 4 : 1);
         const int n_mg_groups = mask5 ? (n + WPB * G - 1) / (WPB * G) : 0;
         dim3 grid((unsigned)(n_mg_groups + n_enc_groups));
-        if (G == 1) hipLaunchKernelGGL((k_wave_rules<NBE, 1>), grid, dim3(256), 0, s, hb, vb, meta, n, terminal, mask5, planes, n_mg_groups, g_detour_wave);
-        else if (G == 4) hipLaunchKernelGGL((k_wave_rules<NBE, 4>), grid, dim3(256), 0, s, hb, vb, meta, n, terminal, mask5, planes, n_mg_groups, g_detour_wave);
-        else hipLaunchKernelGGL((k_wave_rules<NBE, 2>), grid, dim3(256), 0, s, hb, vb, meta, n, terminal, mask5, planes, n_mg_groups, g_detour_wave);
-        return hipGetLastError();
-    }
-    if (g_movegen_variant == 1) {  // the first kernel of this repo, kept for A/B runs
-        if (mask5 && planes)
-            hipLaunchKernelGGL((k_movegen_encode<true, true>), wave_grid(n), dim3(TPB), 0, s, hb, vb, meta, n, mask5, planes, terminal);
-        else if (mask5)
-            hipLaunchKernelGGL((k_movegen_encode<true, false>), wave_grid(n), dim3(TPB), 0, s, hb, vb, meta, n, mask5, planes, terminal);
-        else
-            hipLaunchKernelGGL((k_movegen_encode<false, true>), wave_grid(n), dim3(TPB), 0, s, hb, vb, meta, n, mask5, planes, terminal);
+        if (G == 1) hipLaunchKernelGGL((k_wave_rules<NBE, 1>), grid, dim3(256), 0, s, hb, vb, meta, n, terminal, mask5, planes, n_mg_groups, ro.detour_wave);
+        else if (G == 4) hipLaunchKernelGGL((k_wave_rules<NBE, 4>), grid, dim3(256), 0, s, hb, vb, meta, n, terminal, mask5, planes, n_mg_groups, ro.detour_wave);
+        else hipLaunchKernelGGL((k_wave_rules<NBE, 2>), grid, dim3(256), 0, s, hb, vb, meta, n, terminal, mask5, planes, n_mg_groups, ro.detour_wave);
         return hipGetLastError();
     }
     PoolBoard* recs = reinterpret_cast<PoolBoard*>(scratch);
@@ -1157,13 +1220,13 @@ hipError_t movegen_encode(const uint64_t* hb, const uint64_t* vb, const uint64_t
     // the rest beside the mask groups (~22 us alone).  Sweep at 32,768 boards, S-mid: 35 % 80 us,
     // 50 % 80, 60 % 77, 70 % 75, 80 % 78, 100 % 82.
     const int enc_total = planes ? (n + NBE - 1) / NBE : 0;
-    const int enc_a = mask5 ? (enc_total * g_enc_split_pct) / 100 : 0;
+    const int enc_a = mask5 ? (enc_total * ro.enc_split_pct) / 100 : 0;
     if (mask5) {
         const int n_path_groups = (2 * n + 255) / 256;
         hipLaunchKernelGGL((k_pool_paths_enc<NBE>), dim3((unsigned)(n_path_groups + enc_a)), dim3(256), 0, s, hb, vb, meta, n,
-                           terminal, recs, tabs, n_path_groups, planes, g_detour_pooled);
+                           terminal, recs, tabs, n_path_groups, planes, ro.detour_pooled);
     }
-    int nbt = g_movegen_variant >= 8 ? g_movegen_variant : (n >= 16384 ? 24 : (n >= 8192 ? 16 : 8));
+    int nbt = ro.variant >= 8 ? ro.variant : (n >= 16384 ? 24 : (n >= 8192 ? 16 : 8));
     const int enc_b = enc_total - enc_a;
     if (nbt >= 32) launch_masks_enc<32>(recs, tabs, n, mask5, hb, vb, meta, terminal, planes, enc_a, enc_b, s);
     else if (nbt >= 24) launch_masks_enc<24>(recs, tabs, n, mask5, hb, vb, meta, terminal, planes, enc_a, enc_b, s);
@@ -1196,14 +1259,21 @@ hipError_t root_children(const EngineDev& E, int32_t* visits, double* q, float* 
 }
 hipError_t update_with_move(const EngineDev& E, const uint8_t* moves, hipStream_t s) {
     hipLaunchKernelGGL(k_update_with_move, wave_grid(E.n_boards), dim3(TPB), 0, s, E, moves);
+    hipLaunchKernelGGL(k_release, wave_grid(E.n_boards), dim3(TPB), 0, s, E);
     return hipGetLastError();
 }
 hipError_t finish_move(const EngineDev& E, const uint8_t* forced, float* pi_out, uint8_t* move_out, hipStream_t s) {
     hipLaunchKernelGGL(k_finish_move, wave_grid(E.n_boards), dim3(TPB), 0, s, E, forced, pi_out, move_out);
+    hipLaunchKernelGGL(k_release, wave_grid(E.n_boards), dim3(TPB), 0, s, E);
     return hipGetLastError();
 }
 hipError_t reset(const EngineDev& E, int reset_boards, hipStream_t s) {
-    hipLaunchKernelGGL(k_reset, dim3((unsigned)((E.n_boards + 255) / 256)), dim3(256), 0, s, E, reset_boards);
+    hipLaunchKernelGGL(k_reset, wave_grid(E.n_boards), dim3(TPB), 0, s, E, reset_boards);
+    return hipGetLastError();
+}
+hipError_t pool_init(const EngineDev& E, hipStream_t s) {
+    const int n = E.tree_pool_pages > E.traj_pool_pages ? E.tree_pool_pages : E.traj_pool_pages;
+    hipLaunchKernelGGL(k_pool_init, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, E);
     return hipGetLastError();
 }
 hipError_t harvest(const EngineDev& E, uint64_t* t_hb, uint64_t* t_vb, uint64_t* t_meta, float* t_pi, float* t_z,
@@ -1211,18 +1281,6 @@ hipError_t harvest(const EngineDev& E, uint64_t* t_hb, uint64_t* t_vb, uint64_t*
     hipLaunchKernelGGL(k_harvest_scan, dim3(1), dim3(1024), 0, s, E);
     hipLaunchKernelGGL(k_harvest_copy, wave_grid(E.n_boards), dim3(TPB), 0, s, E, t_hb, t_vb, t_meta, t_pi, t_z, t_game, cap);
     return hipGetLastError();
-}
-void set_movegen_variant(int v) {
-    if (v >= 300 && v < 309) {  // A/B knob: detour_mode of the pooled (v % 3) and the wave-per-board kernel (v / 3)
-        g_detour_pooled = (v - 300) % 3;
-        g_detour_wave = (v - 300) / 3;
-        return;
-    }
-    if (v >= 100 && v <= 200) {  // A/B knob: share of the encoder tiles that ride beside the path search
-        g_enc_split_pct = v - 100;
-        return;
-    }
-    g_movegen_variant = v;
 }
 hipError_t sqrt_table(double* out, int n, hipStream_t s) {
     hipLaunchKernelGGL(k_sqrt_table, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out, n);

@@ -60,7 +60,8 @@ class TupleBatch:
 
 class SelfPlayEngine:
     def __init__(self, n_boards, n_playout=400, c_puct=5.0, temp=1.0, is_selfplay=1, seed=0, device="cuda:0",
-                 fix_terminal_sign=False, node_cap=0, edge_cap=0, max_plies=0, dirichlet_alpha=0.3, noise_frac=0.25):
+                 fix_terminal_sign=False, node_cap=0, edge_cap=0, max_plies=0, dirichlet_alpha=0.3, noise_frac=0.25,
+                 tree_pool_pages=0, traj_pool_pages=0, traj_page_dwords=0, rules_opts=None):
         if not torch.cuda.is_available():
             raise _cabi.QzError(_cabi.E_NO_DEVICE, "no HIP device: the engine has no CPU path")
         self.L = _cabi.load()
@@ -79,6 +80,10 @@ class SelfPlayEngine:
         cfg.is_selfplay = int(is_selfplay)
         cfg.fix_terminal_sign = int(bool(fix_terminal_sign))
         cfg.node_cap, cfg.edge_cap, cfg.max_plies = int(node_cap), int(edge_cap), int(max_plies)
+        cfg.tree_pool_pages, cfg.traj_pool_pages = int(tree_pool_pages), int(traj_pool_pages)
+        cfg.traj_page_dwords = int(traj_page_dwords)
+        if rules_opts is not None:
+            cfg.rules = rules_opts
         self.cfg = cfg
         h = C.c_void_p()
         with torch.cuda.device(self.device):
@@ -87,8 +92,10 @@ class SelfPlayEngine:
         self.h = h
         B = self.n_boards
         dev = self.device
-        # caller-owned I/O buffers of the step (device resident, reused every step)
-        self.planes = torch.zeros((B, 26, 9, 9), dtype=torch.float32, device=dev)
+        # caller-owned I/O buffers of the step (device resident, reused every step); the planes
+        # (34.5 MB per 4,096 boards) exist only if somebody asks for them: an evaluator that takes
+        # the leaf boards (qz_nn_input_layer) never reads them
+        self._planes = None
         self.leaf_mask = torch.zeros((B, 5), dtype=torch.int32, device=dev)
         self.leaf_term = torch.zeros(B, dtype=torch.uint8, device=dev)
         self.moves = torch.full((B,), 255, dtype=torch.uint8, device=dev)
@@ -96,6 +103,12 @@ class SelfPlayEngine:
         self._graph = None
         self._graph_steps = 0
         self._leaf_ref = None
+
+    @property
+    def planes(self):
+        if self._planes is None:
+            self._planes = torch.zeros((self.n_boards, 26, 9, 9), dtype=torch.float32, device=self.device)
+        return self._planes
 
     # ------------------------------------------------------------------ plumbing
     def _s(self):
@@ -129,21 +142,34 @@ class SelfPlayEngine:
     def set_temp(self, temp: float):
         _cabi.check(self.L.qz_engine_set_temp(self.h, float(temp)))
 
+    def set_rules_opts(self, opts=None):
+        """qz_rules_opts for this engine's leaf rules op (None = library defaults)."""
+        _cabi.check(self.L.qz_engine_set_rules_opts(self.h, C.byref(opts) if opts is not None else None))
+
     # ------------------------------------------------------------------ one playout step
-    def select(self, want_mask=False, events=None):
-        """-> leaf planes [B,26,9,9].  want_mask also copies the leaf masks / terminal flags
-        into self.leaf_mask / self.leaf_term.  events=(start, stop): torch events recorded
-        around the fused movegen+encode launch only (bench.py's roofline measurement)."""
+    def select(self, want_mask=False, events=None, want_planes=True, tree_events=None):
+        """-> leaf planes [B,26,9,9] (None with want_planes=False: actions() only, the leaf boards
+        stay in the engine for qz_nn_input_layer).  want_mask also copies the leaf masks /
+        terminal flags into self.leaf_mask / self.leaf_term.  events=(start, stop): torch events
+        recorded around the rules-op launch only (bench.py's roofline measurement);
+        tree_events=(start, stop): around the descent (k_select)."""
         mp = self.leaf_mask.data_ptr() if want_mask else 0
         tp = self.leaf_term.data_ptr() if want_mask else 0
-        if events is None:
-            _cabi.check(self.L.qz_mcts_select(self.h, self.planes.data_ptr(), mp, tp, self._s()))
+        pp = self.planes.data_ptr() if want_planes else 0
+        if events is None and tree_events is None:
+            _cabi.check(self.L.qz_mcts_select(self.h, pp, mp, tp, self._s()))
         else:
+            if tree_events is not None:
+                tree_events[0].record()
             _cabi.check(self.L.qz_mcts_descend(self.h, self._s()))
-            events[0].record()
-            _cabi.check(self.L.qz_mcts_leaf_inputs(self.h, self.planes.data_ptr(), mp, tp, self._s()))
-            events[1].record()
-        return self.planes
+            if tree_events is not None:
+                tree_events[1].record()
+            if events is not None:
+                events[0].record()
+            _cabi.check(self.L.qz_mcts_leaf_inputs(self.h, pp, mp, tp, self._s()))
+            if events is not None:
+                events[1].record()
+        return self._planes if want_planes else None
 
     def select_boards(self) -> DeviceBoards:
         """-> leaf boards (for host-side policy callbacks); fills leaf_mask / leaf_term."""
@@ -152,10 +178,14 @@ class SelfPlayEngine:
                                                  self.leaf_term.data_ptr(), self._s()))
         return out
 
-    def expand_backup(self, p: torch.Tensor, v: torch.Tensor):
+    def expand_backup(self, p: torch.Tensor, v: torch.Tensor, events=None):
         assert p.dtype == torch.float32 and v.dtype == torch.float32 and p.is_contiguous() and v.is_contiguous()
         assert p.shape == (self.n_boards, 140) and v.numel() == self.n_boards
+        if events is not None:
+            events[0].record()
         _cabi.check(self.L.qz_mcts_expand_backup(self.h, p.data_ptr(), v.data_ptr(), self._s()))
+        if events is not None:
+            events[1].record()
 
     def leaf_ref(self):
         """(qz_boards struct, terminal-flag pointer, n) of the engine's current leaf boards: what a
@@ -168,13 +198,19 @@ class SelfPlayEngine:
             self._leaf_ref = (st, term.value, self.n_boards)
         return self._leaf_ref
 
-    def playout_step(self, evaluator, events=None):
-        planes = self.select(events=events)
-        if getattr(evaluator, "accepts_leaf_boards", False):
+    def playout_step(self, evaluator, events=None, write_planes=None, tree_events=None):
+        """One playout of every board.  An evaluator that computes its first layer from the leaf
+        boards never reads state(), so the rules op then only produces the legal sets
+        (write_planes=True forces the planes anyway: bench.py's roofline of the full op).
+        tree_events = ((start, stop) around k_select, (start, stop) around k_expand_backup)."""
+        takes_boards = getattr(evaluator, "accepts_leaf_boards", False)
+        want_planes = (not takes_boards) if write_planes is None else bool(write_planes) or not takes_boards
+        planes = self.select(events=events, want_planes=want_planes, tree_events=None if tree_events is None else tree_events[0])
+        if takes_boards:
             p, v = evaluator(planes, leaf=self.leaf_ref())
         else:
             p, v = evaluator(planes)
-        self.expand_backup(p, v)
+        self.expand_backup(p, v, events=None if tree_events is None else tree_events[1])
 
     def capture_steps(self, evaluator, steps_per_graph=1, warmup=3):
         """Capture `steps_per_graph` playout steps (select -> net -> expand/backup) into one
@@ -211,7 +247,12 @@ class SelfPlayEngine:
         if forced is not None:
             self._forced = forced.to(device=self.device, dtype=torch.uint8).contiguous()
             fp = self._forced.data_ptr()
+        bad0 = self.stats()["bad_forced_moves"] if forced is not None else 0
         _cabi.check(self.L.qz_mcts_finish_move(self.h, fp, self.pi.data_ptr(), self.moves.data_ptr(), self._s()))
+        if forced is not None:  # forced moves come from host-side drivers (tests, single-game API): a sync is fine
+            bad = self.stats()["bad_forced_moves"] - bad0
+            if bad:
+                raise _cabi.QzError(_cabi.E_INVALID, "%d forced move(s) are not children of their root: those boards did not move" % bad)
         return self.moves, self.pi
 
     def update_with_move(self, moves: torch.Tensor):
@@ -315,11 +356,12 @@ class BoardGroups:
             with torch.cuda.stream(self.streams[g]):
                 yield g, self.engines[g], self.evaluators[g]
 
-    def playout_step(self, events=None):
+    def playout_step(self, events=None, write_planes=None, tree_events=None):
         """One playout of every board; `events` = one (start, end) pair per group around the
-        group's rules-op launch."""
+        group's rules-op launch, `tree_events` = one pair of pairs per group (select, expand/backup)."""
         for g, eng, ev in self._each():
-            eng.playout_step(ev, events=None if events is None else events[g])
+            eng.playout_step(ev, events=None if events is None else events[g], write_planes=write_planes,
+                             tree_events=None if tree_events is None else tree_events[g])
 
     def run_playouts(self, n=None):
         n = self.n_playout if n is None else int(n)

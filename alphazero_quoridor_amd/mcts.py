@@ -61,7 +61,7 @@ class MCTS(object):
         self._n_playout = n_playout
         self._engine = SelfPlayEngine(1, n_playout=n_playout, c_puct=c_puct, temp=1.0, is_selfplay=is_selfplay,
                                       device=_device(), fix_terminal_sign=fix_terminal_sign, node_cap=node_cap,
-                                      edge_cap=edge_cap, max_plies=8)
+                                      edge_cap=edge_cap, traj_pool_pages=1)
         # device route only: replay the playout step (select -> rules -> net -> expand/backup, ~25
         # launches on one board) as a HIP graph; one board is launch-bound, not GPU-bound
         self._use_graph = bool(use_graph)

@@ -302,7 +302,7 @@ class PolicyValueNet:
         if model_file:
             path = model_file if os.path.exists(str(model_file)) else "ckpt/%s.pth" % model_file
             self.policy_value_net.load_state_dict(torch.load(path, map_location=self.device))
-        self._evaluator = None
+        self._evaluators = {}
 
     # engine-facing ---------------------------------------------------------------
     def evaluator(self, bn_mode=None, dtype=torch.float32, channels_last=None) -> LeafEvaluator:
@@ -310,14 +310,18 @@ class PolicyValueNet:
             # MIOpen's NHWC fp32 convolutions are ~20 % faster on MI355X; "batch" mode stays NCHW
             # (MIOpen's NHWC BatchNorm-training path crashed on this stack)
             channels_last = self.device.type == "cuda" and (bn_mode or self.bn_mode) != "batch"
+        # one evaluator per configuration, all kept: engines hold on to theirs (cloned, re-laid-out
+        # weights), and weights_changed() must reach every one of them after a training step
         key = (bn_mode or self.bn_mode, dtype, bool(channels_last))
-        if self._evaluator is None or self._evaluator[0] != key:
-            self._evaluator = (key, LeafEvaluator(self.policy_value_net, key[0], dtype, channels_last))
-        return self._evaluator[1]
+        if key not in self._evaluators:
+            self._evaluators[key] = LeafEvaluator(self.policy_value_net, key[0], dtype, channels_last)
+        return self._evaluators[key]
 
     def weights_changed(self):
-        if self._evaluator is not None:
-            self._evaluator[1].refresh()
+        """Call after the module's parameters changed (train_step does): every live evaluator
+        re-derives its weight copies in place (captured HIP graphs keep pointing at live data)."""
+        for ev in self._evaluators.values():
+            ev.refresh()
 
     # reference API -----------------------------------------------------------------
     def policy_value(self, state_batch):

@@ -37,14 +37,25 @@ def encode(boards: DeviceBoards, out: torch.Tensor | None = None) -> torch.Tenso
     return out
 
 
-def movegen_encode(boards: DeviceBoards, mask: torch.Tensor | None = None, planes: torch.Tensor | None = None):
+def rules_opts(variant=0, detour_pooled=None, detour_wave=None, enc_split_pct=None) -> _cabi.qz_rules_opts:
+    """qz_rules_opts (include/qz_abi.h): which formulation of the rules op to run.  None = the
+    library default; detour modes are 0 | 1 | 2."""
+    return _cabi.qz_rules_opts(int(variant), 0 if detour_pooled is None else 1 + int(detour_pooled),
+                               0 if detour_wave is None else 1 + int(detour_wave), int(enc_split_pct or 0))
+
+
+def movegen_encode(boards: DeviceBoards, mask: torch.Tensor | None = None, planes: torch.Tensor | None = None, opts=None):
+    """actions() + state() in one pass; `opts` = rules_opts(...) forces a kernel formulation."""
+    import ctypes as C
+
     L = _cabi.load()
     if mask is None:
         mask = torch.empty((boards.n, 5), dtype=torch.int32, device=boards.device)
     if planes is None:
         planes = torch.empty((boards.n, 26, 9, 9), dtype=torch.float32, device=boards.device)
     with torch.cuda.device(boards.device):
-        _cabi.check(L.qz_movegen_encode(boards.byref(), boards.n, mask.data_ptr(), planes.data_ptr(), _stream(boards.device)))
+        _cabi.check(L.qz_movegen_encode_opts(boards.byref(), boards.n, mask.data_ptr(), planes.data_ptr(),
+                                             C.byref(opts) if opts is not None else None, _stream(boards.device)))
     return mask, planes
 
 

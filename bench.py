@@ -2,7 +2,10 @@
 """bench.py -- self-play games/sec on N MI355X GPUs (BASELINE.json's metric).
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
+    N > 1: either launched by torch.distributed.run (one rank per GPU, RCCL; RANK / WORLD_SIZE in
+    the environment), or started plainly -- then this process only spawns the N ranks itself
+    (python -m torch.distributed.run ... bench.py, before anything here touches a GPU), relays
+    rank 0's JSON line and exits with the ranks' status.
 
 Workload (config.workload): BASELINE.json configs[3] per GPU = 4096 concurrent boards,
 n_playout=400, 9x9, reference defaults (10 walls, c_puct=5, temp=1, Dirichlet 0.3/0.25),
@@ -123,6 +126,37 @@ def c3_microbench(dev, launches=60):
             "avg_launch_us": us, "launches": launches, "algorithmic_bytes_per_launch": n * BYTES_PER_BOARD}
 
 
+def launch_ranks(n_gpus, argv):
+    """`python bench.py --gpus N` without a launcher: become the launcher.  The ranks are CHILD
+    processes (this process never initialises HIP and never re-execs); stdout of the job is the
+    single JSON line rank 0 prints, everything else goes to stderr."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for out in proc.stdout:
+        if out.startswith("{") and line is None:
+            line = out.rstrip("\n")
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        sys.stderr.write("bench.py: the ranks exited cleanly but printed no JSON line\n")
+        rc = 1
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -145,17 +179,15 @@ def main():
                          "searches avoid winning and games run for thousands of plies)")
     ap.add_argument("--no-c3", action="store_true", help="skip the 32,768-board microbenchmark line (roofline_c3)")
     args = ap.parse_args()
+    if args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     from alphazero_quoridor_amd import dist as qdist
     from alphazero_quoridor_amd.engine import BoardGroups
     from alphazero_quoridor_amd.policy_value_net import PolicyValueNet
 
-    if os.environ.get("QZ_DEBUG_VARIANT"):  # A/B knobs of include/qz_abi.h (qz_debug_set_movegen_variant), comma separated
-        from alphazero_quoridor_amd import _cabi
-        for v in os.environ["QZ_DEBUG_VARIANT"].split(","):
-            _cabi.load().qz_debug_set_movegen_variant(int(v))
     rank, local, world = qdist.init_from_env("cuda")
-    assert world == args.gpus or world == 1, "WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
+    assert world == args.gpus, "WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU path)"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
@@ -216,7 +248,7 @@ def main():
     k = 0
     for _ in range(args.steps):
         for _ in range(args.playouts):
-            eng.playout_step(events=evs[k])
+            eng.playout_step(events=evs[k], write_planes=True)
             k += 1
         games += end_of_ply()
     barrier()

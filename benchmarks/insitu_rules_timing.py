@@ -8,11 +8,11 @@ net = PolicyValueNet(use_gpu=True); ev = net.evaluator("per_leaf")
 eng = SelfPlayEngine(4096, n_playout=400, seed=1, device=dev)
 for _ in range(300):
     eng.run_playouts(ev, 4); eng.finish_move(); eng.harvest()
+import ctypes as C
 L = _cabi.load()
 for variant in (0, 2, 4, 0):  # boards per wavefront of k_wave_rules: 1 (default), 2, 4
-    L.qz_debug_set_movegen_variant(variant)
+    L.qz_engine_set_rules_opts(eng.h, C.byref(_cabi.qz_rules_opts(variant, 0, 0, 0)))
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(200)]
     for i in range(200): eng.playout_step(ev, events=evs[i])
     torch.cuda.synchronize()
     print("variant", variant, "avg rules-op us", sum(a.elapsed_time(b) for a, b in evs) / 200 * 1e3)
-L.qz_debug_set_movegen_variant(0)

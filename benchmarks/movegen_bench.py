@@ -90,16 +90,12 @@ def main():
     ap.add_argument("--boards", type=int, default=32768)
     ap.add_argument("--launches", type=int, default=60)
     ap.add_argument("--only", default="S-open,S-mid,S-dense")
-    ap.add_argument("--variant", type=int, default=0, help="qz_debug_set_movegen_variant: 0 pooled (default), 1 wave-per-board, 8/16/32 tile size")
+    ap.add_argument("--variant", type=int, default=0, help="qz_rules_opts.variant: 0 by size (default), 2|3|4 wave-per-board, 8..32 pooled tile size")
     ap.add_argument("--enc-split", type=int, default=-1, help="A/B: percent of the encoder tiles launched beside the path search")
     ap.add_argument("--detour", type=int, default=-1, help="A/B: pool_k1 detour_mode, pooled + 3 * wave-per-board (0..8)")
     args = ap.parse_args()
-    from alphazero_quoridor_amd import _cabi
-    _cabi.load().qz_debug_set_movegen_variant(args.variant)
-    if args.detour >= 0:
-        _cabi.load().qz_debug_set_movegen_variant(300 + args.detour)
-    if args.enc_split >= 0:
-        _cabi.load().qz_debug_set_movegen_variant(100 + args.enc_split)
+    opts = rules.rules_opts(args.variant, None if args.detour < 0 else args.detour % 3, None if args.detour < 0 else args.detour // 3,
+                            None if args.enc_split < 0 else max(args.enc_split, 1))
     dev = torch.device("cuda:0")
     n = args.boards
     mask = torch.empty((n, 5), dtype=torch.int32, device=dev)
@@ -107,12 +103,12 @@ def main():
     for name in args.only.split(","):
         db = position_set(name, n, dev)
         for _ in range(5):
-            rules.movegen_encode(db, mask, planes)
+            rules.movegen_encode(db, mask, planes, opts=opts)
         torch.cuda.synchronize()
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.launches)]
         for a, b in evs:
             a.record()
-            rules.movegen_encode(db, mask, planes)
+            rules.movegen_encode(db, mask, planes, opts=opts)
             b.record()
         torch.cuda.synchronize()
         us = float(np.mean([a.elapsed_time(b) for a, b in evs])) * 1e3

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define QZ_ABI_VERSION 1
+#define QZ_ABI_VERSION 2
 #define QZ_N_ACTIONS 140            /* quoridor.py:12  action_space = 140            */
 #define QZ_PLANES (26 * 81)         /* quoridor.py:58-131  26x9x9 state tensor       */
 #define QZ_MASK_WORDS 5             /* 140-bit legal mask, bit a of word a/32        */
@@ -71,6 +71,21 @@ int qz_encode(const qz_boards* boards, int n, float* planes /*[dev]*/, void* str
 /* both in one pass over the boards (the engine's leaf kernel) */
 int qz_movegen_encode(const qz_boards* boards, int n, uint32_t* mask5 /*[dev]*/,
                       float* planes /*[dev]*/, void* stream);
+/* Which formulation of the rules op a call / an engine uses (tuning and A/B runs; all zero =
+ * the defaults).  Per call and per engine: the library keeps no mutable global state.
+ *   variant        0 = pick by batch size (k_wave_rules below 8,192 boards, pooled pipeline from
+ *                  there on), 2 | 3 | 4 = k_wave_rules with 2 | 1 | 4 boards per wavefront,
+ *                  8 | 12 | 16 | 24 | 32 = pooled pipeline with that many boards per mask workgroup
+ *   detour_pooled  group-detour mode of the pooled pipeline: 0 = default (one group), else 1 + mode
+ *   detour_wave    ... of k_wave_rules: 0 = default (off), else 1 + mode (mode 0 | 1 | 2)
+ *   enc_split_pct  0 = default (70): percent of the encoder groups beside the path groups */
+typedef struct {
+    int32_t variant, detour_pooled, detour_wave, enc_split_pct;
+} qz_rules_opts;
+/* qz_movegen / qz_encode / qz_movegen_encode with explicit options: mask5 or planes may be NULL
+ * (not both), opts may be NULL (defaults). */
+int qz_movegen_encode_opts(const qz_boards* boards, int n, uint32_t* mask5 /*[dev] or NULL*/, float* planes /*[dev] or NULL*/,
+                           const qz_rules_opts* opts, void* stream);
 /* Quoridor.step() + has_a_winner() (quoridor.py:159-186, 193-202, 217-269), in place.
  * done[n] <- 1 if the move ended the game; winner[n] <- 0 | 1 | 2 */
 int qz_step(qz_boards* boards, const uint8_t* action /*[dev]*/, int n, uint8_t* done /*[dev]*/,
@@ -90,10 +105,18 @@ typedef struct {
     int32_t device;            /* HIP device ordinal                                   */
     int32_t is_selfplay;       /* mcts.py:159  1: noise + subtree reuse; 0: reset tree */
     int32_t fix_terminal_sign; /* 0 = reproduce mcts.py:125 (winning edge backed up -1) */
-    int32_t node_cap;          /* expanded nodes per board per arena half (0 = auto)   */
-    int32_t edge_cap;          /* edges per board per arena half (0 = auto)            */
-    int32_t max_plies;         /* trajectory slots per board (0 = auto)                */
-    int32_t reserved[4];
+    /* Memory.  Trees and trajectories live in two pools of 64-KB pages shared by all boards
+     * (a tree page = 2,048 edge records of 32 B; a trajectory page holds ~100-1,000 plies), so
+     * a board only occupies what its tree / game really needs: 32,768 boards x n_playout=400
+     * fit one 288-GB MI355X.  A pool that runs dry never corrupts anything: the expansion is
+     * skipped (node_overflow) / the game is dropped (aborted_pool), and both are counted. */
+    int32_t node_cap;          /* most expanded nodes per tree (0 = no limit)                    */
+    int32_t edge_cap;          /* most edges per tree (0 = the page table's reach: 262,144)      */
+    int32_t max_plies;         /* drop a game after this many plies (0 = no limit; the reference has none) */
+    int32_t tree_pool_pages;   /* 0 = auto: n_boards x max(4, ceil(250 x n_playout / 2,048)), >= 264 */
+    int32_t traj_pool_pages;   /* 0 = auto: 16 per board (1 MB)                                  */
+    int32_t traj_page_dwords;  /* 0 = 16,384 (64 KB); >= 256.  Small pages only make sense in tests */
+    qz_rules_opts rules;       /* formulation of the leaf rules op (all zero = defaults)        */
 } qz_config;
 
 typedef struct {
@@ -102,13 +125,20 @@ typedef struct {
     int64_t playouts;          /* leaf selections                                      */
     int64_t leaf_terminal;     /* playouts that ended on a terminal leaf               */
     int64_t node_overflow;     /* expansions skipped / subtrees truncated: arena full  */
-    int64_t games_aborted;     /* no legal move at the root, or trajectory full        */
+    int64_t games_aborted;     /* dropped games: sum of the three aborted_* causes below */
     int64_t pending_games;     /* finished, not yet harvested                          */
     int64_t pending_plies;
     int64_t arena_bytes;       /* device bytes owned by the engine                     */
     int64_t descent_levels;    /* tree levels walked by all playouts (mean depth = / playouts) */
     int64_t max_nodes;         /* largest tree right now, in nodes / in edges (arena occupancy   */
     int64_t max_edges;         /* against qz_config.node_cap / edge_cap)                         */
+    int64_t aborted_no_move;   /* no legal move at the root (the reference crashes there, mcts.py:195) */
+    int64_t aborted_max_plies; /* qz_config.max_plies reached, or a game outgrew its trajectory page table */
+    int64_t aborted_pool;      /* trajectory pool empty                                           */
+    int64_t bad_forced_moves;  /* forced moves that were not children of the root: those boards did NOT move */
+    int64_t nonfinite_values;  /* descents that met a NaN PUCT value (diverged network); first child taken like Python's max() */
+    int64_t tree_pages_total, tree_pages_in_use, tree_pages_peak;
+    int64_t traj_pages_total, traj_pages_in_use, traj_pages_peak;
 } qz_stats;
 
 /* MCTSPlayer.__init__ / MCTS.__init__ (mcts.py:89-100, 159-161) for n_boards trees +
@@ -123,6 +153,8 @@ int qz_engine_set_boards(qz_engine* e, const qz_boards* src, int reset_trees, vo
 int qz_engine_get_boards(qz_engine* e, const qz_boards* dst, void* stream);
 /* the `temp` argument of get_move_probs / choose_action (mcts.py:129,172) for later calls */
 int qz_engine_set_temp(qz_engine* e, float temp);
+/* change the formulation of this engine's leaf rules op (qz_config.rules) for later calls */
+int qz_engine_set_rules_opts(qz_engine* e, const qz_rules_opts* opts);
 
 /* MCTS._playout, first half (mcts.py:107-117): for every board descend from the root by
  * PUCT (TreeNode.select / get_value, mcts.py:37-42, 64-70) applying Quoridor.step() to a
@@ -162,7 +194,9 @@ int qz_mcts_update_with_move(qz_engine* e, const uint8_t* moves /*[dev]*/, void*
  * (mcts.py:174-187, quoridor.py:585-602): pi from root visits; move ~ 0.75*pi +
  * 0.25*Dirichlet(alpha) (or forced_move[b] != QZ_NO_MOVE); record (board, pi) in the
  * board's trajectory; update_with_move; Quoridor.step(move); finished games are flagged
- * for qz_harvest.  pi_out[n][140] float32 / move_out[n] may be NULL. */
+ * for qz_harvest.  pi_out[n][140] float32 / move_out[n] may be NULL.  A forced move that is not
+ * a child of the root leaves that board untouched (move_out = QZ_NO_MOVE) and counts in
+ * qz_stats.bad_forced_moves -- the reference would raise KeyError in update_with_move's lookup. */
 int qz_mcts_finish_move(qz_engine* e, const uint8_t* forced_move /*[dev]*/, float* pi_out /*[dev]*/,
                         uint8_t* move_out /*[dev]*/, void* stream);
 
@@ -229,12 +263,6 @@ int qz_engine_leaf_boards(qz_engine* e, qz_boards* boards_out, const uint8_t** t
  * uses np.sqrt(parent visits) in float64 (mcts.py:69); the test checks the device result is
  * correctly rounded. */
 int qz_selftest_sqrt(double* out /*[dev]*/, int n, void* stream);
-/* A/B hook for benchmarks and tests: 0 = pick by batch size (default: k_wave_rules below 8,192
- * boards, pooled pipeline above), 1 = the first wave-per-board kernel, 2 | 3 | 4 = k_wave_rules
- * with 2 | 1 | 4 boards per wavefront, 8 | 12 | 16 | 24 | 32 = pooled pipeline with that many
- * boards per mask workgroup; 100 + p = p percent of the encoder groups beside the path groups;
- * 300 + a + 3 b = group-detour mode a (0 | 1 | 2) in the pooled pipeline, b in k_wave_rules */
-int qz_debug_set_movegen_variant(int variant);
 
 #ifdef __cplusplus
 }

@@ -6,7 +6,7 @@ GPU box).  It imports the reference's quoridor.py / mcts.py / policy_value_net.p
 drives them on seeded inputs and stores inputs + expected outputs as small .npz
 files.  No reference source is copied: fixtures are data.
 
-    python tests/golden/gen_golden.py [--only rules,pawn,positions,steps,mcts,episodes,net]
+    python tests/golden/gen_golden.py [--only rules,pawn,positions,steps,mcts,episodes,net,train]
 
 The oracle (oracle/) and the HIP path are both checked against these files.
 """
@@ -534,7 +534,7 @@ def gen_net(out_dir):
     train_p, train_v = pvn.policy_value(states)
     # (c) reference policy_value_fn(): train mode, batch of one
     leaf_acts, leaf_p, leaf_v = [], [], []
-    for g in games[:16]:
+    for g in games:  # all 64 states through the per-leaf API (round 1 stored 16)
         pvn = fresh()
         ap, val = pvn.policy_value_fn(g)
         ap = list(ap)
@@ -551,12 +551,87 @@ def gen_net(out_dir):
         fill_seed=np.array(2024), eval_logp=eval_logp, eval_v=eval_v, train_p=train_p, train_v=train_v,
         leaf_acts=np.stack(leaf_acts), leaf_p=np.stack(leaf_p), leaf_v=np.array(leaf_v, dtype=np.float32),
     )
-    print("net: 64-state batch, eval + train-batch + 16 per-leaf outputs")
+    print("net: 64-state batch, eval + train-batch + 64 per-leaf outputs")
+
+
+# --------------------------------------------------------------------------- F9
+def gen_train(out_dir):
+    """Three consecutive PolicyValueNet.train_step calls of the REAL reference module on a
+    128-tuple minibatch (policy_value_net.py:166-192).  Under a modern torch the reference's
+    method raises IndexError on its last line (`loss.data[0]` on a 0-dim tensor) AFTER
+    optimizer.step(), so the post-step weights come from the reference's own code; loss and
+    entropy are recomputed here with the same three expressions (value_loss + policy_loss,
+    entropy) on an identically initialised twin, whose weights are asserted bit-identical to the
+    reference's after every step."""
+    import torch
+    import torch.nn.functional as F
+    import warnings
+
+    warnings.filterwarnings("ignore")
+    torch.set_num_threads(4)
+    from policy_value_net import PolicyValueNet, set_learning_rate
+
+    pos = np.load(os.path.join(out_dir, "rules_positions.npz"))
+    boards, nact, acts = pos["board"], pos["n_actions"], pos["actions"]
+    rng = random.Random(9)
+    live = [i for i in range(len(boards)) if nact[i] > 0 and 0 <= boards[i]["p1"] <= 71 and 9 <= boards[i]["p2"] <= 80]
+    idx = rng.sample(live, 128)
+    games = [game_from_packed(boards[i]) for i in idx]
+    states = np.stack([g.state() for g in games])  # float64 like the replay buffer's tuples
+    rs = np.random.RandomState(77)
+    pi = np.zeros((128, 140), dtype=np.float64)
+    for j, i in enumerate(idx):
+        a = acts[i][: nact[i]].astype(np.int64)
+        pi[j, a] = rs.dirichlet(0.5 * np.ones(len(a)))
+    pi = pi.astype(np.float32).astype(np.float64)   # what the engine's float32 trajectories hold
+    z = rs.choice([-1.0, 1.0], size=128)
+    lrs = [2e-3, 2e-3 * 1.5, 2e-3 / 1.5]
+
+    def fresh():
+        pvn = PolicyValueNet(use_gpu=False)
+        pvn.policy_value_net.load_state_dict(det_fill_state_dict(pvn.policy_value_net.state_dict(), seed=2024))
+        return pvn
+
+    ref, twin = fresh(), fresh()
+    losses, entropies = [], []
+    for lr in lrs:
+        try:
+            ref.train_step(list(states), list(pi), list(z), lr)
+            raise SystemExit("the reference's train_step returned: torch is old enough, record its outputs directly")
+        except IndexError:
+            pass  # `loss.data[0]`: raised after optimizer.step()
+        sb, pb, wb = (torch.FloatTensor(np.asarray(x)) for x in (states, pi, z))
+        twin.optimizer.zero_grad()
+        set_learning_rate(twin.optimizer, lr)
+        logp, value = twin.policy_value_net(sb)
+        loss = F.mse_loss(value.view(-1), wb) + (-torch.mean(torch.sum(pb * logp, 1)))
+        loss.backward()
+        twin.optimizer.step()
+        entropy = -torch.mean(torch.sum(torch.exp(logp) * logp, 1))
+        losses.append(float(loss.item()))
+        entropies.append(float(entropy.item()))
+        a, b = ref.policy_value_net.state_dict(), twin.policy_value_net.state_dict()
+        assert all(torch.equal(a[k], b[k]) for k in a), "restated step diverged from the reference's own"
+    sd = ref.policy_value_net.state_dict()
+    keep = ["fc2.weight", "fc2.bias", "bn1.weight", "bn1.bias", "conv3.weight", "conv2.weight", "bn1.running_mean",
+            "res5.bn2.running_var", "fc3.bias"]
+    out = {"board": boards[idx], "pi": pi.astype(np.float32), "z": z.astype(np.float32), "lr": np.array(lrs),
+           "loss": np.array(losses), "entropy": np.array(entropies), "fill_seed": np.array(2024),
+           "keys": np.array(list(sd.keys())),
+           "sum": np.array([float(v.double().sum()) for v in sd.values()]),
+           "abs_sum": np.array([float(v.double().abs().sum()) for v in sd.values()])}
+    for k in keep:
+        out["w_" + k.replace(".", "_")] = sd[k].numpy()
+    # old/new outputs of policy_value (batch statistics) on the same minibatch after the three steps
+    p_after, v_after = ref.policy_value(states)
+    out["p_after"], out["v_after"] = p_after, v_after
+    np.savez_compressed(os.path.join(out_dir, "train_fixture.npz"), **out)
+    print("train: 3 reference train_step calls on 128 tuples: loss", losses, "entropy", entropies)
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="rules,positions,steps,mcts,episodes,net")
+    ap.add_argument("--only", default="rules,positions,steps,mcts,episodes,net,train")
     ap.add_argument("--procs", type=int, default=8)
     ap.add_argument("--games", type=int, default=160)
     ap.add_argument("--synthetic", type=int, default=120)
@@ -574,6 +649,8 @@ def main():
         gen_episodes(HERE, args.procs)
     if "net" in only:
         gen_net(HERE)
+    if "train" in only:
+        gen_train(HERE)
 
 
 if __name__ == "__main__":

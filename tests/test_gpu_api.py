@@ -120,10 +120,14 @@ def test_network_outputs_match_reference_fixture(gpu_device, golden_dir):
     assert np.abs(v.cpu().numpy() - d["eval_v"].reshape(-1)).max() < TOL
     p, v = pvn.evaluator("batch")(planes)
     assert np.abs(p.cpu().numpy() - d["train_p"]).max() < TOL and np.abs(v.cpu().numpy() - d["train_v"].reshape(-1)).max() < TOL
-    pc, vc = pvn.evaluator("per_leaf", torch.float32, True)(planes[:16])  # channels-last route
-    p, v = pvn.evaluator("per_leaf", torch.float32, False)(planes[:16])  # NCHW route
+    pc, vc = pvn.evaluator("per_leaf", torch.float32, True)(planes)  # channels-last route, first layer from the planes
+    p, v = pvn.evaluator("per_leaf", torch.float32, False)(planes)  # NCHW route
     assert (pc - p).abs().max().item() < TOL and (vc - v).abs().max().item() < TOL
-    p, v = p.cpu().numpy(), v.cpu().numpy()
+    p, v, pc, vc = p.cpu().numpy(), v.cpu().numpy(), pc.cpu().numpy(), vc.cpu().numpy()
+    for i in range(64):
+        acts = d["leaf_acts"][i]
+        k = int((acts != 255).sum())
+        assert np.abs(pc[i][acts[:k]] - d["leaf_p"][i][:k]).max() < TOL and abs(vc[i] - d["leaf_v"][i]) < TOL
     for i in range(16):
         acts = d["leaf_acts"][i]
         k = int((acts != 255).sum())
@@ -143,6 +147,90 @@ def test_network_outputs_match_reference_fixture(gpu_device, golden_dir):
     pb, vb = pvn.evaluator("per_leaf")(big)
     p1, v1 = pvn.evaluator("per_leaf")(planes[:1])
     assert np.abs(pb[0].cpu().numpy() - p1[0].cpu().numpy()).max() < 1e-6
+
+
+def test_engine_route_evaluator_matches_reference_fixture_directly(gpu_device, golden_dir):
+    """The evaluator configuration bench.py times -- first layer from the packed boards
+    (qz_nn_input_layer), channels-last MIOpen trunk with the fused per-leaf normalisation, both
+    heads in qz_nn_head -- against the outputs of the REAL reference's policy_value_fn
+    (policy_value_net.py:145-164) on all 64 fixture states: 1e-5 on p and v, no intermediate route."""
+    from alphazero_quoridor_amd.boards import DeviceBoards
+
+    TOL = 1e-5
+    d = np.load(golden_dir + "/net_fixture.npz")
+    assert d["leaf_p"].shape[0] == 64
+    pvn = _fixture_net(gpu_device)
+    ev = pvn.evaluator("per_leaf", torch.float32, True)
+    assert ev.accepts_leaf_boards and ev.board_input_layer and ev.fused_head and ev.fused_norm
+    db = DeviceBoards.from_packed(d["board"], gpu_device)
+    worst_p = worst_v = 0.0
+    for rep in (1, 64):  # the 64 states once, and inside a 4,096-leaf batch (per-leaf statistics are batch-invariant)
+        big = DeviceBoards(64 * rep, gpu_device)
+        big.hbits, big.vbits, big.meta = db.hbits.repeat(rep), db.vbits.repeat(rep), db.meta.repeat(rep)
+        p, v = ev(None, leaf=(big.struct(), 0, big.n))
+        p, v = p.cpu().numpy(), v.cpu().numpy()
+        for j in range(big.n):
+            i = j % 64
+            acts = d["leaf_acts"][i]
+            k = int((acts != 255).sum())
+            worst_p = max(worst_p, float(np.abs(p[j][acts[:k]] - d["leaf_p"][i][:k]).max()))
+            worst_v = max(worst_v, float(abs(v[j] - d["leaf_v"][i])))
+    print("engine-route evaluator vs reference policy_value_fn: max |dp| %.3g, max |dv| %.3g" % (worst_p, worst_v))
+    assert worst_p < TOL and worst_v < TOL, (worst_p, worst_v)
+
+
+def test_config1_4096_boards_100_playouts_real_net_with_insitu_oracle_samples(gpu_device):
+    """BASELINE configs[1]: 4,096 concurrent boards, n_playout=100, leaf batch 4,096, real
+    (random-init) net on the engine route.  The boards are first spread over all game phases
+    (short searches), then three full plies run; every 25 playout steps 256 of the CURRENT leaf
+    boards (late-game positions, most movers out of walls) are checked against the oracle: legal
+    masks and state planes bit for bit, terminal flags, and after every ply the tree invariants."""
+    import oracle
+    from alphazero_quoridor_amd.engine import SelfPlayEngine
+    from alphazero_quoridor_amd.policy_value_net import PolicyValueNet
+
+    B, NP = 4096, 100
+    torch.manual_seed(1)
+    ev = PolicyValueNet(use_gpu=True, device=gpu_device).evaluator("per_leaf")
+    assert ev.accepts_leaf_boards
+    eng = SelfPlayEngine(B, n_playout=NP, seed=5, device=gpu_device)
+    for _ in range(160):
+        eng.run_playouts(ev, 2)
+        eng.finish_move()
+        eng.harvest()
+    rng = np.random.RandomState(3)
+    checked = walls_on_board = movers_without_walls = 0
+    for ply in range(3):
+        for step in range(NP):
+            if step % 25 == 0:
+                leaf = eng.select_boards().to_packed()          # the descent alone does not change the tree:
+                planes = eng.select(want_mask=True).cpu().numpy()  # ... so this finds the same leaves
+                mask = eng.leaf_mask.cpu().numpy().view(np.uint32)
+                term = eng.leaf_term.cpu().numpy()
+                idx = rng.choice(B, 256, replace=False)
+                won = (leaf["p1"] >= 72) | (leaf["p2"] <= 8)
+                assert np.array_equal(term[idx] != 0, won[idx])
+                live = idx[term[idx] == 0]
+                omask, status = oracle.movegen_batch(leaf[live])
+                assert (status >= 0).all() and np.array_equal(mask[live], omask)
+                assert np.array_equal(planes[live], oracle.encode_batch(leaf[live]))
+                assert not planes[idx[term[idx] != 0]].any() and not mask[idx[term[idx] != 0]].any()
+                checked += len(live)
+                walls_on_board += int((20 - leaf["w1"][live].astype(int) - leaf["w2"][live].astype(int)).sum())
+                movers_without_walls += int((np.where(leaf["cur"][live] == 1, leaf["w1"][live], leaf["w2"][live]) == 0).sum())
+            eng.playout_step(ev)
+        visits, _, _, root_n = eng.root_children()
+        assert int(root_n.min()) >= NP
+        assert bool((visits.clamp(min=0).sum(dim=1) == root_n - 1).all())  # every playout but the expanding one went through a child
+        eng.finish_move()
+        eng.harvest()
+    st = eng.stats()
+    assert st["node_overflow"] == 0 and st["games_aborted"] == 0 and st["nonfinite_values"] == 0
+    assert st["playouts"] == B * (160 * 2 + 3 * NP)
+    print("in-situ leaves checked: %d, mean walls on board %.1f, movers without walls %.0f%%"
+          % (checked, walls_on_board / checked, 100.0 * movers_without_walls / checked))
+    assert checked > 2000
+    eng.close()
 
 
 def test_device_route_equals_callback_route(gpu_device):
@@ -267,6 +355,29 @@ def test_bench_multi_rank_path_on_one_gpu(gpu_device):
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 2
     assert d["playouts_per_s"] > 0 and d["roofline"]["achieved"] > 0
     # both ranks' work is in the aggregate: 2 ranks x 256 boards x 2 plies
+    assert abs(d["plies_per_s"] * d["ms_per_step"] * 2 / 1e3 - 2 * 256 * 2) < 2 * 256 * 2 * 0.05
+
+
+def test_bench_launches_its_own_ranks(gpu_device):
+    """`python bench.py --gpus 2` with NO launcher around it (the driver's command shape): the
+    process spawns its two ranks itself and relays rank 0's single JSON line with n_gpus = 2.
+    Same gloo / shared-device hooks as above (one GPU on this box)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(QZ_DIST_BACKEND="gloo", QZ_SHARE_DEVICE="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--boards", "256",
+                        "--playouts", "16", "--desync-plies", "100", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]   # stdout is the JSON line and nothing else
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 2 and d["value"] >= 0
     assert abs(d["plies_per_s"] * d["ms_per_step"] * 2 / 1e3 - 2 * 256 * 2) < 2 * 256 * 2 * 0.05
 
 

@@ -272,3 +272,170 @@ def _after(og, a):
 def _wins(og, a):
     c = og.copy()
     return c.step(a)
+
+
+def test_tree_pool_exhaustion_is_safe(gpu_device):
+    """A shared tree pool that is far too small: expansions are skipped and subtrees truncated
+    (both counted), nothing is corrupted, pages are recycled and play continues."""
+    from alphazero_quoridor_amd.boards import opening_packed
+
+    B = 96
+    eng = make_engine(opening_packed(B), 40, tree_pool_pages=100, seed=3)  # ~1 page per board, 2 needed to re-root
+    for _ in range(6):
+        run_playouts(eng, "hash", 40)
+        visits, _, _, root_n = (t.cpu().numpy() for t in eng.root_children())
+        assert (np.where(visits >= 0, visits, 0).sum(axis=1) <= root_n).all()
+        eng.finish_move()
+    st = eng.stats()
+    assert st["node_overflow"] > 0 and st["playouts"] == B * 240
+    assert st["tree_pages_total"] == 100 and st["tree_pages_peak"] <= 100 and st["tree_pages_in_use"] <= 100
+    eng.reset()
+    assert eng.stats()["tree_pages_in_use"] == 0  # every page came back
+    eng.close()
+
+
+def test_pages_are_recycled_and_pool_accounting_balances(gpu_device):
+    """After any number of plies the pages in use are exactly the pages the live trees map."""
+    from alphazero_quoridor_amd.boards import opening_packed
+
+    B = 64
+    eng = make_engine(opening_packed(B), 24, seed=5, fix_terminal_sign=True)
+    peak = 0
+    for ply in range(60):
+        run_playouts(eng, "hash", 24)
+        eng.finish_move()
+        eng.harvest()
+        st = eng.stats()
+        # a re-rooted tree owns ceil(n_edges / 2048) pages, allowing for the skipped page tails
+        assert st["tree_pages_in_use"] <= B * (st["max_edges"] // 2048 + 2)
+        peak = max(peak, st["tree_pages_in_use"])
+    st = eng.stats()
+    assert st["node_overflow"] == 0 and st["tree_pages_peak"] >= peak
+    eng.reset()
+    st = eng.stats()
+    assert st["tree_pages_in_use"] == 0 and st["traj_pages_in_use"] == 0
+    eng.close()
+
+
+def test_games_cross_trajectory_pages_and_come_back_intact(gpu_device):
+    """Games are never dropped for length: a game's variable-length records run over many
+    trajectory pages (256-dword pages here, so that every game crosses dozens of them; 64 KB in
+    production) and the harvested tuples equal what finish_move reported ply by ply (board before
+    the move, float32 pi)."""
+    from alphazero_quoridor_amd.boards import opening_packed
+
+    B = 16
+    eng = make_engine(opening_packed(B), 3, seed=11, fix_terminal_sign=True, traj_page_dwords=256, traj_pool_pages=B * 200)
+    log = [[] for _ in range(B)]
+    games, longest = 0, 0
+    for ply in range(600):
+        before = eng.get_boards().to_packed()
+        run_playouts(eng, "hash", 3)
+        moves, pi = eng.finish_move()
+        moves, pi = moves.cpu().numpy(), pi.cpu().numpy()
+        mid = eng.get_boards().to_packed()
+        for b in range(B):
+            assert moves[b] != 255
+            log[b].append((before[b].tobytes(), pi[b].copy()))
+        fin = [b for b in range(B) if mid[b]["p1"] >= 72 or mid[b]["p2"] <= 8]   # has_a_winner (quoridor.py:193-202)
+        tb = eng.harvest()
+        assert (tb is None) == (not fin)
+        if tb is None:
+            continue
+        packed, tpi, gid = tb.boards.to_packed(), tb.pi.cpu().numpy(), tb.game.cpu().numpy()
+        assert len(fin) == tb.n_games
+        for g, b in enumerate(fin):  # games come in board order
+            rows = np.nonzero(gid == g)[0]
+            assert len(rows) == len(log[b])
+            for t, r in enumerate(rows):
+                assert packed[r].tobytes() == log[b][t][0] and np.array_equal(tpi[r], log[b][t][1])
+            longest = max(longest, len(rows))
+            log[b] = []
+            games += 1
+        if games >= 10 and longest >= 60:
+            break
+    assert games >= 10 and longest >= 60, (games, longest)
+    st = eng.stats()
+    assert st["games_aborted"] == 0 and st["traj_pages_peak"] >= 3 * B
+    eng.close()
+
+
+def test_max_plies_and_trajectory_pool_aborts_are_counted_by_cause(gpu_device):
+    from alphazero_quoridor_amd.boards import opening_packed
+
+    eng = make_engine(opening_packed(4), 2, seed=1, max_plies=5)
+    for _ in range(8):
+        run_playouts(eng, "uniform", 2)
+        eng.finish_move()
+    st = eng.stats()
+    assert st["aborted_max_plies"] == 4 and st["aborted_pool"] == 0 and st["aborted_no_move"] == 0 and st["games_aborted"] == 4
+    assert st["plies_played"] == 4 * 7  # 5 plies, the dropped attempt, 2 plies of the restarted game
+    eng.close()
+    eng = make_engine(opening_packed(4), 2, seed=1, traj_pool_pages=2)  # two boards never get a page
+    run_playouts(eng, "uniform", 2)
+    eng.finish_move()
+    st = eng.stats()
+    assert st["aborted_pool"] == 2 and st["plies_played"] == 2 and st["games_aborted"] == 2
+    eng.close()
+
+
+def test_illegal_forced_move_is_an_error_not_a_substitution(gpu_device):
+    from alphazero_quoridor_amd import _cabi
+    from alphazero_quoridor_amd.boards import opening_packed
+
+    eng = make_engine(opening_packed(2), 8)
+    run_playouts(eng, "hash", 8)
+    before = eng.get_boards().to_packed()
+    with pytest.raises(_cabi.QzError):
+        eng.finish_move(forced=torch.tensor([1, 0], dtype=torch.uint8))  # action 1 (south) is illegal for P1 at the opening
+    after = eng.get_boards().to_packed()
+    assert after[0].tobytes() == before[0].tobytes()          # the board with the bad move did not move
+    assert after[1].tobytes() != before[1].tobytes()          # the other one did
+    assert eng.moves.cpu().numpy().tolist() == [255, 0]
+    assert eng.stats()["bad_forced_moves"] == 1
+    eng.close()
+
+
+def test_nonfinite_network_outputs_do_not_corrupt_the_tree(gpu_device):
+    """A diverged network (NaN priors / values): every PUCT comparison is false, Python's max()
+    returns the first child (mcts.py:42) -- so does the descent, in bounds, and it is counted."""
+    from alphazero_quoridor_amd.boards import opening_packed
+
+    B = 16
+    eng = make_engine(opening_packed(B), 12)
+    for i in range(12):
+        eng.select_boards()
+        p = torch.full((B, 140), float("nan"), dtype=torch.float32, device=eng.device)
+        v = torch.full((B,), float("nan"), dtype=torch.float32, device=eng.device)
+        eng.expand_backup(p, v)
+    visits, _, _, root_n = (t.cpu().numpy() for t in eng.root_children())
+    assert (root_n == 12).all()
+    assert (visits[:, 0] == 11).all()  # always the first child in actions() order (action 0)
+    st = eng.stats()
+    assert st["nonfinite_values"] > 0 and st["node_overflow"] == 0
+    eng.finish_move()
+    eng.close()
+
+
+def test_32768_boards_at_400_playouts_fit_one_gpu(gpu_device):
+    """BASELINE configs[2]: the engine for 32,768 concurrent boards x n_playout=400 is created
+    with the default pools (round 1 needed 393 GB for it) and plays plies with the real net;
+    nothing overflows, nothing is dropped."""
+    from alphazero_quoridor_amd.engine import SelfPlayEngine
+    from alphazero_quoridor_amd.policy_value_net import PolicyValueNet
+
+    torch.manual_seed(0)
+    eng = SelfPlayEngine(32768, n_playout=400, seed=9, device=gpu_device)
+    st = eng.stats()
+    assert st["arena_bytes"] < 200e9, st["arena_bytes"]
+    ev = PolicyValueNet(use_gpu=True, device=gpu_device).evaluator("per_leaf")
+    for ply in range(2):
+        eng.run_playouts(ev, 400 if ply == 0 else 60)
+        visits, _, _, root_n = eng.root_children()
+        assert int(root_n.min()) >= 60 and bool((visits.clamp(min=0).sum(dim=1) < root_n).all())
+        eng.finish_move()
+        eng.harvest()
+    st = eng.stats()
+    assert st["node_overflow"] == 0 and st["games_aborted"] == 0 and st["plies_played"] == 2 * 32768
+    assert st["playouts"] == 32768 * 460 and st["tree_pages_peak"] <= st["tree_pages_total"]
+    eng.close()

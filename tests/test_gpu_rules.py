@@ -128,13 +128,33 @@ def test_device_sqrt_is_correctly_rounded(gpu_device):
     assert np.array_equal(out.cpu().numpy(), np.sqrt(np.arange(n, dtype=np.float64)))
 
 
+def _first_kernel(db, want_mask=True, want_planes=True):
+    """The test-only first-generation kernel (tests/hip/libqz_testkernels.so): an independent HIP
+    implementation of actions() + state(), not part of the product library."""
+    import ctypes as C
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hip", "libqz_testkernels.so")
+    assert os.path.exists(path), "build it with `make -C tests/hip` (or __graft_entry__.build())"
+    T = C.CDLL(path)
+    T.qzt_movegen_encode_v1.restype = C.c_int
+    T.qzt_movegen_encode_v1.argtypes = [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 4
+    mask = torch.empty((db.n, 5), dtype=torch.int32, device=db.device) if want_mask else None
+    planes = torch.empty((db.n, 26, 9, 9), dtype=torch.float32, device=db.device) if want_planes else None
+    rc = T.qzt_movegen_encode_v1(db.hbits.data_ptr(), db.vbits.data_ptr(), db.meta.data_ptr(), db.n,
+                                 mask.data_ptr() if want_mask else None, planes.data_ptr() if want_planes else None, None,
+                                 torch.cuda.current_stream(db.device).cuda_stream)
+    assert rc == 0
+    return mask, planes
+
+
 @pytest.mark.parametrize("variant", [1, 2, 3, 4, 8, 12, 16, 24, 32])
 def test_every_movegen_kernel_variant_matches_the_oracle(gpu_device, golden_dir, variant):
-    """The library picks k_wave_rules (2) for small batches and the pooled pipeline (tile sizes
-    8..32) for large ones; 1 is the first kernel, kept for A/B.  Force each on the same inputs
-    (odd batch size; terminal flags are exercised through the engine tests)."""
+    """The library picks k_wave_rules (3) for small batches and the pooled pipeline (tile sizes
+    8..32) for large ones; 1 is the first kernel of round 1 (test-only library).  Force each on
+    the same inputs through qz_rules_opts (odd batch size; terminal flags are exercised through
+    the engine tests)."""
     import oracle
-    from alphazero_quoridor_amd import _cabi, rules
+    from alphazero_quoridor_amd import rules
     from alphazero_quoridor_amd.boards import DeviceBoards
     from synth import synth_positions
 
@@ -142,17 +162,19 @@ def test_every_movegen_kernel_variant_matches_the_oracle(gpu_device, golden_dir,
     boards = np.concatenate([d["board"][::3], synth_positions(3001, seed=31337)])
     omask, status = oracle.movegen_batch(boards)
     oplanes = oracle.encode_batch(boards)
-    L = _cabi.load()
-    try:
-        L.qz_debug_set_movegen_variant(variant)
-        db = DeviceBoards.from_packed(boards, gpu_device)
-        mask, planes = rules.movegen_encode(db)
-        assert np.array_equal(mask.cpu().numpy().view(np.uint32), omask)
-        assert np.array_equal(planes.cpu().numpy(), oplanes)
-        assert np.array_equal(rules.movegen(db).cpu().numpy().view(np.uint32), omask)
-        assert np.array_equal(rules.encode(db).cpu().numpy(), oplanes)
-    finally:
-        L.qz_debug_set_movegen_variant(0)
+    db = DeviceBoards.from_packed(boards, gpu_device)
+    if variant == 1:
+        mask, planes = _first_kernel(db)
+        m_only, _ = _first_kernel(db, want_planes=False)
+        _, p_only = _first_kernel(db, want_mask=False)
+    else:
+        opts = rules.rules_opts(variant)
+        mask, planes = rules.movegen_encode(db, opts=opts)
+        m_only, p_only = rules.movegen(db), rules.encode(db)
+    assert np.array_equal(mask.cpu().numpy().view(np.uint32), omask)
+    assert np.array_equal(planes.cpu().numpy(), oplanes)
+    assert np.array_equal(m_only.cpu().numpy().view(np.uint32), omask)
+    assert np.array_equal(p_only.cpu().numpy(), oplanes)
 
 
 def test_c3_size_kernel_families_agree_and_match_oracle_sample(gpu_device):
@@ -164,36 +186,29 @@ def test_c3_size_kernel_families_agree_and_match_oracle_sample(gpu_device):
     import sys
 
     import oracle
-    from alphazero_quoridor_amd import _cabi, rules
+    from alphazero_quoridor_amd import rules
 
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "benchmarks"))
     from movegen_bench import position_set
 
-    L = _cabi.load()
     n = 32768
-    try:
-        for name in ("S-mid", "S-dense"):
-            db = position_set(name, n, gpu_device)
-            L.qz_debug_set_movegen_variant(0)
-            L.qz_debug_set_movegen_variant(301)          # pooled pipeline, one detour group (the default)
-            mask, planes = rules.movegen_encode(db)
-            mask2, planes2 = rules.movegen_encode(db)
-            assert torch.equal(mask, mask2) and torch.equal(planes, planes2)
-            for knob in (300, 302):                       # no detours / three detour groups
-                L.qz_debug_set_movegen_variant(knob)
-                m, _ = rules.movegen_encode(db)
-                assert torch.equal(m, mask), (name, knob)
-            L.qz_debug_set_movegen_variant(301)
-            for variant in (3, 1):                        # wave-per-board kernel, first kernel of the repo
-                L.qz_debug_set_movegen_variant(variant)
-                m, p = rules.movegen_encode(db)
-                assert torch.equal(m, mask) and torch.equal(p, planes), (name, variant)
-            L.qz_debug_set_movegen_variant(0)
-            sample = db.to_packed()[::16]
-            omask, status = oracle.movegen_batch(sample)
-            assert (status >= 0).all()
-            assert np.array_equal(mask.cpu().numpy().view(np.uint32)[::16], omask), name
-            assert np.array_equal(planes.cpu().numpy()[::16], oracle.encode_batch(sample)), name
-    finally:
-        L.qz_debug_set_movegen_variant(0)
-        L.qz_debug_set_movegen_variant(301)
+    for name in ("S-mid", "S-dense"):
+        db = position_set(name, n, gpu_device)
+        mask, planes = rules.movegen_encode(db)          # pooled pipeline, one detour group (the default)
+        mask2, planes2 = rules.movegen_encode(db)
+        assert torch.equal(mask, mask2) and torch.equal(planes, planes2)
+        for mode in (0, 2):                               # no detours / three detour groups
+            m, _ = rules.movegen_encode(db, opts=rules.rules_opts(0, detour_pooled=mode))
+            assert torch.equal(m, mask), (name, mode)
+        m, p = rules.movegen_encode(db, opts=rules.rules_opts(3))   # wave-per-board kernel
+        assert torch.equal(m, mask) and torch.equal(p, planes), name
+        for mode in (1, 2):
+            m, _ = rules.movegen_encode(db, opts=rules.rules_opts(3, detour_wave=mode))
+            assert torch.equal(m, mask), (name, "wave", mode)
+        m, p = _first_kernel(db)                          # first kernel of the repo (test-only library)
+        assert torch.equal(m, mask) and torch.equal(p, planes), (name, "first kernel")
+        sample = db.to_packed()[::16]
+        omask, status = oracle.movegen_batch(sample)
+        assert (status >= 0).all()
+        assert np.array_equal(mask.cpu().numpy().view(np.uint32)[::16], omask), name
+        assert np.array_equal(planes.cpu().numpy()[::16], oracle.encode_batch(sample)), name

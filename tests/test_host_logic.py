@@ -33,9 +33,19 @@ def test_library_exports_every_declared_symbol(lib):
     for name in declared:
         assert hasattr(lib, name), "libqzero_hip.so does not export %s" % name
     assert sorted(_cabi.exported_symbols()) == declared  # the binding covers the whole header
-    assert lib.qz_version() == 1
-    # struct layouts agree with the header (sizes the C side was compiled with)
-    assert C.sizeof(_cabi.qz_config) == 72 and C.sizeof(_cabi.qz_stats) == 96 and C.sizeof(_cabi.qz_boards) == 24
+    assert lib.qz_version() == _cabi.ABI_VERSION == int(re.search(r"#define QZ_ABI_VERSION (\d+)", header).group(1))
+    assert "qz_debug" not in header  # no process-global knobs in the product ABI
+    # struct layouts of the binding agree with what a C compiler makes of the header
+    import subprocess
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as td:
+        src = os.path.join(td, "sz.c")
+        open(src, "w").write('#include <stdio.h>\n#include "qz_abi.h"\nint main(void){printf("%zu %zu %zu %zu\\n", sizeof(qz_config), '
+                             'sizeof(qz_stats), sizeof(qz_boards), sizeof(qz_rules_opts));return 0;}\n')
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", os.path.join(td, "sz"), src])
+        sizes = [int(x) for x in subprocess.check_output([os.path.join(td, "sz")]).split()]
+    assert sizes == [C.sizeof(_cabi.qz_config), C.sizeof(_cabi.qz_stats), C.sizeof(_cabi.qz_boards), C.sizeof(_cabi.qz_rules_opts)]
 
 
 def test_no_cpu_fallback(lib):
@@ -173,18 +183,20 @@ def test_network_mirror_matches_reference_fixture_cpu():
     assert np.abs(p.numpy() - np.exp(d["eval_logp"])).max() < TOL and np.abs(v.numpy() - d["eval_v"].reshape(-1)).max() < TOL
     p, v = LeafEvaluator(pvn.policy_value_net, "batch")(x)
     assert np.abs(p.numpy() - d["train_p"]).max() < TOL and np.abs(v.numpy() - d["train_v"].reshape(-1)).max() < TOL
-    p, v = LeafEvaluator(pvn.policy_value_net, "per_leaf")(x[:16])
-    for i in range(16):
+    p, v = LeafEvaluator(pvn.policy_value_net, "per_leaf")(x)
+    for i in range(64):
         acts = d["leaf_acts"][i]
         k = int((acts != 255).sum())
         assert np.abs(p[i].numpy()[acts[:k]] - d["leaf_p"][i][:k]).max() < TOL and abs(v[i].item() - d["leaf_v"][i]) < TOL
     # train_step works on a modern torch (the reference's .data[0] does not) and refreshes the evaluator
-    ev = LeafEvaluator(pvn.policy_value_net, "per_leaf")
-    pvn._evaluator = (("per_leaf", torch.float32, False), ev)
-    before = ev(x[:4])[0].clone()
+    # ... every evaluator handed out so far, not only the last one asked for (an engine keeps its own)
+    ev = pvn.evaluator("per_leaf")
+    ev_eval = pvn.evaluator("eval")
+    assert pvn.evaluator("per_leaf") is ev and ev_eval is not ev
+    before, before_eval = ev(x[:4])[0].clone(), ev_eval(x[:4])[0].clone()
     loss, ent = pvn.train_step(x[:32].numpy(), np.full((32, 140), 1 / 140, dtype=np.float32), np.ones(32, dtype=np.float32), 1e-2)
     assert isinstance(loss, float) and isinstance(ent, float)
-    assert not torch.equal(ev(x[:4])[0], before)
+    assert not torch.equal(ev(x[:4])[0], before) and not torch.equal(ev_eval(x[:4])[0], before_eval)
 
 
 def test_checkpoint_keys_and_roundtrip(tmp_path, monkeypatch):
@@ -213,3 +225,37 @@ def test_checkpoint_keys_and_roundtrip(tmp_path, monkeypatch):
     b = PolicyValueNet(model_file="current_policy", use_gpu=False)
     for k in sd:
         assert torch.equal(sd[k], b.get_policy_param()[k]), k
+
+
+def test_bench_self_launch_spawns_children_and_relays_one_line(tmp_path, monkeypatch):
+    """bench.launch_ranks: the parent builds a torch.distributed.run command for N ranks of
+    bench.py itself, relays the one JSON line of rank 0 on stdout, everything else on stderr,
+    and returns the children's exit status -- without importing anything that touches a GPU.
+    (The launcher is replaced by a stub so the test needs no GPU.)"""
+    import importlib
+    import subprocess
+
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    class FakeProc:
+        def __init__(self, cmd, stdout=None, env=None, text=None):
+            seen["cmd"], seen["env"] = cmd, env
+            self.stdout = iter(["rank 1 chatter\n", '{"n_gpus": 4, "value": 1.5}\n', "trailing\n"])
+
+        def wait(self):
+            return 0
+
+    monkeypatch.setattr(subprocess, "Popen", FakeProc)
+    import io
+    out, err = io.StringIO(), io.StringIO()
+    monkeypatch.setattr(sys, "stdout", out)
+    monkeypatch.setattr(sys, "stderr", err)
+    rc = bench.launch_ranks(4, ["--gpus", "4", "--steps", "3"])
+    monkeypatch.undo()
+    assert rc == 0 and out.getvalue() == '{"n_gpus": 4, "value": 1.5}\n' and "chatter" in err.getvalue()
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
+    assert os.path.basename(cmd[cmd.index("--master-port") + 2]) == "bench.py"
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
