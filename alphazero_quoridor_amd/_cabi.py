@@ -93,6 +93,8 @@ class qz_stats(C.Structure):
         ("traj_pages_total", C.c_int64),
         ("traj_pages_in_use", C.c_int64),
         ("traj_pages_peak", C.c_int64),
+        ("edges_scanned", C.c_int64),
+        ("edges_expanded", C.c_int64),
     ]
 
 

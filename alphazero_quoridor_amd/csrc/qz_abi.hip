@@ -299,6 +299,8 @@ int qz_engine_create(const qz_config* cfg, qz_engine** out) {
     ALLOC(bc_overflow, B);
     ALLOC(bc_nonfinite, B);
     ALLOC(bc_levels, B);
+    ALLOC(bc_scanned, B);
+    ALLOC(bc_expanded, B);
 #undef ALLOC
     if (!rc) {
         uint8_t* sc = nullptr;
@@ -324,6 +326,8 @@ int qz_engine_create(const qz_config* cfg, qz_engine** out) {
     if (he == hipSuccess) he = hipMemset(d.release, 0, B);
     if (he == hipSuccess) he = qzl::pool_init(d, nullptr);
     if (he == hipSuccess) he = hipMemset(d.bc_levels, 0, B * sizeof(unsigned long long));
+    if (he == hipSuccess) he = hipMemset(d.bc_scanned, 0, B * sizeof(unsigned long long));
+    if (he == hipSuccess) he = hipMemset(d.bc_expanded, 0, B * sizeof(unsigned long long));
     if (he == hipSuccess) he = hipMemset(d.leaf_mask, 0, B * 5 * sizeof(uint32_t));
     if (he == hipSuccess) he = qzl::reset(d, 1, nullptr);
     if (he == hipSuccess) he = hipDeviceSynchronize();
@@ -492,7 +496,7 @@ int qz_engine_stats(qz_engine* e, qz_stats* out, void* stream) {
     const size_t B = (size_t)e->cfg.n_boards;
     std::vector<uint32_t> bp(B), bt(B), bo(B), nn(B), ne(B), bf(B);
     int pw[QZ_P_COUNT];
-    std::vector<unsigned long long> bl(B);
+    std::vector<unsigned long long> bl(B), bs(B), be(B);
     HIP_TRY(hipMemcpyAsync(h, e->dev.counters, sizeof(h), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(bp.data(), e->dev.bc_playouts, B * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(bt.data(), e->dev.bc_terminal, B * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -500,11 +504,13 @@ int qz_engine_stats(qz_engine* e, qz_stats* out, void* stream) {
     HIP_TRY(hipMemcpyAsync(bf.data(), e->dev.bc_nonfinite, B * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(pw, e->dev.pool_words, sizeof(pw), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(bl.data(), e->dev.bc_levels, B * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(bs.data(), e->dev.bc_scanned, B * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(be.data(), e->dev.bc_expanded, B * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(nn.data(), e->dev.n_nodes, B * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(ne.data(), e->dev.n_edges, B * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     // per-board counters wrap at 2^32 playouts per board (years); sums are 64-bit
-    unsigned long long sp = 0, st = 0, so = 0, sl = 0, sf = 0;
+    unsigned long long sp = 0, st = 0, so = 0, sl = 0, sf = 0, ss = 0, se = 0;
     uint32_t mn = 0, me = 0;
     for (size_t i = 0; i < B; i++) {
         mn = nn[i] > mn ? nn[i] : mn;
@@ -513,6 +519,8 @@ int qz_engine_stats(qz_engine* e, qz_stats* out, void* stream) {
         st += bt[i];
         so += bo[i];
         sf += bf[i];
+        ss += bs[i];
+        se += be[i];
         sl += bl[i];
     }
     memset(out, 0, sizeof(*out));
@@ -527,6 +535,8 @@ int qz_engine_stats(qz_engine* e, qz_stats* out, void* stream) {
     out->games_aborted = out->aborted_no_move + out->aborted_max_plies + out->aborted_pool;
     out->bad_forced_moves = (int64_t)h[QZ_C_BAD_FORCED];
     out->nonfinite_values = (int64_t)sf;
+    out->edges_scanned = (int64_t)ss;
+    out->edges_expanded = (int64_t)se;
     out->tree_pages_total = e->cfg.tree_pool_pages;
     out->tree_pages_in_use = e->cfg.tree_pool_pages - pw[QZ_P_TREE_TOP];
     out->tree_pages_peak = e->cfg.tree_pool_pages - pw[QZ_P_TREE_LOW];

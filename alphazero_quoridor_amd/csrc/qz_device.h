@@ -121,7 +121,7 @@ struct EngineDev {
     // per-board counters for the per-playout statistics: a shared atomic would serialise all
     // boards of a step on one address (~88 atomics/us on MI355X); summed by qz_engine_stats
     uint32_t *bc_playouts, *bc_terminal, *bc_overflow, *bc_nonfinite;
-    unsigned long long* bc_levels;
+    unsigned long long *bc_levels, *bc_scanned, *bc_expanded;  // tree levels walked, edge records read by k_select, edges created
 };
 
 #if defined(__HIPCC__)

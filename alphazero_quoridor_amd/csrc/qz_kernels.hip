@@ -425,13 +425,14 @@ __global__ __launch_bounds__(TPB) void k_select(EngineDev E) {
     int ne = (int)rfl(E.root_ne[b]);
     bool done = false, nonfinite = false;
     const bool live = rfl(E.status[b]) == QZ_PLAYING;
-    uint32_t plen = 0u;
+    uint32_t plen = 0u, scanned = 0u;
     if (live && ne > 0) {
         const TreeView T = tree_view(E, b, rfl(E.tree_half[b]), lane);
         uint32_t eoff = rfl(E.root_eoff[b]);
         uint32_t* path = E.path_edges + (size_t)b * QZ_PATH_CAP;
         for (int depth = 0; depth < 1000000; depth++) {
             const uint32_t base = tree_phys(T, eoff);
+            scanned += (uint32_t)ne;
             double sq = sqrt((double)parentN);  // np.sqrt(self._parent._n_visits), float64
             double best = -__builtin_inf();
             int bestk = 0x7fffffff;
@@ -487,6 +488,7 @@ __global__ __launch_bounds__(TPB) void k_select(EngineDev E) {
         else if (done) t = (winner_of(bd) == bd.cur) ? 1 : 2;
         E.leaf_term[b] = t;
         if (nonfinite) E.bc_nonfinite[b] += 1u;
+        E.bc_scanned[b] += (unsigned long long)scanned;
     }
 }
 
@@ -545,6 +547,7 @@ __global__ __launch_bounds__(TPB) void k_expand_backup(EngineDev E, const float*
                     E.n_nodes[b] = nn + 1u;
                     E.n_edges[b] = neu;
                     E.tree_npages[slot] = np;
+                    E.bc_expanded[b] += (unsigned long long)k;
                 }
             } else if (lane == 0) {
                 E.bc_overflow[b] += 1u;

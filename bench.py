@@ -12,33 +12,50 @@ n_playout=400, 9x9, reference defaults (10 walls, c_puct=5, temp=1, Dirichlet 0.
 random-init policy_value_net evaluated in fp32 with the reference's per-leaf BatchNorm
 statistics; weak scaling (4096 boards on every rank), finished tuples all-gathered every ply.
 
-A STEP is one ply of every board: 400 playout steps (select -> movegen+encode -> net ->
+A STEP is one ply of every board: 400 playout steps (select -> actions()+state() -> net ->
 expand/backup on the whole 4096-leaf batch) + finish_move + harvest (+ all-gather).  Nothing
 inside a step is skipped or cached.
 
-games/sec needs finished games, and a 400-playout game takes ~20 min of wall clock, so the
-boards are first DESYNCHRONISED (untimed): they play `--desync-plies` plies with
-`--desync-playouts` playouts per move so that the population is spread over all game phases
-(continuous refill).  value = games that finished inside the K timed steps / their wall
-time; plies/s, playouts/s and the mean length of the games seen are reported next to it
-(plies/s is the robust statistic: game length varies 4-10x).
+games/sec needs finished games, and a reference-faithful 400-playout game lasts thousands of
+plies (hours of wall clock per board), so the boards are first DESYNCHRONISED (untimed): they
+play `--desync-plies` plies with `--desync-playouts` playouts per move so that the population
+is spread over all game phases (continuous refill).
+  value                     = games that finished inside the K timed steps / their wall time
+                              (a small Poisson count on a population that is not yet stationary)
+  games_per_s_steady_state  = plies/s of the timed region / mean length of 400-playout games,
+                              the length distribution being the one measured by the long run
+                              under profiles/ (benchmarks/game_length.py), with its sample size
+                              and a 95 % interval -- the number a long job converges to
+  plies_per_s, playouts_per_s are length-independent and are what GPU and CPU are compared on.
+Game lengths seen here are reported per phase (desync games are 4-playout games, NOT 400-playout games).
 
-roofline: the move-generation + encoder op of every playout step (qz_mcts_leaf_inputs: the
-single-launch k_wave_rules below 8,192 boards, the pooled pipeline k_pool_stage1 + k_pool_masks
-from there on), timed with HIP events around every one of its invocations in
-the timed region on the launch stream; algorithmic bytes =
-8,468 B/board (24 B board + 20 B mask + 26*81*4 B planes) x 4096 boards.  `traffic` is the
-PMC-measured HBM traffic of the same op at the same size (profiles/round1/pmc_traffic.json,
-collected with rocprofv3 --pmc in separate passes), or null if that file is absent.
-cpu_baseline: the CPU oracle (oracle/, scalar C port of the reference's algorithm, one
-playout at a time, batch-1 network on the CPU like the reference) timed on this host.
+roofline       the rules op of every playout step (qz_mcts_leaf_inputs = Quoridor.actions() +
+               state() of the leaf batch), HIP events around every launch in the timed region on
+               the launch stream; algorithmic bytes = 8,468 B/board (24 B board + 20 B mask +
+               26*81*4 B planes) x boards.  NOTE the default evaluator computes its first layer
+               from the 24-byte boards, so the planes this op writes are not read in this run
+               (they are the reference's state() API output); 34.5 MB per launch also fits the
+               256-MiB Infinity Cache -- `traffic` (PMC, separate rocprofv3 passes) says what
+               reached HBM.
+roofline_tree  k_select and k_expand_backup, same method; bytes from the engine's counters
+               (32-B edge records read by the descents / created by the expansions).
+roofline_c3    the rules op on 32,768 mid-game boards (BASELINE configs[2]), timed right after
+               the timed region.
+cpu_baseline   the CPU oracle (oracle/, scalar C port of the reference's algorithm, one playout
+               at a time, batch-1 network on the CPU like the reference) on this host: one core
+               and all cores (independent processes), plus the reference-on-this-host estimate
+               through the port/reference ratio measured in the build container.
 """
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import os
+import re
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -49,44 +66,159 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 BYTES_PER_BOARD = 24 + 20 + 26 * 81 * 4
+PROFILES = os.path.join(ROOT, "profiles")
 
 
-def cpu_baseline(seconds, mean_plies_per_game, n_playout):
-    """Scalar port of the reference on one host core: playouts/s at n_playout=400 from the
-    opening, batch-1 network forward on the CPU per leaf (policy_value_net.py:145-164)."""
-    import oracle
-    from alphazero_quoridor_amd.policy_value_net import PolicyValueNet
+def _latest_profile(name):
+    """profiles/round*/<name> of the newest round that has it."""
+    hits = sorted(glob.glob(os.path.join(PROFILES, "round*", name)), key=lambda p: int(re.search(r"round(\d+)", p).group(1)))
+    return hits[-1] if hits else None
 
-    torch.set_num_threads(1)
-    net = PolicyValueNet(use_gpu=False)
-    mod = net.policy_value_net  # train mode, batch of one: the reference's behaviour
 
-    def policy(game, legal):
-        x = torch.from_numpy(game.state().reshape(1, 26, 9, 9).astype(np.float32))
-        with torch.no_grad():
-            logp, v = mod(x)
-        p = np.exp(logp.numpy().reshape(-1))
-        return legal, p[legal], float(v.reshape(-1)[0])
+def _load_json(path):
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except (OSError, ValueError, TypeError):
+        return None
 
-    g = oracle.OracleGame()
-    m = oracle.OracleMCTS(policy, c_puct=5, n_playout=n_playout)
-    for _ in range(3):
-        m.playout(g)
-    n, t0 = 0, time.time()
-    while time.time() - t0 < seconds:
-        for _ in range(10):
-            m.playout(g)
-        n += 10
-    dt = time.time() - t0
-    playouts_s = n / dt
-    games_s = playouts_s / n_playout / max(mean_plies_per_game, 1.0)
-    return {
-        "value": games_s, "unit": "games/s", "cores": 1, "kind": "port",
-        "sample": "%d playouts in %.1fs of the first ply at n_playout=%d from the opening (131 legal moves), oracle C port + "
-                  "batch-1 fp32 torch-CPU forward per leaf; games/s = playouts/s / %d / %.0f plies per game (mean of the GPU run)"
-                  % (n, dt, n_playout, n_playout, mean_plies_per_game),
-        "playouts_per_s": playouts_s,
+
+# ------------------------------------------------------------------------------ clocks / power
+class ClockSampler(threading.Thread):
+    """Samples the GPU's shader clock, power and temperature while the timed region runs (sysfs
+    when readable, else `rocm-smi --json` as a child process): evidence for the gap between the
+    step time of a short profile and of a sustained run."""
+
+    def __init__(self, index=0, period=1.0):
+        super().__init__(daemon=True)
+        self.index, self.period = index, period
+        self.samples = []
+        self._stop_ev = threading.Event()
+        self.source = None
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
+        self._sysfs = os.path.dirname(cards[index]) if index < len(cards) else None
+
+    def _read_sysfs(self):
+        d = self._sysfs
+        out = {}
+        with open(os.path.join(d, "pp_dpm_sclk")) as f:
+            cur = [ln for ln in f.read().splitlines() if ln.rstrip().endswith("*")]
+        m = re.search(r"(\d+)\s*[Mm][Hh]z", cur[0]) if cur else None
+        if m:
+            out["sclk_mhz"] = float(m.group(1))
+        for hw in glob.glob(os.path.join(d, "hwmon", "hwmon*")):
+            for key, fn, scale in (("power_w", "power1_average", 1e-6), ("power_w", "power1_input", 1e-6), ("temp_c", "temp1_input", 1e-3)):
+                p = os.path.join(hw, fn)
+                if key not in out and os.path.exists(p):
+                    try:
+                        out[key] = float(open(p).read().strip()) * scale
+                    except (OSError, ValueError):
+                        pass
+        return out
+
+    def _read_smi(self):
+        r = subprocess.run(["rocm-smi", "-d", str(self.index), "--showclocks", "--showpower", "--showtemp", "--json"],
+                           capture_output=True, text=True, timeout=20)
+        card = next(iter(json.loads(r.stdout).values()))
+        out = {}
+        for k, v in card.items():
+            kl = k.lower()
+            m = re.search(r"([\d.]+)", str(v))
+            if not m:
+                continue
+            if kl.startswith("sclk"):
+                out["sclk_mhz"] = float(m.group(1))
+            elif "power" in kl and "power_w" not in out:
+                out["power_w"] = float(m.group(1))
+            elif "temperature" in kl and ("junction" in kl or "temp_c" not in out):
+                out["temp_c"] = float(m.group(1))
+        return out
+
+    def run(self):
+        t0 = time.perf_counter()
+        while not self._stop_ev.is_set():
+            s = None
+            for name, fn in (("sysfs", self._read_sysfs if self._sysfs else None), ("rocm-smi", self._read_smi)):
+                if fn is None or (self.source not in (None, name)):
+                    continue
+                try:
+                    s = fn()
+                    if s:
+                        self.source = name
+                        break
+                except Exception:  # noqa: BLE001 -- monitoring must never break the benchmark
+                    s = None
+            if s:
+                s["t"] = time.perf_counter() - t0
+                self.samples.append(s)
+            elif self.source is None and time.perf_counter() - t0 > 30:
+                return  # nothing readable on this box
+            self._stop_ev.wait(self.period)
+
+    def stop(self):
+        self._stop_ev.set()
+        self.join(timeout=30)
+
+    def summary(self):
+        if not self.samples:
+            return {"source": None, "note": "no clock/power interface readable on this box"}
+        out = {"source": self.source, "samples": len(self.samples)}
+        for k in ("sclk_mhz", "power_w", "temp_c"):
+            v = [s[k] for s in self.samples if k in s]
+            if v:
+                out[k] = {"min": min(v), "mean": sum(v) / len(v), "max": max(v), "first": v[0], "last": v[-1]}
+        return out
+
+
+# ------------------------------------------------------------------------------ CPU baseline
+def cpu_baseline(seconds, n_playout, mean_plies_per_game, length_source):
+    """The oracle port on this host: 1 process, then os.cpu_count() independent processes side
+    by side (python -m oracle.cpu_baseline: one torch thread each).  playouts/s is the measured
+    quantity; games/s divides it by n_playout and by the SAME plies-per-game the GPU's
+    steady-state estimate uses."""
+    cores = os.cpu_count() or 1
+    half = max(seconds / 2.0, 2.0)
+    env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "oracle.cpu_baseline", "--seconds", "%.1f" % half, "--n-playout", str(n_playout)]
+
+    def run_many(k):
+        procs = [subprocess.Popen(cmd + ["--seed", str(i)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env, cwd=ROOT)
+                 for i in range(k)]
+        res = []
+        for p in procs:
+            out = p.communicate()[0]
+            lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+            if p.returncode == 0 and lines:
+                res.append(json.loads(lines[-1]))
+        return res
+
+    one = run_many(1)
+    many = run_many(cores)
+    if not one or not many:
+        return {"value": None, "unit": "games/s", "cores": cores, "kind": "port", "sample": "oracle.cpu_baseline failed to run"}
+    pps1 = one[0]["playouts"] / one[0]["seconds"]
+    ppsN = sum(r["playouts"] / r["seconds"] for r in many)
+    cal = _load_json(_latest_profile("cpu_calibration.json") or "")
+    out = {
+        "value": (ppsN / n_playout / mean_plies_per_game) if mean_plies_per_game else None,
+        "unit": "games/s", "cores": len(many), "kind": "port",
+        "sample": "%d + %d x %d playouts (%.0f s on 1 core, then %.0f s on %d cores as independent processes) of the first ply at "
+                  "n_playout=%d from the opening (131 legal moves): oracle C port + batch-1 fp32 torch-CPU forward per leaf, 1 torch "
+                  "thread per process; games/s = playouts/s / %d / %s plies per game (%s)"
+                  % (one[0]["playouts"], len(many), int(np.mean([r["playouts"] for r in many])), half, half, len(many), n_playout,
+                     n_playout, "%.0f" % mean_plies_per_game if mean_plies_per_game else "?", length_source),
+        "compare_on": "playouts_per_s (length-independent)",
+        "playouts_per_s_1core": pps1, "playouts_per_s_allcores": ppsN,
+        "games_per_s_1core": (pps1 / n_playout / mean_plies_per_game) if mean_plies_per_game else None,
     }
+    if cal and cal.get("port_over_reference"):
+        r = float(cal["port_over_reference"])
+        out["reference_estimate"] = {
+            "playouts_per_s_1core": pps1 / r, "playouts_per_s_allcores": ppsN / r, "port_over_reference": r,
+            "calibration": "pure-Python reference vs this C port on the build container's host (%s; %.2f vs %.1f playouts/s): "
+                           "benchmarks/calibrate_cpu_port.py" % (cal.get("host_cpu", "?"), cal["reference_playouts_per_s"], cal["port_playouts_per_s"]),
+        }
+    return out
 
 
 def c3_microbench(dev, launches=60):
@@ -113,17 +245,14 @@ def c3_microbench(dev, launches=60):
     torch.cuda.synchronize(dev)
     us = sum(a.elapsed_time(b) for a, b in evs) / launches * 1e3
     gbs = n * BYTES_PER_BOARD / us / 1e3
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "round1", "pmc_traffic_c3.json")) as f:
-            traffic = json.load(f)["traffic_bytes_per_launch"]
-    except (OSError, ValueError, KeyError):
-        pass
+    t = _load_json(_latest_profile("pmc_traffic_c3.json") or "")
     return {"workload": "BASELINE configs[2] microbenchmark: 32,768 boards (S-mid: 0..20 plies of random legal play, mover has a wall), "
                         "actions() + state(), inputs resident in HBM, NOT part of the timed region",
             "kernel": "k_pool_paths_enc + k_pool_masks_enc (pooled pipeline, two launches)",
-            "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
-            "avg_launch_us": us, "launches": launches, "algorithmic_bytes_per_launch": n * BYTES_PER_BOARD}
+            "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+            "traffic": t.get("traffic_bytes_per_launch") if t else None,
+            "avg_launch_us": us, "launches": launches, "algorithmic_bytes_per_launch": n * BYTES_PER_BOARD,
+            "cache_note": "277 MB written per launch: larger than the 256-MiB Infinity Cache, the stores reach HBM"}
 
 
 def launch_ranks(n_gpus, argv):
@@ -131,7 +260,6 @@ def launch_ranks(n_gpus, argv):
     processes (this process never initialises HIP and never re-execs); stdout of the job is the
     single JSON line rank 0 prints, everything else goes to stderr."""
     import socket
-    import subprocess
 
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
@@ -157,6 +285,22 @@ def launch_ranks(n_gpus, argv):
     return rc
 
 
+def steady_state(plies_per_s, length_file):
+    """plies/s / E[length of a 400-playout game], with a 95 % interval from the length sample
+    (Kaplan-Meier mean of benchmarks/game_length.py when games were still running at its end)."""
+    d = _load_json(length_file or "")
+    if not d or not d.get("mean_plies_per_game"):
+        return None
+    L = float(d["mean_plies_per_game"])
+    lo, hi = (d.get("mean_ci95") or [None, None])[:2]
+    return {
+        "value": plies_per_s / L, "unit": "games/s", "plies_per_s": plies_per_s, "mean_plies_per_game": L,
+        "ci95": [plies_per_s / hi, plies_per_s / lo] if lo and hi else None,
+        "n_games_in_length_sample": d.get("games_finished"), "n_games_censored": d.get("games_censored"),
+        "length_estimator": d.get("estimator"), "length_source": os.path.relpath(length_file, ROOT),
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -172,12 +316,18 @@ def main():
     ap.add_argument("--desync-plies", type=int, default=700)
     ap.add_argument("--desync-playouts", type=int, default=4)
     ap.add_argument("--seed", type=int, default=2026)
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=16.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fix-terminal-sign", action="store_true",
                     help="NOT the headline: back a winning move up as +1 (the reference backs it up as -1, mcts.py:125, which makes "
                          "searches avoid winning and games run for thousands of plies)")
     ap.add_argument("--no-c3", action="store_true", help="skip the 32,768-board microbenchmark line (roofline_c3)")
+    ap.add_argument("--no-planes", action="store_true",
+                    help="product default of the engine route (the evaluator reads the leaf boards, state() is never materialised); "
+                         "the rules op then only produces the legal sets and `roofline` is computed on 44 B/board")
+    ap.add_argument("--length-file", default=None,
+                    help="game-length sample for games_per_s_steady_state (default: newest profiles/round*/game_length_<n>playouts.json)")
+    ap.add_argument("--clock-log", default=None, help="write the clock / power samples of the timed region to this JSON file")
     args = ap.parse_args()
     if args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and "RANK" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
@@ -200,13 +350,16 @@ def main():
                       n_playout=args.playouts, c_puct=5, temp=1.0, is_selfplay=1, fix_terminal_sign=args.fix_terminal_sign)
     group_boards = args.boards // args.groups
     is_dist = world > 1
+    write_planes = not args.no_planes
+    planes_consumed = not getattr(eng.evaluators[0], "accepts_leaf_boards", False)
 
     def barrier():
         if is_dist:
             torch.distributed.barrier()
         torch.cuda.synchronize(dev)
 
-    lengths = []
+    lengths = {"desync": [], "warmup": [], "timed": []}
+    phase = ["desync"]
 
     def end_of_ply():
         eng.finish_move()
@@ -216,7 +369,7 @@ def main():
             n_games += tb.n_games
             gid = tb.game.cpu().numpy()
             assert gid.size and 0 <= int(gid.min()) and int(gid.max()) < tb.n_games, "corrupt game ids in a harvest"
-            lengths.extend(np.bincount(gid, minlength=tb.n_games).tolist())
+            lengths[phase[0]].extend(np.bincount(gid, minlength=tb.n_games).tolist())
         if is_dist:  # the path's only exchange: finished tuples -> every rank's replay buffer
             eng.synchronize()
             bufs = [qdist.pack_tuples(tb.boards.hbits, tb.boards.vbits, tb.boards.meta, tb.pi, tb.z) for tb in tbs]
@@ -230,29 +383,42 @@ def main():
         eng.run_playouts(args.desync_playouts)
         end_of_ply()
     desync_s = time.time() - t0
-    desync_games = len(lengths)
 
     # ---- warmup steps at the full playout count (untimed)
+    phase[0] = "warmup"
     for _ in range(args.warmup):
         eng.run_playouts()
         end_of_ply()
 
     # ---- timed region
+    phase[0] = "timed"
     n_launch = args.steps * args.playouts
-    evs = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.groups)]
-           for _ in range(n_launch)]
+
+    def ev_pair():
+        return (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+
+    evs = [[ev_pair() for _ in range(args.groups)] for _ in range(n_launch)]
+    tevs = [[(ev_pair(), ev_pair()) for _ in range(args.groups)] for _ in range(n_launch)]
+    sampler = ClockSampler(local) if rank == 0 else None
     st0 = eng.stats()
     barrier()
+    if sampler:
+        sampler.start()
     t0 = time.perf_counter()
     games = 0
     k = 0
+    step_ms = []
     for _ in range(args.steps):
+        ts = time.perf_counter()
         for _ in range(args.playouts):
-            eng.playout_step(events=evs[k], write_planes=True)
+            eng.playout_step(events=evs[k], write_planes=write_planes, tree_events=tevs[k])
             k += 1
-        games += end_of_ply()
+        games += end_of_ply()  # harvest synchronises with the device (qz_harvest_counts), so this is the ply's wall time
+        step_ms.append((time.perf_counter() - ts) * 1e3)
     barrier()
     elapsed = time.perf_counter() - t0
+    if sampler:
+        sampler.stop()
     st1 = eng.stats()
 
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -266,18 +432,42 @@ def main():
 
     n_evs = len(evs) * args.groups
     kern_ms = sum(a.elapsed_time(b) for row in evs for a, b in row) / n_evs
-    achieved = group_boards * BYTES_PER_BOARD / (kern_ms * 1e-3) / 1e9
+    sel_ms = sum(g[0][0].elapsed_time(g[0][1]) for row in tevs for g in row) / n_evs
+    exp_ms = sum(g[1][0].elapsed_time(g[1][1]) for row in tevs for g in row) / n_evs
+    planes_written = bool(write_planes or planes_consumed)
+    bytes_per_board = BYTES_PER_BOARD if planes_written else 44
+    achieved = group_boards * bytes_per_board / (kern_ms * 1e-3) / 1e9
     traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "round1", "pmc_traffic.json")) as f:
-            t = json.load(f)
-        if int(t.get("boards", -1)) == group_boards:
-            traffic = t["traffic_bytes_per_launch"]
-    except (OSError, ValueError, KeyError):
-        pass
+    t = _load_json(_latest_profile("pmc_traffic.json") or "")
+    if t and int(t.get("boards", -1)) == group_boards and bool(t.get("planes", True)) == planes_written:
+        traffic = t["traffic_bytes_per_launch"]
 
     if rank == 0:
-        mean_len = float(np.mean(lengths)) if lengths else float("nan")
+        d = {kk: st1[kk] - st0[kk] for kk in ("playouts", "leaf_terminal", "descent_levels", "edges_scanned", "edges_expanded")}
+        launches = n_launch * args.groups
+        # k_select: every level reads the node's edge records (32 B each); per board 24 B root board in,
+        # 37 B leaf record out, 4 B per level of path.  k_expand_backup: per expansion a 560-B prior row in and
+        # k 32-B records out (+ 8 B in the parent edge); per level 12 B read + 12 B written; per board mask + value in
+        sel_bytes = (d["edges_scanned"] * 32 + d["descent_levels"] * 4 + d["playouts"] * (24 + 37)) / launches
+        exp_bytes = (d["edges_expanded"] * 32 + (d["playouts"] - d["leaf_terminal"]) * (560 + 8) + d["descent_levels"] * 24
+                     + d["playouts"] * (20 + 4 + 9)) / launches
+        tt = _load_json(_latest_profile("pmc_traffic_tree.json") or "") or {}
+
+        def tree_line(kernel, ms, nbytes, note):
+            gbs = nbytes / (ms * 1e-3) / 1e9
+            return {"kernel": kernel, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                    "traffic": (tt.get(kernel) or {}).get("traffic_bytes_per_launch"), "avg_launch_us": ms * 1e3, "launches": launches,
+                    "algorithmic_bytes_per_launch": nbytes, "note": note}
+
+        mean_depth = d["descent_levels"] / max(d["playouts"], 1)
+        length_file = args.length_file or _latest_profile("game_length_%dplayouts.json" % args.playouts)
+        if args.fix_terminal_sign:
+            length_file = args.length_file  # the committed sample is for the reference-faithful sign
+        ss = steady_state(plies_all / elapsed, length_file)
+
+        def len_stats(v):
+            return {"n": len(v), "mean": float(np.mean(v)) if v else None, "median": float(np.median(v)) if v else None}
+
         out = {
             "metric": "self-play games/sec (9x9, n_playout=%d)" % args.playouts,
             "value": games_all / elapsed,
@@ -295,35 +485,64 @@ def main():
                 "workload": "BASELINE configs[3] per GPU: %d concurrent boards/GPU, n_playout=%d, 9x9, 10 walls/player, "
                             "c_puct=5, temp=1.0, leaf batch=%d, finished tuples all-gathered every ply"
                             % (args.boards, args.playouts, args.boards),
-                "boards_per_gpu": args.boards, "board_groups": args.groups, "fix_terminal_sign": bool(args.fix_terminal_sign), "n_playout": args.playouts, "bn_mode": args.bn,
+                "boards_per_gpu": args.boards, "board_groups": args.groups, "fix_terminal_sign": bool(args.fix_terminal_sign),
+                "n_playout": args.playouts, "bn_mode": args.bn,
                 "nn_dtype": args.nn_dtype, "channels_last": bool(args.channels_last),
                 "step": "one ply of every board (n_playout playout steps + finish_move + harvest)",
                 "desync": "%d untimed plies at %d playouts/move (%.0fs, %d games finished)"
-                          % (args.desync_plies, args.desync_playouts, desync_s, desync_games),
+                          % (args.desync_plies, args.desync_playouts, desync_s, len(lengths["desync"])),
             },
+            "value_is": "games finished inside the timed region / wall time (Poisson count of %d; the population was desynchronised with "
+                        "%d-playout games and is not stationary for %d-playout games) -- see games_per_s_steady_state"
+                        % (int(games_all), args.desync_playouts, args.playouts),
             "games_in_timed_region": games_all,
+            "games_per_s_steady_state": ss,
             "plies_per_s": plies_all / elapsed,
             "playouts_per_s": playouts_all / elapsed,
             "leaf_evals_per_s": playouts_all / elapsed,
             "terminal_leaf_frac": term_all / max(playouts_all, 1.0),
-            "mean_plies_per_game": mean_len,
-            "mean_descent_depth": (st1["descent_levels"] - st0["descent_levels"]) / max(st1["playouts"] - st0["playouts"], 1),
-            "games_per_s_from_plies": (plies_all / elapsed) / mean_len if lengths else None,
+            "game_lengths_seen": {"timed_region_%d_playouts" % args.playouts: len_stats(lengths["timed"] + lengths["warmup"]),
+                                  "desync_phase_%d_playouts" % args.desync_playouts: len_stats(lengths["desync"]),
+                                  "note": "games finishing in the timed region started in the desync phase; neither is the length of a "
+                                          "%d-playout game" % args.playouts},
+            "mean_descent_depth": mean_depth,
+            "ms_per_step_series": [round(x, 1) for x in step_ms],
             "roofline": {
                 "kernel": ("k_wave_rules (fused Quoridor.actions() + state() of the leaf batch: one wave per board + encoder groups, one launch)"
                            if group_boards < 8192 else
-                           "k_pool_stage1 + k_pool_masks (Quoridor.actions() + state() of the leaf batch, pooled, two launches)"),
+                           "k_pool_paths_enc + k_pool_masks_enc (Quoridor.actions() + state() of the leaf batch, pooled, two launches)"),
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "avg_launch_us": kern_ms * 1e3, "launches": n_evs,
-                "algorithmic_bytes_per_launch": group_boards * BYTES_PER_BOARD,
+                "algorithmic_bytes_per_launch": group_boards * bytes_per_board,
+                "planes_written": planes_written, "planes_consumed_by_evaluator": bool(planes_consumed),
+                "cache_note": ("%.1f MB written per launch: fits the 256-MiB Infinity Cache, so the stores need not reach HBM before they are "
+                               "overwritten; `traffic` is what the PMC counters saw at the memory controllers"
+                               % (group_boards * bytes_per_board / 1e6)),
             },
-            "engine_stats": {k: st1[k] for k in ("node_overflow", "games_aborted", "arena_bytes", "max_nodes", "max_edges")},
+            "roofline_tree": [
+                tree_line("k_select", sel_ms, sel_bytes, "dependent-load latency: duration = deepest of %d descents (mean depth %.1f), one "
+                          "HBM/L2 round trip per level; bytes = edge records scanned" % (group_boards, mean_depth)),
+                tree_line("k_expand_backup", exp_ms, exp_bytes, "one expansion (<= 131 records) + lane-parallel backup per board"),
+            ],
+            "engine_stats": {kk: st1[kk] for kk in ("node_overflow", "games_aborted", "aborted_no_move", "aborted_max_plies", "aborted_pool",
+                                                    "nonfinite_values", "arena_bytes", "max_nodes", "max_edges", "tree_pages_total",
+                                                    "tree_pages_peak", "traj_pages_total", "traj_pages_peak")},
+            "clocks": sampler.summary() if sampler else None,
         }
+        if st1["games_aborted"]:
+            sys.stderr.write("bench.py: WARNING %d games were dropped (no_move %d, max_plies %d, pool %d)\n"
+                             % (st1["games_aborted"], st1["aborted_no_move"], st1["aborted_max_plies"], st1["aborted_pool"]))
+        if args.clock_log and sampler:
+            with open(args.clock_log, "w") as f:
+                json.dump({"step_ms": step_ms, "samples": sampler.samples}, f)
         if world == 1 and not args.no_c3:
             out["roofline_c3"] = c3_microbench(dev)
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, mean_len if lengths else 600.0, args.playouts)
+            eng.close()
+            torch.cuda.empty_cache()
+            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, args.playouts, ss["mean_plies_per_game"] if ss else None,
+                                               ss["length_source"] if ss else "no length sample")
         print(json.dumps(out))
     eng.close()
     if is_dist:

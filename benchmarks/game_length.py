@@ -1,7 +1,16 @@
-"""How long are self-play games at a given playout count?  (bench.py's games/s depends on
-it: steady-state games/s = plies/s / mean plies per game.)  Plays `--boards` games for up to
-`--plies` plies and reports the length distribution of the FIRST generation of games (those
-started at ply 0), plus how many of them are still running when the run stops."""
+"""How long are reference-faithful self-play games at a given playout count?  bench.py's
+steady-state games/s is plies/s / E[plies per game], so this run measures E[plies per game]:
+`--boards` boards play continuously (finished boards restart at once) for `--seconds`; every
+game contributes either its length (finished) or the plies it had played when the run stopped
+(right-censored: its start time, hence its censoring time, does not depend on its length).
+
+Estimator: Kaplan-Meier survival S(t) in plies; E[L] = integral of S up to the longest observed
+time T plus S(T)/lambda, lambda = the hazard measured over [T/2, T] (finish events / plies at
+risk) -- an exponential tail beyond the observation window; the per-bin hazards are printed so
+the assumption can be checked.  95 % interval: bootstrap over games.
+
+    python benchmarks/game_length.py --boards 512 --playouts 400 --seconds 2400 --out profiles/round2/game_length_400playouts.json
+"""
 import argparse
 import json
 import os
@@ -18,46 +27,110 @@ from alphazero_quoridor_amd.engine import SelfPlayEngine  # noqa: E402
 from alphazero_quoridor_amd.policy_value_net import PolicyValueNet  # noqa: E402
 
 
+def km_mean(times, events):
+    """(E[L] with exponential tail, restricted mean, S(T), lambda_tail, T)."""
+    times = np.asarray(times, dtype=np.float64)
+    events = np.asarray(events, dtype=bool)
+    order = np.argsort(times, kind="stable")
+    t, e = times[order], events[order]
+    n = len(t)
+    at_risk = n - np.arange(n)
+    # survival just after each observation (ties: events before censorings at equal times does not matter for the mean at this resolution)
+    factors = np.where(e, 1.0 - 1.0 / at_risk, 1.0)
+    S = np.cumprod(factors)
+    T = t[-1]
+    # integral of the step function S over [0, T]
+    prev_t = np.concatenate([[0.0], t[:-1]])
+    prev_S = np.concatenate([[1.0], S[:-1]])
+    rmst = float(np.sum(prev_S * (t - prev_t)))
+    lo = T / 2.0
+    exposure = float(np.sum(np.clip(t, lo, T) - lo))        # plies at risk inside [T/2, T]
+    tail_events = int(np.sum(e & (t > lo)))
+    lam = tail_events / exposure if exposure > 0 and tail_events > 0 else None
+    ST = float(S[-1]) if not e[-1] else float(S[-1])
+    mean = rmst + (ST / lam if lam else 0.0)
+    return mean, rmst, ST, lam, float(T)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--boards", type=int, default=512)
     ap.add_argument("--playouts", type=int, default=400)
-    ap.add_argument("--plies", type=int, default=1200)
     ap.add_argument("--seconds", type=float, default=600)
+    ap.add_argument("--max-plies", type=int, default=1000000)
     ap.add_argument("--bn", default="per_leaf")
     ap.add_argument("--fix-sign", type=int, default=0)
+    ap.add_argument("--graph", type=int, default=8, help="playout steps per captured HIP graph (0 = eager)")
+    ap.add_argument("--out", default=None)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(2026)
     torch.backends.cudnn.benchmark = True
     net = PolicyValueNet(use_gpu=True)
     ev = net.evaluator(args.bn)
-    eng = SelfPlayEngine(args.boards, n_playout=args.playouts, seed=5, device=dev, fix_terminal_sign=bool(args.fix_sign),
-                         max_plies=args.plies + 8)
-    first = []
-    lengths_all = []
+    B = args.boards
+    eng = SelfPlayEngine(B, n_playout=args.playouts, seed=5, device=dev, fix_terminal_sign=bool(args.fix_sign))
+    if args.graph:
+        eng.capture_steps(ev, steps_per_graph=args.graph, warmup=2)
+        eng.reset()
+    age = torch.zeros(B, dtype=torch.int64, device=dev)     # plies of the board's current game
+    finished = []
     t0 = time.time()
     ply = 0
-    for ply in range(1, args.plies + 1):
+    while ply < args.max_plies and time.time() - t0 < args.seconds:
         eng.run_playouts(ev)
         eng.finish_move()
-        tb = eng.harvest()
-        if tb is not None:
-            lens = np.bincount(tb.game.cpu().numpy()).tolist()
-            lengths_all.extend(lens)
-            first.extend(L for L in lens if L == ply)  # started at ply 0 <=> length == elapsed plies
-        if time.time() - t0 > args.seconds:
-            break
+        ply += 1
+        age += 1
+        bd = eng.get_boards()
+        p1 = ((bd.meta & 0xFF) ^ 0x80) - 0x80            # int8 fields of the meta word
+        p2 = (((bd.meta >> 8) & 0xFF) ^ 0x80) - 0x80
+        done = (p1 >= 72) | (p2 <= 8)                      # has_a_winner (quoridor.py:193-202)
+        if bool(done.any()):
+            finished.extend(age[done].cpu().tolist())
+            age[done] = 0
+            tb = eng.harvest()
+            assert tb is not None and tb.n_games == int(done.sum())
+    seconds = time.time() - t0
     st = eng.stats()
-    fl = np.array(first)
-    print(json.dumps({
-        "boards": args.boards, "n_playout": args.playouts, "plies_run": ply, "seconds": time.time() - t0,
-        "first_generation_finished": int(len(fl)), "first_generation_unfinished": int(args.boards - len(fl)),
-        "first_gen_mean_len_finished": float(fl.mean()) if len(fl) else None,
-        "first_gen_percentiles_10_50_90": [float(x) for x in np.percentile(fl, [10, 50, 90])] if len(fl) else None,
-        "all_finished_games": len(lengths_all), "all_mean_len": float(np.mean(lengths_all)) if lengths_all else None,
-        "stats": st, "fix_sign": args.fix_sign,
-    }))
+    censored = age[age > 0].cpu().tolist()
+    times = np.array(finished + censored, dtype=np.float64)
+    events = np.array([True] * len(finished) + [False] * len(censored))
+    mean, rmst, ST, lam, T = km_mean(times, events)
+    rng = np.random.RandomState(0)
+    boots = []
+    for _ in range(300):
+        idx = rng.randint(0, len(times), len(times))
+        if events[idx].sum() < 2:
+            continue
+        boots.append(km_mean(times[idx], events[idx])[0])
+    ci = [float(np.percentile(boots, 2.5)), float(np.percentile(boots, 97.5))] if boots else None
+    edges = np.linspace(0, T, 9)
+    hazards = []
+    for a, b in zip(edges[:-1], edges[1:]):
+        exposure = float(np.sum(np.clip(times, a, b) - a))
+        n_ev = int(np.sum(events & (times > a) & (times <= b)))
+        hazards.append({"plies": [float(a), float(b)], "events": n_ev, "plies_at_risk": exposure, "hazard_per_ply": n_ev / exposure if exposure else None})
+    out = {
+        "boards": B, "n_playout": args.playouts, "fix_terminal_sign": bool(args.fix_sign), "plies_run": ply, "seconds": seconds,
+        "plies_per_s": st["plies_played"] / seconds,
+        "games_finished": len(finished), "games_censored": len(censored),
+        "finished_length_percentiles_10_50_90": [float(x) for x in np.percentile(finished, [10, 50, 90])] if finished else None,
+        "finished_mean": float(np.mean(finished)) if finished else None,
+        "estimator": "Kaplan-Meier restricted mean up to T = %.0f plies (%.0f) + S(T) / lambda with S(T) = %.3f and the hazard over [T/2, T] "
+                     "lambda = %s per ply (exponential tail)" % (T, rmst, ST, ("%.3g" % lam) if lam else "n/a"),
+        "mean_plies_per_game": mean, "mean_ci95": ci, "restricted_mean": rmst, "survival_at_T": ST, "tail_hazard_per_ply": lam, "T": T,
+        "hazard_by_bin": hazards,
+        "stats": {k: st[k] for k in ("games_finished", "plies_played", "playouts", "leaf_terminal", "node_overflow", "games_aborted",
+                                     "aborted_no_move", "aborted_max_plies", "aborted_pool", "tree_pages_peak", "tree_pages_total",
+                                     "traj_pages_peak", "traj_pages_total", "max_edges")},
+    }
+    text = json.dumps(out)
+    if args.out:
+        os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
+        with open(args.out, "w") as f:
+            f.write(text + "\n")
+    print(text)
 
 
 if __name__ == "__main__":

@@ -139,6 +139,8 @@ typedef struct {
     int64_t nonfinite_values;  /* descents that met a NaN PUCT value (diverged network); first child taken like Python's max() */
     int64_t tree_pages_total, tree_pages_in_use, tree_pages_peak;
     int64_t traj_pages_total, traj_pages_in_use, traj_pages_peak;
+    int64_t edges_scanned;     /* 32-byte edge records read by the descents (k_select's algorithmic bytes / 32) */
+    int64_t edges_expanded;    /* edge records created by expansions                                    */
 } qz_stats;
 
 /* MCTSPlayer.__init__ / MCTS.__init__ (mcts.py:89-100, 159-161) for n_boards trees +
