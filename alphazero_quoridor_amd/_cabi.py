@@ -117,6 +117,8 @@ _SIGNATURES = {
     "qz_movegen_encode": (C.c_int, [C.POINTER(qz_boards), C.c_int, _P, _P, _P]),
     "qz_movegen_encode_opts": (C.c_int, [C.POINTER(qz_boards), C.c_int, _P, _P, C.POINTER(qz_rules_opts), _P]),
     "qz_step": (C.c_int, [C.POINTER(qz_boards), _P, C.c_int, _P, _P, _P]),
+    "qz_rollout_scratch_bytes": (C.c_int64, [C.c_int]),
+    "qz_rollout": (C.c_int, [C.POINTER(qz_boards), C.c_int, C.c_int, C.c_uint64, _P, _P, _P]),
     "qz_engine_create": (C.c_int, [C.POINTER(qz_config), C.POINTER(_P)]),
     "qz_engine_destroy": (C.c_int, [_P]),
     "qz_engine_reset": (C.c_int, [_P, _P]),

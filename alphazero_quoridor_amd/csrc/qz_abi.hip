@@ -28,6 +28,8 @@ hipError_t reset(const EngineDev&, int, hipStream_t);
 hipError_t pool_init(const EngineDev&, hipStream_t);
 hipError_t harvest(const EngineDev&, uint64_t*, uint64_t*, uint64_t*, float*, float*, int32_t*, long long, hipStream_t);
 hipError_t sqrt_table(double*, int, hipStream_t);
+hipError_t rollout_begin(const uint64_t*, const uint64_t*, const uint64_t*, int, uint8_t*, uint8_t*, int8_t*, int*, hipStream_t);
+hipError_t rollout_step(uint64_t*, uint64_t*, uint64_t*, const uint32_t*, int, const uint8_t*, uint8_t*, int8_t*, int*, uint64_t, int, int, hipStream_t);
 hipError_t instnorm_act(const float*, const float*, const float*, const float*, float*, long long, int, int, float, hipStream_t);
 hipError_t instnorm_act_nhwc(const float*, const float*, const float*, const float*, float*, long long, int, int, float, hipStream_t);
 hipError_t input_layer(const uint64_t*, const uint64_t*, const uint64_t*, const uint8_t*, long long, const float*, const float*,
@@ -184,6 +186,41 @@ int qz_step(qz_boards* boards, const uint8_t* action, int n, uint8_t* done, uint
     if (n > 0 && !action) return fail(QZ_E_INVALID, "action is null");
     if (n == 0) return 0;
     HIP_TRY(qzl::step(boards->hbits, boards->vbits, boards->meta, action, n, done, winner, (hipStream_t)stream));
+    return 0;
+}
+
+// scratch layout of qz_rollout: mask5 [n][5] u32 | player0 [n] u8 | done [n] u8 | n_done int (16-byte aligned blocks)
+static size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+int64_t qz_rollout_scratch_bytes(int n) {
+    if (n < 0) return 0;
+    return (int64_t)(align16((size_t)n * 20) + 2 * align16((size_t)n) + 16 + qzl::movegen_scratch_bytes(n));
+}
+int qz_rollout(qz_boards* boards, int n, int limit, uint64_t seed, int8_t* value, void* scratch, void* stream) {
+    int r;
+    if ((r = device_check()) || (r = check_boards(boards, n))) return r;
+    if (n == 0) return 0;
+    if (!value || !scratch || limit <= 0) return fail(QZ_E_INVALID, "value / scratch is null or limit <= 0");
+    hipStream_t s = (hipStream_t)stream;
+    uint8_t* base = (uint8_t*)scratch;
+    uint32_t* mask5 = (uint32_t*)base;
+    uint8_t* player0 = base + align16((size_t)n * 20);
+    uint8_t* done = player0 + align16((size_t)n);
+    int* n_done = (int*)(done + align16((size_t)n));
+    void* mg_scratch = (uint8_t*)n_done + 16;
+    const RulesOpts ro;
+    HIP_TRY(qzl::rollout_begin(boards->hbits, boards->vbits, boards->meta, n, player0, done, value, n_done, s));
+    for (int step = 0; step < limit; step++) {
+        // actions() of every board still playing (finished ones are skipped through the terminal flags)
+        HIP_TRY(qzl::movegen_encode(boards->hbits, boards->vbits, boards->meta, n, mask5, nullptr, done, mg_scratch, ro, s));
+        HIP_TRY(qzl::rollout_step(boards->hbits, boards->vbits, boards->meta, mask5, n, player0, done, value, n_done, seed, step, limit, s));
+        if ((step & 15) == 15 || step == limit - 1) {
+            int h = 0;
+            HIP_TRY(hipMemcpyAsync(&h, n_done, sizeof(int), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            if (h >= n) break;
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(s));
     return 0;
 }
 

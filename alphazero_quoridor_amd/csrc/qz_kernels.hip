@@ -1065,6 +1065,71 @@ __global__ __launch_bounds__(TPB) void k_finish_move(EngineDev E, const uint8_t*
     }
 }
 
+// ---------------------------------------------------------------------------- random rollouts
+// MCTS._evaluate_rollout (pure_mcts.py:81-103) for a batch of boards, one launch per iteration.
+// The reference's loop: has_a_winner() first; at iteration limit-1 an unfinished game stops with
+// "no winner" (value 0); otherwise a uniformly random legal action (the max over np.random.rand of
+// the legal list, pure_mcts.py:7-10, 94-98) is played.  Here the winner test follows the move
+// immediately (the same decision one iteration earlier, and move generation never sees a finished
+// board, whose winning pawn may stand off the board).  `mask5` = actions() of the boards as they
+// are now (this iteration's move-generation launch); value[b] = +1 if the winner is `player0[b]`
+// (the side to move when the rollout began), -1 if the other, 0 without a winner.
+__global__ __launch_bounds__(256) void k_rollout_step(uint64_t* hb, uint64_t* vb, uint64_t* meta, const uint32_t* __restrict__ mask5,
+                                                      int n, const uint8_t* __restrict__ player0, uint8_t* __restrict__ done,
+                                                      int8_t* __restrict__ value, int* __restrict__ n_done, uint64_t seed, int step,
+                                                      int limit) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n || done[i]) return;
+    uint32_t m[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) m[k] = mask5[(size_t)i * 5 + k];
+    const int cnt = __popc(m[0]) + __popc(m[1]) + __popc(m[2]) + __popc(m[3]) + __popc(m[4]);
+    if (step >= limit - 1 || cnt == 0) {
+        // cnt == 0 on a live board: the reference's max() over an empty list raises; here: no winner
+        value[i] = 0;
+        done[i] = 1;
+        atomicAdd(n_done, 1);
+        return;
+    }
+    Board b = unpack(hb[i], vb[i], meta[i]);
+    Philox ph{(uint32_t)seed, (uint32_t)(seed >> 32)};
+    const uint4 r = ph((uint32_t)i, (uint32_t)step, 0x524F4C4Cu, 0u);
+    int pick = (int)(((uint64_t)r.x * (uint64_t)cnt) >> 32);  // uniform in [0, cnt)
+    int a = 0;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const int c = __popc(m[k]);
+        if (pick >= 0 && pick < c) {
+            uint32_t word = m[k];
+            for (int j = 0; j < pick; j++) word &= word - 1u;  // drop the `pick` lowest set bits
+            a = 32 * k + (__ffs((int)word) - 1);
+            pick = -1;
+        } else if (pick >= 0) {
+            pick -= c;
+        }
+    }
+    const bool won = apply_action(b, a);
+    hb[i] = b.hb;
+    vb[i] = b.vb;
+    meta[i] = pack_meta(b);
+    if (won) {
+        value[i] = (int8_t)(winner_of(b) == (int)player0[i] ? 1 : -1);
+        done[i] = 1;
+        atomicAdd(n_done, 1);
+    }
+}
+__global__ void k_rollout_begin(const uint64_t* __restrict__ hb, const uint64_t* __restrict__ vb, const uint64_t* __restrict__ meta, int n,
+                                uint8_t* player0, uint8_t* done, int8_t* value, int* n_done) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n) return;
+    const Board b = unpack(hb[i], vb[i], meta[i]);
+    player0[i] = (uint8_t)b.cur;  // game.get_current_player() at the start (pure_mcts.py:82)
+    const int w = winner_of(b);   // a rollout from a finished game ends at once (pure_mcts.py:84-87)
+    done[i] = w != 0;
+    value[i] = (int8_t)(w == 0 ? 0 : (w == b.cur ? 1 : -1));
+    if (w != 0) atomicAdd(n_done, 1);
+}
+
 // ---------------------------------------------------------------------------- harvest
 // exclusive prefix over finished boards (board order) -> tuple offsets / game ids
 __global__ __launch_bounds__(1024) void k_harvest_scan(EngineDev E) {
@@ -1283,6 +1348,19 @@ hipError_t harvest(const EngineDev& E, uint64_t* t_hb, uint64_t* t_vb, uint64_t*
                    int32_t* t_game, long long cap, hipStream_t s) {
     hipLaunchKernelGGL(k_harvest_scan, dim3(1), dim3(1024), 0, s, E);
     hipLaunchKernelGGL(k_harvest_copy, wave_grid(E.n_boards), dim3(TPB), 0, s, E, t_hb, t_vb, t_meta, t_pi, t_z, t_game, cap);
+    return hipGetLastError();
+}
+hipError_t rollout_begin(const uint64_t* hb, const uint64_t* vb, const uint64_t* meta, int n, uint8_t* player0, uint8_t* done,
+                         int8_t* value, int* n_done, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(n_done, 0, sizeof(int), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_rollout_begin, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, hb, vb, meta, n, player0, done, value, n_done);
+    return hipGetLastError();
+}
+hipError_t rollout_step(uint64_t* hb, uint64_t* vb, uint64_t* meta, const uint32_t* mask5, int n, const uint8_t* player0, uint8_t* done,
+                        int8_t* value, int* n_done, uint64_t seed, int step, int limit, hipStream_t s) {
+    hipLaunchKernelGGL(k_rollout_step, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, hb, vb, meta, mask5, n, player0, done, value,
+                       n_done, seed, step, limit);
     return hipGetLastError();
 }
 hipError_t sqrt_table(double* out, int n, hipStream_t s) {

@@ -203,6 +203,11 @@ class SelfPlayEngine:
         boards never reads state(), so the rules op then only produces the legal sets
         (write_planes=True forces the planes anyway: bench.py's roofline of the full op).
         tree_events = ((start, stop) around k_select, (start, stop) around k_expand_backup)."""
+        if getattr(evaluator, "takes_leaf_copy", False):  # e.g. pure_mcts.RolloutEvaluator: plays its copy of the leaves out
+            leaf = self.select_boards()
+            p, v = evaluator.from_boards(leaf, self.leaf_mask)
+            self.expand_backup(p, v)
+            return
         takes_boards = getattr(evaluator, "accepts_leaf_boards", False)
         want_planes = (not takes_boards) if write_planes is None else bool(write_planes) or not takes_boards
         planes = self.select(events=events, want_planes=want_planes, tree_events=None if tree_events is None else tree_events[0])

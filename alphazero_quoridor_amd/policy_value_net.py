@@ -323,14 +323,97 @@ class PolicyValueNet:
         for ev in self._evaluators.values():
             ev.refresh()
 
+    # device-tensor API (what TrainPipeline uses: nothing goes through numpy) ---------------------
+    def _as_states(self, state_batch):
+        if isinstance(state_batch, torch.Tensor):
+            return state_batch.to(self.device, torch.float32)
+        return torch.as_tensor(np.asarray(state_batch), dtype=torch.float32, device=self.device)
+
+    @torch.no_grad()
+    def policy_value_t(self, states: torch.Tensor):
+        """states float32 [B,26,9,9] on the device -> (act_probs [B,140], value [B,1]) device
+        tensors.  Like the reference's policy_value (policy_value_net.py:127-143) the module is in
+        train mode, so BatchNorm uses the batch's statistics (and updates its running ones)."""
+        logp, v = self.policy_value_net(states)
+        return torch.exp(logp), v
+
+    def train_step_t(self, states, mcts_probs, winners, lr):
+        """One optimiser step on device tensors (policy_value_net.py:166-192):
+        loss = mse(v, z) - mean(sum(pi * log p)) (+ L2 through Adam's weight decay).  Returns
+        (loss, entropy) as 0-dim device tensors: no host synchronisation here.  With
+        torch.distributed initialised (one rank per GPU) the gradients are averaged over the ranks
+        by ONE all-reduce of a flat 1.8-MB bucket (RCCL over xGMI) before the step, so replicas
+        that started from the same weights stay identical."""
+        self.optimizer.zero_grad(set_to_none=False)
+        set_learning_rate(self.optimizer, lr)
+        logp, v = self.policy_value_net(states)
+        value_loss = F.mse_loss(v.view(-1), winners)
+        policy_loss = -torch.mean(torch.sum(mcts_probs * logp, 1))
+        loss = value_loss + policy_loss
+        loss.backward()
+        self._allreduce_grads()
+        self.optimizer.step()
+        with torch.no_grad():
+            entropy = -torch.mean(torch.sum(torch.exp(logp) * logp, 1))
+        self.weights_changed()
+        return loss.detach(), entropy
+
+    def _world(self):
+        import torch.distributed as dist
+
+        return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+    def _allreduce_grads(self):
+        world = self._world()
+        if world == 1:
+            return
+        import torch.distributed as dist
+
+        params = [p for p in self.policy_value_net.parameters() if p.grad is not None]
+        flat = torch.cat([p.grad.reshape(-1) for p in params])
+        dist.all_reduce(flat)
+        flat.div_(world)
+        off = 0
+        for p in params:
+            n = p.grad.numel()
+            p.grad.copy_(flat[off:off + n].view_as(p.grad))
+            off += n
+
+    def sync_from_rank0(self):
+        """Every rank takes rank 0's weights, BatchNorm buffers and optimiser step count: replicas
+        must start identical for the gradient all-reduce to keep them identical."""
+        if self._world() == 1:
+            return
+        import torch.distributed as dist
+
+        with torch.no_grad():
+            for t in list(self.policy_value_net.parameters()) + list(self.policy_value_net.buffers()):
+                dist.broadcast(t, src=0)
+        self.weights_changed()
+
+    def average_buffers(self):
+        """BatchNorm running statistics are fed by each rank's own minibatches: average them."""
+        world = self._world()
+        if world == 1:
+            return
+        import torch.distributed as dist
+
+        with torch.no_grad():
+            bufs = [b for b in self.policy_value_net.buffers() if b.dtype.is_floating_point]
+            flat = torch.cat([b.reshape(-1) for b in bufs])
+            dist.all_reduce(flat)
+            flat.div_(world)
+            off = 0
+            for b in bufs:
+                b.copy_(flat[off:off + b.numel()].view_as(b))
+                off += b.numel()
+
     # reference API -----------------------------------------------------------------
     def policy_value(self, state_batch):
         """batch of states -> (act_probs float32 [B,140], value float32 [B,1]) as numpy
         (policy_value_net.py:127-143; module in train mode => batch statistics)."""
-        x = torch.as_tensor(np.asarray(state_batch), dtype=torch.float32, device=self.device)
-        with torch.no_grad():
-            logp, v = self.policy_value_net(x)
-        return np.exp(logp.cpu().numpy()), v.cpu().numpy()
+        probs, v = self.policy_value_t(self._as_states(state_batch))
+        return probs.cpu().numpy(), v.cpu().numpy()
 
     def policy_value_fn(self, game):
         """game -> (iterable[(action, prob)], value) (policy_value_net.py:145-164)."""
@@ -343,20 +426,11 @@ class PolicyValueNet:
         return zip(legal, probs[legal]), float(v.reshape(-1)[0])
 
     def train_step(self, state_batch, mcts_probs, winner_batch, lr):
-        """loss = (z - v)^2 - pi^T log p (+ L2 via weight decay); returns (loss, entropy) as
-        Python floats (policy_value_net.py:166-192, with the torch>=0.4 `.item()` fix)."""
-        s = torch.as_tensor(np.asarray(state_batch), dtype=torch.float32, device=self.device)
+        """The reference's signature (lists / arrays in, Python floats out: policy_value_net.py:
+        166-192, whose `.data[0]` no longer works on a modern torch)."""
         pi = torch.as_tensor(np.asarray(mcts_probs), dtype=torch.float32, device=self.device)
         z = torch.as_tensor(np.asarray(winner_batch), dtype=torch.float32, device=self.device)
-        self.optimizer.zero_grad()
-        set_learning_rate(self.optimizer, lr)
-        logp, v = self.policy_value_net(s)
-        loss = F.mse_loss(v.view(-1), z) - torch.mean(torch.sum(pi * logp, 1))
-        loss.backward()
-        self.optimizer.step()
-        with torch.no_grad():
-            entropy = -torch.mean(torch.sum(torch.exp(logp) * logp, 1))
-        self.weights_changed()
+        loss, entropy = self.train_step_t(self._as_states(state_batch), pi, z, lr)
         return loss.item(), entropy.item()
 
     def get_policy_param(self):

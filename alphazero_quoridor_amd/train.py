@@ -1,33 +1,39 @@
-"""``TrainPipeline`` with the reference's attribute names and defaults (train.py:12-116);
-``collect_selfplay_data`` is the accelerated path.
+"""``TrainPipeline`` with the reference's attribute names and defaults (train.py:12-116).
 
-Where the reference plays one game at a time through ``Quoridor.start_self_play``
-(train.py:55-63), this pipeline keeps ``n_boards`` games in flight inside a
-``SelfPlayEngine`` and returns as soon as ``n_games`` of them have finished; the other
-boards keep their trees and positions for the next call (continuous refill).  The replay
-buffer receives the reference's tuple format: (float64 state [26,9,9], float64 pi [140],
-float64 z).  With torch.distributed initialised (one process per GPU) every rank's finished
-tuples are all-gathered into every rank's buffer.
+What the reference does one game at a time on the host, this pipeline keeps on the GPU:
+
+* ``collect_selfplay_data``: ``n_boards`` games in flight inside a ``SelfPlayEngine``; returns as
+  soon as ``n_games`` more of them have finished, the others keep their trees and positions
+  (continuous refill).  Finished (board, pi, z) tuples go straight into a device-resident
+  ``ReplayBuffer`` (588 B per ply; the reference's deque holds 72 KB of float64 per ply).
+* ``policy_update``: the minibatch is gathered and re-encoded on the device, old/new policies,
+  KL, explained variance are device tensors; per epoch ONE scalar crosses to the host (the KL
+  that decides whether to stop early, train.py:79-80).
+* multi-GPU (one process per GPU, torch.distributed / RCCL): every rank plays its own boards,
+  finished tuples are all-gathered into every rank's buffer, all ranks start from rank 0's
+  weights and average their gradients, so the replicas stay one model; rank 0 alone writes
+  checkpoints and ``loss.txt``.
+* ``policy_evaluate``: the win-rate gate against the pure-MCTS rollout player (train.py:30-31 and
+  the commented call at :108; pure_mcts.py), all games of the match played side by side.
 """
 from __future__ import annotations
 
 import random
-from collections import deque
 
 import numpy as np
 import torch
 
 from . import dist as qdist
-from .boards import DeviceBoards
-from .engine import BoardGroups, TupleBatch
+from .engine import BoardGroups
 from .mcts import MCTSPlayer
 from .policy_value_net import PolicyValueNet
 from .quoridor import Quoridor
+from .replay import ReplayBuffer, ShardWriter
 
 
 class TrainPipeline(object):
     def __init__(self, init_model=None, n_boards=1024, device=None, seed=0, bn_mode="per_leaf",
-                 nn_dtype=torch.float32, use_graph=False, n_groups=1):
+                 nn_dtype=torch.float32, use_graph=False, n_groups=1, shard_dir=None):
         self.game = Quoridor()
         # the reference's hyper-parameters, same names and values (train.py:17-31)
         self.learn_rate = 2e-3
@@ -37,7 +43,6 @@ class TrainPipeline(object):
         self.c_puct = 5
         self.buffer_size = 10000
         self.batch_size = 128
-        self.data_buffer = deque(maxlen=self.buffer_size)
         self.play_batch_size = 1
         self.epochs = 5
         self.kl_targ = 0.02
@@ -45,7 +50,9 @@ class TrainPipeline(object):
         self.game_batch_num = 1500
         self.best_win_ratio = 0.0
         self.pure_mcts_playout_num = 1000
+        self.pure_mcts_rollout_limit = 1000   # pure_mcts.py:81 `limit`
         self.policy_value_net = PolicyValueNet(model_file=init_model, bn_mode=bn_mode, device=device)
+        self.data_buffer = ReplayBuffer(self.buffer_size, self.policy_value_net.device)
         self._mcts_player = None
         # engine knobs (new)
         self.n_boards = n_boards
@@ -56,6 +63,18 @@ class TrainPipeline(object):
         self.n_groups = n_groups  # board groups on separate HIP streams (engine.BoardGroups)
         self.episode_len = 0
         self._engine = None
+        self.shards = ShardWriter(shard_dir, rank=self._rank(), n_playout=self.n_playout) if shard_dir else None
+        self.policy_value_net.sync_from_rank0()
+        self.last_update = {}
+
+    # ------------------------------------------------------------------ plumbing
+    @staticmethod
+    def _rank():
+        return torch.distributed.get_rank() if torch.distributed.is_available() and torch.distributed.is_initialized() else 0
+
+    @staticmethod
+    def _is_dist():
+        return torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
 
     @property
     def mcts_player(self):
@@ -67,38 +86,37 @@ class TrainPipeline(object):
 
     def engine(self) -> BoardGroups:
         if self._engine is None:
-            rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
             net = self.policy_value_net
+            if len(self.data_buffer) == 0 and self.data_buffer.capacity != self.buffer_size:
+                self.data_buffer = ReplayBuffer(self.buffer_size, net.device)  # buffer_size was changed after __init__, like the other knobs
             self._engine = BoardGroups(self.n_boards, self.n_groups, lambda: net.evaluator(self.bn_mode, self.nn_dtype),
-                                       seed=qdist.shard_seed(self.seed, rank), device=net.device,
+                                       seed=qdist.shard_seed(self.seed, self._rank()), device=net.device,
                                        n_playout=self.n_playout, c_puct=self.c_puct, temp=self.temp, is_selfplay=1)
             if self.use_graph and self.n_groups == 1:
                 with torch.cuda.stream(self._engine.streams[0]):
                     self._engine.engines[0].capture_steps(self._engine.evaluators[0], 1, warmup=2)
         return self._engine
 
-    def _is_dist(self):
-        return torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
-
+    # ------------------------------------------------------------------ self-play -> replay buffer
     def _extend_buffer(self, tbs):
-        """Finished tuples of this ply -> replay buffer; returns the number of games they hold.
-        Multi-GPU: ONE all-gather per ply on every rank, whether or not this rank finished a
-        game, and the game count is the sum over ranks (identical everywhere), so all ranks
-        leave collect_selfplay_data after the same ply."""
+        """Finished tuples of this ply -> replay buffer (device to device); returns the number of
+        games they hold.  Multi-GPU: ONE all-gather per ply on every rank, whether or not this rank
+        finished a game, and the game count is the sum over ranks (identical everywhere), so all
+        ranks leave collect_selfplay_data after the same ply."""
         n_games = sum(tb.n_games for tb in tbs)
-        if self._is_dist():
-            dev = self.policy_value_net.device
-            bufs = [qdist.pack_tuples(tb.boards.hbits, tb.boards.vbits, tb.boards.meta, tb.pi, tb.z) for tb in tbs]
-            bufs.append(torch.zeros((0, qdist.TUPLE_BYTES), dtype=torch.uint8, device=dev))
-            buf, n_games = qdist.allgather_tuples(torch.cat(bufs), n_games=n_games)
-            if buf.shape[0] == 0:
-                return n_games
-            hb, vb, meta, pi, z = qdist.unpack_tuples(buf)
-            boards = DeviceBoards(len(hb), hb.device)
-            boards.hbits, boards.vbits, boards.meta = hb, vb, meta
-            tbs = [TupleBatch(boards, pi, z, None, n_games)]
-        for tb in tbs:
-            self.data_buffer.extend(tb.to_reference_tuples())
+        if self.shards is not None:
+            for tb in tbs:
+                self.shards.add(tb)
+        if not self._is_dist():
+            for tb in tbs:
+                self.data_buffer.extend(tb)
+            return n_games
+        dev = self.policy_value_net.device
+        bufs = [qdist.pack_tuples(tb.boards.hbits, tb.boards.vbits, tb.boards.meta, tb.pi, tb.z) for tb in tbs]
+        bufs.append(torch.zeros((0, qdist.TUPLE_BYTES), dtype=torch.uint8, device=dev))
+        buf, n_games = qdist.allgather_tuples(torch.cat(bufs), n_games=n_games)
+        if buf.shape[0]:
+            self.data_buffer.extend(buf)
         return n_games
 
     def collect_selfplay_data(self, n_games=1):
@@ -115,46 +133,95 @@ class TrainPipeline(object):
             eng.synchronize()
             got += self._extend_buffer(tbs)
 
+    # ------------------------------------------------------------------ training
+    def _mean_over_ranks(self, x: torch.Tensor) -> torch.Tensor:
+        if self._is_dist():
+            torch.distributed.all_reduce(x)
+            x = x / torch.distributed.get_world_size()
+        return x
+
     def policy_update(self):
-        """KL-adaptive policy/value update (train.py:65-92)."""
-        mini_batch = random.sample(self.data_buffer, self.batch_size)
-        state_batch = [d[0] for d in mini_batch]
-        mcts_probs_batch = [d[1] for d in mini_batch]
-        winner_batch = [d[2] for d in mini_batch]
-        old_probs, old_v = self.policy_value_net.policy_value(state_batch)
+        """One KL-controlled update of the policy-value net on a replay minibatch (train.py:65-92):
+        up to `epochs` optimiser steps on the same minibatch, stopped early when the policy moved
+        more than 4 kl_targ away from where it started; afterwards the learning-rate multiplier is
+        lowered (KL > 2 kl_targ) or raised (KL < kl_targ / 2) by 1.5 within [0.1, 10]."""
+        net = self.policy_value_net
+        states, pi, z = self.data_buffer.sample(self.batch_size)  # random.sample positions, states re-encoded on the GPU
+        old_probs, old_v = net.policy_value_t(states)
+        old_logp = torch.log(old_probs + 1e-10)
+        loss = entropy = None
+        new_v = old_v
+        kl = 0.0
+        steps = 0
         for _ in range(self.epochs):
-            loss, entropy = self.policy_value_net.train_step(state_batch, mcts_probs_batch, winner_batch,
-                                                             self.learn_rate * self.lr_multiplier)
-            new_probs, new_v = self.policy_value_net.policy_value(state_batch)
-            kl = np.mean(np.sum(old_probs * (np.log(old_probs + 1e-10) - np.log(new_probs + 1e-10)), axis=1))
+            loss, entropy = net.train_step_t(states, pi, z, self.learn_rate * self.lr_multiplier)
+            new_probs, new_v = net.policy_value_t(states)
+            kl_t = torch.mean(torch.sum(old_probs * (old_logp - torch.log(new_probs + 1e-10)), dim=1))
+            kl = float(self._mean_over_ranks(kl_t))  # the one host read per epoch; identical on all ranks
+            steps += 1
             if kl > self.kl_targ * 4:
                 break
         if kl > self.kl_targ * 2 and self.lr_multiplier > 0.1:
             self.lr_multiplier /= 1.5
         elif kl < self.kl_targ / 2 and self.lr_multiplier < 10:
             self.lr_multiplier *= 1.5
-        z = np.array(winner_batch)
-        ev_old = 1 - np.var(z - old_v.flatten()) / np.var(z)
-        ev_new = 1 - np.var(z - new_v.flatten()) / np.var(z)
-        print("kl:{:.5f},lr_multiplier:{:.3f},loss:{},entropy:{},explained_var_old:{:.3f},explained_var_new:{:.3f}"
-              .format(kl, self.lr_multiplier, loss, entropy, ev_old, ev_new))
+        net.average_buffers()
+        var_z = torch.var(z, unbiased=False)
+        ev_old = 1 - torch.var(z - old_v.flatten(), unbiased=False) / var_z
+        ev_new = 1 - torch.var(z - new_v.flatten(), unbiased=False) / var_z
+        loss, entropy = float(loss), float(entropy)
+        self.last_update = {"kl": kl, "lr_multiplier": self.lr_multiplier, "loss": loss, "entropy": entropy, "optimizer_steps": steps,
+                            "explained_var_old": float(ev_old), "explained_var_new": float(ev_new)}
+        if self._rank() == 0:
+            print("kl:{kl:.5f},lr_multiplier:{lr_multiplier:.3f},loss:{loss},entropy:{entropy},"
+                  "explained_var_old:{explained_var_old:.3f},explained_var_new:{explained_var_new:.3f}".format(**self.last_update))
         return loss, entropy
 
-    def run(self):
+    # ------------------------------------------------------------------ evaluation gate
+    def policy_evaluate(self, n_games=10, max_plies=2000):
+        """Win ratio of the current net's MCTS player against the pure-MCTS rollout player with
+        `pure_mcts_playout_num` playouts (train.py:30-31, :108), alternating who starts; all
+        games run side by side on the GPU (pure_mcts.evaluate_against_pure_mcts)."""
+        from .pure_mcts import evaluate_against_pure_mcts
+
+        res = evaluate_against_pure_mcts(self.policy_value_net, n_games=n_games, n_playout=self.n_playout, c_puct=self.c_puct,
+                                         pure_n_playout=self.pure_mcts_playout_num, seed=self.seed, max_plies=max_plies,
+                                         rollout_limit=self.pure_mcts_rollout_limit, bn_mode=self.bn_mode)
+        win_ratio = (res["wins"] + 0.5 * res["ties"]) / n_games
+        if self._rank() == 0:
+            print("num_playouts:{}, win: {}, lose: {}, tie:{}".format(self.pure_mcts_playout_num, res["wins"], res["losses"], res["ties"]))
+        return win_ratio
+
+    # ------------------------------------------------------------------ the loop
+    def run(self, evaluate=False):
+        """train.py:94-111.  `evaluate=True` also runs the win-rate gate every check_freq batches
+        (commented out in the reference) and keeps ckpt/best_policy.pth."""
+        rank0 = self._rank() == 0
         try:
             for i in range(self.game_batch_num):
                 self.collect_selfplay_data(self.play_batch_size)
-                print("batch i:{}, episode_len:{}".format(i + 1, self.episode_len))
+                if rank0:
+                    print("batch i:{}, episode_len:{}".format(i + 1, self.episode_len))
                 if len(self.data_buffer) > self.batch_size:
-                    loss, entropy = self.policy_update()
-                    print("LOSS:", loss)
-                    with open("loss.txt", "a") as f:
-                        f.writelines(str(loss) + "\n")
+                    loss, _ = self.policy_update()
+                    if rank0:
+                        print("LOSS:", loss)
+                        with open("loss.txt", "a") as f:
+                            f.write(str(loss) + "\n")
                 if (i + 1) % self.check_freq == 0:
-                    print("current self-play batch: {}".format(i + 1))
-                    self.policy_value_net.save_model("current_policy")
+                    if rank0:
+                        print("current self-play batch: {}".format(i + 1))
+                        self.policy_value_net.save_model("current_policy")
+                    if evaluate:
+                        ratio = self.policy_evaluate()
+                        if ratio > self.best_win_ratio and rank0:
+                            self.best_win_ratio = ratio
+                            self.policy_value_net.save_model("best_policy")
         except KeyboardInterrupt:
             print("\n\rquit")
+        finally:
+            if self.shards is not None:
+                self.shards.flush()
 
 
 if __name__ == "__main__":

@@ -91,6 +91,17 @@ int qz_movegen_encode_opts(const qz_boards* boards, int n, uint32_t* mask5 /*[de
 int qz_step(qz_boards* boards, const uint8_t* action /*[dev]*/, int n, uint8_t* done /*[dev]*/,
             uint8_t* winner /*[dev]*/, void* stream);
 
+/* MCTS._evaluate_rollout (pure_mcts.py:81-103) for n boards at once, IN PLACE: uniformly random
+ * legal moves (rollout_policy_fn, pure_mcts.py:7-10) until somebody has won or `limit` (1000 in
+ * the reference) iterations have passed.  value[n] int8 <- +1 if the winner is the side that
+ * was to move when the rollout began, -1 if the other, 0 if nobody won within the limit.  Each
+ * iteration is one move-generation launch (actions() of every live board) + one pick-and-step
+ * launch; the loop ends early once every board is done (checked every 16 iterations).  Random
+ * stream: Philox keyed by `seed`, counter (board, iteration).  scratch: caller-provided device
+ * memory of qz_rollout_scratch_bytes(n) bytes.  SYNC. */
+int64_t qz_rollout_scratch_bytes(int n);
+int qz_rollout(qz_boards* boards, int n, int limit, uint64_t seed, int8_t* value /*[dev]*/, void* scratch /*[dev]*/, void* stream);
+
 /* ---------------------------------------------------------------- engine */
 typedef struct qz_engine qz_engine;
 

@@ -6,7 +6,7 @@ GPU box).  It imports the reference's quoridor.py / mcts.py / policy_value_net.p
 drives them on seeded inputs and stores inputs + expected outputs as small .npz
 files.  No reference source is copied: fixtures are data.
 
-    python tests/golden/gen_golden.py [--only rules,pawn,positions,steps,mcts,episodes,net,train]
+    python tests/golden/gen_golden.py [--only rules,pawn,positions,steps,mcts,episodes,net,train,rollouts]
 
 The oracle (oracle/) and the HIP path are both checked against these files.
 """
@@ -629,9 +629,44 @@ def gen_train(out_dir):
     print("train: 3 reference train_step calls on 128 tuples: loss", losses, "entropy", entropies)
 
 
+# --------------------------------------------------------------------------- F10
+def _rollout_worker(job):
+    rec, seed, n = job
+    import pure_mcts  # the reference's (sys.path[0] is the reference)
+
+    np.random.seed(seed)
+    m = pure_mcts.MCTS(pure_mcts.policy_value_fn, 5, 10)
+    out = [0, 0, 0]
+    with quiet():
+        for _ in range(n):
+            g = game_from_packed(rec)
+            v = m._evaluate_rollout(g)  # pure_mcts.py:81-103, limit=1000
+            out[{1: 0, -1: 1, 0: 2}[int(v)]] += 1
+    return out
+
+
+def gen_rollouts(out_dir, procs, per_position=320):
+    """Outcome frequencies of the REAL reference's random rollouts (pure_mcts.MCTS._evaluate_rollout,
+    limit 1000) from 10 late-middle-game positions: counts of +1 / -1 / 0 from the point of view of
+    the side to move.  The HIP rollouts use another random stream, so the comparison is statistical."""
+    pos = np.load(os.path.join(out_dir, "rules_positions.npz"))
+    boards, nact = pos["board"], pos["n_actions"]
+    rng = random.Random(21)
+    cand = [i for i in range(len(boards)) if nact[i] > 0 and 0 <= boards[i]["p1"] <= 71 and 9 <= boards[i]["p2"] <= 80
+            and int(boards[i]["w1"]) + int(boards[i]["w2"]) <= 6]
+    idx = rng.sample(cand, 10)
+    jobs = [(boards[i], 1000 + 17 * j + k, per_position // 4) for j, i in enumerate(idx) for k in range(4)]
+    t0 = time.time()
+    with get_context("fork").Pool(procs) as pool:
+        res = pool.map(_rollout_worker, jobs)
+    counts = np.array(res).reshape(10, 4, 3).sum(axis=1)
+    np.savez_compressed(os.path.join(out_dir, "rollout_fixture.npz"), board=boards[idx], counts=counts, limit=np.array(1000))
+    print("rollouts: 10 positions x %d reference rollouts in %.0fs:" % (per_position, time.time() - t0), counts.tolist())
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="rules,positions,steps,mcts,episodes,net,train")
+    ap.add_argument("--only", default="rules,positions,steps,mcts,episodes,net,train,rollouts")
     ap.add_argument("--procs", type=int, default=8)
     ap.add_argument("--games", type=int, default=160)
     ap.add_argument("--synthetic", type=int, default=120)
@@ -651,6 +686,8 @@ def main():
         gen_net(HERE)
     if "train" in only:
         gen_train(HERE)
+    if "rollouts" in only:
+        gen_rollouts(HERE, args.procs)
 
 
 if __name__ == "__main__":

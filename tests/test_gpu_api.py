@@ -266,7 +266,8 @@ def test_train_pipeline_collects_reference_shaped_tuples(gpu_device):
     tp.n_playout = 2
     tp.collect_selfplay_data(1)
     assert len(tp.data_buffer) >= tp.episode_len > 0
-    s, pi, z = tp.data_buffer[0]
+    assert tp.data_buffer.pi.is_cuda and tp.data_buffer.maxlen == 10000   # the replay ring lives on the device
+    s, pi, z = tp.data_buffer.to_reference_tuples()[0]                   # ... and still yields the reference's tuple format
     assert s.shape == (26, 9, 9) and s.dtype == np.float64 and pi.shape == (140,) and pi.dtype == np.float64
     assert z in (1.0, -1.0) and abs(pi.sum() - 1.0) < 1e-5
     assert s.reshape(26, 81).sum(axis=1).tolist() == [64, 0, 0, 1, 1] + [0] * 9 + [81] + [0] * 9 + [81, 0]

@@ -259,3 +259,139 @@ def test_bench_self_launch_spawns_children_and_relays_one_line(tmp_path, monkeyp
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
     assert os.path.basename(cmd[cmd.index("--master-port") + 2]) == "bench.py"
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_replay_shard_file_roundtrip_and_corruption(tmp_path):
+    """*.qzr: header + packed 588-byte tuples; reader rejects foreign, truncated and corrupted files."""
+    from alphazero_quoridor_amd import replay
+
+    rs = np.random.RandomState(0)
+    packed = rs.randint(0, 256, size=(37, replay.TUPLE_BYTES)).astype(np.uint8)
+    path = tmp_path / "a.qzr"
+    assert replay.write_shard(path, packed, n_games=3, n_playout=400) == 37
+    assert os.path.getsize(path) == replay.SHARD_HEADER + 37 * 588 and not os.path.exists(str(path) + ".tmp")
+    back, meta = replay.read_shard(path)
+    assert np.array_equal(back, packed) and meta == {"n_games": 3, "n_playout": 400, "version": 1}
+    replay.write_shard(tmp_path / "empty.qzr", np.zeros((0, 588), dtype=np.uint8))
+    assert replay.read_shard(tmp_path / "empty.qzr")[0].shape == (0, 588)
+    raw = bytearray(open(path, "rb").read())
+    for name, data in (("magic", b"XXXX" + bytes(raw[4:])), ("trunc", bytes(raw[:-5])), ("flip", bytes(raw[:200]) + bytes([raw[200] ^ 1]) + bytes(raw[201:]))):
+        bad = tmp_path / (name + ".qzr")
+        open(bad, "wb").write(data)
+        with pytest.raises(ValueError):
+            replay.read_shard(bad)
+
+
+def test_replay_buffer_is_a_deque_of_packed_tuples(tmp_path):
+    """ReplayBuffer == deque(maxlen) of the reference (train.py:23): order, overwrite of the
+    oldest, random.sample positions, shard interchange; reference-shaped tuples can enter it
+    (state planes -> packed board is exact)."""
+    import random
+    from collections import deque
+
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import oracle
+    from alphazero_quoridor_amd import dist as qdist
+    from alphazero_quoridor_amd import replay
+
+    d = np.load(os.path.join(ROOT, "tests", "golden", "rules_positions.npz"))
+    b = d["board"]
+    b = b[(b["p1"] >= 0) & (b["p1"] <= 71) & (b["p2"] >= 9) & (b["p2"] <= 80)][:500]
+    rs = np.random.RandomState(1)
+    pi = rs.dirichlet(np.ones(140), size=len(b)).astype(np.float32)
+    z = rs.choice([-1.0, 1.0], size=len(b)).astype(np.float32)
+    words = b.view(np.uint64).reshape(-1, 3).view(np.int64)
+    packed = qdist.pack_tuples(*(torch.from_numpy(np.ascontiguousarray(words[:, i])) for i in range(3)), torch.from_numpy(pi), torch.from_numpy(z))
+    buf = replay.ReplayBuffer(capacity=200, device="cpu")
+    ref = deque(maxlen=200)
+    for lo, hi in ((0, 150), (150, 260), (260, 500)):  # fills, wraps, overwrites more than once
+        buf.extend(packed[lo:hi])
+        ref.extend(range(lo, hi))
+        assert len(buf) == len(ref)
+        assert torch.equal(buf.packed(), packed[list(ref)])
+    random.seed(5)
+    want = random.sample(ref, 64)
+    random.seed(5)
+    boards, spi, sz = buf.gather(buf.sample_indices(64))
+    assert np.array_equal(boards.to_packed().tobytes(), b[want].tobytes()) and np.array_equal(spi.numpy(), pi[want]) and np.array_equal(sz.numpy(), z[want])
+    # shard interchange: a self-play job writes, a training job reads
+    buf.save_shard(tmp_path / "s.qzr", n_games=7, n_playout=400)
+    other = replay.ReplayBuffer(capacity=1000, device="cpu")
+    assert other.load_shard(tmp_path / "s.qzr")["n_games"] == 7 and torch.equal(other.packed(), buf.packed())
+    # reference-shaped tuples (float64 planes) -> packed boards, exactly
+    planes = oracle.encode_batch(b[:300]).astype(np.float64)
+    third = replay.ReplayBuffer(capacity=300, device="cpu")
+    third.extend([(planes[i], pi[i].astype(np.float64), float(z[i])) for i in range(300)])
+    got = third.gather(list(range(300)))[0].to_packed()
+    assert np.array_equal(oracle.encode_batch(got), oracle.encode_batch(b[:300]))  # same state() (10/0 walls alias, quoridor.py:79-80)
+    assert torch.equal(third.pi, torch.from_numpy(pi[:300]))
+
+
+def test_train_step_matches_reference_fixture_cpu():
+    """policy_value_net.py:166-192 on the mirror module, CPU: three optimiser steps on the
+    reference's own minibatch reproduce its loss, entropy and post-step weights (same torch, same
+    ops => tight tolerances)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import oracle
+    from _stubs import det_fill_state_dict
+    from alphazero_quoridor_amd.policy_value_net import PolicyValueNet
+
+    d = np.load(os.path.join(ROOT, "tests", "golden", "train_fixture.npz"))
+    torch.set_num_threads(4)
+    pvn = PolicyValueNet(use_gpu=False)
+    pvn.policy_value_net.load_state_dict(det_fill_state_dict(pvn.policy_value_net.state_dict(), int(d["fill_seed"])))
+    states = torch.from_numpy(oracle.encode_batch(d["board"]))
+    pi, z = torch.from_numpy(d["pi"]), torch.from_numpy(d["z"])
+    for i, lr in enumerate(d["lr"]):
+        loss, ent = pvn.train_step_t(states, pi, z, float(lr))
+        assert abs(float(loss) - d["loss"][i]) < 1e-5 * abs(d["loss"][i]) and abs(float(ent) - d["entropy"][i]) < 1e-5
+    sd = pvn.get_policy_param()
+    for k, s_ref, a_ref in zip(d["keys"], d["sum"], d["abs_sum"]):
+        t = sd[str(k)].double()
+        assert abs(float(t.sum()) - s_ref) <= 1e-6 * max(1.0, a_ref) and abs(float(t.abs().sum()) - a_ref) <= 1e-6 * max(1.0, a_ref), k
+    for k in ("fc2.weight", "bn1.weight", "conv3.weight"):
+        assert np.abs(sd[k].numpy() - d["w_" + k.replace(".", "_")]).max() < 1e-6, k
+    p, v = pvn.policy_value(states.numpy())
+    assert np.abs(p - d["p_after"]).max() < 1e-5 and np.abs(v - d["v_after"]).max() < 1e-5
+    # the fixture's BatchNorm buffers were stored after that last train-mode forward (it updates them)
+    for k in ("bn1.running_mean", "res5.bn2.running_var"):
+        assert np.abs(sd[k].numpy() - d["w_" + k.replace(".", "_")]).max() < 1e-6, k
+
+
+def _ddp_worker(rank, world, port, tmpdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from alphazero_quoridor_amd.policy_value_net import PolicyValueNet
+
+    torch.manual_seed(100 + rank)  # different initial weights and different minibatches per rank
+    pvn = PolicyValueNet(use_gpu=False)
+    pvn.sync_from_rank0()
+    x = (torch.rand(16, 26, 9, 9) > 0.7).float()
+    pi = torch.softmax(torch.randn(16, 140), dim=1)
+    z = torch.sign(torch.randn(16))
+    for _ in range(3):
+        pvn.train_step_t(x, pi, z, 2e-3)
+    pvn.average_buffers()
+    flat = torch.cat([t.reshape(-1).double() for t in pvn.get_policy_param().values()])
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    same = all(torch.equal(gathered[0], g) for g in gathered)
+    open(os.path.join(tmpdir, "ddp_%d_%s" % (rank, "ok" if same else "DIVERGED")), "w").close()
+    dist.destroy_process_group()
+
+
+def test_multi_rank_training_keeps_replicas_identical_gloo_world2(tmp_path):
+    """One process per GPU trains ONE model: rank 0's weights are broadcast at the start and the
+    gradients of every step are averaged over the ranks (one flat all-reduce), so after three
+    steps on different minibatches both replicas hold bit-identical parameters."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_ddp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ddp_0_ok").exists() and (tmp_path / "ddp_1_ok").exists(), os.listdir(tmp_path)
