@@ -100,7 +100,7 @@ class qz_stats(C.Structure):
 
 def build(force: bool = False) -> str:
     """Compile libqzero_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("qz_kernels.hip", "qz_abi.hip", "qz_nn.hip", "qz_rules.h", "qz_movegen_pool.h", "qz_device.h")] + [HEADER]
+    srcs = [os.path.join(CSRC, f) for f in ("qz_kernels.hip", "qz_abi.hip", "qz_nn.hip", "qz_conv.hip", "qz_rules.h", "qz_movegen_pool.h", "qz_device.h")] + [HEADER]
     stale = force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if stale:
         subprocess.check_call(["make", "-C", CSRC, "-s"])
@@ -142,6 +142,7 @@ _SIGNATURES = {
     "qz_nn_instnorm_act_nhwc": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_float, _P]),
     "qz_nn_input_layer": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P, _P, _P, _P, C.c_float, _P]),
     "qz_engine_leaf_boards": (C.c_int, [_P, _P, _P]),
+    "qz_nn_conv3x3_norm": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, C.c_float, C.c_int, C.c_float, _P]),
     "qz_nn_head": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, _P]),
     "qz_selftest_sqrt": (C.c_int, [_P, C.c_int, _P]),
 }

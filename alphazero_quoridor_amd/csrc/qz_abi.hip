@@ -28,6 +28,7 @@ hipError_t reset(const EngineDev&, int, hipStream_t);
 hipError_t pool_init(const EngineDev&, hipStream_t);
 hipError_t harvest(const EngineDev&, uint64_t*, uint64_t*, uint64_t*, float*, float*, int32_t*, long long, hipStream_t);
 hipError_t sqrt_table(double*, int, hipStream_t);
+hipError_t conv3x3_norm(const float*, const void*, const float*, const float*, const float*, float*, long long, float, int, float, hipStream_t);
 hipError_t rollout_begin(const uint64_t*, const uint64_t*, const uint64_t*, int, uint8_t*, uint8_t*, int8_t*, int*, hipStream_t);
 hipError_t rollout_step(uint64_t*, uint64_t*, uint64_t*, const uint32_t*, int, const uint8_t*, uint8_t*, int8_t*, int*, uint64_t, int, int, hipStream_t);
 hipError_t instnorm_act(const float*, const float*, const float*, const float*, float*, long long, int, int, float, hipStream_t);
@@ -635,6 +636,17 @@ int qz_nn_head(const float* t, int64_t n, const float* w6k, const float* gamma6,
     if (!t || !w6k || !beta6 || !w1t || !b1 || !w2 || !b2 || !w3t || !b3 || !p_out || !v_out) return fail(QZ_E_INVALID, "null tensor");
     if (((uintptr_t)t & 15) != 0) return fail(QZ_E_INVALID, "t must be 16-byte aligned");
     HIP_TRY(qzl::head(t, (long long)n, w6k, gamma6, beta6, w1t, b1, w2, b2, w3t, b3, p_out, v_out, eps, (hipStream_t)stream));
+    return 0;
+}
+int qz_nn_conv3x3_norm(const float* x, const void* w16, const float* gamma, const float* beta, const float* residual, float* out, int64_t n,
+                       float inv_scale, int relu, float eps, void* stream) {
+    int r;
+    if ((r = device_check())) return r;
+    if (n < 0) return fail(QZ_E_INVALID, "n < 0");
+    if (n == 0) return 0;
+    if (!x || !w16 || !gamma || !beta || !out) return fail(QZ_E_INVALID, "null tensor");
+    if ((((uintptr_t)x | (uintptr_t)w16 | (uintptr_t)out | (uintptr_t)residual) & 15) != 0) return fail(QZ_E_INVALID, "tensors must be 16-byte aligned");
+    HIP_TRY(qzl::conv3x3_norm(x, w16, gamma, beta, residual, out, (long long)n, inv_scale, relu, eps, (hipStream_t)stream));
     return 0;
 }
 int qz_engine_leaf_boards(qz_engine* e, qz_boards* boards_out, const uint8_t** terminal_out) {

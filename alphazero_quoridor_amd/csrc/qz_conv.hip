@@ -1,0 +1,214 @@
+// qz_conv.hip -- the trunk convolution of the leaf evaluator on the matrix cores, at fp32 accuracy.
+//
+// One launch = conv3x3(64 -> 64, pad 1, no bias) + the reference's per-leaf BatchNorm (training
+// mode on a batch of one: statistics over the 81 positions of every (leaf, channel),
+// policy_value_net.py:20-48,154) [+ residual] [+ ReLU] on channels-last fp32 activations
+// x[B][81][64] -> out[B][81][64].  It replaces MIOpen's fp32 implicit GEMM (195 us at B = 4,096:
+// 125 of the 157 TFLOP/s the f32 MFMA can do), MIOpen's zero-fill launch (14 us) and the separate
+// normalisation pass (26-38 us) of every trunk layer.
+//
+// fp32 accuracy on the fp16 matrix pipe (16x the f32 MFMA rate): every operand is split in two
+// halves, v = hi + lo with hi = fp16(v), lo = fp16(v - hi) (a 22-bit significand: the split loses
+// <= 2^-22 |v|, or 2^-25 absolute where lo is an fp16 subnormal), and
+//     x*w  ~=  x_hi*w_hi + x_hi*w_lo + x_lo*w_hi          (three MFMAs, fp32 accumulation)
+// drops only x_lo*w_lo (<= 2^-22 |x w|).  Error per product ~3 x 2^-22 -- the size of the fp32
+// rounding noise of a 576-term dot product; measured against F.conv2d in tests/test_gpu_conv.py.
+// The weights are pre-scaled by a power of two (so that w_lo is an fp16 normal) and the
+// accumulator is scaled back exactly before the statistics.
+//
+// Mapping (implicit GEMM, M = positions, N = 64 output channels, K = 9 taps x 64 input channels):
+//   workgroup = 256 threads = CS (2) leaves: M = 162 rows in 6 tiles of 32 (rows 162..191 idle)
+//   wave w: output channels 32 (w & 1) .. +31, M tiles 3 (w >> 1) .. +2: nine MFMAs
+//           (v_mfma_f32_32x32x16_f16) per 16-channel K step, 324 per layer
+//   A (activations): staged once per workgroup in LDS as fp16 hi / lo images [leaf][82 rows][64 ch],
+//           row 81 all zero (the padding taps point there), 144-byte rows so that 16 consecutive
+//           rows cover all 64 banks: a fragment is one conflict-free ds_read_b128 per lane
+//   B (weights): [part hi|lo][tap][k chunk][channel out][16 channels in] fp16, 147 KB per layer,
+//           read straight from L2 (one coalesced global_load_dwordx4 per fragment)
+//   epilogue: two-pass mean / variance over a leaf's 81 rows: in registers, across the two lane
+//           halves by shuffle, across the two wave groups through 2 KB of LDS
+// No MFMA-free fallback and no library call: this file is plain HIP for gfx950.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int CS = 2;        // leaves per workgroup
+constexpr int NPOS = 81;
+constexpr int ROWS = 82;     // 81 positions + one all-zero row per leaf
+constexpr int RSTR = 72;     // halfs per LDS row (144 B)
+constexpr int C = 64;
+constexpr int ZERO_ROW = NPOS;  // of leaf 0
+
+struct ConvShared {
+    _Float16 a_hi[CS * ROWS * RSTR];
+    _Float16 a_lo[CS * ROWS * RSTR];
+    float red[2][2][CS][C];  // [pass][wave group][leaf][channel]
+};
+
+// stage CS leaves of x (fp32, [81][64] each) as fp16 hi / lo images
+__device__ __forceinline__ void stage_input(ConvShared& sm, const float* __restrict__ x, long long b0, long long n, int tid) {
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    for (int i = tid; i < CS * NPOS * 16; i += 256) {
+        const int s = i / (NPOS * 16), rem = i - s * (NPOS * 16);
+        const int p = rem >> 4, c4 = rem & 15;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (b0 + s < n) v = x4[((b0 + s) * NPOS + p) * 16 + c4];
+        half4 hi, lo;
+        hi[0] = (_Float16)v.x;
+        hi[1] = (_Float16)v.y;
+        hi[2] = (_Float16)v.z;
+        hi[3] = (_Float16)v.w;
+        lo[0] = (_Float16)(v.x - (float)hi[0]);
+        lo[1] = (_Float16)(v.y - (float)hi[1]);
+        lo[2] = (_Float16)(v.z - (float)hi[2]);
+        lo[3] = (_Float16)(v.w - (float)hi[3]);
+        const int o = (s * ROWS + p) * RSTR + c4 * 4;
+        *reinterpret_cast<half4*>(&sm.a_hi[o]) = hi;
+        *reinterpret_cast<half4*>(&sm.a_lo[o]) = lo;
+    }
+    if (tid < CS * 16) {  // the zero rows
+        const int s = tid >> 4, c4 = tid & 15;
+        half4 z;
+        z[0] = z[1] = z[2] = z[3] = (_Float16)0.f;
+        const int o = (s * ROWS + NPOS) * RSTR + c4 * 4;
+        *reinterpret_cast<half4*>(&sm.a_hi[o]) = z;
+        *reinterpret_cast<half4*>(&sm.a_lo[o]) = z;
+    }
+}
+
+// w16: [2][9][4][64][16] fp16 (hi part, then lo part)
+__global__ __launch_bounds__(256) void k_conv3x3_norm(const float* __restrict__ x, const _Float16* __restrict__ w16,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const float* __restrict__ residual, float* __restrict__ out, long long n,
+                                                      float inv_scale, int relu, float eps) {
+    __shared__ ConvShared sm;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int nt = wave & 1, mg = wave >> 1;
+    const long long b0 = (long long)blockIdx.x * CS;
+
+    stage_input(sm, x, b0, n, tid);
+
+    // LDS offsets (in halfs) of this lane's A rows: [tile][tap]; rows outside the board / past the
+    // last leaf read the zero row
+    int rowoff[3][9];
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+        const int m = 32 * (3 * mg + t) + r;
+        const bool live = m < CS * NPOS;
+        const int s = m >= NPOS ? 1 : 0, p = m - NPOS * s;
+        const int y = p / 9, xx = p - 9 * y;
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            const int yy = y + tap / 3 - 1, x2 = xx + tap % 3 - 1;
+            const bool ok = live && (unsigned)yy < 9u && (unsigned)x2 < 9u;
+            rowoff[t][tap] = (ok ? (s * ROWS + yy * 9 + x2) : ZERO_ROW) * RSTR + 8 * h;
+        }
+    }
+    floatx16 acc[3];
+#pragma unroll
+    for (int t = 0; t < 3; t++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[t][i] = 0.f;
+    __syncthreads();
+
+    const _Float16* wb = w16 + (size_t)(32 * nt + r) * 16 + 8 * h;  // this lane's slice of every B fragment
+    constexpr size_t PART = (size_t)9 * 4 * C * 16;
+#pragma unroll
+    for (int tap = 0; tap < 9; tap++) {
+#pragma unroll
+        for (int kc = 0; kc < 4; kc++) {
+            const size_t bo = (size_t)(tap * 4 + kc) * C * 16;
+            const half8 b_hi = *reinterpret_cast<const half8*>(wb + bo);
+            const half8 b_lo = *reinterpret_cast<const half8*>(wb + PART + bo);
+#pragma unroll
+            for (int t = 0; t < 3; t++) {
+                const half8 a_hi = *reinterpret_cast<const half8*>(&sm.a_hi[rowoff[t][tap] + 16 * kc]);
+                const half8 a_lo = *reinterpret_cast<const half8*>(&sm.a_lo[rowoff[t][tap] + 16 * kc]);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, acc[t], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: this lane owns channel co, rows m(t, i) = 32 (3 mg + t) + (i & 3) + 8 (i >> 2) + 4 h
+    const int co = 32 * nt + r;
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 3; t++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int m = 32 * (3 * mg + t) + (i & 3) + 8 * (i >> 2) + 4 * h;
+            const float y = acc[t][i] * inv_scale;  // exact: a power of two
+            acc[t][i] = y;
+            if (m < NPOS) s0 += y;
+            else if (m < 2 * NPOS) s1 += y;
+        }
+    s0 += __shfl_xor(s0, 32, 64);
+    s1 += __shfl_xor(s1, 32, 64);
+    if (h == 0) {
+        sm.red[0][mg][0][co] = s0;
+        sm.red[0][mg][1][co] = s1;
+    }
+    __syncthreads();
+    const float mean0 = (sm.red[0][0][0][co] + sm.red[0][1][0][co]) * (1.0f / 81.0f);
+    const float mean1 = (sm.red[0][0][1][co] + sm.red[0][1][1][co]) * (1.0f / 81.0f);
+    float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 3; t++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int m = 32 * (3 * mg + t) + (i & 3) + 8 * (i >> 2) + 4 * h;
+            if (m < NPOS) {
+                const float d = acc[t][i] - mean0;
+                q0 += d * d;
+            } else if (m < 2 * NPOS) {
+                const float d = acc[t][i] - mean1;
+                q1 += d * d;
+            }
+        }
+    q0 += __shfl_xor(q0, 32, 64);
+    q1 += __shfl_xor(q1, 32, 64);
+    if (h == 0) {
+        sm.red[1][mg][0][co] = q0;
+        sm.red[1][mg][1][co] = q1;
+    }
+    __syncthreads();
+    const float g = gamma[co], bt = beta[co];
+    const float k0 = g / sqrtf((sm.red[1][0][0][co] + sm.red[1][1][0][co]) * (1.0f / 81.0f) + eps);
+    const float k1 = g / sqrtf((sm.red[1][0][1][co] + sm.red[1][1][1][co]) * (1.0f / 81.0f) + eps);
+#pragma unroll
+    for (int t = 0; t < 3; t++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int m = 32 * (3 * mg + t) + (i & 3) + 8 * (i >> 2) + 4 * h;
+            if (m < 2 * NPOS) {
+                const int s = m >= NPOS ? 1 : 0;
+                if (b0 + s < n) {
+                    const size_t idx = ((size_t)(b0 + s) * NPOS + (size_t)(m - NPOS * s)) * C + (size_t)co;
+                    float v = (acc[t][i] - (s ? mean1 : mean0)) * (s ? k1 : k0) + bt;
+                    if (residual) v += residual[idx];
+                    if (relu) v = fmaxf(v, 0.f);
+                    out[idx] = v;
+                }
+            }
+        }
+}
+
+}  // namespace
+
+namespace qzl {
+hipError_t conv3x3_norm(const float* x, const void* w16, const float* gamma, const float* beta, const float* residual, float* out,
+                        long long n, float inv_scale, int relu, float eps, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_conv3x3_norm, dim3((unsigned)((n + CS - 1) / CS)), dim3(256), 0, s, x, reinterpret_cast<const _Float16*>(w16), gamma,
+                       beta, residual, out, n, inv_scale, relu, eps);
+    return hipGetLastError();
+}
+}  // namespace qzl

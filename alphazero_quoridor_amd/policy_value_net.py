@@ -94,7 +94,7 @@ class LeafEvaluator:
     """
 
     def __init__(self, net: nn.Module, bn_mode="per_leaf", dtype=torch.float32, channels_last=False, fused_norm=True,
-                 board_input_layer=True, fused_head=True):
+                 board_input_layer=True, fused_head=True, mfma_trunk=True):
         assert bn_mode in ("per_leaf", "batch", "eval")
         self.fused_norm = fused_norm  # per_leaf on the GPU: use the one-pass HIP normalisation kernel
         # first layer straight from the packed boards (qz_nn_input_layer) when the caller hands them
@@ -108,6 +108,10 @@ class LeafEvaluator:
         self.fused_head = fused_head and fused_norm and bn_mode in ("per_leaf", "eval") and dtype == torch.float32 \
             and channels_last
         self._head = None
+        # trunk layers (conv3x3 64->64 + per-leaf norm + residual + ReLU) as ONE HIP kernel each on the fp16
+        # matrix cores with split operands (fp32 accuracy; qz_nn_conv3x3_norm): fp32, channels-last, per-leaf
+        self.mfma_trunk = mfma_trunk and fused_norm and bn_mode == "per_leaf" and dtype == torch.float32 and channels_last
+        self._w16 = None
         self.net = net
         self.bn_mode = bn_mode
         self.dtype = dtype
@@ -158,6 +162,14 @@ class LeafEvaluator:
             else:
                 for o, t in zip(self._head, head):
                     o.copy_(t)
+        if self.mfma_trunk and layers[0][0].is_cuda:
+            w16 = [self._split_weight(layers[i][0]) for i in range(1, 1 + 2 * N_RES)]
+            if self._w16 is None:
+                self._w16 = w16
+            else:
+                for (o, _), (t, sc) in zip(self._w16, w16):
+                    o.copy_(t)
+                self._w16 = [(o, sc) for (o, _), (_, sc) in zip(self._w16, w16)]
         if self.board_input_layer and layers[0][0].is_cuda:
             tabs = self._input_tables(layers[0][0])
             if self._in_tables is None:
@@ -172,6 +184,29 @@ class LeafEvaluator:
                 for o, t in zip(old, new):
                     if o is not None:
                         o.copy_(t)
+
+    @staticmethod
+    def _split_weight(w):
+        """conv weight [64,64,3,3] fp32 -> (fp16 [2,9,4,64,16] = [hi|lo][tap][c_in chunk][c_out][c_in in chunk] of
+        w * scale, 1 / scale): the B operand of qz_nn_conv3x3_norm (include/qz_abi.h).  scale is the power
+        of two that brings max |w| into [1, 2), so that the lo parts are fp16 normals."""
+        W = w.detach().to(torch.float32).contiguous()
+        mx = float(W.abs().max())
+        scale = 2.0 ** (-np.floor(np.log2(mx))) if mx > 0 else 1.0
+        ws = (W * scale).permute(2, 3, 1, 0).reshape(9, 4, 16, 64).permute(0, 1, 3, 2).contiguous()  # [tap][chunk][c_out][16 c_in]
+        hi = ws.to(torch.float16)
+        lo = (ws - hi.to(torch.float32)).to(torch.float16)
+        return torch.stack([hi, lo]).contiguous(), float(1.0 / scale)
+
+    def _conv_norm_mfma(self, x, i, relu=True, residual=None):
+        from . import _cabi
+        w16, inv_scale = self._w16[i - 1]
+        _, _, gamma, beta = self._layers[i]
+        out = torch.empty_like(x, memory_format=torch.channels_last)
+        _cabi.check(_cabi.load().qz_nn_conv3x3_norm(
+            x.data_ptr(), w16.data_ptr(), gamma.data_ptr(), beta.data_ptr(), residual.data_ptr() if residual is not None else 0,
+            out.data_ptr(), x.shape[0], inv_scale, int(relu), BN_EPS, torch.cuda.current_stream(x.device).cuda_stream))
+        return out
 
     @staticmethod
     def _input_tables(w):
@@ -211,6 +246,10 @@ class LeafEvaluator:
 
     def _cbn(self, x, i, relu=True, residual=None):
         w, bias, gamma, beta = self._layers[i]
+        if self.mfma_trunk and self._w16 is not None and 1 <= i <= 2 * N_RES and x.is_cuda and x.dtype == torch.float32 \
+                and x.shape[1] == WIDTH and x.is_contiguous(memory_format=torch.channels_last) \
+                and (residual is None or residual.is_contiguous(memory_format=torch.channels_last)):
+            return self._conv_norm_mfma(x, i, relu, residual)
         y = F.conv2d(x, w, bias, 1, 1)
         if self.bn_mode == "per_leaf" and self.fused_norm and y.is_cuda and y.dtype == torch.float32 and y.dim() == 4 \
                 and y.shape[1] > 1 and y.shape[1] <= 64 and y.is_contiguous(memory_format=torch.channels_last) \

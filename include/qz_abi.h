@@ -268,6 +268,18 @@ int qz_nn_input_layer(const qz_boards* boards /*[dev]*/, const uint8_t* terminal
 int qz_nn_head(const float* t /*[dev]*/, int64_t n, const float* w6k, const float* gamma6 /*or NULL*/, const float* beta6,
                const float* w1t, const float* b1, const float* w2, const float* b2, const float* w3t, const float* b3,
                float* p_out /*[dev] n*140*/, float* v_out /*[dev] n*/, float eps, void* stream);
+/* One trunk layer of the policy-value net on the matrix cores (policy_value_net.py:20-48: conv3x3
+ * 64 -> 64, pad 1, no bias; BatchNorm in training mode on a batch of one = statistics over the 81
+ * positions of every (leaf, channel); + residual; ReLU), channels-last fp32 in and out:
+ *   out = act(gamma * (conv(x, W) - mean) / sqrt(var + eps) + beta [+ residual])
+ * x / residual / out: NHWC storage [n][81][64]; out may alias x.  fp32 accuracy on the fp16 MFMA
+ * pipe by operand splitting (csrc/qz_conv.hip).  w16: the weight prepared by the caller as
+ * fp16 [2][9][4][64][16] = [hi | lo part][tap 3 ky + kx][16-channel chunk of c_in][c_out][c_in in chunk]
+ * of W * scale (scale = a power of two that makes the lo parts fp16 normals), hi = fp16(W scale),
+ * lo = fp16(W scale - hi); inv_scale = 1 / scale. */
+int qz_nn_conv3x3_norm(const float* x /*[dev]*/, const void* w16 /*[dev]*/, const float* gamma /*[dev][64]*/,
+                       const float* beta /*[dev][64]*/, const float* residual /*[dev] or NULL*/, float* out /*[dev]*/, int64_t n,
+                       float inv_scale, int relu, float eps, void* stream);
 /* the engine's current leaf boards (what qz_mcts_select just produced) and their terminal flags,
  * as device pointers owned by the engine: input of qz_nn_input_layer */
 int qz_engine_leaf_boards(qz_engine* e, qz_boards* boards_out, const uint8_t** terminal_out);

@@ -1,0 +1,114 @@
+"""GPU parity of the split-fp16 MFMA trunk layer (csrc/qz_conv.hip) against plain PyTorch fp32:
+conv3x3 + per-sample (training-mode, batch of one) BatchNorm + residual + ReLU."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(x, w, gamma, beta, res, relu, eps=1e-5):
+    """float64 reference on the CPU: F.conv2d, then every (sample, channel) plane normalised with its
+    own mean / biased variance (BatchNorm2d.train() on a batch of one, policy_value_net.py:20-48)."""
+    x, w = x.double().cpu(), w.double().cpu()
+    y = F.conv2d(x, w, None, 1, 1)
+    mean = y.mean(dim=(2, 3), keepdim=True)
+    var = y.var(dim=(2, 3), unbiased=False, keepdim=True)
+    y = (y - mean) / torch.sqrt(var + eps) * gamma.double().cpu().view(1, -1, 1, 1) + beta.double().cpu().view(1, -1, 1, 1)
+    if res is not None:
+        y = y + res.double().cpu()
+    return F.relu(y) if relu else y
+
+
+def _run(x, w, gamma, beta, res, relu):
+    from alphazero_quoridor_amd import _cabi
+    from alphazero_quoridor_amd.policy_value_net import LeafEvaluator
+
+    w16, inv_scale = LeafEvaluator._split_weight(w)
+    out = torch.empty_like(x, memory_format=torch.channels_last)
+    _cabi.check(_cabi.load().qz_nn_conv3x3_norm(x.data_ptr(), w16.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                                res.data_ptr() if res is not None else 0, out.data_ptr(), x.shape[0], inv_scale,
+                                                int(relu), 1e-5, torch.cuda.current_stream(x.device).cuda_stream))
+    return out
+
+
+def test_mfma_operand_maps_with_exact_integer_data(gpu_device):
+    """Small-integer activations and weights are exact in fp16 and in the fp32 accumulator, so the
+    un-normalised convolution must be reproduced EXACTLY: any wrong lane -> element map, tap offset
+    or padding shows up as a bit difference.  (gamma = std, beta = mean would need the statistics;
+    instead the kernel's normalisation is inverted on the host in float64.)"""
+    g = torch.Generator().manual_seed(1)
+    for B in (1, 2, 3, 7):
+        x = torch.randint(-4, 5, (B, 64, 9, 9), generator=g).float()
+        w = torch.randint(-3, 4, (64, 64, 3, 3), generator=g).float()  # asymmetric in every index
+        xd = x.to(gpu_device).contiguous(memory_format=torch.channels_last)
+        gamma = torch.ones(64, device=gpu_device)
+        beta = torch.zeros(64, device=gpu_device)
+        out = _run(xd, w.to(gpu_device), gamma, beta, None, relu=False).cpu().double()
+        y = F.conv2d(x.double(), w.double(), None, 1, 1)
+        mean = y.mean(dim=(2, 3), keepdim=True)
+        std = torch.sqrt(y.var(dim=(2, 3), unbiased=False, keepdim=True) + 1e-5)
+        back = out * std + mean  # undo the normalisation: integers again
+        assert (back - y).abs().max().item() < 2e-3, B
+        assert torch.equal(torch.round(back), y), B
+
+
+def test_trunk_layer_matches_fp32_reference(gpu_device):
+    """Random fp32 data with the network's magnitudes: |error| vs a float64 reference must be at
+    the level of an fp32 convolution's own rounding noise (MIOpen's is measured next to it)."""
+    g = torch.Generator().manual_seed(7)
+    for B in (1, 2, 5, 64, 257):
+        x = (torch.randn((B, 64, 9, 9), generator=g).clamp(min=-0.3) * 1.3).to(gpu_device).contiguous(memory_format=torch.channels_last)
+        w = ((torch.rand((64, 64, 3, 3), generator=g) * 2 - 1) / 24.0).to(gpu_device)
+        gamma = (torch.rand(64, generator=g) + 0.5).to(gpu_device)
+        beta = torch.randn(64, generator=g).to(gpu_device)
+        res = torch.randn((B, 64, 9, 9), generator=g).to(gpu_device).contiguous(memory_format=torch.channels_last)
+        for use_res in (False, True):
+            for relu in (False, True):
+                want = _ref(x, w, gamma, beta, res if use_res else None, relu)
+                got = _run(x, w, gamma, beta, res if use_res else None, relu)
+                assert got.is_contiguous(memory_format=torch.channels_last)
+                err = (got.cpu().double() - want).abs().max().item()
+                # the library path on the same inputs
+                y = F.conv2d(x, w.contiguous(memory_format=torch.channels_last), None, 1, 1)
+                y = F.instance_norm(y, None, None, gamma, beta, True, 0.0, 1e-5)
+                if use_res:
+                    y = y + res
+                if relu:
+                    y = F.relu(y)
+                lib = (y.cpu().double() - want).abs().max().item()
+                if B == 257 and use_res and relu:
+                    print("max |err| vs float64: split-fp16 MFMA %.3g, MIOpen fp32 %.3g" % (err, lib))
+                assert err < 4e-6, (B, use_res, relu, err, lib)
+    # in place (out aliases x) is allowed
+    x2 = x.clone(memory_format=torch.preserve_format)
+    from alphazero_quoridor_amd import _cabi
+    from alphazero_quoridor_amd.policy_value_net import LeafEvaluator
+    w16, inv_scale = LeafEvaluator._split_weight(w)
+    _cabi.check(_cabi.load().qz_nn_conv3x3_norm(x2.data_ptr(), w16.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 0, x2.data_ptr(),
+                                                x2.shape[0], inv_scale, 1, 1e-5, torch.cuda.current_stream().cuda_stream))
+    assert torch.equal(x2, _run(x, w, gamma, beta, None, True))
+
+
+def test_evaluator_with_mfma_trunk_equals_library_trunk(gpu_device, golden_dir):
+    """The whole evaluator (board input layer -> 10 MFMA trunk layers -> fused heads) against the
+    same evaluator on MIOpen's fp32 convolutions, on the fixture positions and on 4,096 leaves."""
+    from _stubs import det_fill_state_dict
+    from alphazero_quoridor_amd import rules
+    from alphazero_quoridor_amd.boards import DeviceBoards
+    from alphazero_quoridor_amd.policy_value_net import LeafEvaluator, PolicyValueNet
+    from synth import synth_positions
+
+    pvn = PolicyValueNet(use_gpu=True, device=gpu_device)
+    pvn.policy_value_net.load_state_dict(det_fill_state_dict(pvn.policy_value_net.state_dict(), 2024))
+    boards = synth_positions(4096, seed=5)
+    planes = rules.encode(DeviceBoards.from_packed(boards, gpu_device))
+    fast = LeafEvaluator(pvn.policy_value_net, "per_leaf", channels_last=True, mfma_trunk=True)
+    slow = LeafEvaluator(pvn.policy_value_net, "per_leaf", channels_last=True, mfma_trunk=False)
+    assert fast.mfma_trunk and fast._w16 is not None and not slow.mfma_trunk
+    p1, v1 = fast(planes)
+    p2, v2 = slow(planes)
+    dp, dv = (p1 - p2).abs().max().item(), (v1 - v2).abs().max().item()
+    print("MFMA trunk vs MIOpen trunk on 4,096 leaves: max |dp| %.3g, max |dv| %.3g" % (dp, dv))
+    assert dp < 5e-6 and dv < 5e-6

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(lib):
 
     header = open(os.path.join(ROOT, "include", "qz_abi.h")).read()
     header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
-    declared = sorted(set(re.findall(r"\b(qz_[a-z_]+)\s*\(", header)))
+    declared = sorted(set(re.findall(r"\b(qz_[a-z0-9_]+)\s*\(", header)))
     assert len(declared) >= 24
     for name in declared:
         assert hasattr(lib, name), "libqzero_hip.so does not export %s" % name
