@@ -180,3 +180,23 @@ def test_pure_mcts_player_and_win_rate_gate(gpu_device):
     with quiet():
         ratio = tp.policy_evaluate(n_games=4, max_plies=120)
     assert 0.0 <= ratio <= 1.0
+
+
+def test_interactive_loop_on_the_real_game(gpu_device):
+    """game.play (the fixed game.py loop) with the drop-in Quoridor: a scripted player against the
+    pure-MCTS player for a few plies, then step_result on a winning move (golden transition)."""
+    from alphazero_quoridor_amd import pure_mcts
+    from alphazero_quoridor_amd.agents import HistoricalAgent
+    from alphazero_quoridor_amd.game import play, step_result
+    from alphazero_quoridor_amd.quoridor import Quoridor
+
+    g = Quoridor()
+    with quiet():
+        winner, hist = play(g, {1: HistoricalAgent("script", [0, 0, 0]), 2: pure_mcts.MCTSPlayer(n_playout=12, seed=3)}, max_plies=5,
+                            log=lambda *_: None)
+    assert winner is None and [p for p, _ in hist] == [1, 2, 1, 2, 1] and g._positions[1] == 4 + 27 or g._positions[1] >= 22
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rules_positions.npz"))
+    i = int(np.nonzero(d["done"])[0][0])
+    won = Quoridor.from_packed(d["board"][i])
+    with quiet():
+        assert step_result(won, int(d["action"][i])) == (True, int(d["winner"][i]))

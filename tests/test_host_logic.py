@@ -395,3 +395,47 @@ def test_multi_rank_training_keeps_replicas_identical_gloo_world2(tmp_path):
         port = sk.getsockname()[1]
     mp.spawn(_ddp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "ddp_0_ok").exists() and (tmp_path / "ddp_1_ok").exists(), os.listdir(tmp_path)
+
+
+def test_interactive_adapter_step_result_and_loop():
+    """game.py:117,133,154 unpack `done, winner = game.step(a)`; the drop-in step() returns `done`
+    only (quoridor.py:159-186).  step_result / play bridge the two; agents mirror agents/*.py."""
+    from alphazero_quoridor_amd.agents import HistoricalAgent, ManualCLIAgent, ManualPygameAgent
+    from alphazero_quoridor_amd.game import play, step_result
+
+    class FakeGame:  # duck-typed on the reference's Quoridor surface
+        def __init__(self):
+            self.current_player, self.pos, self.moves = 1, {1: 0, 2: 0}, []
+
+        def actions(self):
+            return [] if self.has_a_winner()[0] else [0, 2, 3]
+
+        def step(self, a):
+            self.pos[self.current_player] += 1 if a == 0 else 0
+            self.moves.append(a)
+            if self.has_a_winner()[0]:
+                return True
+            self.current_player = 3 - self.current_player
+            return False
+
+        def has_a_winner(self):
+            for p in (2, 1):
+                if self.pos[p] >= 3:
+                    return True, p
+            return False, None
+
+        def print_board(self):
+            pass
+
+    g = FakeGame()
+    assert step_result(g, 0) == (False, None) and g.current_player == 2
+    typed = iter(["9", "x", "2", "0", "0"])
+    said = []
+    human = ManualCLIAgent("h", read=lambda prompt: next(typed), write=said.append)
+    gui = ManualPygameAgent("gui")
+    gui.receive_action(0)
+    winner, hist = play(g, {1: HistoricalAgent("rec", [0, 0]), 2: human}, log=lambda *_: None)
+    assert winner == 1 and hist == [(2, 2), (1, 0), (2, 0), (1, 0)] and any("Invalid Action" in str(s) for s in said)
+    assert gui.choose_action(g) == 0
+    with pytest.raises(ValueError):
+        play(FakeGame(), {1: HistoricalAgent("bad", [7]), 2: gui}, log=lambda *_: None)

@@ -12,6 +12,7 @@ import pytest
 import oracle
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
 G = os.path.join(HERE, "golden")
 
 
@@ -262,3 +263,46 @@ def test_episode_traces():
         end, winner = g.has_a_winner()
         assert end and winner == int(key("winner"))
         assert np.array_equal(np.where(players == winner, 1.0, -1.0), z)  # quoridor.py:599-602
+
+
+def test_oracle_under_address_and_ub_sanitizers():
+    """`make -C oracle libqz_oracle_asan.so` (gcc -fsanitize=address,undefined) really runs: the
+    rules fixtures, a slice of the position fixtures, MCTS searches with subtree reuse and the
+    episode traces go through the sanitizer build in a child interpreter with libasan preloaded.
+    Any out-of-bounds access, use-after-free or undefined behaviour in the C restatement aborts it."""
+    import subprocess
+    import sys
+
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "libqz_oracle_asan.so"])
+    asan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"], text=True).strip()
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import oracle
+assert oracle._LIB_PATH.endswith("libqz_oracle_asan.so")
+d = np.load(%r + "/rules_positions.npz")
+b = d["board"][::9]
+live = d["n_actions"][::9] > 0
+mask, status = oracle.movegen_batch(b)
+for i in np.nonzero(live)[0][:600]:
+    assert oracle.mask_to_actions(mask[i]) == d["actions"][::9][i][: d["n_actions"][::9][i]].tolist()
+ok = (b["p1"] >= 0) & (b["p1"] <= 80) & (b["p2"] >= 0) & (b["p2"] <= 80)
+oracle.encode_batch(b[ok])
+nb, done, win = oracle.step_batch(b[live], d["action"][::9][live])
+assert np.array_equal(done, d["done"][::9][live])
+m = oracle.OracleMCTS("hash", c_puct=5, n_playout=120)
+g = oracle.OracleGame()
+for ply in range(6):
+    acts, visits, _ = m.get_move_probs(g, 1.0)
+    mv = acts[int(np.argmax(visits))]
+    m.update_with_move(mv)
+    g.step(mv)
+m2 = oracle.OracleMCTS("uniform", c_puct=5, n_playout=60, fix_terminal_sign=True)
+m2.get_move_probs(oracle.OracleGame.from_packed(b[live][5]), 1.0)
+del m, m2
+print("sanitizer run ok")
+""" % (ROOT, os.path.join(ROOT, "tests", "golden"), os.path.join(ROOT, "tests", "golden"))
+    env = dict(os.environ, QZ_ORACLE_SANITIZE="1", LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1",
+               UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "sanitizer run ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
