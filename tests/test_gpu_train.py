@@ -190,11 +190,15 @@ def test_interactive_loop_on_the_real_game(gpu_device):
     from alphazero_quoridor_amd.game import play, step_result
     from alphazero_quoridor_amd.quoridor import Quoridor
 
+    class FirstLegal:
+        def choose_action(self, game):
+            return game.actions()[0]
+
     g = Quoridor()
     with quiet():
-        winner, hist = play(g, {1: HistoricalAgent("script", [0, 0, 0]), 2: pure_mcts.MCTSPlayer(n_playout=12, seed=3)}, max_plies=5,
-                            log=lambda *_: None)
-    assert winner is None and [p for p, _ in hist] == [1, 2, 1, 2, 1] and g._positions[1] == 4 + 27 or g._positions[1] >= 22
+        winner, hist = play(g, {1: FirstLegal(), 2: pure_mcts.MCTSPlayer(n_playout=12, seed=3)}, max_plies=5, log=lambda *_: None)
+    assert winner is None and [p for p, _ in hist] == [1, 2, 1, 2, 1] and g.current_player == 2
+    assert HistoricalAgent("rec", [5, 6]).choose_action(g) == 5
     d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rules_positions.npz"))
     i = int(np.nonzero(d["done"])[0][0])
     won = Quoridor.from_packed(d["board"][i])
