@@ -320,6 +320,7 @@ int qz_engine_create(const qz_config* cfg, qz_engine** out) {
     ALLOC(root_eoff, B);
     ALLOC(root_ne, B);
     ALLOC(path_edges, B * (size_t)QZ_PATH_CAP);
+    ALLOC(path_blocks, B * (size_t)QZ_PATH_CAP);
     ALLOC(path_len, B);
     ALLOC(tree_half, B);
     ALLOC(n_nodes, B);
@@ -647,6 +648,24 @@ int qz_nn_conv3x3_norm(const float* x, const void* w16, const float* gamma, cons
     if (!x || !w16 || !gamma || !beta || !out) return fail(QZ_E_INVALID, "null tensor");
     if ((((uintptr_t)x | (uintptr_t)w16 | (uintptr_t)out | (uintptr_t)residual) & 15) != 0) return fail(QZ_E_INVALID, "tensors must be 16-byte aligned");
     HIP_TRY(qzl::conv3x3_norm(x, w16, gamma, beta, residual, out, (long long)n, inv_scale, relu, eps, (hipStream_t)stream));
+    return 0;
+}
+int qz_nn_trunk(float* x, float* tmp, int64_t n, int n_blocks, const void* const* w16, const float* const* gamma, const float* const* beta,
+                const float* inv_scale, float eps, void* stream) {
+    int r;
+    if ((r = device_check())) return r;
+    if (n < 0 || n_blocks < 0) return fail(QZ_E_INVALID, "n < 0 or n_blocks < 0");
+    if (n == 0 || n_blocks == 0) return 0;
+    if (!x || !tmp || !w16 || !gamma || !beta || !inv_scale) return fail(QZ_E_INVALID, "null argument");
+    if ((((uintptr_t)x | (uintptr_t)tmp) & 15) != 0) return fail(QZ_E_INVALID, "tensors must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    for (int b = 0; b < n_blocks; b++) {
+        const int l0 = 2 * b, l1 = 2 * b + 1;
+        if (!w16[l0] || !w16[l1] || !gamma[l0] || !gamma[l1] || !beta[l0] || !beta[l1]) return fail(QZ_E_INVALID, "null layer tensor");
+        // y = relu(bn1(conv1(x)));  x = relu(bn2(conv2(y)) + x)   (policy_value_net.py:33-48)
+        HIP_TRY(qzl::conv3x3_norm(x, w16[l0], gamma[l0], beta[l0], nullptr, tmp, (long long)n, inv_scale[l0], 1, eps, s));
+        HIP_TRY(qzl::conv3x3_norm(tmp, w16[l1], gamma[l1], beta[l1], x, x, (long long)n, inv_scale[l1], 1, eps, s));
+    }
     return 0;
 }
 int qz_engine_leaf_boards(qz_engine* e, qz_boards* boards_out, const uint8_t** terminal_out) {

@@ -111,6 +111,7 @@ struct EngineDev {
     uint32_t* free_traj;      // [traj_pool_pages]
     int* pool_words;          // QZ_P_COUNT
     uint32_t *path_edges, *path_len;
+    unsigned long long* path_blocks;  // [B][QZ_PATH_CAP] (first physical edge << 8 | edge count) of the node at every level of the last descent
     uint8_t* tree_half;
     uint8_t* release;         // [B] bit0: the other table half holds pages to give back
     uint32_t *n_nodes, *n_edges, *root_N, *root_eoff, *root_ne;

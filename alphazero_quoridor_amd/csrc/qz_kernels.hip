@@ -414,63 +414,112 @@ __device__ __forceinline__ uint32_t tree_alloc(const EngineDev& E, TreeView& T, 
     return off;
 }
 
-// MCTS._playout descent (mcts.py:107-113) + TreeNode.select/get_value (mcts.py:37-42, 64-70)
+// MCTS._playout descent (mcts.py:107-113) + TreeNode.select/get_value (mcts.py:37-42, 64-70).
+// The kernel lasts as long as the DEEPEST of the batch's descents, and a descent is one chain of
+// dependent steps per level: edge block -> PUCT values -> argmax -> child block.  Three things
+// shorten a level without touching its arithmetic:
+//  * the blocks the previous playout walked through are touched up front (one parallel round of
+//    loads, narrow nodes only): late-game lines are forced, successive playouts share most of their
+//    path, so the chain then runs on L2 hits instead of Infinity-Cache / HBM round trips;
+//  * every lane takes the float64 square root of ITS OWN edge's visit count while the division
+//    is in flight: the winner's is the next level's sqrt(N_parent), off the critical path;
+//  * nodes with <= 8 children (most of a long game: a mover without walls has 2-5 moves) pick
+//    their maximum by a uniform scan over readlanes instead of six rounds of LDS-crossbar shuffles.
+__device__ __forceinline__ double rdl_f64(double v, int l) {
+    const uint64_t u = (uint64_t)__double_as_longlong(v);
+    return __longlong_as_double((long long)((uint64_t)rdl((uint32_t)u, l) | ((uint64_t)rdl((uint32_t)(u >> 32), l) << 32)));
+}
 __global__ __launch_bounds__(TPB) void k_select(EngineDev E) {
     const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
     const int b = (int)blockIdx.x * WPB + wave;
     if (b >= E.n_boards) return;
+    uint32_t* path = E.path_edges + (size_t)b * QZ_PATH_CAP;
+    unsigned long long* pblk = E.path_blocks + (size_t)b * QZ_PATH_CAP;
     Board bd = load_board(E.root_hb, E.root_vb, E.root_meta, b);
     uint32_t pedge = QZ_NONE;
-    uint32_t parentN = rfl(E.root_N[b]);
+    const uint32_t rootN = rfl(E.root_N[b]);
     int ne = (int)rfl(E.root_ne[b]);
     bool done = false, nonfinite = false;
     const bool live = rfl(E.status[b]) == QZ_PLAYING;
     uint32_t plen = 0u, scanned = 0u;
+    {   // warm the caches along the previous descent (path_blocks = first edge << 8 | edge count per
+        // level): one parallel round of loads next to the root's own loads above
+        const uint32_t prev = rfl(E.path_len[b]);
+        const uint32_t lim = prev < (uint32_t)QZ_PATH_CAP ? prev : (uint32_t)QZ_PATH_CAP;
+        uint32_t touched = 0u;
+        for (uint32_t i = (uint32_t)lane; i < lim; i += 64u) {
+            const unsigned long long pb = pblk[i];
+            const uint32_t cnt = (uint32_t)(pb & 0xFFull);
+            if (cnt >= 1u && cnt <= 8u) {  // <= 256 bytes = at most three lines; wide early-game nodes are not worth the traffic
+                const uint32_t* p = reinterpret_cast<const uint32_t*>(E.edge_pool + (size_t)(pb >> 8));
+                touched ^= p[0] ^ p[cnt * 8u - 1u];
+                if (cnt > 4u) touched ^= p[32];
+            }
+        }
+        asm volatile("" ::"v"(touched));  // the lines have landed: the chain below runs on cache hits
+    }
     if (live && ne > 0) {
         const TreeView T = tree_view(E, b, rfl(E.tree_half[b]), lane);
         uint32_t eoff = rfl(E.root_eoff[b]);
-        uint32_t* path = E.path_edges + (size_t)b * QZ_PATH_CAP;
+        double sq = sqrt((double)rootN);  // np.sqrt(self._parent._n_visits), float64
         for (int depth = 0; depth < 1000000; depth++) {
             const uint32_t base = tree_phys(T, eoff);
             scanned += (uint32_t)ne;
-            double sq = sqrt((double)parentN);  // np.sqrt(self._parent._n_visits), float64
             double best = -__builtin_inf();
             int bestk = 0x7fffffff;
             // everything the descent needs about the winning edge rides along with the
             // candidates, so the next level costs one dependent round trip, not three
-            uint32_t mN = 0u, mCOff = 0u, mMisc = 0u;
+            uint32_t mCOff = 0u, mMisc = 0u;
+            double mSq = 0.0;
             for (int k = lane; k < ne; k += 64) {
                 const Edge ed = T.pool[base + (uint32_t)k];        // one 32-byte record per lane
                 uint32_t N = ed.N;
                 float cp = E.c_puct * ed.P;                         // c_puct * self._P in float32
                 double u = (double)cp * sq / (double)(1u + N);      // mcts.py:69
                 double val = ed.Q + u;                              // mcts.py:70
+                double sqN = sqrt((double)N);                       // the next level's sqrt(N_parent) if this edge wins
                 uint32_t misc = (uint32_t)ed.act | ((uint32_t)ed.cne << 8);
                 // a lane's first candidate is always taken: with non-finite values (a diverged
                 // network) every comparison is false and Python's max() keeps the first child
                 if (val > best || bestk == 0x7fffffff) {
                     best = val;
                     bestk = k;
-                    mN = N;
+                    mSq = sqN;
                     mCOff = ed.coff;
                     mMisc = misc;
                 }
             }
-            wave_argmax(best, bestk);
-            const int kk = (int)rfl((uint32_t)bestk);  // lane 0 always holds a valid pair (k = 0 is its own)
-            nonfinite = nonfinite || !(best == best);
+            int kk;
+            if (ne <= 8) {  // wave-uniform: lane k < ne holds (val_k, k); first maximum wins like max()
+                double bv = rdl_f64(best, 0);
+                kk = 0;
+                for (int j = 1; j < ne; j++) {
+                    const double vj = rdl_f64(best, j);
+                    if (vj > bv) {
+                        bv = vj;
+                        kk = j;
+                    }
+                }
+                nonfinite = nonfinite || !(bv == bv);
+            } else {
+                wave_argmax(best, bestk);
+                kk = (int)rfl((uint32_t)bestk);  // lane 0 always holds a valid pair (k = 0 is its own)
+                nonfinite = nonfinite || !(best == best);
+            }
             const int wl = kk & 63;  // the winning edge is the winning lane's own best candidate
             const uint32_t e = base + (uint32_t)kk;
             const uint32_t misc = rdl(mMisc, wl);
             const int a = (int)(misc & 0xFFu);
-            const uint32_t childN = rdl(mN, wl);
             done = apply_action(bd, a);  // game.step(action), mcts.py:113
             pedge = e;
-            if (lane == 0 && plen < (uint32_t)QZ_PATH_CAP) path[plen] = e;
+            if (lane == 0 && plen < (uint32_t)QZ_PATH_CAP) {
+                path[plen] = e;
+                pblk[plen] = ((unsigned long long)base << 8) | (unsigned long long)(ne > 255 ? 255 : ne);
+            }
             plen++;
             const int cne = (int)((misc >> 8) & 0xFFu);
             if (cne == 0) break;  // TreeNode.is_leaf(): never expanded (or terminal)
-            parentN = childN;
+            sq = rdl_f64(mSq, wl);
             eoff = rdl(mCOff, wl);
             ne = cne;
         }

@@ -112,6 +112,7 @@ class LeafEvaluator:
         # matrix cores with split operands (fp32 accuracy; qz_nn_conv3x3_norm): fp32, channels-last, per-leaf
         self.mfma_trunk = mfma_trunk and fused_norm and bn_mode == "per_leaf" and dtype == torch.float32 and channels_last
         self._w16 = None
+        self.trunk_events = None   # bench.py: a list that receives (start, end) HIP events around trunk-layer launches
         self.net = net
         self.bn_mode = bn_mode
         self.dtype = dtype
@@ -170,6 +171,7 @@ class LeafEvaluator:
                 for (o, _), (t, sc) in zip(self._w16, w16):
                     o.copy_(t)
                 self._w16 = [(o, sc) for (o, _), (_, sc) in zip(self._w16, w16)]
+            self._trunk_args = None  # host-side pointer tables of qz_nn_trunk, rebuilt on the next call
         if self.board_input_layer and layers[0][0].is_cuda:
             tabs = self._input_tables(layers[0][0])
             if self._in_tables is None:
@@ -203,10 +205,35 @@ class LeafEvaluator:
         w16, inv_scale = self._w16[i - 1]
         _, _, gamma, beta = self._layers[i]
         out = torch.empty_like(x, memory_format=torch.channels_last)
+        ev = None
+        if self.trunk_events is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         _cabi.check(_cabi.load().qz_nn_conv3x3_norm(
             x.data_ptr(), w16.data_ptr(), gamma.data_ptr(), beta.data_ptr(), residual.data_ptr() if residual is not None else 0,
             out.data_ptr(), x.shape[0], inv_scale, int(relu), BN_EPS, torch.cuda.current_stream(x.device).cuda_stream))
+        if ev is not None:
+            ev[1].record()
+            self.trunk_events.append(ev)
         return out
+
+    def _trunk_mfma(self, x):
+        """All ten trunk layers from one library call (qz_nn_trunk); x is updated in place."""
+        import ctypes as C
+        from . import _cabi
+        if getattr(self, "_trunk_args", None) is None:
+            L = 2 * N_RES
+            self._trunk_args = ((C.c_void_p * L)(*[self._w16[i][0].data_ptr() for i in range(L)]),
+                                (C.c_void_p * L)(*[self._layers[i + 1][2].data_ptr() for i in range(L)]),
+                                (C.c_void_p * L)(*[self._layers[i + 1][3].data_ptr() for i in range(L)]),
+                                (C.c_float * L)(*[self._w16[i][1] for i in range(L)]))
+        w, g, b, sc = self._trunk_args
+        tmp = getattr(self, "_trunk_tmp", None)
+        if tmp is None or tmp.shape != x.shape or tmp.device != x.device:
+            tmp = self._trunk_tmp = torch.empty_like(x, memory_format=torch.channels_last)
+        _cabi.check(_cabi.load().qz_nn_trunk(x.data_ptr(), tmp.data_ptr(), x.shape[0], N_RES, w, g, b, sc, BN_EPS,
+                                             torch.cuda.current_stream(x.device).cuda_stream))
+        return x
 
     @staticmethod
     def _input_tables(w):
@@ -291,10 +318,15 @@ class LeafEvaluator:
                 x = x.contiguous(memory_format=torch.channels_last)
             x = self._cbn(x, 0)
         li = 1
-        for _ in range(N_RES):
-            y = self._cbn(x, li)
-            x = self._cbn(y, li + 1, relu=True, residual=x)
-            li += 2
+        if self.mfma_trunk and self._w16 is not None and self.trunk_events is None and x.is_cuda and x.dtype == torch.float32 \
+                and x.is_contiguous(memory_format=torch.channels_last) and x.shape[1] == WIDTH:
+            x = self._trunk_mfma(x)  # ten launches, one library call; x (the first layer's output) is updated in place
+            li += 2 * N_RES
+        else:
+            for _ in range(N_RES):
+                y = self._cbn(x, li)
+                x = self._cbn(y, li + 1, relu=True, residual=x)
+                li += 2
         B = x.shape[0]
         if self.fused_head and self._head is not None and x.is_cuda and x.is_contiguous(memory_format=torch.channels_last):
             from . import _cabi

@@ -325,6 +325,9 @@ def main():
     ap.add_argument("--no-planes", action="store_true",
                     help="product default of the engine route (the evaluator reads the leaf boards, state() is never materialised); "
                          "the rules op then only produces the legal sets and `roofline` is computed on 44 B/board")
+    ap.add_argument("--library-trunk", action="store_true",
+                    help="NOT the default: run the trunk convolutions through MIOpen (fp32 implicit GEMM) + the separate normalisation "
+                         "kernel instead of the split-fp16 MFMA kernel (qz_nn_conv3x3_norm), for A/B runs")
     ap.add_argument("--length-file", default=None,
                     help="game-length sample for games_per_s_steady_state (default: newest profiles/round*/game_length_<n>playouts.json)")
     ap.add_argument("--clock-log", default=None, help="write the clock / power samples of the timed region to this JSON file")
@@ -345,7 +348,13 @@ def main():
     torch.manual_seed(args.seed)  # identical random-init weights on every rank
     net = PolicyValueNet(use_gpu=True, device=dev)
     dt = torch.float32 if args.nn_dtype == "fp32" else torch.bfloat16
-    eng = BoardGroups(args.boards, args.groups, lambda: net.evaluator(args.bn, dt, bool(args.channels_last)),
+    if args.library_trunk:
+        from alphazero_quoridor_amd.policy_value_net import LeafEvaluator
+        lib_ev = LeafEvaluator(net.policy_value_net, args.bn, dt, bool(args.channels_last), mfma_trunk=False)
+        make_ev = lambda: lib_ev  # noqa: E731
+    else:
+        make_ev = lambda: net.evaluator(args.bn, dt, bool(args.channels_last))  # noqa: E731
+    eng = BoardGroups(args.boards, args.groups, make_ev,
                       seed=qdist.shard_seed(args.seed, rank), device=dev,
                       n_playout=args.playouts, c_puct=5, temp=1.0, is_selfplay=1, fix_terminal_sign=args.fix_terminal_sign)
     group_boards = args.boards // args.groups
@@ -408,9 +417,13 @@ def main():
     games = 0
     k = 0
     step_ms = []
+    ev0 = eng.evaluators[0]
+    trunk_evs = []
     for _ in range(args.steps):
         ts = time.perf_counter()
         for _ in range(args.playouts):
+            if hasattr(ev0, "trunk_events"):  # the trunk layers of every 16th playout step are bracketed with HIP events
+                ev0.trunk_events = trunk_evs if (k & 15) == 0 and getattr(ev0, "mfma_trunk", False) else None
             eng.playout_step(events=evs[k], write_planes=write_planes, tree_events=tevs[k])
             k += 1
         games += end_of_ply()  # harvest synchronises with the device (qz_harvest_counts), so this is the ply's wall time
@@ -525,11 +538,26 @@ def main():
                           "HBM/L2 round trip per level; bytes = edge records scanned" % (group_boards, mean_depth)),
                 tree_line("k_expand_backup", exp_ms, exp_bytes, "one expansion (<= 131 records) + lane-parallel backup per board"),
             ],
+            "roofline_nn": None,
             "engine_stats": {kk: st1[kk] for kk in ("node_overflow", "games_aborted", "aborted_no_move", "aborted_max_plies", "aborted_pool",
                                                     "nonfinite_values", "arena_bytes", "max_nodes", "max_edges", "tree_pages_total",
                                                     "tree_pages_peak", "traj_pages_total", "traj_pages_peak")},
             "clocks": sampler.summary() if sampler else None,
         }
+        if trunk_evs:
+            conv_ms = sum(a.elapsed_time(b) for a, b in trunk_evs) / len(trunk_evs)
+            flops = 2.0 * group_boards * 81 * 64 * 576  # the convolution's own multiply-adds: what an fp32 kernel would do
+            out["roofline_nn"] = {
+                "kernel": "k_conv3x3_norm (one trunk layer: conv3x3 64->64 as implicit GEMM on v_mfma_f32_32x32x16_f16 with split fp16 "
+                          "operands, per-leaf normalisation, residual, ReLU; 10 launches per playout step)",
+                "bound": "mfma", "achieved": flops / (conv_ms * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
+                "frac": flops / (conv_ms * 1e-3) / 1e12 / 2500.0, "traffic": None,
+                "avg_launch_us": conv_ms * 1e3, "launches": len(trunk_evs), "algorithmic_flops_per_launch": flops,
+                "executed_mfma_tflops": 3.0 * (192.0 / 162.0) * flops / (conv_ms * 1e-3) / 1e12,
+                "note": "achieved = fp32-equivalent convolution FLOPs / time; peak = dense fp16 MFMA (MI355X_MICROARCH.md). fp32 accuracy costs "
+                        "three fp16 MFMAs per product (hi*hi + hi*lo + lo*hi) and 162 of 192 tile rows are live, so the matrix pipe executes "
+                        "3.56x the algorithmic FLOPs (executed_mfma_tflops); the f32-input MFMA peak this replaces is 157 TFLOP/s",
+            }
         if st1["games_aborted"]:
             sys.stderr.write("bench.py: WARNING %d games were dropped (no_move %d, max_plies %d, pool %d)\n"
                              % (st1["games_aborted"], st1["aborted_no_move"], st1["aborted_max_plies"], st1["aborted_pool"]))
