@@ -65,6 +65,7 @@ class qz_config(C.Structure):
         ("traj_pool_pages", C.c_int32),
         ("traj_page_dwords", C.c_int32),
         ("rules", qz_rules_opts),
+        ("select_opts", C.c_int32),
     ]
 
 
@@ -95,6 +96,7 @@ class qz_stats(C.Structure):
         ("traj_pages_peak", C.c_int64),
         ("edges_scanned", C.c_int64),
         ("edges_expanded", C.c_int64),
+        ("max_depth", C.c_int64),
     ]
 
 

@@ -293,6 +293,7 @@ int qz_engine_create(const qz_config* cfg, qz_engine** out) {
     d.seed = c.seed;
     d.is_selfplay = c.is_selfplay;
     d.fix_terminal_sign = c.fix_terminal_sign;
+    d.select_opts = c.select_opts;
     const size_t B = (size_t)c.n_boards;
     int rc = 0;
 #define ALLOC(field, count) \
@@ -337,6 +338,7 @@ int qz_engine_create(const qz_config* cfg, qz_engine** out) {
     ALLOC(bc_terminal, B);
     ALLOC(bc_overflow, B);
     ALLOC(bc_nonfinite, B);
+    ALLOC(bc_maxdepth, B);
     ALLOC(bc_levels, B);
     ALLOC(bc_scanned, B);
     ALLOC(bc_expanded, B);
@@ -359,6 +361,7 @@ int qz_engine_create(const qz_config* cfg, qz_engine** out) {
     if (he == hipSuccess) he = hipMemset(d.bc_terminal, 0, B * sizeof(uint32_t));
     if (he == hipSuccess) he = hipMemset(d.bc_overflow, 0, B * sizeof(uint32_t));
     if (he == hipSuccess) he = hipMemset(d.bc_nonfinite, 0, B * sizeof(uint32_t));
+    if (he == hipSuccess) he = hipMemset(d.bc_maxdepth, 0, B * sizeof(uint32_t));
     if (he == hipSuccess) he = hipMemset(d.tree_npages, 0, 2 * B * sizeof(uint32_t));
     if (he == hipSuccess) he = hipMemset(d.traj_npages, 0, B * sizeof(uint32_t));
     if (he == hipSuccess) he = hipMemset(d.traj_cursor, 0, B * sizeof(uint32_t));
@@ -533,7 +536,7 @@ int qz_engine_stats(qz_engine* e, qz_stats* out, void* stream) {
     unsigned long long h[QZ_C_COUNT];
     hipStream_t s = (hipStream_t)stream;
     const size_t B = (size_t)e->cfg.n_boards;
-    std::vector<uint32_t> bp(B), bt(B), bo(B), nn(B), ne(B), bf(B);
+    std::vector<uint32_t> bp(B), bt(B), bo(B), nn(B), ne(B), bf(B), bd(B);
     int pw[QZ_P_COUNT];
     std::vector<unsigned long long> bl(B), bs(B), be(B);
     HIP_TRY(hipMemcpyAsync(h, e->dev.counters, sizeof(h), hipMemcpyDeviceToHost, s));
@@ -541,6 +544,7 @@ int qz_engine_stats(qz_engine* e, qz_stats* out, void* stream) {
     HIP_TRY(hipMemcpyAsync(bt.data(), e->dev.bc_terminal, B * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(bo.data(), e->dev.bc_overflow, B * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(bf.data(), e->dev.bc_nonfinite, B * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(bd.data(), e->dev.bc_maxdepth, B * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(pw, e->dev.pool_words, sizeof(pw), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(bl.data(), e->dev.bc_levels, B * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(bs.data(), e->dev.bc_scanned, B * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
@@ -550,7 +554,7 @@ int qz_engine_stats(qz_engine* e, qz_stats* out, void* stream) {
     HIP_TRY(hipStreamSynchronize(s));
     // per-board counters wrap at 2^32 playouts per board (years); sums are 64-bit
     unsigned long long sp = 0, st = 0, so = 0, sl = 0, sf = 0, ss = 0, se = 0;
-    uint32_t mn = 0, me = 0;
+    uint32_t mn = 0, me = 0, md = 0;
     for (size_t i = 0; i < B; i++) {
         mn = nn[i] > mn ? nn[i] : mn;
         me = ne[i] > me ? ne[i] : me;
@@ -558,6 +562,7 @@ int qz_engine_stats(qz_engine* e, qz_stats* out, void* stream) {
         st += bt[i];
         so += bo[i];
         sf += bf[i];
+        md = bd[i] > md ? bd[i] : md;
         ss += bs[i];
         se += be[i];
         sl += bl[i];
@@ -574,6 +579,7 @@ int qz_engine_stats(qz_engine* e, qz_stats* out, void* stream) {
     out->games_aborted = out->aborted_no_move + out->aborted_max_plies + out->aborted_pool;
     out->bad_forced_moves = (int64_t)h[QZ_C_BAD_FORCED];
     out->nonfinite_values = (int64_t)sf;
+    out->max_depth = (int64_t)md;
     out->edges_scanned = (int64_t)ss;
     out->edges_expanded = (int64_t)se;
     out->tree_pages_total = e->cfg.tree_pool_pages;

@@ -41,12 +41,13 @@ constexpr int CS = 2;        // leaves per workgroup
 constexpr int NPOS = 81;
 constexpr int ROWS = 82;     // 81 positions + one all-zero row per leaf
 constexpr int RSTR = 72;     // halfs per LDS row (144 B)
+constexpr int RV = RSTR / 8; // ... in 16-byte vectors
 constexpr int C = 64;
 constexpr int ZERO_ROW = NPOS;  // of leaf 0
 
 struct ConvShared {
-    _Float16 a_hi[CS * ROWS * RSTR];
-    _Float16 a_lo[CS * ROWS * RSTR];
+    half8 a_hi[CS * ROWS * RV];  // 16-byte vectors: a fragment is ONE ds_read_b128
+    half8 a_lo[CS * ROWS * RV];
     float red[2][2][CS][C];  // [pass][wave group][leaf][channel]
 };
 
@@ -68,24 +69,25 @@ __device__ __forceinline__ void stage_input(ConvShared& sm, const float* __restr
         lo[2] = (_Float16)(v.z - (float)hi[2]);
         lo[3] = (_Float16)(v.w - (float)hi[3]);
         const int o = (s * ROWS + p) * RSTR + c4 * 4;
-        *reinterpret_cast<half4*>(&sm.a_hi[o]) = hi;
-        *reinterpret_cast<half4*>(&sm.a_lo[o]) = lo;
+        *reinterpret_cast<half4*>(reinterpret_cast<_Float16*>(sm.a_hi) + o) = hi;
+        *reinterpret_cast<half4*>(reinterpret_cast<_Float16*>(sm.a_lo) + o) = lo;
     }
     if (tid < CS * 16) {  // the zero rows
         const int s = tid >> 4, c4 = tid & 15;
         half4 z;
         z[0] = z[1] = z[2] = z[3] = (_Float16)0.f;
         const int o = (s * ROWS + NPOS) * RSTR + c4 * 4;
-        *reinterpret_cast<half4*>(&sm.a_hi[o]) = z;
-        *reinterpret_cast<half4*>(&sm.a_lo[o]) = z;
+        *reinterpret_cast<half4*>(reinterpret_cast<_Float16*>(sm.a_hi) + o) = z;
+        *reinterpret_cast<half4*>(reinterpret_cast<_Float16*>(sm.a_lo) + o) = z;
     }
 }
 
 // w16: [2][9][4][64][16] fp16 (hi part, then lo part)
-__global__ __launch_bounds__(256) void k_conv3x3_norm(const float* __restrict__ x, const _Float16* __restrict__ w16,
+template <bool RES, bool RELU>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_conv3x3_norm(const float* __restrict__ x, const _Float16* __restrict__ w16,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       const float* __restrict__ residual, float* __restrict__ out, long long n,
-                                                      float inv_scale, int relu, float eps) {
+                                                      float inv_scale, float eps) {
     __shared__ ConvShared sm;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -94,8 +96,8 @@ __global__ __launch_bounds__(256) void k_conv3x3_norm(const float* __restrict__ 
 
     stage_input(sm, x, b0, n, tid);
 
-    // LDS offsets (in halfs) of this lane's A rows: [tile][tap]; rows outside the board / past the
-    // last leaf read the zero row
+    // LDS offsets (in 16-byte vectors) of this lane's A rows: [tile][tap]; rows outside the board /
+    // past the last leaf read the zero row
     int rowoff[3][9];
 #pragma unroll
     for (int t = 0; t < 3; t++) {
@@ -107,7 +109,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_norm(const float* __restrict__ 
         for (int tap = 0; tap < 9; tap++) {
             const int yy = y + tap / 3 - 1, x2 = xx + tap % 3 - 1;
             const bool ok = live && (unsigned)yy < 9u && (unsigned)x2 < 9u;
-            rowoff[t][tap] = (ok ? (s * ROWS + yy * 9 + x2) : ZERO_ROW) * RSTR + 8 * h;
+            rowoff[t][tap] = (ok ? (s * ROWS + yy * 9 + x2) : ZERO_ROW) * RV + h;
         }
     }
     floatx16 acc[3];
@@ -117,27 +119,40 @@ __global__ __launch_bounds__(256) void k_conv3x3_norm(const float* __restrict__ 
         for (int i = 0; i < 16; i++) acc[t][i] = 0.f;
     __syncthreads();
 
-    const _Float16* wb = w16 + (size_t)(32 * nt + r) * 16 + 8 * h;  // this lane's slice of every B fragment
-    constexpr size_t PART = (size_t)9 * 4 * C * 16;
+    // B fragments come straight from L2: this lane's 16 bytes of fragment f = (part, k step) sit at
+    // wb[f * 128] (in 16-byte vectors).  They are requested TWO k steps (18 MFMAs, ~600 cycles) ahead
+    // into a ring of three register sets, so the matrix pipe never waits for an L2 round trip.
+    const half8* wb = reinterpret_cast<const half8*>(w16) + (size_t)(32 * nt + r) * 2 + h;
+    constexpr int PARTV = 9 * 4 * C * 2;  // 16-byte vectors per part (hi | lo)
+    half8 bh[3], bl[3];
 #pragma unroll
-    for (int tap = 0; tap < 9; tap++) {
+    for (int k = 0; k < 2; k++) {
+        bh[k] = wb[k * (C * 2)];
+        bl[k] = wb[PARTV + k * (C * 2)];
+    }
 #pragma unroll
-        for (int kc = 0; kc < 4; kc++) {
-            const size_t bo = (size_t)(tap * 4 + kc) * C * 16;
-            const half8 b_hi = *reinterpret_cast<const half8*>(wb + bo);
-            const half8 b_lo = *reinterpret_cast<const half8*>(wb + PART + bo);
+    for (int k = 0; k < 36; k++) {  // k = 4 tap + (16-channel chunk)
+        if (k + 2 < 36) {
+            bh[(k + 2) % 3] = wb[(k + 2) * (C * 2)];
+            bl[(k + 2) % 3] = wb[PARTV + (k + 2) * (C * 2)];
+        }
+        asm volatile("" ::: "memory");  // the prefetch stays ahead of this step's LDS reads
+        const int tap = k >> 2, kc = k & 3;
+        const half8 b_hi = bh[k % 3], b_lo = bl[k % 3];
 #pragma unroll
-            for (int t = 0; t < 3; t++) {
-                const half8 a_hi = *reinterpret_cast<const half8*>(&sm.a_hi[rowoff[t][tap] + 16 * kc]);
-                const half8 a_lo = *reinterpret_cast<const half8*>(&sm.a_lo[rowoff[t][tap] + 16 * kc]);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, acc[t], 0, 0, 0);
-            }
+        for (int t = 0; t < 3; t++) {
+            const half8 a_hi = sm.a_hi[rowoff[t][tap] + 2 * kc];
+            const half8 a_lo = sm.a_lo[rowoff[t][tap] + 2 * kc];
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, acc[t], 0, 0, 0);
         }
     }
 
-    // ---- epilogue: this lane owns channel co, rows m(t, i) = 32 (3 mg + t) + (i & 3) + 8 (i >> 2) + 4 h
+    // ---- epilogue: this lane owns channel co, rows m(t, i) = 32 (3 mg + t) + (i & 3) + 8 (i >> 2) + 4 h.
+    // Branch-free on purpose: selects for the statistics, and the 16 residual loads / 16 stores of a
+    // tile are issued as batches (element (leaf s, position p, channel co) of the output sits at
+    // (b0 * 81 + m) * 64 + co whichever leaf row m belongs to).
     const int co = 32 * nt + r;
     float s0 = 0.f, s1 = 0.f;
 #pragma unroll
@@ -147,8 +162,8 @@ __global__ __launch_bounds__(256) void k_conv3x3_norm(const float* __restrict__ 
             const int m = 32 * (3 * mg + t) + (i & 3) + 8 * (i >> 2) + 4 * h;
             const float y = acc[t][i] * inv_scale;  // exact: a power of two
             acc[t][i] = y;
-            if (m < NPOS) s0 += y;
-            else if (m < 2 * NPOS) s1 += y;
+            s0 += m < NPOS ? y : 0.f;
+            s1 += (m >= NPOS && m < 2 * NPOS) ? y : 0.f;
         }
     s0 += __shfl_xor(s0, 32, 64);
     s1 += __shfl_xor(s1, 32, 64);
@@ -165,13 +180,9 @@ __global__ __launch_bounds__(256) void k_conv3x3_norm(const float* __restrict__ 
 #pragma unroll
         for (int i = 0; i < 16; i++) {
             const int m = 32 * (3 * mg + t) + (i & 3) + 8 * (i >> 2) + 4 * h;
-            if (m < NPOS) {
-                const float d = acc[t][i] - mean0;
-                q0 += d * d;
-            } else if (m < 2 * NPOS) {
-                const float d = acc[t][i] - mean1;
-                q1 += d * d;
-            }
+            const float d0 = acc[t][i] - mean0, d1 = acc[t][i] - mean1;
+            q0 += m < NPOS ? d0 * d0 : 0.f;
+            q1 += (m >= NPOS && m < 2 * NPOS) ? d1 * d1 : 0.f;
         }
     q0 += __shfl_xor(q0, 32, 64);
     q1 += __shfl_xor(q1, 32, 64);
@@ -183,22 +194,39 @@ __global__ __launch_bounds__(256) void k_conv3x3_norm(const float* __restrict__ 
     const float g = gamma[co], bt = beta[co];
     const float k0 = g / sqrtf((sm.red[1][0][0][co] + sm.red[1][1][0][co]) * (1.0f / 81.0f) + eps);
     const float k1 = g / sqrtf((sm.red[1][0][1][co] + sm.red[1][1][1][co]) * (1.0f / 81.0f) + eps);
+    const size_t obase = (size_t)b0 * NPOS * C + (size_t)co;
 #pragma unroll
-    for (int t = 0; t < 3; t++)
+    for (int t = 0; t < 3; t++) {
+        const int tile = 3 * mg + t;  // wave-uniform
+        const int m0 = 32 * tile + 4 * h;
+        if (tile < 5 && b0 + CS <= n) {  // every row of the tile is a real position of a real leaf
+            float rv[16];
+            if (RES) {
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const int m = 32 * (3 * mg + t) + (i & 3) + 8 * (i >> 2) + 4 * h;
-            if (m < 2 * NPOS) {
-                const int s = m >= NPOS ? 1 : 0;
-                if (b0 + s < n) {
-                    const size_t idx = ((size_t)(b0 + s) * NPOS + (size_t)(m - NPOS * s)) * C + (size_t)co;
-                    float v = (acc[t][i] - (s ? mean1 : mean0)) * (s ? k1 : k0) + bt;
-                    if (residual) v += residual[idx];
-                    if (relu) v = fmaxf(v, 0.f);
-                    out[idx] = v;
+                for (int i = 0; i < 16; i++) rv[i] = residual[obase + (size_t)(m0 + (i & 3) + 8 * (i >> 2)) * C];
+            }
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int m = m0 + (i & 3) + 8 * (i >> 2);
+                float v = (acc[t][i] - (m >= NPOS ? mean1 : mean0)) * (m >= NPOS ? k1 : k0) + bt;
+                if (RES) v += rv[i];
+                if (RELU) v = fmaxf(v, 0.f);
+                out[obase + (size_t)m * C] = v;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int m = m0 + (i & 3) + 8 * (i >> 2);
+                const int sidx = m >= NPOS ? 1 : 0;
+                if (m < 2 * NPOS && b0 + sidx < n) {
+                    float v = (acc[t][i] - (sidx ? mean1 : mean0)) * (sidx ? k1 : k0) + bt;
+                    if (RES) v += residual[obase + (size_t)m * C];
+                    if (RELU) v = fmaxf(v, 0.f);
+                    out[obase + (size_t)m * C] = v;
                 }
             }
         }
+    }
 }
 
 }  // namespace
@@ -207,8 +235,12 @@ namespace qzl {
 hipError_t conv3x3_norm(const float* x, const void* w16, const float* gamma, const float* beta, const float* residual, float* out,
                         long long n, float inv_scale, int relu, float eps, hipStream_t s) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_conv3x3_norm, dim3((unsigned)((n + CS - 1) / CS)), dim3(256), 0, s, x, reinterpret_cast<const _Float16*>(w16), gamma,
-                       beta, residual, out, n, inv_scale, relu, eps);
+    const dim3 grid((unsigned)((n + CS - 1) / CS));
+    const _Float16* w = reinterpret_cast<const _Float16*>(w16);
+    if (residual && relu) hipLaunchKernelGGL((k_conv3x3_norm<true, true>), grid, dim3(256), 0, s, x, w, gamma, beta, residual, out, n, inv_scale, eps);
+    else if (residual) hipLaunchKernelGGL((k_conv3x3_norm<true, false>), grid, dim3(256), 0, s, x, w, gamma, beta, residual, out, n, inv_scale, eps);
+    else if (relu) hipLaunchKernelGGL((k_conv3x3_norm<false, true>), grid, dim3(256), 0, s, x, w, gamma, beta, residual, out, n, inv_scale, eps);
+    else hipLaunchKernelGGL((k_conv3x3_norm<false, false>), grid, dim3(256), 0, s, x, w, gamma, beta, residual, out, n, inv_scale, eps);
     return hipGetLastError();
 }
 }  // namespace qzl

@@ -40,7 +40,7 @@
 #define QZ_PLANES_N 2106
 #define QZ_NONE 0xFFFFFFFFu
 #define QZ_NO_MOVE_U8 255
-#define QZ_PATH_CAP 256
+#define QZ_PATH_CAP 2048   // levels of a descent that are recorded (late-game lines are forced and hundreds of plies deep)
 
 #define QZ_PAGE_SHIFT 11
 #define QZ_PAGE_EDGES (1u << QZ_PAGE_SHIFT)  // 2,048 x 32 B = 64 KB
@@ -94,6 +94,7 @@ struct EngineDev {
     float c_puct, temp, dirichlet_alpha, noise_frac;
     uint64_t seed;
     int is_selfplay, fix_terminal_sign;
+    int select_opts;
     // boards
     uint64_t *root_hb, *root_vb, *root_meta;
     uint64_t *leaf_hb, *leaf_vb, *leaf_meta;
@@ -121,7 +122,7 @@ struct EngineDev {
     unsigned long long* counters;  // QZ_C_COUNT (touched once per ply / harvest)
     // per-board counters for the per-playout statistics: a shared atomic would serialise all
     // boards of a step on one address (~88 atomics/us on MI355X); summed by qz_engine_stats
-    uint32_t *bc_playouts, *bc_terminal, *bc_overflow, *bc_nonfinite;
+    uint32_t *bc_playouts, *bc_terminal, *bc_overflow, *bc_nonfinite, *bc_maxdepth;
     unsigned long long *bc_levels, *bc_scanned, *bc_expanded;  // tree levels walked, edge records read by k_select, edges created
 };
 

@@ -445,7 +445,7 @@ __global__ __launch_bounds__(TPB) void k_select(EngineDev E) {
     {   // warm the caches along the previous descent (path_blocks = first edge << 8 | edge count per
         // level): one parallel round of loads next to the root's own loads above
         const uint32_t prev = rfl(E.path_len[b]);
-        const uint32_t lim = prev < (uint32_t)QZ_PATH_CAP ? prev : (uint32_t)QZ_PATH_CAP;
+        const uint32_t lim = (E.select_opts & 1) ? 0u : (prev < (uint32_t)QZ_PATH_CAP ? prev : (uint32_t)QZ_PATH_CAP);
         uint32_t touched = 0u;
         for (uint32_t i = (uint32_t)lane; i < lim; i += 64u) {
             const unsigned long long pb = pblk[i];
@@ -490,7 +490,7 @@ __global__ __launch_bounds__(TPB) void k_select(EngineDev E) {
                 }
             }
             int kk;
-            if (ne <= 8) {  // wave-uniform: lane k < ne holds (val_k, k); first maximum wins like max()
+            if (ne <= 8 && !(E.select_opts & 2)) {  // wave-uniform: lane k < ne holds (val_k, k); first maximum wins like max()
                 double bv = rdl_f64(best, 0);
                 kk = 0;
                 for (int j = 1; j < ne; j++) {
@@ -538,6 +538,7 @@ __global__ __launch_bounds__(TPB) void k_select(EngineDev E) {
         E.leaf_term[b] = t;
         if (nonfinite) E.bc_nonfinite[b] += 1u;
         E.bc_scanned[b] += (unsigned long long)scanned;
+        if (plen > E.bc_maxdepth[b]) E.bc_maxdepth[b] = plen;
     }
 }
 

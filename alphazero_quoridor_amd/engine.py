@@ -61,7 +61,7 @@ class TupleBatch:
 class SelfPlayEngine:
     def __init__(self, n_boards, n_playout=400, c_puct=5.0, temp=1.0, is_selfplay=1, seed=0, device="cuda:0",
                  fix_terminal_sign=False, node_cap=0, edge_cap=0, max_plies=0, dirichlet_alpha=0.3, noise_frac=0.25,
-                 tree_pool_pages=0, traj_pool_pages=0, traj_page_dwords=0, rules_opts=None):
+                 tree_pool_pages=0, traj_pool_pages=0, traj_page_dwords=0, rules_opts=None, select_opts=0):
         if not torch.cuda.is_available():
             raise _cabi.QzError(_cabi.E_NO_DEVICE, "no HIP device: the engine has no CPU path")
         self.L = _cabi.load()
@@ -82,6 +82,7 @@ class SelfPlayEngine:
         cfg.node_cap, cfg.edge_cap, cfg.max_plies = int(node_cap), int(edge_cap), int(max_plies)
         cfg.tree_pool_pages, cfg.traj_pool_pages = int(tree_pool_pages), int(traj_pool_pages)
         cfg.traj_page_dwords = int(traj_page_dwords)
+        cfg.select_opts = int(select_opts)
         if rules_opts is not None:
             cfg.rules = rules_opts
         self.cfg = cfg

@@ -228,9 +228,9 @@ class LeafEvaluator:
                                 (C.c_void_p * L)(*[self._layers[i + 1][3].data_ptr() for i in range(L)]),
                                 (C.c_float * L)(*[self._w16[i][1] for i in range(L)]))
         w, g, b, sc = self._trunk_args
-        tmp = getattr(self, "_trunk_tmp", None)
-        if tmp is None or tmp.shape != x.shape or tmp.device != x.device:
-            tmp = self._trunk_tmp = torch.empty_like(x, memory_format=torch.channels_last)
+        # scratch of the call: from the caching allocator every time (one evaluator may serve several board
+        # groups on different streams at once, so nothing mutable is kept on the object)
+        tmp = torch.empty_like(x, memory_format=torch.channels_last)
         _cabi.check(_cabi.load().qz_nn_trunk(x.data_ptr(), tmp.data_ptr(), x.shape[0], N_RES, w, g, b, sc, BN_EPS,
                                              torch.cuda.current_stream(x.device).cuda_stream))
         return x

@@ -95,8 +95,26 @@ class ClockSampler(threading.Thread):
         self.samples = []
         self._stop_ev = threading.Event()
         self.source = None
-        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
-        self._sysfs = os.path.dirname(cards[index]) if index < len(cards) else None
+        self._sysfs = self._find_card(index)
+
+    @staticmethod
+    def _find_card(index):
+        """/sys/class/drm/cardN/device of HIP device `index`, matched by PCI address (a box shows
+        every GPU / partition of the host in sysfs, the process sees only its own)."""
+        try:
+            import ctypes
+
+            hip = ctypes.CDLL("libamdhip64.so")
+            buf = ctypes.create_string_buffer(64)
+            if hip.hipDeviceGetPCIBusId(buf, 64, int(index)) != 0:
+                return None
+            bdf = buf.value.decode().lower()
+            for card in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+                if os.path.basename(os.path.realpath(card)).lower() == bdf and os.path.exists(os.path.join(card, "pp_dpm_sclk")):
+                    return card
+        except Exception:  # noqa: BLE001
+            pass
+        return None
 
     def _read_sysfs(self):
         d = self._sysfs
@@ -162,7 +180,7 @@ class ClockSampler(threading.Thread):
     def summary(self):
         if not self.samples:
             return {"source": None, "note": "no clock/power interface readable on this box"}
-        out = {"source": self.source, "samples": len(self.samples)}
+        out = {"source": self.source, "samples": len(self.samples), "sysfs_card": self._sysfs}
         for k in ("sclk_mhz", "power_w", "temp_c"):
             v = [s[k] for s in self.samples if k in s]
             if v:
@@ -171,12 +189,31 @@ class ClockSampler(threading.Thread):
 
 
 # ------------------------------------------------------------------------------ CPU baseline
+def usable_cores():
+    """Cores this process may really use: the scheduler affinity mask, capped by the cgroup CPU
+    quota (os.cpu_count() reports the host's 256 hardware threads on a box that grants far fewer)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    n = min(n, max(1, q // int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())))
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1, n)
+
+
 def cpu_baseline(seconds, n_playout, mean_plies_per_game, length_source):
     """The oracle port on this host: 1 process, then os.cpu_count() independent processes side
     by side (python -m oracle.cpu_baseline: one torch thread each).  playouts/s is the measured
     quantity; games/s divides it by n_playout and by the SAME plies-per-game the GPU's
     steady-state estimate uses."""
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     half = max(seconds / 2.0, 2.0)
     env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "oracle.cpu_baseline", "--seconds", "%.1f" % half, "--n-playout", str(n_playout)]
@@ -201,7 +238,7 @@ def cpu_baseline(seconds, n_playout, mean_plies_per_game, length_source):
     cal = _load_json(_latest_profile("cpu_calibration.json") or "")
     out = {
         "value": (ppsN / n_playout / mean_plies_per_game) if mean_plies_per_game else None,
-        "unit": "games/s", "cores": len(many), "kind": "port",
+        "unit": "games/s", "cores": len(many), "host_hardware_threads": os.cpu_count(), "kind": "port",
         "sample": "%d + %d x %d playouts (%.0f s on 1 core, then %.0f s on %d cores as independent processes) of the first ply at "
                   "n_playout=%d from the opening (131 legal moves): oracle C port + batch-1 fp32 torch-CPU forward per leaf, 1 torch "
                   "thread per process; games/s = playouts/s / %d / %s plies per game (%s)"
@@ -328,6 +365,7 @@ def main():
     ap.add_argument("--library-trunk", action="store_true",
                     help="NOT the default: run the trunk convolutions through MIOpen (fp32 implicit GEMM) + the separate normalisation "
                          "kernel instead of the split-fp16 MFMA kernel (qz_nn_conv3x3_norm), for A/B runs")
+    ap.add_argument("--select-opts", type=int, default=0, help="A/B switches of k_select (qz_config.select_opts)")
     ap.add_argument("--length-file", default=None,
                     help="game-length sample for games_per_s_steady_state (default: newest profiles/round*/game_length_<n>playouts.json)")
     ap.add_argument("--clock-log", default=None, help="write the clock / power samples of the timed region to this JSON file")
@@ -356,7 +394,8 @@ def main():
         make_ev = lambda: net.evaluator(args.bn, dt, bool(args.channels_last))  # noqa: E731
     eng = BoardGroups(args.boards, args.groups, make_ev,
                       seed=qdist.shard_seed(args.seed, rank), device=dev,
-                      n_playout=args.playouts, c_puct=5, temp=1.0, is_selfplay=1, fix_terminal_sign=args.fix_terminal_sign)
+                      n_playout=args.playouts, c_puct=5, temp=1.0, is_selfplay=1, fix_terminal_sign=args.fix_terminal_sign,
+                      select_opts=args.select_opts)
     group_boards = args.boards // args.groups
     is_dist = world > 1
     write_planes = not args.no_planes
@@ -540,7 +579,7 @@ def main():
             ],
             "roofline_nn": None,
             "engine_stats": {kk: st1[kk] for kk in ("node_overflow", "games_aborted", "aborted_no_move", "aborted_max_plies", "aborted_pool",
-                                                    "nonfinite_values", "arena_bytes", "max_nodes", "max_edges", "tree_pages_total",
+                                                    "nonfinite_values", "arena_bytes", "max_nodes", "max_edges", "max_depth", "tree_pages_total",
                                                     "tree_pages_peak", "traj_pages_total", "traj_pages_peak")},
             "clocks": sampler.summary() if sampler else None,
         }

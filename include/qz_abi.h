@@ -128,6 +128,8 @@ typedef struct {
     int32_t traj_pool_pages;   /* 0 = auto: 16 per board (1 MB)                                  */
     int32_t traj_page_dwords;  /* 0 = 16,384 (64 KB); >= 256.  Small pages only make sense in tests */
     qz_rules_opts rules;       /* formulation of the leaf rules op (all zero = defaults)        */
+    int32_t select_opts;       /* A/B switches of the descent kernel (0 = defaults): bit 0 = do not warm the caches along
+                                  the previous descent, bit 1 = no readlane scan for nodes with <= 8 children */
 } qz_config;
 
 typedef struct {
@@ -152,6 +154,7 @@ typedef struct {
     int64_t traj_pages_total, traj_pages_in_use, traj_pages_peak;
     int64_t edges_scanned;     /* 32-byte edge records read by the descents (k_select's algorithmic bytes / 32) */
     int64_t edges_expanded;    /* edge records created by expansions                                    */
+    int64_t max_depth;         /* deepest descent so far (tree levels); descents beyond 2,048 levels back up by walking parent links */
 } qz_stats;
 
 /* MCTSPlayer.__init__ / MCTS.__init__ (mcts.py:89-100, 159-161) for n_boards trees +
