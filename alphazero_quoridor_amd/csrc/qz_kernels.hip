@@ -416,11 +416,15 @@ __device__ __forceinline__ uint32_t tree_alloc(const EngineDev& E, TreeView& T, 
 
 // MCTS._playout descent (mcts.py:107-113) + TreeNode.select/get_value (mcts.py:37-42, 64-70).
 // The kernel lasts as long as the DEEPEST of the batch's descents, and a descent is one chain of
-// dependent steps per level: edge block -> PUCT values -> argmax -> child block.  Three things
-// shorten a level without touching its arithmetic:
-//  * the blocks the previous playout walked through are touched up front (one parallel round of
-//    loads, narrow nodes only): late-game lines are forced, successive playouts share most of their
-//    path, so the chain then runs on L2 hits instead of Infinity-Cache / HBM round trips;
+// dependent steps per level: edge block -> PUCT values -> argmax -> child block.  Late-game lines
+// are forced and a tree that is re-used ply after ply grows hundreds of levels deep, so:
+//  * SPECULATIVE REPLAY.  Successive playouts of a tree share most of their path (a visit changes
+//    Q + u of a well-visited node far too little to change its argmax; they part near the bottom).
+//    The previous descent is on record (path_edges / path_blocks), so its levels are re-evaluated
+//    64 at a time, lane = level: level i needs only its own edge block and sqrt(N) of the edge
+//    chosen at level i-1 -- both in memory.  The longest prefix whose argmax comes out as before is
+//    exactly what the sequential walk would have done (same loads, same float64 expressions); the
+//    walk resumes at the first level that differs.  Nodes with more than 8 children end the replay.
 //  * every lane takes the float64 square root of ITS OWN edge's visit count while the division
 //    is in flight: the winner's is the next level's sqrt(N_parent), off the critical path;
 //  * nodes with <= 8 children (most of a long game: a mover without walls has 2-5 moves) pick
@@ -442,28 +446,71 @@ __global__ __launch_bounds__(TPB) void k_select(EngineDev E) {
     bool done = false, nonfinite = false;
     const bool live = rfl(E.status[b]) == QZ_PLAYING;
     uint32_t plen = 0u, scanned = 0u;
-    {   // warm the caches along the previous descent (path_blocks = first edge << 8 | edge count per
-        // level): one parallel round of loads next to the root's own loads above
-        const uint32_t prev = rfl(E.path_len[b]);
-        const uint32_t lim = (E.select_opts & 1) ? 0u : (prev < (uint32_t)QZ_PATH_CAP ? prev : (uint32_t)QZ_PATH_CAP);
-        uint32_t touched = 0u;
-        for (uint32_t i = (uint32_t)lane; i < lim; i += 64u) {
-            const unsigned long long pb = pblk[i];
-            const uint32_t cnt = (uint32_t)(pb & 0xFFull);
-            if (cnt >= 1u && cnt <= 8u) {  // <= 256 bytes = at most three lines; wide early-game nodes are not worth the traffic
-                const uint32_t* p = reinterpret_cast<const uint32_t*>(E.edge_pool + (size_t)(pb >> 8));
-                touched ^= p[0] ^ p[cnt * 8u - 1u];
-                if (cnt > 4u) touched ^= p[32];
-            }
-        }
-        asm volatile("" ::"v"(touched));  // the lines have landed: the chain below runs on cache hits
-    }
     if (live && ne > 0) {
         const TreeView T = tree_view(E, b, rfl(E.tree_half[b]), lane);
-        uint32_t eoff = rfl(E.root_eoff[b]);
+        const Edge* pool = T.pool;
+        uint32_t base = tree_phys(T, rfl(E.root_eoff[b]));
         double sq = sqrt((double)rootN);  // np.sqrt(self._parent._n_visits), float64
-        for (int depth = 0; depth < 1000000; depth++) {
-            const uint32_t base = tree_phys(T, eoff);
+        bool at_leaf = false;
+        // ---- replay of the previous descent, 64 levels per round
+        const uint32_t prev0 = rfl(E.path_len[b]);
+        const uint32_t prev = (E.select_opts & 1) ? 0u : (prev0 < (uint32_t)QZ_PATH_CAP ? prev0 : (uint32_t)QZ_PATH_CAP);
+        for (uint32_t c0 = 0; c0 < prev; c0 += 64u) {
+            const uint32_t i = c0 + (uint32_t)lane;
+            bool ok = i < prev;
+            uint32_t lbase = 0u, chosen = 0u, pN = rootN;
+            int lne = 0;
+            if (ok) {
+                const unsigned long long pb = pblk[i];
+                lbase = (uint32_t)(pb >> 8);
+                lne = (int)(pb & 0xFFull);
+                chosen = path[i];
+                if (i > 0u) pN = pool[path[i - 1u]].N;
+                ok = lne >= 1 && lne <= 8 && (i > 0u || lbase == base);
+            }
+            uint32_t lact = 0u, lcne = 0u, lN = 0u, lcoff = 0u;
+            if (ok) {
+                const double lsq = sqrt((double)pN);
+                double lbest = 0.0;
+                int arg = 0;
+                for (int k = 0; k < lne; k++) {
+                    const Edge ed = pool[lbase + (uint32_t)k];
+                    const float cp = E.c_puct * ed.P;
+                    const double u = (double)cp * lsq / (double)(1u + ed.N);
+                    const double val = ed.Q + u;
+                    if (k == 0 || val > lbest) {  // first maximum, like max() over the children dict
+                        lbest = val;
+                        arg = k;
+                        lact = ed.act;
+                        lcne = ed.cne;
+                        lN = ed.N;
+                        lcoff = ed.coff;
+                    }
+                }
+                ok = (lbase + (uint32_t)arg == chosen) && (lbest == lbest);
+            }
+            const uint64_t bad = ~__ballot(ok);
+            const int nconf = bad ? (__ffsll((unsigned long long)bad) - 1) : 64;  // leading levels of this round that came out as before
+            for (int jj = 0; jj < nconf; jj++) {  // wave-uniform: replay the confirmed moves on the scratch board
+                done = apply_action(bd, (int)rdl(lact, jj));
+                scanned += rdl((uint32_t)lne, jj);
+            }
+            plen += (uint32_t)nconf;
+            if (nconf > 0) {
+                const int last = nconf - 1;
+                pedge = rdl(chosen, last);
+                const int cne = (int)rdl(lcne, last);
+                if (cne == 0) {  // the confirmed prefix ends on a leaf (or a finished game)
+                    at_leaf = true;
+                    break;
+                }
+                sq = sqrt((double)rdl(lN, last));
+                base = tree_phys(T, rdl(lcoff, last));
+                ne = cne;
+            }
+            if (nconf < 64) break;
+        }
+        for (int depth = 0; depth < 1000000 && !at_leaf; depth++) {
             scanned += (uint32_t)ne;
             double best = -__builtin_inf();
             int bestk = 0x7fffffff;
@@ -472,7 +519,7 @@ __global__ __launch_bounds__(TPB) void k_select(EngineDev E) {
             uint32_t mCOff = 0u, mMisc = 0u;
             double mSq = 0.0;
             for (int k = lane; k < ne; k += 64) {
-                const Edge ed = T.pool[base + (uint32_t)k];        // one 32-byte record per lane
+                const Edge ed = pool[base + (uint32_t)k];          // one 32-byte record per lane
                 uint32_t N = ed.N;
                 float cp = E.c_puct * ed.P;                         // c_puct * self._P in float32
                 double u = (double)cp * sq / (double)(1u + N);      // mcts.py:69
@@ -520,7 +567,7 @@ __global__ __launch_bounds__(TPB) void k_select(EngineDev E) {
             const int cne = (int)((misc >> 8) & 0xFFu);
             if (cne == 0) break;  // TreeNode.is_leaf(): never expanded (or terminal)
             sq = rdl_f64(mSq, wl);
-            eoff = rdl(mCOff, wl);
+            base = tree_phys(T, rdl(mCOff, wl));
             ne = cne;
         }
     }
@@ -816,6 +863,7 @@ __device__ __forceinline__ void wave_reroot(EngineDev& E, int b, int lane, uint3
             E.tree_half[b] = (uint8_t)(half ^ 1u);
             E.tree_npages[tree_slot(E, b, half ^ 1u)] = dnp;
         }
+        E.path_len[b] = 0u;  // the recorded descent belongs to the tree that was just replaced
         E.n_nodes[b] = new_nodes;
         E.n_edges[b] = new_edges;
         E.root_N[b] = childN;
@@ -836,6 +884,7 @@ __device__ __forceinline__ void reset_board_state(EngineDev& E, int b) {
     E.root_N[b] = 0u;
     E.root_ne[b] = 0u;
     E.root_eoff[b] = 0u;
+    E.path_len[b] = 0u;
     E.ply[b] = 0u;
     E.status[b] = QZ_PLAYING;
     E.winner[b] = 0;
@@ -860,6 +909,7 @@ __global__ __launch_bounds__(TPB) void k_reset(EngineDev E, int reset_boards) {
         E.root_N[b] = 0u;
         E.root_ne[b] = 0u;
         E.root_eoff[b] = 0u;
+        E.path_len[b] = 0u;
         E.release[b] = 0;
     }
 }
