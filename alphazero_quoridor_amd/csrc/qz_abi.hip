@@ -29,6 +29,7 @@ hipError_t pool_init(const EngineDev&, hipStream_t);
 hipError_t harvest(const EngineDev&, uint64_t*, uint64_t*, uint64_t*, float*, float*, int32_t*, long long, hipStream_t);
 hipError_t sqrt_table(double*, int, hipStream_t);
 hipError_t conv3x3_norm(const float*, const void*, const float*, const float*, const float*, float*, long long, float, int, float, hipStream_t);
+hipError_t trunk(float*, float*, long long, int, const void* const*, const float* const*, const float* const*, const float*, float, int, hipStream_t);
 hipError_t rollout_begin(const uint64_t*, const uint64_t*, const uint64_t*, int, uint8_t*, uint8_t*, int8_t*, int*, hipStream_t);
 hipError_t rollout_step(uint64_t*, uint64_t*, uint64_t*, const uint32_t*, int, const uint8_t*, uint8_t*, int8_t*, int*, uint64_t, int, int, hipStream_t);
 hipError_t instnorm_act(const float*, const float*, const float*, const float*, float*, long long, int, int, float, hipStream_t);
@@ -657,21 +658,16 @@ int qz_nn_conv3x3_norm(const float* x, const void* w16, const float* gamma, cons
     return 0;
 }
 int qz_nn_trunk(float* x, float* tmp, int64_t n, int n_blocks, const void* const* w16, const float* const* gamma, const float* const* beta,
-                const float* inv_scale, float eps, void* stream) {
+                const float* inv_scale, float eps, int fused, void* stream) {
     int r;
     if ((r = device_check())) return r;
     if (n < 0 || n_blocks < 0) return fail(QZ_E_INVALID, "n < 0 or n_blocks < 0");
     if (n == 0 || n_blocks == 0) return 0;
-    if (!x || !tmp || !w16 || !gamma || !beta || !inv_scale) return fail(QZ_E_INVALID, "null argument");
+    if (!x || !w16 || !gamma || !beta || !inv_scale || (!fused && !tmp)) return fail(QZ_E_INVALID, "null argument");
     if ((((uintptr_t)x | (uintptr_t)tmp) & 15) != 0) return fail(QZ_E_INVALID, "tensors must be 16-byte aligned");
-    hipStream_t s = (hipStream_t)stream;
-    for (int b = 0; b < n_blocks; b++) {
-        const int l0 = 2 * b, l1 = 2 * b + 1;
-        if (!w16[l0] || !w16[l1] || !gamma[l0] || !gamma[l1] || !beta[l0] || !beta[l1]) return fail(QZ_E_INVALID, "null layer tensor");
-        // y = relu(bn1(conv1(x)));  x = relu(bn2(conv2(y)) + x)   (policy_value_net.py:33-48)
-        HIP_TRY(qzl::conv3x3_norm(x, w16[l0], gamma[l0], beta[l0], nullptr, tmp, (long long)n, inv_scale[l0], 1, eps, s));
-        HIP_TRY(qzl::conv3x3_norm(tmp, w16[l1], gamma[l1], beta[l1], x, x, (long long)n, inv_scale[l1], 1, eps, s));
-    }
+    for (int l = 0; l < 2 * n_blocks; l++)
+        if (!w16[l] || !gamma[l] || !beta[l]) return fail(QZ_E_INVALID, "null layer tensor");
+    HIP_TRY(qzl::trunk(x, tmp, (long long)n, n_blocks, w16, gamma, beta, inv_scale, eps, fused, (hipStream_t)stream));
     return 0;
 }
 int qz_engine_leaf_boards(qz_engine* e, qz_boards* boards_out, const uint8_t** terminal_out) {

@@ -229,6 +229,180 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// k_trunk: the WHOLE residual trunk (2 n_blocks layers) in one launch.  A workgroup keeps its two
+// leaves on the CU for all layers: the next layer's input never leaves LDS (the epilogue writes
+// the normalised activations straight into the fp16 hi / lo images), and the residual of a block
+// never leaves the registers -- the lane that owns output element (row, channel) of one layer owns
+// the same element of every layer, so the block input it needs two layers later is a value it
+// produced itself.  HBM traffic: the first layer's input once, the last layer's output once
+// (170 MB per 4,096 leaves instead of 2.1 GB for ten separate launches), and the convolution
+// runs at the matrix pipe's pace instead of HBM's.
+constexpr int MAX_TRUNK_LAYERS = 16;
+struct TrunkArgs {
+    const _Float16* w16[MAX_TRUNK_LAYERS];
+    const float* gamma[MAX_TRUNK_LAYERS];
+    const float* beta[MAX_TRUNK_LAYERS];
+    float inv_scale[MAX_TRUNK_LAYERS];
+};
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_trunk(const float* __restrict__ x, float* __restrict__ out,
+                                                                                           TrunkArgs A, int n_layers, long long n, float eps) {
+    __shared__ ConvShared sm;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int nt = wave & 1, mg = wave >> 1;
+    const long long b0 = (long long)blockIdx.x * CS;
+    const int co = 32 * nt + r;
+    const size_t obase = (size_t)b0 * NPOS * C + (size_t)co;
+    const bool full = b0 + CS <= n;
+
+    stage_input(sm, x, b0, n, tid);
+
+    // this lane's A rows per tile: vector offset of (leaf, position) and which of the 9 taps stay on the
+    // board (the others, and rows past the last leaf, read the zero row)
+    int rbase[3];
+    uint32_t vmask[3];
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+        const int m = 32 * (3 * mg + t) + r;
+        const bool live = m < CS * NPOS;
+        const int s = m >= NPOS ? 1 : 0, p = m - NPOS * s;
+        const int y = p / 9, xx = p - 9 * y;
+        rbase[t] = (s * ROWS + p) * RV + h;
+        uint32_t vm = 0u;
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            const int yy = y + tap / 3 - 1, x2 = xx + tap % 3 - 1;
+            if (live && (unsigned)yy < 9u && (unsigned)x2 < 9u) vm |= 1u << tap;
+        }
+        vmask[t] = vm;
+    }
+    // the block input at this lane's own output elements (= the trunk input for the first block)
+    floatx16 resid[3];
+#pragma unroll
+    for (int t = 0; t < 3; t++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int m = 32 * (3 * mg + t) + 4 * h + (i & 3) + 8 * (i >> 2);
+            const int sidx = m >= NPOS ? 1 : 0;
+            resid[t][i] = (m < 2 * NPOS && b0 + sidx < n) ? x[obase + (size_t)m * C] : 0.f;
+        }
+    __syncthreads();
+
+    constexpr int PARTV = 9 * 4 * C * 2;
+#pragma unroll 1
+    for (int l = 0; l < n_layers; l++) {
+        floatx16 acc[3];
+#pragma unroll
+        for (int t = 0; t < 3; t++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[t][i] = 0.f;
+        const half8* wb = reinterpret_cast<const half8*>(A.w16[l]) + (size_t)(32 * nt + r) * 2 + h;
+        // B ring of four register sets (slot = k & 3), filled two k steps ahead
+        half8 bh[4], bl[4];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            bh[k] = wb[k * (C * 2)];
+            bl[k] = wb[PARTV + k * (C * 2)];
+        }
+#pragma unroll 1
+        for (int tap = 0; tap < 9; tap++) {
+            int ro[3];
+            const int delta = ((tap / 3 - 1) * 9 + (tap % 3 - 1)) * RV;
+#pragma unroll
+            for (int t = 0; t < 3; t++) ro[t] = ((vmask[t] >> tap) & 1u) ? rbase[t] + delta : ZERO_ROW * RV + h;
+#pragma unroll
+            for (int kc = 0; kc < 4; kc++) {
+                const int k = 4 * tap + kc;
+                if (k + 2 < 36) {
+                    bh[(kc + 2) & 3] = wb[(k + 2) * (C * 2)];
+                    bl[(kc + 2) & 3] = wb[PARTV + (k + 2) * (C * 2)];
+                }
+                asm volatile("" ::: "memory");
+                const half8 b_hi = bh[kc], b_lo = bl[kc];
+#pragma unroll
+                for (int t = 0; t < 3; t++) {
+                    const half8 a_hi = sm.a_hi[ro[t] + 2 * kc];
+                    const half8 a_lo = sm.a_lo[ro[t] + 2 * kc];
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, acc[t], 0, 0, 0);
+                }
+            }
+        }
+        // ---- per-leaf statistics (two passes), exactly as in k_conv3x3_norm
+        const float inv_scale = A.inv_scale[l];
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int t = 0; t < 3; t++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int m = 32 * (3 * mg + t) + (i & 3) + 8 * (i >> 2) + 4 * h;
+                const float y = acc[t][i] * inv_scale;
+                acc[t][i] = y;
+                s0 += m < NPOS ? y : 0.f;
+                s1 += (m >= NPOS && m < 2 * NPOS) ? y : 0.f;
+            }
+        s0 += __shfl_xor(s0, 32, 64);
+        s1 += __shfl_xor(s1, 32, 64);
+        if (h == 0) {
+            sm.red[0][mg][0][co] = s0;
+            sm.red[0][mg][1][co] = s1;
+        }
+        __syncthreads();  // also: every wave is done reading this layer's input images
+        const float mean0 = (sm.red[0][0][0][co] + sm.red[0][1][0][co]) * (1.0f / 81.0f);
+        const float mean1 = (sm.red[0][0][1][co] + sm.red[0][1][1][co]) * (1.0f / 81.0f);
+        float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+        for (int t = 0; t < 3; t++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int m = 32 * (3 * mg + t) + (i & 3) + 8 * (i >> 2) + 4 * h;
+                const float d0 = acc[t][i] - mean0, d1 = acc[t][i] - mean1;
+                q0 += m < NPOS ? d0 * d0 : 0.f;
+                q1 += (m >= NPOS && m < 2 * NPOS) ? d1 * d1 : 0.f;
+            }
+        q0 += __shfl_xor(q0, 32, 64);
+        q1 += __shfl_xor(q1, 32, 64);
+        if (h == 0) {
+            sm.red[1][mg][0][co] = q0;
+            sm.red[1][mg][1][co] = q1;
+        }
+        __syncthreads();
+        const float g = A.gamma[l][co], bt = A.beta[l][co];
+        const float k0 = g / sqrtf((sm.red[1][0][0][co] + sm.red[1][1][0][co]) * (1.0f / 81.0f) + eps);
+        const float k1 = g / sqrtf((sm.red[1][0][1][co] + sm.red[1][1][1][co]) * (1.0f / 81.0f) + eps);
+        const bool second = (l & 1) != 0;        // conv2 of a block: + block input, result = next block input
+        const bool last = l == n_layers - 1;
+        _Float16* img_hi = reinterpret_cast<_Float16*>(sm.a_hi);
+        _Float16* img_lo = reinterpret_cast<_Float16*>(sm.a_lo);
+#pragma unroll
+        for (int t = 0; t < 3; t++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int m = 32 * (3 * mg + t) + 4 * h + (i & 3) + 8 * (i >> 2);
+                const int sidx = m >= NPOS ? 1 : 0;
+                float v = (acc[t][i] - (sidx ? mean1 : mean0)) * (sidx ? k1 : k0) + bt;
+                if (second) v += resid[t][i];
+                v = fmaxf(v, 0.f);
+                if (second) resid[t][i] = v;
+                if (m < 2 * NPOS) {
+                    if (last) {
+                        if (full || b0 + sidx < n) out[obase + (size_t)m * C] = v;
+                    } else {  // the next layer's input image: row = leaf * 82 + position, column = channel
+                        const int o = (sidx * ROWS + (m - NPOS * sidx)) * RSTR + co;
+                        const _Float16 hi = (_Float16)v;
+                        img_hi[o] = hi;
+                        img_lo[o] = (_Float16)(v - (float)hi);
+                    }
+                }
+            }
+        __syncthreads();  // the new images are complete before anybody reads them
+    }
+}
+
 }  // namespace
 
 namespace qzl {
@@ -242,5 +416,34 @@ hipError_t conv3x3_norm(const float* x, const void* w16, const float* gamma, con
     else if (relu) hipLaunchKernelGGL((k_conv3x3_norm<false, true>), grid, dim3(256), 0, s, x, w, gamma, beta, residual, out, n, inv_scale, eps);
     else hipLaunchKernelGGL((k_conv3x3_norm<false, false>), grid, dim3(256), 0, s, x, w, gamma, beta, residual, out, n, inv_scale, eps);
     return hipGetLastError();
+}
+hipError_t trunk(float* x, float* tmp, long long n, int n_blocks, const void* const* w16, const float* const* gamma, const float* const* beta,
+                 const float* inv_scale, float eps, int fused, hipStream_t s) {
+    if (n <= 0 || n_blocks <= 0) return hipSuccess;
+    const int nl = 2 * n_blocks;
+    if (fused && nl <= MAX_TRUNK_LAYERS) {  // one persistent launch: activations stay on the CU
+        TrunkArgs A;
+        for (int l = 0; l < nl; l++) {
+            A.w16[l] = reinterpret_cast<const _Float16*>(w16[l]);
+            A.gamma[l] = gamma[l];
+            A.beta[l] = beta[l];
+            A.inv_scale[l] = inv_scale[l];
+        }
+        for (int l = nl; l < MAX_TRUNK_LAYERS; l++) {
+            A.w16[l] = nullptr;
+            A.gamma[l] = A.beta[l] = nullptr;
+            A.inv_scale[l] = 0.f;
+        }
+        hipLaunchKernelGGL(k_trunk, dim3((unsigned)((n + CS - 1) / CS)), dim3(256), 0, s, x, x, A, nl, n, eps);
+        return hipGetLastError();
+    }
+    for (int b = 0; b < n_blocks; b++) {
+        // y = relu(bn1(conv1(x)));  x = relu(bn2(conv2(y)) + x)   (policy_value_net.py:33-48)
+        hipError_t e = conv3x3_norm(x, w16[2 * b], gamma[2 * b], beta[2 * b], nullptr, tmp, n, inv_scale[2 * b], 1, eps, s);
+        if (e != hipSuccess) return e;
+        e = conv3x3_norm(tmp, w16[2 * b + 1], gamma[2 * b + 1], beta[2 * b + 1], x, x, n, inv_scale[2 * b + 1], 1, eps, s);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 }  // namespace qzl

@@ -94,7 +94,7 @@ class LeafEvaluator:
     """
 
     def __init__(self, net: nn.Module, bn_mode="per_leaf", dtype=torch.float32, channels_last=False, fused_norm=True,
-                 board_input_layer=True, fused_head=True, mfma_trunk=True):
+                 board_input_layer=True, fused_head=True, mfma_trunk=True, fused_trunk=True):
         assert bn_mode in ("per_leaf", "batch", "eval")
         self.fused_norm = fused_norm  # per_leaf on the GPU: use the one-pass HIP normalisation kernel
         # first layer straight from the packed boards (qz_nn_input_layer) when the caller hands them
@@ -112,6 +112,7 @@ class LeafEvaluator:
         # matrix cores with split operands (fp32 accuracy; qz_nn_conv3x3_norm): fp32, channels-last, per-leaf
         self.mfma_trunk = mfma_trunk and fused_norm and bn_mode == "per_leaf" and dtype == torch.float32 and channels_last
         self._w16 = None
+        self.fused_trunk = fused_trunk  # all ten layers in ONE persistent launch (activations stay on the CU)
         self.trunk_events = None   # bench.py: a list that receives (start, end) HIP events around trunk-layer launches
         self.net = net
         self.bn_mode = bn_mode
@@ -228,11 +229,11 @@ class LeafEvaluator:
                                 (C.c_void_p * L)(*[self._layers[i + 1][3].data_ptr() for i in range(L)]),
                                 (C.c_float * L)(*[self._w16[i][1] for i in range(L)]))
         w, g, b, sc = self._trunk_args
-        # scratch of the call: from the caching allocator every time (one evaluator may serve several board
-        # groups on different streams at once, so nothing mutable is kept on the object)
-        tmp = torch.empty_like(x, memory_format=torch.channels_last)
-        _cabi.check(_cabi.load().qz_nn_trunk(x.data_ptr(), tmp.data_ptr(), x.shape[0], N_RES, w, g, b, sc, BN_EPS,
-                                             torch.cuda.current_stream(x.device).cuda_stream))
+        # scratch of the layer-by-layer route: from the caching allocator every time (one evaluator may serve
+        # several board groups on different streams at once, so nothing mutable is kept on the object)
+        tmp = None if self.fused_trunk else torch.empty_like(x, memory_format=torch.channels_last)
+        _cabi.check(_cabi.load().qz_nn_trunk(x.data_ptr(), tmp.data_ptr() if tmp is not None else 0, x.shape[0], N_RES, w, g, b, sc, BN_EPS,
+                                             int(self.fused_trunk), torch.cuda.current_stream(x.device).cuda_stream))
         return x
 
     @staticmethod

@@ -284,12 +284,15 @@ int qz_nn_conv3x3_norm(const float* x /*[dev]*/, const void* w16 /*[dev]*/, cons
                        const float* beta /*[dev][64]*/, const float* residual /*[dev] or NULL*/, float* out /*[dev]*/, int64_t n,
                        float inv_scale, int relu, float eps, void* stream);
 /* The whole residual trunk (policy_value_net.py:75-83: n_blocks x [conv-bn-relu-conv-bn-(+x)-relu])
- * as 2 n_blocks launches of the layer above from ONE call: x is updated in place, tmp is a scratch
- * tensor of the same size.  w16 / gamma / beta / inv_scale: [2 n_blocks] HOST arrays (of device
- * pointers / of floats), layer order res1.conv1, res1.conv2, res2.conv1, ... */
-int qz_nn_trunk(float* x /*[dev] in/out*/, float* tmp /*[dev]*/, int64_t n, int n_blocks, const void* const* w16 /*[host]*/,
+ * from ONE call; x is updated in place.  fused != 0 (n_blocks <= 8): ONE persistent launch in which
+ * a workgroup keeps its leaves' activations in LDS / registers across all layers -- HBM sees the
+ * input once and the output once; tmp is not used (may be NULL).  fused == 0: 2 n_blocks launches
+ * of the layer kernel above through the scratch tensor tmp (same size as x).  Same values either
+ * way.  w16 / gamma / beta / inv_scale: [2 n_blocks] HOST arrays (of device pointers / of floats),
+ * layer order res1.conv1, res1.conv2, res2.conv1, ... */
+int qz_nn_trunk(float* x /*[dev] in/out*/, float* tmp /*[dev] or NULL*/, int64_t n, int n_blocks, const void* const* w16 /*[host]*/,
                 const float* const* gamma /*[host]*/, const float* const* beta /*[host]*/, const float* inv_scale /*[host]*/,
-                float eps, void* stream);
+                float eps, int fused, void* stream);
 /* the engine's current leaf boards (what qz_mcts_select just produced) and their terminal flags,
  * as device pointers owned by the engine: input of qz_nn_input_layer */
 int qz_engine_leaf_boards(qz_engine* e, qz_boards* boards_out, const uint8_t** terminal_out);

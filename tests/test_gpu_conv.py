@@ -124,3 +124,26 @@ def test_evaluator_with_mfma_trunk_vs_float64_and_library_trunk(gpu_device, gold
     assert e_fast[0] < 2e-6 and e_fast[1] < 1e-5
     assert e_fast[1] <= max(2.0 * e_slow[1], 6e-6)   # no worse than the library's fp32 path (within its own noise)
     assert dp < 5e-6 and dv < 2e-5
+
+
+def test_fused_trunk_equals_layer_by_layer(gpu_device):
+    """qz_nn_trunk: the persistent one-launch trunk (activations resident on the CU) computes the
+    same floats as ten launches of the layer kernel -- same MFMA sequence, same epilogue
+    arithmetic -- for batch sizes with and without a ragged last workgroup."""
+    from _stubs import det_fill_state_dict
+    from alphazero_quoridor_amd.policy_value_net import LeafEvaluator, PolicyValueNet
+
+    pvn = PolicyValueNet(use_gpu=True, device=gpu_device)
+    pvn.policy_value_net.load_state_dict(det_fill_state_dict(pvn.policy_value_net.state_dict(), 2024))
+    fused = LeafEvaluator(pvn.policy_value_net, "per_leaf", channels_last=True, fused_trunk=True)
+    layered = LeafEvaluator(pvn.policy_value_net, "per_leaf", channels_last=True, fused_trunk=False)
+    g = torch.Generator().manual_seed(11)
+    for B in (1, 2, 3, 64, 777, 4096):
+        x = torch.relu(torch.randn((B, 64, 9, 9), generator=g)).to(gpu_device).contiguous(memory_format=torch.channels_last)
+        a = fused._trunk_mfma(x.clone(memory_format=torch.preserve_format))
+        b = layered._trunk_mfma(x.clone(memory_format=torch.preserve_format))
+        assert torch.isfinite(a).all() and torch.equal(a, b), (B, (a - b).abs().max().item())
+    planes = (torch.rand((130, 26, 9, 9), generator=g) > 0.8).float().to(gpu_device)
+    p1, v1 = fused(planes)
+    p2, v2 = layered(planes)
+    assert torch.equal(p1, p2) and torch.equal(v1, v2)
