@@ -608,8 +608,13 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             eng.close()
             torch.cuda.empty_cache()
-            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, args.playouts, ss["mean_plies_per_game"] if ss else None,
-                                               ss["length_source"] if ss else "no length sample")
+            if ss:
+                L_cpu, L_src = ss["mean_plies_per_game"], ss["length_source"]
+            else:  # no length sample for this playout count: fall back to the games seen in this run, and say so
+                seen = lengths["timed"] + lengths["warmup"] + lengths["desync"]
+                L_cpu = float(np.mean(seen)) if seen else None
+                L_src = "NO length sample for n_playout=%d: mean length of the %d games finished in this run (mostly desync games)" % (args.playouts, len(seen))
+            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, args.playouts, L_cpu, L_src)
         print(json.dumps(out))
     eng.close()
     if is_dist:

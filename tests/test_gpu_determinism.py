@@ -56,6 +56,63 @@ def test_trunk_kernel_is_deterministic_and_stream_safe(gpu_device):
     assert torch.equal(solo[0], ref[3][100])
 
 
+def _concurrent_equal(fn, inputs, reps=8):
+    """fn(input, stream) -> tensors; the same on the main stream alone and on one stream per input at once"""
+    torch.cuda.synchronize()
+    main = torch.cuda.current_stream()
+    ref = [fn(x, main) for x in inputs]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in inputs]
+    for rep in range(reps):
+        outs = []
+        for x, st in zip(inputs, streams):
+            with torch.cuda.stream(st):
+                outs.append(fn(x, st))
+        torch.cuda.synchronize()
+        for i, (a, b) in enumerate(zip(ref, outs)):
+            for ta, tb in zip(a, b):
+                if not torch.equal(ta, tb):
+                    return "input %d differs in round %d (max |d| %.3g)" % (i, rep, (ta.float() - tb.float()).abs().max().item())
+    return None
+
+
+def test_input_layer_and_head_kernels_are_stream_safe(gpu_device):
+    """The two ends of the network, each alone, on several streams at once."""
+    import ctypes as C
+
+    from alphazero_quoridor_amd import _cabi
+    from alphazero_quoridor_amd.boards import DeviceBoards
+    from synth import synth_positions
+
+    ev = _net(gpu_device).evaluator("per_leaf")
+    L = _cabi.load()
+    dbs = [DeviceBoards.from_packed(synth_positions(32 + 7 * i, seed=40 + i), gpu_device) for i in range(4)]
+
+    def first_layer(db, st):
+        return (ev._first_layer_from_boards((db.struct(), 0, db.n)),)
+
+    assert _concurrent_equal(first_layer, dbs) is None, "k_input_layer"
+    g = torch.Generator().manual_seed(9)
+    xs = [torch.relu(torch.randn((32 + 7 * i, 64, 9, 9), generator=g)).to(gpu_device).contiguous(memory_format=torch.channels_last) for i in range(4)]
+    hd = ev._head
+
+    def head(x, st):
+        B = x.shape[0]
+        p = torch.empty((B, 140), dtype=torch.float32, device=x.device)
+        v = torch.empty(B, dtype=torch.float32, device=x.device)
+        _cabi.check(L.qz_nn_head(x.data_ptr(), B, hd[0].data_ptr(), hd[8].data_ptr() if len(hd) > 8 else 0, hd[1].data_ptr(), hd[2].data_ptr(),
+                                 hd[3].data_ptr(), hd[4].data_ptr(), hd[5].data_ptr(), hd[6].data_ptr(), hd[7].data_ptr(), p.data_ptr(),
+                                 v.data_ptr(), 1e-5, st.cuda_stream))
+        return p, v
+
+    assert _concurrent_equal(head, xs) is None, "k_head"
+
+    def trunk(x, st):
+        return (ev._trunk_mfma(x.clone(memory_format=torch.preserve_format)),)
+
+    assert _concurrent_equal(trunk, xs) is None, "qz_nn_trunk"
+
+
 def test_evaluator_is_deterministic_across_streams(gpu_device):
     from alphazero_quoridor_amd import rules
     from alphazero_quoridor_amd.boards import DeviceBoards
