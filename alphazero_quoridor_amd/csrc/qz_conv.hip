@@ -44,6 +44,8 @@ constexpr int RSTR = 72;     // halfs per LDS row (144 B)
 constexpr int RV = RSTR / 8; // ... in 16-byte vectors
 constexpr int C = 64;
 constexpr int ZERO_ROW = NPOS;  // of leaf 0
+constexpr int SSTR = 72;     // floats per row of the fp32 hand-over image of k_trunk (4 x 72 = 32 mod 64 banks)
+static_assert(CS * NPOS * SSTR * 4 <= 2 * CS * ROWS * RSTR * 2, "the fp32 hand-over image must fit in the two fp16 images");
 
 struct ConvShared {
     half8 a_hi[CS * ROWS * RV];  // 16-byte vectors: a fragment is ONE ds_read_b128
@@ -376,8 +378,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const float k1 = g / sqrtf((sm.red[1][0][1][co] + sm.red[1][1][1][co]) * (1.0f / 81.0f) + eps);
         const bool second = (l & 1) != 0;        // conv2 of a block: + block input, result = next block input
         const bool last = l == n_layers - 1;
-        _Float16* img_hi = reinterpret_cast<_Float16*>(sm.a_hi);
-        _Float16* img_lo = reinterpret_cast<_Float16*>(sm.a_lo);
+        // The layer's output as fp32 [row][channel] in the memory of the (now dead) input images, row stride
+        // 72 floats: a wave's 64 stores (32 channels of row m, 32 of row m + 4) hit 64 different banks.
+        float* stage = reinterpret_cast<float*>(sm.a_hi);
 #pragma unroll
         for (int t = 0; t < 3; t++)
 #pragma unroll
@@ -391,14 +394,51 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 if (m < 2 * NPOS) {
                     if (last) {
                         if (full || b0 + sidx < n) out[obase + (size_t)m * C] = v;
-                    } else {  // the next layer's input image: row = leaf * 82 + position, column = channel
-                        const int o = (sidx * ROWS + (m - NPOS * sidx)) * RSTR + co;
-                        const _Float16 hi = (_Float16)v;
-                        img_hi[o] = hi;
-                        img_lo[o] = (_Float16)(v - (float)hi);
+                    } else {
+                        stage[m * SSTR + co] = v;
                     }
                 }
             }
+        if (last) break;
+        __syncthreads();
+        // every thread picks up its share of the output as float4 (16 lanes = one row = all 64 banks) ...
+        float4 pick[11];
+#pragma unroll
+        for (int q = 0; q < 11; q++) {
+            const int idx = tid + 256 * q;  // (row, channel quad): 162 x 16 = 2,592 float4
+            pick[q] = idx < CS * NPOS * 16 ? *reinterpret_cast<const float4*>(&stage[(idx >> 4) * SSTR + (idx & 15) * 4]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();
+        // ... and writes it back as the next layer's fp16 hi / lo images (the zero rows are untouched)
+#pragma unroll
+        for (int q = 0; q < 11; q++) {
+            const int idx = tid + 256 * q;
+            if (idx < CS * NPOS * 16) {
+                const int m = idx >> 4, c4 = idx & 15;
+                const int sidx = m >= NPOS ? 1 : 0;
+                const float4 v = pick[q];
+                half4 hi, lo;
+                hi[0] = (_Float16)v.x;
+                hi[1] = (_Float16)v.y;
+                hi[2] = (_Float16)v.z;
+                hi[3] = (_Float16)v.w;
+                lo[0] = (_Float16)(v.x - (float)hi[0]);
+                lo[1] = (_Float16)(v.y - (float)hi[1]);
+                lo[2] = (_Float16)(v.z - (float)hi[2]);
+                lo[3] = (_Float16)(v.w - (float)hi[3]);
+                const int o = (sidx * ROWS + (m - NPOS * sidx)) * RSTR + c4 * 4;
+                *reinterpret_cast<half4*>(reinterpret_cast<_Float16*>(sm.a_hi) + o) = hi;
+                *reinterpret_cast<half4*>(reinterpret_cast<_Float16*>(sm.a_lo) + o) = lo;
+            }
+        }
+        if (tid < CS * 16) {  // the hand-over image covered the all-zero rows: restore them
+            const int sz = tid >> 4, c4 = tid & 15;
+            half4 z;
+            z[0] = z[1] = z[2] = z[3] = (_Float16)0.f;
+            const int o = (sz * ROWS + NPOS) * RSTR + c4 * 4;
+            *reinterpret_cast<half4*>(reinterpret_cast<_Float16*>(sm.a_hi) + o) = z;
+            *reinterpret_cast<half4*>(reinterpret_cast<_Float16*>(sm.a_lo) + o) = z;
+        }
         __syncthreads();  // the new images are complete before anybody reads them
     }
 }
