@@ -44,8 +44,6 @@ constexpr int RSTR = 72;     // halfs per LDS row (144 B)
 constexpr int RV = RSTR / 8; // ... in 16-byte vectors
 constexpr int C = 64;
 constexpr int ZERO_ROW = NPOS;  // of leaf 0
-constexpr int SSTR = 72;     // floats per row of the fp32 hand-over image of k_trunk (4 x 72 = 32 mod 64 banks)
-static_assert(CS * NPOS * SSTR * 4 <= 2 * CS * ROWS * RSTR * 2, "the fp32 hand-over image must fit in the two fp16 images");
 
 struct ConvShared {
     half8 a_hi[CS * ROWS * RV];  // 16-byte vectors: a fragment is ONE ds_read_b128
@@ -233,14 +231,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 
 
 // ------------------------------------------------------------------------------------------------
-// k_trunk: the WHOLE residual trunk (2 n_blocks layers) in one launch.  A workgroup keeps its two
-// leaves on the CU for all layers: the next layer's input never leaves LDS (the epilogue writes
-// the normalised activations straight into the fp16 hi / lo images), and the residual of a block
-// never leaves the registers -- the lane that owns output element (row, channel) of one layer owns
-// the same element of every layer, so the block input it needs two layers later is a value it
-// produced itself.  HBM traffic: the first layer's input once, the last layer's output once
-// (170 MB per 4,096 leaves instead of 2.1 GB for ten separate launches), and the convolution
-// runs at the matrix pipe's pace instead of HBM's.
+// k_trunk: the WHOLE residual trunk (2 n_blocks layers) in one launch.  A workgroup of TWO waves
+// keeps ONE leaf on the CU for all layers:
+//   * wave w owns output channels 32 w .. 32 w + 31 of all 81 positions (three 32-row tiles, rows
+//     81..95 idle), so the per-leaf statistics never leave the wave: registers + one shuffle
+//     between the lane halves, no LDS, no barrier;
+//   * the next layer's input never leaves LDS: the epilogue converts the normalised activations to
+//     fp16 hi / lo in registers, pairs of neighbouring channels meet by one DPP move and go
+//     straight into the two images as packed 32-bit stores;
+//   * the residual of a block never leaves the registers: the lane that owns output element
+//     (position, channel) of one layer owns it in every layer, so the block input it needs two
+//     layers later is a value it produced itself.
+// Two barriers per layer (both waves are done reading the images / the new images are complete),
+// between two waves only.  HBM traffic: the first layer's input once, the last layer's output
+// once: 170 MB per 4,096 leaves instead of 2.1 GB for ten separate launches -- whose workgroups
+// all start together, stage together (HBM burst, matrix pipe idle), multiply together (HBM idle)
+// and store together: the layer-by-layer route spends half its time in those bursts.
 constexpr int MAX_TRUNK_LAYERS = 16;
 struct TrunkArgs {
     const _Float16* w16[MAX_TRUNK_LAYERS];
@@ -248,50 +254,83 @@ struct TrunkArgs {
     const float* beta[MAX_TRUNK_LAYERS];
     float inv_scale[MAX_TRUNK_LAYERS];
 };
+struct TrunkShared {
+    half8 a_hi[ROWS * RV];  // one leaf: 81 positions + the all-zero row, 144-byte rows
+    half8 a_lo[ROWS * RV];
+};
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_trunk(const float* __restrict__ x, float* __restrict__ out,
-                                                                                           TrunkArgs A, int n_layers, long long n, float eps) {
-    __shared__ ConvShared sm;
-    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_trunk(const float* __restrict__ x, float* __restrict__ out, TrunkArgs A, int n_layers, float eps
+#ifdef QZ_TRUNK_STAMPS
+                                               , unsigned long long* stamps  // [workgroup][wave][8]: diagnostic build only
+#endif
+                                               ) {
+    __shared__ TrunkShared sm;
+    const int tid = (int)threadIdx.x, lane = tid & 63, nt = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int nt = wave & 1, mg = wave >> 1;
-    const long long b0 = (long long)blockIdx.x * CS;
     const int co = 32 * nt + r;
-    const size_t obase = (size_t)b0 * NPOS * C + (size_t)co;
-    const bool full = b0 + CS <= n;
-
-    stage_input(sm, x, b0, n, tid);
-
-    // this lane's A rows per tile: vector offset of (leaf, position) and which of the 9 taps stay on the
-    // board (the others, and rows past the last leaf, read the zero row)
+    const size_t obase = (size_t)blockIdx.x * NPOS * C + (size_t)co;
+#ifdef QZ_TRUNK_STAMPS
+    unsigned long long t_stage = 0, t_loop = 0, t_stat = 0, t_hand = 0, t_mark = __builtin_amdgcn_s_memtime();
+    const unsigned long long t_begin = t_mark;
+#define QZ_STAMP(acc_var) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc_var += now_ - t_mark; t_mark = now_; }
+#else
+#define QZ_STAMP(acc_var)
+#endif
+    {   // stage the leaf (fp32 [81][64]) as fp16 hi / lo images
+        const float4* x4 = reinterpret_cast<const float4*>(x) + (size_t)blockIdx.x * NPOS * 16;
+        _Float16* ih = reinterpret_cast<_Float16*>(sm.a_hi);
+        _Float16* il = reinterpret_cast<_Float16*>(sm.a_lo);
+        for (int i = tid; i < NPOS * 16; i += 128) {
+            const int p = i >> 4, c4 = i & 15;
+            const float4 v = x4[i];
+            half4 hi, lo;
+            hi[0] = (_Float16)v.x;
+            hi[1] = (_Float16)v.y;
+            hi[2] = (_Float16)v.z;
+            hi[3] = (_Float16)v.w;
+            lo[0] = (_Float16)(v.x - (float)hi[0]);
+            lo[1] = (_Float16)(v.y - (float)hi[1]);
+            lo[2] = (_Float16)(v.z - (float)hi[2]);
+            lo[3] = (_Float16)(v.w - (float)hi[3]);
+            *reinterpret_cast<half4*>(ih + p * RSTR + c4 * 4) = hi;
+            *reinterpret_cast<half4*>(il + p * RSTR + c4 * 4) = lo;
+        }
+        if (tid < 16) {
+            half4 z;
+            z[0] = z[1] = z[2] = z[3] = (_Float16)0.f;
+            *reinterpret_cast<half4*>(ih + NPOS * RSTR + tid * 4) = z;
+            *reinterpret_cast<half4*>(il + NPOS * RSTR + tid * 4) = z;
+        }
+    }
+    // this lane's A rows per tile (row m = 32 t + r): vector offset of the position and which of the 9 taps
+    // stay on the board (the others, and rows 81..95, read the zero row)
     int rbase[3];
     uint32_t vmask[3];
 #pragma unroll
     for (int t = 0; t < 3; t++) {
-        const int m = 32 * (3 * mg + t) + r;
-        const bool live = m < CS * NPOS;
-        const int s = m >= NPOS ? 1 : 0, p = m - NPOS * s;
-        const int y = p / 9, xx = p - 9 * y;
-        rbase[t] = (s * ROWS + p) * RV + h;
+        const int m = 32 * t + r;
+        const int y = m / 9, xx = m - 9 * y;
+        rbase[t] = m * RV + h;
         uint32_t vm = 0u;
 #pragma unroll
         for (int tap = 0; tap < 9; tap++) {
             const int yy = y + tap / 3 - 1, x2 = xx + tap % 3 - 1;
-            if (live && (unsigned)yy < 9u && (unsigned)x2 < 9u) vm |= 1u << tap;
+            if (m < NPOS && (unsigned)yy < 9u && (unsigned)x2 < 9u) vm |= 1u << tap;
         }
         vmask[t] = vm;
     }
-    // the block input at this lane's own output elements (= the trunk input for the first block)
+    // the block input at this lane's own output elements (= the trunk input for the first block);
+    // output element i of tile t is row 32 t + 4 h + (i & 3) + 8 (i >> 2), channel co
     floatx16 resid[3];
 #pragma unroll
     for (int t = 0; t < 3; t++)
 #pragma unroll
         for (int i = 0; i < 16; i++) {
-            const int m = 32 * (3 * mg + t) + 4 * h + (i & 3) + 8 * (i >> 2);
-            const int sidx = m >= NPOS ? 1 : 0;
-            resid[t][i] = (m < 2 * NPOS && b0 + sidx < n) ? x[obase + (size_t)m * C] : 0.f;
+            const int m = 32 * t + 4 * h + (i & 3) + 8 * (i >> 2);
+            resid[t][i] = m < NPOS ? x[obase + (size_t)m * C] : 0.f;
         }
     __syncthreads();
+    QZ_STAMP(t_stage)
 
     constexpr int PARTV = 9 * 4 * C * 2;
 #pragma unroll 1
@@ -334,113 +373,85 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
             }
         }
-        // ---- per-leaf statistics (two passes), exactly as in k_conv3x3_norm
+        QZ_STAMP(t_loop)
+        // ---- per-leaf statistics of channel co over the 81 rows: all of them live in this wave
         const float inv_scale = A.inv_scale[l];
-        float s0 = 0.f, s1 = 0.f;
+        float s0 = 0.f;
 #pragma unroll
         for (int t = 0; t < 3; t++)
 #pragma unroll
             for (int i = 0; i < 16; i++) {
-                const int m = 32 * (3 * mg + t) + (i & 3) + 8 * (i >> 2) + 4 * h;
-                const float y = acc[t][i] * inv_scale;
+                const int m = 32 * t + (i & 3) + 8 * (i >> 2) + 4 * h;
+                const float y = acc[t][i] * inv_scale;  // exact: a power of two
                 acc[t][i] = y;
                 s0 += m < NPOS ? y : 0.f;
-                s1 += (m >= NPOS && m < 2 * NPOS) ? y : 0.f;
             }
         s0 += __shfl_xor(s0, 32, 64);
-        s1 += __shfl_xor(s1, 32, 64);
-        if (h == 0) {
-            sm.red[0][mg][0][co] = s0;
-            sm.red[0][mg][1][co] = s1;
-        }
-        __syncthreads();  // also: every wave is done reading this layer's input images
-        const float mean0 = (sm.red[0][0][0][co] + sm.red[0][1][0][co]) * (1.0f / 81.0f);
-        const float mean1 = (sm.red[0][0][1][co] + sm.red[0][1][1][co]) * (1.0f / 81.0f);
-        float q0 = 0.f, q1 = 0.f;
+        const float mean = s0 * (1.0f / 81.0f);
+        float q0 = 0.f;
 #pragma unroll
         for (int t = 0; t < 3; t++)
 #pragma unroll
             for (int i = 0; i < 16; i++) {
-                const int m = 32 * (3 * mg + t) + (i & 3) + 8 * (i >> 2) + 4 * h;
-                const float d0 = acc[t][i] - mean0, d1 = acc[t][i] - mean1;
-                q0 += m < NPOS ? d0 * d0 : 0.f;
-                q1 += (m >= NPOS && m < 2 * NPOS) ? d1 * d1 : 0.f;
+                const int m = 32 * t + (i & 3) + 8 * (i >> 2) + 4 * h;
+                const float d = acc[t][i] - mean;
+                q0 += m < NPOS ? d * d : 0.f;
             }
         q0 += __shfl_xor(q0, 32, 64);
-        q1 += __shfl_xor(q1, 32, 64);
-        if (h == 0) {
-            sm.red[1][mg][0][co] = q0;
-            sm.red[1][mg][1][co] = q1;
-        }
-        __syncthreads();
-        const float g = A.gamma[l][co], bt = A.beta[l][co];
-        const float k0 = g / sqrtf((sm.red[1][0][0][co] + sm.red[1][1][0][co]) * (1.0f / 81.0f) + eps);
-        const float k1 = g / sqrtf((sm.red[1][0][1][co] + sm.red[1][1][1][co]) * (1.0f / 81.0f) + eps);
-        const bool second = (l & 1) != 0;        // conv2 of a block: + block input, result = next block input
+        const float bt = A.beta[l][co];
+        const float kn = A.gamma[l][co] / sqrtf(q0 * (1.0f / 81.0f) + eps);
+        QZ_STAMP(t_stat)
+        const bool second = (l & 1) != 0;  // conv2 of a block: + block input, result = next block input
         const bool last = l == n_layers - 1;
-        // The layer's output as fp32 [row][channel] in the memory of the (now dead) input images, row stride
-        // 72 floats: a wave's 64 stores (32 channels of row m, 32 of row m + 4) hit 64 different banks.
-        float* stage = reinterpret_cast<float*>(sm.a_hi);
 #pragma unroll
         for (int t = 0; t < 3; t++)
 #pragma unroll
             for (int i = 0; i < 16; i++) {
-                const int m = 32 * (3 * mg + t) + 4 * h + (i & 3) + 8 * (i >> 2);
-                const int sidx = m >= NPOS ? 1 : 0;
-                float v = (acc[t][i] - (sidx ? mean1 : mean0)) * (sidx ? k1 : k0) + bt;
+                float v = (acc[t][i] - mean) * kn + bt;
                 if (second) v += resid[t][i];
                 v = fmaxf(v, 0.f);
                 if (second) resid[t][i] = v;
-                if (m < 2 * NPOS) {
-                    if (last) {
-                        if (full || b0 + sidx < n) out[obase + (size_t)m * C] = v;
-                    } else {
-                        stage[m * SSTR + co] = v;
-                    }
+                acc[t][i] = v;
+            }
+        if (last) {
+#pragma unroll
+            for (int t = 0; t < 3; t++)
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const int m = 32 * t + 4 * h + (i & 3) + 8 * (i >> 2);
+                    if (m < NPOS) out[obase + (size_t)m * C] = acc[t][i];
                 }
-            }
-        if (last) break;
-        __syncthreads();
-        // every thread picks up its share of the output as float4 (16 lanes = one row = all 64 banks) ...
-        float4 pick[11];
+            break;
+        }
+        __syncthreads();  // both waves are done reading this layer's input images
+        // hand-over: v -> (hi, lo) fp16; the lane pair (co even, co + 1) swaps one packed word by DPP, the even
+        // lane stores both hi halves into a_hi, the odd lane both lo halves into a_lo: one 32-bit store each
+        uint32_t* img = reinterpret_cast<uint32_t*>((lane & 1) ? static_cast<void*>(sm.a_lo) : static_cast<void*>(sm.a_hi));
+        const int cpair = (co & ~1) >> 1;
 #pragma unroll
-        for (int q = 0; q < 11; q++) {
-            const int idx = tid + 256 * q;  // (row, channel quad): 162 x 16 = 2,592 float4
-            pick[q] = idx < CS * NPOS * 16 ? *reinterpret_cast<const float4*>(&stage[(idx >> 4) * SSTR + (idx & 15) * 4]) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        __syncthreads();
-        // ... and writes it back as the next layer's fp16 hi / lo images (the zero rows are untouched)
+        for (int t = 0; t < 3; t++)
 #pragma unroll
-        for (int q = 0; q < 11; q++) {
-            const int idx = tid + 256 * q;
-            if (idx < CS * NPOS * 16) {
-                const int m = idx >> 4, c4 = idx & 15;
-                const int sidx = m >= NPOS ? 1 : 0;
-                const float4 v = pick[q];
-                half4 hi, lo;
-                hi[0] = (_Float16)v.x;
-                hi[1] = (_Float16)v.y;
-                hi[2] = (_Float16)v.z;
-                hi[3] = (_Float16)v.w;
-                lo[0] = (_Float16)(v.x - (float)hi[0]);
-                lo[1] = (_Float16)(v.y - (float)hi[1]);
-                lo[2] = (_Float16)(v.z - (float)hi[2]);
-                lo[3] = (_Float16)(v.w - (float)hi[3]);
-                const int o = (sidx * ROWS + (m - NPOS * sidx)) * RSTR + c4 * 4;
-                *reinterpret_cast<half4*>(reinterpret_cast<_Float16*>(sm.a_hi) + o) = hi;
-                *reinterpret_cast<half4*>(reinterpret_cast<_Float16*>(sm.a_lo) + o) = lo;
+            for (int i = 0; i < 16; i++) {
+                const int m = 32 * t + 4 * h + (i & 3) + 8 * (i >> 2);
+                const float v = acc[t][i];
+                const _Float16 hi = (_Float16)v;
+                const _Float16 lo = (_Float16)(v - (float)hi);
+                const uint32_t mine = (uint32_t)__builtin_bit_cast(unsigned short, hi) | ((uint32_t)__builtin_bit_cast(unsigned short, lo) << 16);
+                const uint32_t other = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine, 0xB1, 0xF, 0xF, true);  // lane ^ 1
+                // even lane: (my hi, partner's hi); odd lane: (partner's lo, my lo) -- channel co & ~1 in the low half
+                const uint32_t word = (lane & 1) ? ((other >> 16) | (mine & 0xFFFF0000u)) : ((mine & 0xFFFFu) | (other << 16));
+                if (m < NPOS) img[m * (RSTR / 2) + cpair] = word;
             }
-        }
-        if (tid < CS * 16) {  // the hand-over image covered the all-zero rows: restore them
-            const int sz = tid >> 4, c4 = tid & 15;
-            half4 z;
-            z[0] = z[1] = z[2] = z[3] = (_Float16)0.f;
-            const int o = (sz * ROWS + NPOS) * RSTR + c4 * 4;
-            *reinterpret_cast<half4*>(reinterpret_cast<_Float16*>(sm.a_hi) + o) = z;
-            *reinterpret_cast<half4*>(reinterpret_cast<_Float16*>(sm.a_lo) + o) = z;
-        }
         __syncthreads();  // the new images are complete before anybody reads them
+        QZ_STAMP(t_hand)
     }
+#ifdef QZ_TRUNK_STAMPS
+    if (lane == 0) {
+        unsigned long long* o = stamps + ((size_t)blockIdx.x * 2 + nt) * 8;
+        o[0] = t_stage; o[1] = t_loop; o[2] = t_stat; o[3] = t_hand; o[4] = __builtin_amdgcn_s_memtime() - t_begin; o[5] = t_begin;
+        o[6] = __builtin_amdgcn_s_memrealtime(); o[7] = __smid();
+    }
+#endif
 }
 
 }  // namespace
@@ -474,8 +485,12 @@ hipError_t trunk(float* x, float* tmp, long long n, int n_blocks, const void* co
             A.gamma[l] = A.beta[l] = nullptr;
             A.inv_scale[l] = 0.f;
         }
-        hipLaunchKernelGGL(k_trunk, dim3((unsigned)((n + CS - 1) / CS)), dim3(256), 0, s, x, x, A, nl, n, eps);
+#ifdef QZ_TRUNK_STAMPS
+        return hipErrorNotSupported;  // the diagnostic build launches the kernel itself (tests/hip/qz_conv_stamps.hip)
+#else
+        hipLaunchKernelGGL(k_trunk, dim3((unsigned)n), dim3(128), 0, s, x, x, A, nl, eps);
         return hipGetLastError();
+#endif
     }
     for (int b = 0; b < n_blocks; b++) {
         // y = relu(bn1(conv1(x)));  x = relu(bn2(conv2(y)) + x)   (policy_value_net.py:33-48)

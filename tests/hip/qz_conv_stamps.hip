@@ -1,0 +1,18 @@
+// qz_conv_stamps.hip -- TEST-ONLY diagnostic build of the fused trunk kernel with s_memtime stamps
+// (cycles a wave spends staging / in the MFMA loop / in the statistics / in the hand-over), see
+// benchmarks/trunk_stamps.py.  The product library is built WITHOUT the stamps.
+#define QZ_TRUNK_STAMPS 1
+#include "../../alphazero_quoridor_amd/csrc/qz_conv.hip"
+
+extern "C" int qzt_trunk_stamps(float* x, long long n, int n_layers, const void* const* w16, const float* const* gamma, const float* const* beta,
+                                const float* inv_scale, unsigned long long* stamps, void* stream) {
+    TrunkArgs A;
+    for (int l = 0; l < MAX_TRUNK_LAYERS; l++) {
+        A.w16[l] = l < n_layers ? reinterpret_cast<const _Float16*>(w16[l]) : nullptr;
+        A.gamma[l] = l < n_layers ? gamma[l] : nullptr;
+        A.beta[l] = l < n_layers ? beta[l] : nullptr;
+        A.inv_scale[l] = l < n_layers ? inv_scale[l] : 0.f;
+    }
+    hipLaunchKernelGGL(k_trunk, dim3((unsigned)n), dim3(128), 0, (hipStream_t)stream, x, x, A, n_layers, 1e-5f, stamps);
+    return (int)hipGetLastError();
+}

@@ -127,9 +127,10 @@ def test_evaluator_with_mfma_trunk_vs_float64_and_library_trunk(gpu_device, gold
 
 
 def test_fused_trunk_equals_layer_by_layer(gpu_device):
-    """qz_nn_trunk: the persistent one-launch trunk (activations resident on the CU) computes the
-    same floats as ten launches of the layer kernel -- same MFMA sequence, same epilogue
-    arithmetic -- for batch sizes with and without a ragged last workgroup."""
+    """qz_nn_trunk: the persistent one-launch trunk (activations resident on the CU) against ten
+    launches of the layer kernel: the same MFMA sequence per element; the per-leaf statistics are
+    summed in another order (inside one wave instead of across two), so the results agree to fp32
+    rounding, not bit for bit.  Batch sizes with and without a ragged last workgroup."""
     from _stubs import det_fill_state_dict
     from alphazero_quoridor_amd.policy_value_net import LeafEvaluator, PolicyValueNet
 
@@ -142,8 +143,9 @@ def test_fused_trunk_equals_layer_by_layer(gpu_device):
         x = torch.relu(torch.randn((B, 64, 9, 9), generator=g)).to(gpu_device).contiguous(memory_format=torch.channels_last)
         a = fused._trunk_mfma(x.clone(memory_format=torch.preserve_format))
         b = layered._trunk_mfma(x.clone(memory_format=torch.preserve_format))
-        assert torch.isfinite(a).all() and torch.equal(a, b), (B, (a - b).abs().max().item())
+        err = (a - b).abs().max().item()
+        assert torch.isfinite(a).all() and err < 2e-5 * max(1.0, b.abs().max().item()), (B, err)
     planes = (torch.rand((130, 26, 9, 9), generator=g) > 0.8).float().to(gpu_device)
     p1, v1 = fused(planes)
     p2, v2 = layered(planes)
-    assert torch.equal(p1, p2) and torch.equal(v1, v2)
+    assert (p1 - p2).abs().max().item() < 2e-6 and (v1 - v2).abs().max().item() < 1e-5
