@@ -341,14 +341,14 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int i = 0; i < 16; i++) acc[t][i] = 0.f;
         const half8* wb = reinterpret_cast<const half8*>(A.w16[l]) + (size_t)(32 * nt + r) * 2 + h;
-        // B ring of four register sets (slot = k & 3), filled two k steps ahead
-        half8 bh[4], bl[4];
+        // B ring of three register sets, filled two k steps ahead (the loop of k_conv3x3_norm, fully unrolled)
+        half8 bh[3], bl[3];
 #pragma unroll
         for (int k = 0; k < 2; k++) {
             bh[k] = wb[k * (C * 2)];
             bl[k] = wb[PARTV + k * (C * 2)];
         }
-#pragma unroll 1
+#pragma unroll
         for (int tap = 0; tap < 9; tap++) {
             int ro[3];
             const int delta = ((tap / 3 - 1) * 9 + (tap % 3 - 1)) * RV;
@@ -358,11 +358,11 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int kc = 0; kc < 4; kc++) {
                 const int k = 4 * tap + kc;
                 if (k + 2 < 36) {
-                    bh[(kc + 2) & 3] = wb[(k + 2) * (C * 2)];
-                    bl[(kc + 2) & 3] = wb[PARTV + (k + 2) * (C * 2)];
+                    bh[(k + 2) % 3] = wb[(k + 2) * (C * 2)];
+                    bl[(k + 2) % 3] = wb[PARTV + (k + 2) * (C * 2)];
                 }
                 asm volatile("" ::: "memory");
-                const half8 b_hi = bh[kc], b_lo = bl[kc];
+                const half8 b_hi = bh[k % 3], b_lo = bl[k % 3];
 #pragma unroll
                 for (int t = 0; t < 3; t++) {
                     const half8 a_hi = sm.a_hi[ro[t] + 2 * kc];

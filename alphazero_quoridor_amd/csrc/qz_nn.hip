@@ -491,11 +491,14 @@ __global__ __launch_bounds__(HT) void k_head(const float* __restrict__ t, long l
                             const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
 #pragma unroll
                             for (int j = 0; j < 4; j++) {
-                                const f2_t xx = {xs[j], xs[j]};
+                                // plain v_fma_f32 on purpose: packed fp32 VALU ops (v_pk_fma_f32) were measured to
+                                // return wrong values on MI355X while another wave's MFMAs run on the same SIMD
+                                // (benchmarks/diag_head.py, diag_victims.py); the library is built with
+                                // -fno-slp-vectorize for the same reason
 #pragma unroll
                                 for (int k = 0; k < 3; k++) {
-                                    const f2_t wk = {w[6 * j + 2 * k], w[6 * j + 2 * k + 1]};
-                                    acc[sl][k] = __builtin_elementwise_fma(wk, xx, acc[sl][k]);
+                                    acc[sl][k].x = __builtin_fmaf(w[6 * j + 2 * k], xs[j], acc[sl][k].x);
+                                    acc[sl][k].y = __builtin_fmaf(w[6 * j + 2 * k + 1], xs[j], acc[sl][k].y);
                                 }
                             }
                         }

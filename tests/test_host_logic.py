@@ -439,3 +439,16 @@ def test_interactive_adapter_step_result_and_loop():
     assert gui.choose_action(g) == 0
     with pytest.raises(ValueError):
         play(FakeGame(), {1: HistoricalAgent("bad", [7]), 2: gui}, log=lambda *_: None)
+
+
+def test_no_packed_fp32_instruction_in_the_device_code():
+    """Packed fp32 VALU instructions (v_pk_fma_f32 & co) were measured to return wrong values on
+    MI355X while another wave's MFMAs run on the same SIMD (profiles/round2/packed_fp32_next_to_mfma.txt).
+    The library is built with SLP vectorisation off and the packed-fp32 target feature disabled;
+    this disassembles every device source and fails if one of those instructions comes back."""
+    import subprocess
+
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "alphazero_quoridor_amd", "csrc"), "-s", "check_no_packed_fp32"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count(": 0 packed-fp32 instructions") == 3, r.stdout
