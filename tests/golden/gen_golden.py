@@ -594,12 +594,18 @@ def gen_train(out_dir):
 
     ref, twin = fresh(), fresh()
     losses, entropies = [], []
+    grad_keys = ["conv1.weight", "res1.conv1.weight", "res5.conv2.weight", "res3.bn1.weight", "conv2.weight", "conv3.weight",
+                 "fc1.weight", "fc2.weight", "fc3.weight", "fc3.bias", "bn1.bias"]
+    grads0 = {}
     for lr in lrs:
         try:
             ref.train_step(list(states), list(pi), list(z), lr)
             raise SystemExit("the reference's train_step returned: torch is old enough, record its outputs directly")
         except IndexError:
             pass  # `loss.data[0]`: raised after optimizer.step()
+        if not grads0:  # the gradients of the reference's own backward() of step 0 (same weights on every machine)
+            named = dict(ref.policy_value_net.named_parameters())
+            grads0 = {k: named[k].grad.detach().clone().numpy() for k in grad_keys}
         sb, pb, wb = (torch.FloatTensor(np.asarray(x)) for x in (states, pi, z))
         twin.optimizer.zero_grad()
         set_learning_rate(twin.optimizer, lr)
@@ -622,6 +628,8 @@ def gen_train(out_dir):
            "abs_sum": np.array([float(v.double().abs().sum()) for v in sd.values()])}
     for k in keep:
         out["w_" + k.replace(".", "_")] = sd[k].numpy()
+    for k, g in grads0.items():
+        out["g0_" + k.replace(".", "_")] = g
     # old/new outputs of policy_value (batch statistics) on the same minibatch after the three steps
     p_after, v_after = ref.policy_value(states)
     out["p_after"], out["v_after"] = p_after, v_after
