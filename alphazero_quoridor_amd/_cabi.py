@@ -97,6 +97,10 @@ class qz_stats(C.Structure):
         ("edges_scanned", C.c_int64),
         ("edges_expanded", C.c_int64),
         ("max_depth", C.c_int64),
+        ("deep_descents", C.c_int64),
+        ("deep_descents_cold", C.c_int64),
+        ("deep_levels", C.c_int64),
+        ("deep_levels_replayed", C.c_int64),
     ]
 
 
@@ -146,6 +150,7 @@ _SIGNATURES = {
     "qz_engine_leaf_boards": (C.c_int, [_P, _P, _P]),
     "qz_nn_conv3x3_norm": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, C.c_float, C.c_int, C.c_float, _P]),
     "qz_nn_trunk": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P, _P, _P, _P, C.c_float, C.c_int, _P]),
+    "qz_nn_trunk_heads": (C.c_int, [_P, C.c_int64, C.c_int, _P, _P, _P, _P, _P, C.c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, _P]),
     "qz_nn_head": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, _P]),
     "qz_selftest_sqrt": (C.c_int, [_P, C.c_int, _P]),
 }

@@ -29,7 +29,9 @@ hipError_t pool_init(const EngineDev&, hipStream_t);
 hipError_t harvest(const EngineDev&, uint64_t*, uint64_t*, uint64_t*, float*, float*, int32_t*, long long, hipStream_t);
 hipError_t sqrt_table(double*, int, hipStream_t);
 hipError_t conv3x3_norm(const float*, const void*, const float*, const float*, const float*, float*, long long, float, int, float, hipStream_t);
-hipError_t trunk(float*, float*, long long, int, const void* const*, const float* const*, const float* const*, const float*, float, int, hipStream_t);
+hipError_t trunk(float*, float*, long long, int, const void* const*, const float* const*, const float* const*, const float*, float, int, hipStream_t,
+                 const void*, const float*, const float*, float, float*);
+hipError_t head_fc(const float*, long long, const float*, const float*, const float*, const float*, const float*, const float*, float*, float*, hipStream_t);
 hipError_t rollout_begin(const uint64_t*, const uint64_t*, const uint64_t*, int, uint8_t*, uint8_t*, int8_t*, int*, hipStream_t);
 hipError_t rollout_step(uint64_t*, uint64_t*, uint64_t*, const uint32_t*, int, const uint8_t*, uint8_t*, int8_t*, int*, uint64_t, int, int, hipStream_t);
 hipError_t instnorm_act(const float*, const float*, const float*, const float*, float*, long long, int, int, float, hipStream_t);
@@ -321,9 +323,13 @@ int qz_engine_create(const qz_config* cfg, qz_engine** out) {
     ALLOC(release, B);
     ALLOC(root_eoff, B);
     ALLOC(root_ne, B);
-    ALLOC(path_edges, B * (size_t)QZ_PATH_CAP);
-    ALLOC(path_blocks, B * (size_t)QZ_PATH_CAP);
+    ALLOC(path_edges, B * (size_t)(QZ_PATH_RECS + 1) * QZ_PATH_CAP);
+    ALLOC(path_blocks, B * (size_t)(QZ_PATH_RECS + 1) * QZ_PATH_CAP);
     ALLOC(path_len, B);
+    ALLOC(rec_len, B * QZ_PATH_RECS);
+    ALLOC(rec_stamp, B * QZ_PATH_RECS);
+    ALLOC(rec_last, B);
+    ALLOC(rec_clock, B);
     ALLOC(tree_half, B);
     ALLOC(n_nodes, B);
     ALLOC(n_edges, B);
@@ -358,6 +364,10 @@ int qz_engine_create(const qz_config* cfg, qz_engine** out) {
     if (he == hipSuccess) he = hipMemset(d.counters, 0, QZ_C_COUNT * sizeof(unsigned long long));
     if (he == hipSuccess) he = hipMemset(d.leaf_term, 0, B);
     if (he == hipSuccess) he = hipMemset(d.path_len, 0, B * sizeof(uint32_t));
+    if (he == hipSuccess) he = hipMemset(d.rec_len, 0, B * QZ_PATH_RECS * sizeof(uint32_t));
+    if (he == hipSuccess) he = hipMemset(d.rec_stamp, 0, B * QZ_PATH_RECS * sizeof(uint32_t));
+    if (he == hipSuccess) he = hipMemset(d.rec_last, 0, B * sizeof(uint32_t));
+    if (he == hipSuccess) he = hipMemset(d.rec_clock, 0, B * sizeof(uint32_t));
     if (he == hipSuccess) he = hipMemset(d.bc_playouts, 0, B * sizeof(uint32_t));
     if (he == hipSuccess) he = hipMemset(d.bc_terminal, 0, B * sizeof(uint32_t));
     if (he == hipSuccess) he = hipMemset(d.bc_overflow, 0, B * sizeof(uint32_t));
@@ -581,6 +591,10 @@ int qz_engine_stats(qz_engine* e, qz_stats* out, void* stream) {
     out->bad_forced_moves = (int64_t)h[QZ_C_BAD_FORCED];
     out->nonfinite_values = (int64_t)sf;
     out->max_depth = (int64_t)md;
+    out->deep_descents = (int64_t)h[QZ_C_DEEP_DESCENTS];
+    out->deep_descents_cold = (int64_t)h[QZ_C_DEEP_COLD];
+    out->deep_levels = (int64_t)h[QZ_C_DEEP_LEVELS];
+    out->deep_levels_replayed = (int64_t)h[QZ_C_DEEP_REPLAYED];
     out->edges_scanned = (int64_t)ss;
     out->edges_expanded = (int64_t)se;
     out->tree_pages_total = e->cfg.tree_pool_pages;
@@ -667,7 +681,25 @@ int qz_nn_trunk(float* x, float* tmp, int64_t n, int n_blocks, const void* const
     if ((((uintptr_t)x | (uintptr_t)tmp) & 15) != 0) return fail(QZ_E_INVALID, "tensors must be 16-byte aligned");
     for (int l = 0; l < 2 * n_blocks; l++)
         if (!w16[l] || !gamma[l] || !beta[l]) return fail(QZ_E_INVALID, "null layer tensor");
-    HIP_TRY(qzl::trunk(x, tmp, (long long)n, n_blocks, w16, gamma, beta, inv_scale, eps, fused, (hipStream_t)stream));
+    HIP_TRY(qzl::trunk(x, tmp, (long long)n, n_blocks, w16, gamma, beta, inv_scale, eps, fused, (hipStream_t)stream, nullptr, nullptr, nullptr, 0.f, nullptr));
+    return 0;
+}
+int qz_nn_trunk_heads(const float* x, int64_t n, int n_blocks, const void* const* w16, const float* const* gamma, const float* const* beta,
+                      const float* inv_scale, const void* w6_16, float inv_scale6, const float* gamma6, const float* beta6, const float* w1t,
+                      const float* b1, const float* w2, const float* b2, const float* w3t, const float* b3, float* feat, float* p_out,
+                      float* v_out, float eps, void* stream) {
+    int r;
+    if ((r = device_check())) return r;
+    if (n < 0 || n_blocks <= 0 || n_blocks > 8) return fail(QZ_E_INVALID, "n < 0 or n_blocks outside 1..8");
+    if (n == 0) return 0;
+    if (!x || !w16 || !gamma || !beta || !inv_scale || !w6_16 || !gamma6 || !beta6 || !w1t || !b1 || !w2 || !b2 || !w3t || !b3 || !feat || !p_out || !v_out)
+        return fail(QZ_E_INVALID, "null argument");
+    if ((((uintptr_t)x | (uintptr_t)w6_16) & 15) != 0 || ((uintptr_t)feat & 7) != 0) return fail(QZ_E_INVALID, "x / w6_16 must be 16-byte, feat 8-byte aligned");
+    for (int l = 0; l < 2 * n_blocks; l++)
+        if (!w16[l] || !gamma[l] || !beta[l]) return fail(QZ_E_INVALID, "null layer tensor");
+    HIP_TRY(qzl::trunk(const_cast<float*>(x), nullptr, (long long)n, n_blocks, w16, gamma, beta, inv_scale, eps, 1, (hipStream_t)stream, w6_16, gamma6, beta6,
+                       inv_scale6, feat));
+    HIP_TRY(qzl::head_fc(feat, (long long)n, w1t, b1, w2, b2, w3t, b3, p_out, v_out, (hipStream_t)stream));
     return 0;
 }
 int qz_engine_leaf_boards(qz_engine* e, qz_boards* boards_out, const uint8_t** terminal_out) {

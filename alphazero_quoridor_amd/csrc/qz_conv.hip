@@ -257,9 +257,21 @@ struct TrunkArgs {
 struct TrunkShared {
     half8 a_hi[ROWS * RV];  // one leaf: 81 positions + the all-zero row, 144-byte rows
     half8 a_lo[ROWS * RV];
+    float red6[2][2][32];   // head stage: [pass][wave][head channel]
+};
+// The head stage (optional): the merged 64 -> 6 head convolution (policy_value_net.py:64-65,69-70:
+// conv2 = value channels 0..3, conv3 = policy channels 4..5) + bn2 / bn3 per leaf + ReLU on the
+// last layer's activations while they are still in LDS, as one more implicit GEMM with a 32-column
+// B tile of which 6 columns are real.  feat [n][486] (c * 81 + pos) feeds k_head_fc (qz_nn.hip).
+struct HeadArgs {
+    const _Float16* w6;   // [2][9][4][32][16] fp16 hi | lo of W6 * scale, columns 6..31 zero
+    const float* gamma6;  // [6]
+    const float* beta6;   // [6]
+    float inv_scale6;
+    float* feat;          // [n][486] out; nullptr = no head stage
 };
 
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_trunk(const float* __restrict__ x, float* __restrict__ out, TrunkArgs A, int n_layers, float eps
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_trunk(const float* __restrict__ x, float* __restrict__ out, TrunkArgs A, int n_layers, float eps, HeadArgs H
 #ifdef QZ_TRUNK_STAMPS
                                                , unsigned long long* stamps  // [workgroup][wave][8]: diagnostic build only
 #endif
@@ -414,14 +426,16 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 acc[t][i] = v;
             }
         if (last) {
+            if (out) {
 #pragma unroll
-            for (int t = 0; t < 3; t++)
+                for (int t = 0; t < 3; t++)
 #pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    const int m = 32 * t + 4 * h + (i & 3) + 8 * (i >> 2);
-                    if (m < NPOS) out[obase + (size_t)m * C] = acc[t][i];
-                }
-            break;
+                    for (int i = 0; i < 16; i++) {
+                        const int m = 32 * t + 4 * h + (i & 3) + 8 * (i >> 2);
+                        if (m < NPOS) out[obase + (size_t)m * C] = acc[t][i];
+                    }
+            }
+            if (!H.feat) break;  // else: the trunk output goes to the images once more, for the head stage
         }
         __syncthreads();  // both waves are done reading this layer's input images
         // hand-over: v -> (hi, lo) fp16; the lane pair (co even, co + 1) swaps one packed word by DPP, the even
@@ -444,6 +458,96 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
         __syncthreads();  // the new images are complete before anybody reads them
         QZ_STAMP(t_hand)
+    }
+    if (H.feat) {
+        // ---- head stage.  M tiles: wave 0 takes rows 0..63 (two tiles), wave 1 rows 64..80 (one); lane (r, h)
+        // ends up with head channel r (r < 6 are real) of its tiles' rows
+        const bool two = __builtin_amdgcn_readfirstlane(nt) == 0;
+        const int rb0 = nt ? rbase[2] : rbase[0], rb1 = rbase[1];
+        const uint32_t vm0 = nt ? vmask[2] : vmask[0], vm1 = vmask[1];
+        constexpr int P6 = 36 * 32 * 2;
+        const half8* wb6 = reinterpret_cast<const half8*>(H.w6) + (size_t)r * 2 + h;
+        floatx16 ha0, ha1;
+#pragma unroll
+        for (int i = 0; i < 16; i++) ha0[i] = ha1[i] = 0.f;
+        half8 bh[3], bl[3];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            bh[k] = wb6[k * 64];
+            bl[k] = wb6[P6 + k * 64];
+        }
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            const int delta = ((tap / 3 - 1) * 9 + (tap % 3 - 1)) * RV;
+            const int ro0 = ((vm0 >> tap) & 1u) ? rb0 + delta : ZERO_ROW * RV + h;
+            const int ro1 = ((vm1 >> tap) & 1u) ? rb1 + delta : ZERO_ROW * RV + h;
+#pragma unroll
+            for (int kc = 0; kc < 4; kc++) {
+                const int k = 4 * tap + kc;
+                if (k + 2 < 36) {
+                    bh[(k + 2) % 3] = wb6[(k + 2) * 64];
+                    bl[(k + 2) % 3] = wb6[P6 + (k + 2) * 64];
+                }
+                asm volatile("" ::: "memory");
+                const half8 b_hi = bh[k % 3], b_lo = bl[k % 3];
+                {
+                    const half8 a_hi = sm.a_hi[ro0 + 2 * kc];
+                    const half8 a_lo = sm.a_lo[ro0 + 2 * kc];
+                    ha0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, ha0, 0, 0, 0);
+                    ha0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, ha0, 0, 0, 0);
+                    ha0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, ha0, 0, 0, 0);
+                }
+                if (two) {
+                    const half8 a_hi = sm.a_hi[ro1 + 2 * kc];
+                    const half8 a_lo = sm.a_lo[ro1 + 2 * kc];
+                    ha1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, ha1, 0, 0, 0);
+                    ha1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, ha1, 0, 0, 0);
+                    ha1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, ha1, 0, 0, 0);
+                }
+            }
+        }
+        // per-leaf statistics of head channel r over the 81 rows: this wave's rows, the lane halves by shuffle,
+        // the two waves through LDS
+        const int row0 = (nt ? 64 : 0) + 4 * h;
+        const float is6 = H.inv_scale6;
+        float s0 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int m = row0 + (i & 3) + 8 * (i >> 2);
+            ha0[i] *= is6;
+            ha1[i] *= is6;
+            s0 += m < NPOS ? ha0[i] : 0.f;
+            if (two) s0 += ha1[i];  // rows 32..63
+        }
+        s0 += __shfl_xor(s0, 32, 64);
+        if (h == 0) sm.red6[0][nt][r] = s0;
+        __syncthreads();  // also: both waves are done reading the images
+        const float mean = (sm.red6[0][0][r] + sm.red6[0][1][r]) * (1.0f / 81.0f);
+        float q0 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int m = row0 + (i & 3) + 8 * (i >> 2);
+            const float d0 = ha0[i] - mean, d1 = ha1[i] - mean;
+            q0 += m < NPOS ? d0 * d0 : 0.f;
+            if (two) q0 += d1 * d1;
+        }
+        q0 += __shfl_xor(q0, 32, 64);
+        if (h == 0) sm.red6[1][nt][r] = q0;
+        __syncthreads();
+        float* fb = reinterpret_cast<float*>(sm.a_hi);  // 486 floats; the images are dead
+        if (r < 6) {
+            const float var = (sm.red6[1][0][r] + sm.red6[1][1][r]) * (1.0f / 81.0f);
+            const float kn = H.gamma6[r] / sqrtf(var + eps), bt = H.beta6[r];
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int m = row0 + (i & 3) + 8 * (i >> 2);
+                if (m < NPOS) fb[r * NPOS + m] = fmaxf((ha0[i] - mean) * kn + bt, 0.f);
+                if (two) fb[r * NPOS + m + 32] = fmaxf((ha1[i] - mean) * kn + bt, 0.f);
+            }
+        }
+        __syncthreads();
+        float* fo = H.feat + (size_t)blockIdx.x * (6 * NPOS);
+        for (int i = tid; i < 6 * NPOS; i += 128) fo[i] = fb[i];
     }
 #ifdef QZ_TRUNK_STAMPS
     if (lane == 0) {
@@ -468,10 +572,14 @@ hipError_t conv3x3_norm(const float* x, const void* w16, const float* gamma, con
     else hipLaunchKernelGGL((k_conv3x3_norm<false, false>), grid, dim3(256), 0, s, x, w, gamma, beta, residual, out, n, inv_scale, eps);
     return hipGetLastError();
 }
+// head != nullptr (fused route only): [w6 fp16, gamma6, beta6, feat out] + inv_scale6: the head stage runs in the same
+// launch and the trunk output is NOT written back to x
 hipError_t trunk(float* x, float* tmp, long long n, int n_blocks, const void* const* w16, const float* const* gamma, const float* const* beta,
-                 const float* inv_scale, float eps, int fused, hipStream_t s) {
+                 const float* inv_scale, float eps, int fused, hipStream_t s, const void* w6 = nullptr, const float* gamma6 = nullptr,
+                 const float* beta6 = nullptr, float inv_scale6 = 0.f, float* feat = nullptr) {
     if (n <= 0 || n_blocks <= 0) return hipSuccess;
     const int nl = 2 * n_blocks;
+    if (feat && !(fused && nl <= MAX_TRUNK_LAYERS)) return hipErrorInvalidValue;
     if (fused && nl <= MAX_TRUNK_LAYERS) {  // one persistent launch: activations stay on the CU
         TrunkArgs A;
         for (int l = 0; l < nl; l++) {
@@ -488,7 +596,13 @@ hipError_t trunk(float* x, float* tmp, long long n, int n_blocks, const void* co
 #ifdef QZ_TRUNK_STAMPS
         return hipErrorNotSupported;  // the diagnostic build launches the kernel itself (tests/hip/qz_conv_stamps.hip)
 #else
-        hipLaunchKernelGGL(k_trunk, dim3((unsigned)n), dim3(128), 0, s, x, x, A, nl, eps);
+        HeadArgs H;
+        H.w6 = reinterpret_cast<const _Float16*>(w6);
+        H.gamma6 = gamma6;
+        H.beta6 = beta6;
+        H.inv_scale6 = inv_scale6;
+        H.feat = feat;
+        hipLaunchKernelGGL(k_trunk, dim3((unsigned)n), dim3(128), 0, s, x, feat ? nullptr : x, A, nl, eps, H);
         return hipGetLastError();
 #endif
     }

@@ -25,7 +25,7 @@
 //   Subtree reuse copies the kept subtree breadth-first into FRESH pages (table half h^1), then
 //   the old half's pages go back to the stack (k_release, a push-only kernel: kernels that pop
 //   never push, so the stack needs no ABA protection).
-//   path_edges[B][QZ_PATH_CAP] u32: physical edges of the last descent, root first (parallel backup)
+//   path_edges[B][QZ_PATH_RECS + 1][QZ_PATH_CAP] u32: physical edges of recorded descents (replay) and of the last one (parallel backup), root first
 //
 //   Trajectories: a second pool of 64-KB pages of dwords; one variable-length record per ply
 //       [0] ne | [1] 0 | [2..7] board (hbits, vbits, meta) | [8..8+ne) pi f32 of the root's
@@ -40,6 +40,7 @@
 #define QZ_PLANES_N 2106
 #define QZ_NONE 0xFFFFFFFFu
 #define QZ_NO_MOVE_U8 255
+#define QZ_PATH_RECS 16    // descent records per board (k_select), a power of two
 #define QZ_PATH_CAP 2048   // levels of a descent that are recorded (late-game lines are forced and hundreds of plies deep)
 
 #define QZ_PAGE_SHIFT 11
@@ -60,6 +61,10 @@ enum {
     QZ_C_PENDING_GAMES,
     QZ_C_PENDING_PLIES,
     QZ_C_BAD_FORCED,        // forced moves that were not children of the root (sticky error flag)
+    QZ_C_DEEP_DESCENTS,     // descents of >= 256 levels ...
+    QZ_C_DEEP_COLD,         // ... whose board's previous descent record was shorter than half of that
+    QZ_C_DEEP_LEVELS,       // ... their levels
+    QZ_C_DEEP_REPLAYED,     // ... of which the replay of the recorded descent confirmed this many
     QZ_C_COUNT
 };
 // pool bookkeeping words (int): free-stack tops and low-water marks
@@ -72,8 +77,8 @@ struct Edge {
     uint32_t pedge;
     uint32_t coff;
     uint8_t act, cne;
-    uint16_t pad16;
-    uint32_t pad32;
+    uint16_t rid;    // 1 + the descent record (k_select) that went through this edge last; 0 = none.  A hint: re-verified
+    uint32_t spare;
 };
 static_assert(sizeof(Edge) == 32, "edge record must be 32 bytes");
 
@@ -111,8 +116,12 @@ struct EngineDev {
     uint32_t *traj_npages, *traj_cursor;  // [B]
     uint32_t* free_traj;      // [traj_pool_pages]
     int* pool_words;          // QZ_P_COUNT
-    uint32_t *path_edges, *path_len;
-    unsigned long long* path_blocks;  // [B][QZ_PATH_CAP] (first physical edge << 8 | edge count) of the node at every level of the last descent
+    // k_select's descent records: QZ_PATH_RECS root-to-leaf paths per board + (last slot) the descent of this step
+    uint32_t* path_edges;             // [B][QZ_PATH_RECS + 1][QZ_PATH_CAP] chosen physical edge per level, root first
+    unsigned long long* path_blocks;  // [B][QZ_PATH_RECS + 1][QZ_PATH_CAP] (first physical edge << 8 | edge count) of the node at that level
+    uint32_t* path_len;               // [B] length of the last descent (may exceed QZ_PATH_CAP: then the backup walks parent links)
+    uint32_t *rec_len, *rec_stamp;    // [B][QZ_PATH_RECS] recorded levels; clock value when the record last confirmed levels
+    uint32_t *rec_last, *rec_clock;   // [B] the record of the previous descent; descents so far
     uint8_t* tree_half;
     uint8_t* release;         // [B] bit0: the other table half holds pages to give back
     uint32_t *n_nodes, *n_edges, *root_N, *root_eoff, *root_ne;
@@ -149,6 +158,12 @@ __device__ __forceinline__ uint32_t tree_phys(const TreeView& t, uint32_t e) {
     const uint32_t pg = e >> QZ_PAGE_SHIFT;
     const int l = __builtin_amdgcn_readfirstlane((int)(pg & 63u));
     const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)t.pt0, l), c = (uint32_t)__builtin_amdgcn_readlane((int)t.pt1, l);
+    return ((pg < 64u ? a : c) << QZ_PAGE_SHIFT) | (e & (QZ_PAGE_EDGES - 1u));
+}
+// the same for a per-lane e (ALL lanes must call it: the page table is read from other lanes' registers)
+__device__ __forceinline__ uint32_t tree_phys_lanes(const TreeView& t, uint32_t e) {
+    const uint32_t pg = e >> QZ_PAGE_SHIFT;
+    const uint32_t a = (uint32_t)__shfl((int)t.pt0, (int)(pg & 63u), 64), c = (uint32_t)__shfl((int)t.pt1, (int)(pg & 63u), 64);
     return ((pg < 64u ? a : c) << QZ_PAGE_SHIFT) | (e & (QZ_PAGE_EDGES - 1u));
 }
 #endif

@@ -416,15 +416,27 @@ __device__ __forceinline__ uint32_t tree_alloc(const EngineDev& E, TreeView& T, 
 
 // MCTS._playout descent (mcts.py:107-113) + TreeNode.select/get_value (mcts.py:37-42, 64-70).
 // The kernel lasts as long as the DEEPEST of the batch's descents, and a descent is one chain of
-// dependent steps per level: edge block -> PUCT values -> argmax -> child block.  Late-game lines
-// are forced and a tree that is re-used ply after ply grows hundreds of levels deep, so:
+// dependent steps per level: edge block -> PUCT values -> argmax -> child block, ~0.4 us per level.
+// Late-game lines are forced and a tree that is re-used ply after ply grows hundreds of levels
+// deep, so:
 //  * SPECULATIVE REPLAY.  Successive playouts of a tree share most of their path (a visit changes
-//    Q + u of a well-visited node far too little to change its argmax; they part near the bottom).
-//    The previous descent is on record (path_edges / path_blocks), so its levels are re-evaluated
-//    64 at a time, lane = level: level i needs only its own edge block and sqrt(N) of the edge
-//    chosen at level i-1 -- both in memory.  The longest prefix whose argmax comes out as before is
-//    exactly what the sequential walk would have done (same loads, same float64 expressions); the
-//    walk resumes at the first level that differs.  Nodes with more than 8 children end the replay.
+//    Q + u of a well-visited node far too little to change its argmax).  Earlier descents are on
+//    record, level after level, as (chosen edge, edge block) entries, and a recorded run of levels
+//    is re-evaluated 64 at a time, lane = level: level i needs only its own edge block and
+//    sqrt(N) of the edge chosen at level i-1 -- both in memory, so the 64 chains of loads run side
+//    by side.  The longest prefix whose argmax comes out as recorded is exactly what the walk would
+//    have done (same loads, same float64 expressions); the confirmed moves are applied to the
+//    scratch board in one step (pawn deltas by ballot, walls one by one).  Nothing in a record is
+//    taken on trust: an entry counts only if its block is the child block of the entry above.
+//  * QZ_PATH_RECS RECORDS per board, each a whole root-to-leaf path.  A search alternates between
+//    a deep line and its alternatives; one record would be overwritten by every shallow playout and
+//    the next deep one would walk its hundreds of levels one by one.  Every edge remembers which
+//    record went through it last (Edge::rid); where the path leaves the record it is following,
+//    it goes on in the record of the edge it took, at the same level.  A descent that only extends
+//    its record is appended to it; any other is copied over the least recently useful record.
+//  * a round costs about five walked levels, so it is only tried where the record has eight more
+//    levels to offer, and after a round that ended early the next eight levels are walked (in
+//    step with the record: the replay can resume at any level);
 //  * every lane takes the float64 square root of ITS OWN edge's visit count while the division
 //    is in flight: the winner's is the next level's sqrt(N_parent), off the critical path;
 //  * nodes with <= 8 children (most of a long game: a mover without walls has 2-5 moves) pick
@@ -433,84 +445,173 @@ __device__ __forceinline__ double rdl_f64(double v, int l) {
     const uint64_t u = (uint64_t)__double_as_longlong(v);
     return __longlong_as_double((long long)((uint64_t)rdl((uint32_t)u, l) | ((uint64_t)rdl((uint32_t)(u >> 32), l) << 32)));
 }
+// the moves of lanes 0 .. n-1 (lane j = j-th move from `bd`, movers alternate) applied at once; returns done
+__device__ __forceinline__ bool apply_actions_wave(Board& bd, uint32_t act, int n, int lane) {
+    const uint64_t in = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+    const uint64_t even = 0x5555555555555555ull & in, odd = 0xAAAAAAAAAAAAAAAAull & in;  // lane parity = mover: even lanes the current player
+    int d_even = 0, d_odd = 0;
+#pragma unroll
+    for (int a = 0; a < 12; a++) {
+        const uint64_t m = __ballot(act == (uint32_t)a);
+        d_even += action_delta(a) * __popcll(m & even);
+        d_odd += action_delta(a) * __popcll(m & odd);
+    }
+    uint64_t walls = __ballot(act >= 12u) & in;
+    const int w_even = __popcll(walls & even), w_odd = __popcll(walls & odd);
+    while (walls) {
+        const int j = __ffsll((unsigned long long)walls) - 1;
+        walls &= walls - 1ull;
+        const int w = (int)rdl(act, j) - 12;
+        if (w < 64) bd.hb |= 1ull << w;
+        else bd.vb |= 1ull << (w - 64);
+    }
+    if (bd.cur == 1) {
+        bd.p1 += d_even; bd.p2 += d_odd; bd.w1 -= w_even; bd.w2 -= w_odd;
+    } else {
+        bd.p2 += d_even; bd.p1 += d_odd; bd.w2 -= w_even; bd.w1 -= w_odd;
+    }
+    // only the last move can end the game (a finished position has no children): rotate n times, or n - 1
+    const bool done = winner_of(bd) != 0;
+    const int rot = done ? n - 1 : n;
+    if (rot & 1) bd.cur = 3 - bd.cur;
+    return done;
+}
+#ifdef QZ_SELECT_STAMPS  // diagnostic build only (tests/hip/Makefile, benchmarks/select_stamps.py): where a descent's time goes
+__device__ unsigned int g_sel_stamps[64][4096][8];
+#define QZ_SEL_MARK(acc) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc += (unsigned int)(now_ - t_mark); t_mark = now_; }
+#define QZ_SEL_COUNT(x) x
+#else
+#define QZ_SEL_MARK(acc)
+#define QZ_SEL_COUNT(x)
+#endif
 __global__ __launch_bounds__(TPB) void k_select(EngineDev E) {
     const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
     const int b = (int)blockIdx.x * WPB + wave;
     if (b >= E.n_boards) return;
-    uint32_t* path = E.path_edges + (size_t)b * QZ_PATH_CAP;
-    unsigned long long* pblk = E.path_blocks + (size_t)b * QZ_PATH_CAP;
+#ifdef QZ_SELECT_STAMPS
+    unsigned long long t_mark = __builtin_amdgcn_s_memtime();
+    const unsigned long long t_begin = t_mark;
+    unsigned int t_replay = 0, t_walk = 0, n_rounds = 0, n_narrow = 0, n_wide = 0;
+#endif
     Board bd = load_board(E.root_hb, E.root_vb, E.root_meta, b);
     uint32_t pedge = QZ_NONE;
     const uint32_t rootN = rfl(E.root_N[b]);
     int ne = (int)rfl(E.root_ne[b]);
     bool done = false, nonfinite = false;
     const bool live = rfl(E.status[b]) == QZ_PLAYING;
-    uint32_t plen = 0u, scanned = 0u;
+    uint32_t plen = 0u, scanned = 0u, replayed = 0u;
     if (live && ne > 0) {
+        constexpr uint32_t R = QZ_PATH_RECS, CAP = QZ_PATH_CAP;
         const TreeView T = tree_view(E, b, rfl(E.tree_half[b]), lane);
-        const Edge* pool = T.pool;
+        Edge* const pool = T.pool;
         uint32_t base = tree_phys(T, rfl(E.root_eoff[b]));
         double sq = sqrt((double)rootN);  // np.sqrt(self._parent._n_visits), float64
+        uint32_t* const pe0 = E.path_edges + (size_t)b * (R + 1u) * CAP;
+        unsigned long long* const pb0 = E.path_blocks + (size_t)b * (R + 1u) * CAP;
+        uint32_t* const we = pe0 + (size_t)R * CAP;  // this descent (what the backup reads)
+        unsigned long long* const wb = pb0 + (size_t)R * CAP;
+        const bool use = (E.select_opts & 1) == 0;
+        // lane r < R keeps record r's length and the time it was last useful
+        uint32_t rlen = (use && lane < (int)R) ? E.rec_len[(size_t)b * R + lane] : 0u;
+        uint32_t rstamp = (lane < (int)R) ? E.rec_stamp[(size_t)b * R + lane] : 0u;
+        const uint32_t src = rfl(E.rec_last[b]) & (R - 1u);  // the record of the previous descent
+        const uint32_t src_len = rdl(rlen, (int)src);
+        // the record being followed: its levels below plen are this descent's (records are whole root-to-leaf paths and
+        // the path to an edge is unique).  QZ_NONE: none -- then left_rec / left_at say which record was left last, where
+        uint32_t cur = src_len > 0u ? src : QZ_NONE, cur_len = src_len;
+        uint32_t left_rec = QZ_NONE, left_at = 0u;
+        uint32_t used = 0u;                     // records that confirmed levels
+        uint32_t walk_credit = 0u;
         bool at_leaf = false;
-        // ---- replay of the previous descent, 64 levels per round
-        const uint32_t prev0 = rfl(E.path_len[b]);
-        const uint32_t prev = (E.select_opts & 1) ? 0u : (prev0 < (uint32_t)QZ_PATH_CAP ? prev0 : (uint32_t)QZ_PATH_CAP);
-        for (uint32_t c0 = 0; c0 < prev; c0 += 64u) {
-            const uint32_t i = c0 + (uint32_t)lane;
-            bool ok = i < prev;
-            uint32_t lbase = 0u, chosen = 0u, pN = rootN;
-            int lne = 0;
-            if (ok) {
-                const unsigned long long pb = pblk[i];
-                lbase = (uint32_t)(pb >> 8);
-                lne = (int)(pb & 0xFFull);
-                chosen = path[i];
-                if (i > 0u) pN = pool[path[i - 1u]].N;
-                ok = lne >= 1 && lne <= 8 && (i > 0u || lbase == base);
-            }
-            uint32_t lact = 0u, lcne = 0u, lN = 0u, lcoff = 0u;
-            if (ok) {
-                const double lsq = sqrt((double)pN);
-                double lbest = 0.0;
-                int arg = 0;
-                for (int k = 0; k < lne; k++) {
-                    const Edge ed = pool[lbase + (uint32_t)k];
-                    const float cp = E.c_puct * ed.P;
-                    const double u = (double)cp * lsq / (double)(1u + ed.N);
-                    const double val = ed.Q + u;
-                    if (k == 0 || val > lbest) {  // first maximum, like max() over the children dict
-                        lbest = val;
-                        arg = k;
-                        lact = ed.act;
-                        lcne = ed.cne;
-                        lN = ed.N;
-                        lcoff = ed.coff;
+        while (!at_leaf) {
+            // ---- replay of record cur from level plen, 64 levels per round
+            bool left = false;
+            QZ_SEL_MARK(t_walk)
+            while (cur != QZ_NONE && walk_credit == 0u && plen + 8u <= cur_len && !left) {
+                QZ_SEL_COUNT(n_rounds++;)
+                const uint32_t* const pe = pe0 + (size_t)cur * CAP;
+                const unsigned long long* const pb = pb0 + (size_t)cur * CAP;
+                const uint32_t i = plen + (uint32_t)lane;
+                bool ok = i < cur_len;
+                uint32_t lbase = 0u, chosen = 0u, pN = 0u, pcoff = 0u;
+                unsigned long long w = 0ull;
+                int lne = 0;
+                if (ok) {
+                    w = pb[i];
+                    lbase = (uint32_t)(w >> 8);
+                    lne = (int)(w & 0xFFull);
+                    chosen = pe[i];
+                    if (lane > 0) {
+                        const Edge* pv = &pool[pe[i - 1u]];
+                        pN = pv->N;
+                        pcoff = pv->coff;
                     }
                 }
-                ok = (lbase + (uint32_t)arg == chosen) && (lbest == lbest);
-            }
-            const uint64_t bad = ~__ballot(ok);
-            const int nconf = bad ? (__ffsll((unsigned long long)bad) - 1) : 64;  // leading levels of this round that came out as before
-            for (int jj = 0; jj < nconf; jj++) {  // wave-uniform: replay the confirmed moves on the scratch board
-                done = apply_action(bd, (int)rdl(lact, jj));
-                scanned += rdl((uint32_t)lne, jj);
-            }
-            plen += (uint32_t)nconf;
-            if (nconf > 0) {
-                const int last = nconf - 1;
-                pedge = rdl(chosen, last);
-                const int cne = (int)rdl(lcne, last);
-                if (cne == 0) {  // the confirmed prefix ends on a leaf (or a finished game)
-                    at_leaf = true;
-                    break;
+                // an entry counts only if its block IS the child block of the entry above (lane 0: the current node)
+                const uint32_t linked = tree_phys_lanes(T, pcoff);
+                ok = ok && lne >= 1 && lne <= 8 && lbase == (lane > 0 ? linked : base);
+                uint32_t lact = 0u, lcne = 0u, lN = 0u, lcoff = 0u;
+                if (ok) {
+                    const double lsq = lane > 0 ? sqrt((double)pN) : sq;
+                    Edge ed[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++)
+                        if (j < lne) ed[j] = pool[lbase + (uint32_t)j];
+                    double lbest = 0.0;
+                    int arg = 0;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        if (j < lne) {
+                            const float cp = E.c_puct * ed[j].P;
+                            const double u = (double)cp * lsq / (double)(1u + ed[j].N);
+                            const double val = ed[j].Q + u;
+                            if (j == 0 || val > lbest) {  // first maximum, like max() over the children dict
+                                lbest = val;
+                                arg = j;
+                                lact = ed[j].act;
+                                lcne = ed[j].cne;
+                                lN = ed[j].N;
+                                lcoff = ed[j].coff;
+                            }
+                        }
+                    }
+                    ok = (lbase + (uint32_t)arg == chosen) && (lbest == lbest);
                 }
-                sq = sqrt((double)rdl(lN, last));
-                base = tree_phys(T, rdl(lcoff, last));
-                ne = cne;
+                const uint64_t bad = ~__ballot(ok);
+                const int nconf = bad ? (__ffsll((unsigned long long)bad) - 1) : 64;  // leading levels of this round that came out as recorded
+                if (nconf > 0) {
+                    if (lane < nconf && i < CAP) {
+                        we[i] = chosen;
+                        wb[i] = w;
+                    }
+                    used |= 1u << cur;
+                    done = apply_actions_wave(bd, lact, nconf, lane);
+                    uint32_t sc = (lane < nconf) ? (uint32_t)lne : 0u;
+                    for (int o = 32; o > 0; o >>= 1) sc += __shfl_xor(sc, o);
+                    scanned += rfl(sc);
+                    plen += (uint32_t)nconf;
+                    replayed += (uint32_t)nconf;
+                    const int last = nconf - 1;
+                    pedge = rdl(chosen, last);
+                    const int cne = (int)rdl(lcne, last);
+                    if (cne == 0) {  // the confirmed prefix ends on a leaf (or a finished game)
+                        at_leaf = true;
+                        break;
+                    }
+                    sq = sqrt((double)rdl(lN, last));
+                    base = tree_phys(T, rdl(lcoff, last));
+                    ne = cne;
+                }
+                if (nconf < 64) left = true;
+                if (nconf < 8) walk_credit = 8u;
             }
-            if (nconf < 64) break;
-        }
-        for (int depth = 0; depth < 1000000 && !at_leaf; depth++) {
+            QZ_SEL_MARK(t_replay)
+            if (at_leaf) break;
+            if (walk_credit > 0u) walk_credit--;
+            QZ_SEL_COUNT(if (ne <= 8) n_narrow++; else n_wide++;)
+            // ---- one level of the walk (all lanes scan this node's children)
+            uint32_t recorded = QZ_NONE;
+            if (cur != QZ_NONE && plen < cur_len) recorded = pe0[(size_t)cur * CAP + plen];  // uniform load, in flight during the scan
             scanned += (uint32_t)ne;
             double best = -__builtin_inf();
             int bestk = 0x7fffffff;
@@ -518,26 +619,26 @@ __global__ __launch_bounds__(TPB) void k_select(EngineDev E) {
             // candidates, so the next level costs one dependent round trip, not three
             uint32_t mCOff = 0u, mMisc = 0u;
             double mSq = 0.0;
-            for (int k = lane; k < ne; k += 64) {
-                const Edge ed = pool[base + (uint32_t)k];          // one 32-byte record per lane
+            for (int j = lane; j < ne; j += 64) {
+                const Edge ed = pool[base + (uint32_t)j];          // one 32-byte record per lane
                 uint32_t N = ed.N;
                 float cp = E.c_puct * ed.P;                         // c_puct * self._P in float32
                 double u = (double)cp * sq / (double)(1u + N);      // mcts.py:69
                 double val = ed.Q + u;                              // mcts.py:70
                 double sqN = sqrt((double)N);                       // the next level's sqrt(N_parent) if this edge wins
-                uint32_t misc = (uint32_t)ed.act | ((uint32_t)ed.cne << 8);
+                uint32_t misc = (uint32_t)ed.act | ((uint32_t)ed.cne << 8) | ((uint32_t)ed.rid << 16);
                 // a lane's first candidate is always taken: with non-finite values (a diverged
                 // network) every comparison is false and Python's max() keeps the first child
                 if (val > best || bestk == 0x7fffffff) {
                     best = val;
-                    bestk = k;
+                    bestk = j;
                     mSq = sqN;
                     mCOff = ed.coff;
                     mMisc = misc;
                 }
             }
             int kk;
-            if (ne <= 8 && !(E.select_opts & 2)) {  // wave-uniform: lane k < ne holds (val_k, k); first maximum wins like max()
+            if (ne <= 8 && !(E.select_opts & 2)) {  // wave-uniform: lane j < ne holds (val_j, j); first maximum wins like max()
                 double bv = rdl_f64(best, 0);
                 kk = 0;
                 for (int j = 1; j < ne; j++) {
@@ -558,11 +659,28 @@ __global__ __launch_bounds__(TPB) void k_select(EngineDev E) {
             const uint32_t misc = rdl(mMisc, wl);
             const int a = (int)(misc & 0xFFu);
             done = apply_action(bd, a);  // game.step(action), mcts.py:113
-            pedge = e;
-            if (lane == 0 && plen < (uint32_t)QZ_PATH_CAP) {
-                path[plen] = e;
-                pblk[plen] = ((unsigned long long)base << 8) | (unsigned long long)(ne > 255 ? 255 : ne);
+            if (lane == 0 && plen < CAP) {
+                we[plen] = e;
+                wb[plen] = ((unsigned long long)base << 8) | (unsigned long long)(ne > 255 ? 255 : ne);
             }
+            if (use && rfl(recorded) != e && !(cur != QZ_NONE && plen >= cur_len)) {  // (beyond the end of the record it follows, a descent extends it)
+                // the path leaves the record it was following (or follows none): go on in the record that took this
+                // edge last, if that record still holds the edge at this level
+                if (cur != QZ_NONE) {
+                    left_rec = cur;
+                    left_at = plen;
+                }
+                const uint32_t rid = misc >> 16;
+                cur = QZ_NONE;
+                if (rid >= 1u && rid <= R && plen < CAP) {
+                    const uint32_t rl = rdl(rlen, (int)(rid - 1u));
+                    if (rl > plen && rfl(pe0[(size_t)(rid - 1u) * CAP + plen]) == e) {
+                        cur = rid - 1u;
+                        cur_len = rl;
+                    }
+                }
+            }
+            pedge = e;
             plen++;
             const int cne = (int)((misc >> 8) & 0xFFu);
             if (cne == 0) break;  // TreeNode.is_leaf(): never expanded (or terminal)
@@ -570,7 +688,70 @@ __global__ __launch_bounds__(TPB) void k_select(EngineDev E) {
             base = tree_phys(T, rdl(mCOff, wl));
             ne = cne;
         }
+        // ---- put this descent on record
+        if (use) {
+            const uint32_t n = plen < CAP ? plen : CAP;
+            const uint32_t clock = rfl(E.rec_clock[b]) + 1u;
+            uint32_t dest, from;  // levels [from, n) of this descent go into record dest, and their edges point at it
+            if (cur != QZ_NONE) {
+                dest = cur;  // the descent is record cur, or extends it
+                from = n > cur_len ? cur_len : n;
+            } else {
+                // the descent left its last record at left_at and walked the rest.  In place if the new levels are at least as
+                // many as the recorded ones they replace, else over the record that has been useless for the longest time
+                const uint32_t l_left = left_rec != QZ_NONE ? rdl(rlen, (int)left_rec) : 0u;
+                if (left_rec != QZ_NONE && n - left_at >= l_left - left_at) {
+                    dest = left_rec;
+                    from = left_at;
+                } else {
+                    uint32_t bestv = 0xFFFFFFFFu;
+                    dest = 0u;
+                    for (uint32_t r = 0; r < R; r++) {
+                        // (a long record is worth more than its age says: losing it costs a walk of its length)
+                        const uint32_t l = rdl(rlen, (int)r), v = l == 0u ? 0u : rdl(rstamp, (int)r) + 4u * l;
+                        if (v < bestv && r != left_rec && !((used >> r) & 1u)) {
+                            bestv = v;
+                            dest = r;
+                        }
+                    }
+                    if (bestv == 0xFFFFFFFFu) dest = left_rec != QZ_NONE ? left_rec : 0u;  // every record was useful just now
+                    from = 0u;
+                }
+            }
+            const uint32_t first = from > 0u ? from : (left_rec != QZ_NONE ? left_at : 0u);
+            if (from < n) {
+                wave_sync();  // lane 0 stored walked levels into the descent buffer, all lanes read it below
+                uint32_t* const qe = pe0 + (size_t)dest * CAP;
+                unsigned long long* const qb = pb0 + (size_t)dest * CAP;
+                for (uint32_t i = from + (uint32_t)lane; i < n; i += 64u) {
+                    const uint32_t ed = we[i];
+                    qe[i] = ed;
+                    qb[i] = wb[i];
+                    if (i >= first) pool[ed].rid = (uint16_t)(dest + 1u);
+                }
+            }
+            if (lane < (int)R) {
+                if ((uint32_t)lane == dest) {
+                    if (from < n) rlen = n;
+                    rstamp = clock;
+                } else if ((used >> lane) & 1u) rstamp = clock;
+                E.rec_len[(size_t)b * R + lane] = rlen;
+                E.rec_stamp[(size_t)b * R + lane] = rstamp;
+            }
+            if (lane == 0) {
+                E.rec_last[b] = dest;
+                E.rec_clock[b] = clock;
+            }
+        }
     }
+#ifdef QZ_SELECT_STAMPS
+    QZ_SEL_MARK(t_walk)
+    if (lane == 0 && b < 4096) {
+        unsigned int* o = g_sel_stamps[E.bc_playouts[b] & 63u][b];
+        o[0] = (unsigned int)(__builtin_amdgcn_s_memtime() - t_begin); o[1] = t_replay; o[2] = t_walk; o[3] = n_rounds;
+        o[4] = n_narrow; o[5] = n_wide; o[6] = plen; o[7] = replayed;
+    }
+#endif
     if (lane == 0) {
         E.leaf_hb[b] = bd.hb;
         E.leaf_vb[b] = bd.vb;
@@ -586,6 +767,12 @@ __global__ __launch_bounds__(TPB) void k_select(EngineDev E) {
         if (nonfinite) E.bc_nonfinite[b] += 1u;
         E.bc_scanned[b] += (unsigned long long)scanned;
         if (plen > E.bc_maxdepth[b]) E.bc_maxdepth[b] = plen;
+        if (plen >= 256u) {  // telemetry of the descents that set the kernel's duration (a handful of boards)
+            atomicAdd(&E.counters[QZ_C_DEEP_DESCENTS], 1ull);
+            if (2u * replayed < plen) atomicAdd(&E.counters[QZ_C_DEEP_COLD], 1ull);
+            atomicAdd(&E.counters[QZ_C_DEEP_LEVELS], (unsigned long long)plen);
+            atomicAdd(&E.counters[QZ_C_DEEP_REPLAYED], (unsigned long long)replayed);
+        }
     }
 }
 
@@ -628,8 +815,8 @@ __global__ __launch_bounds__(TPB) void k_expand_backup(EngineDev E, const float*
                         ed.coff = 0u;
                         ed.act = (uint8_t)a;
                         ed.cne = 0;
-                        ed.pad16 = 0;
-                        ed.pad32 = 0u;
+                        ed.rid = 0;
+                        ed.spare = QZ_NONE;
                         T.pool[e] = ed;
                     }
                 }
@@ -664,7 +851,7 @@ __global__ __launch_bounds__(TPB) void k_expand_backup(EngineDev E, const float*
     Edge* pool = E.edge_pool;
     const uint32_t plen = rfl(E.path_len[b]);
     if (plen <= (uint32_t)QZ_PATH_CAP) {
-        const uint32_t* path = E.path_edges + (size_t)b * QZ_PATH_CAP;
+        const uint32_t* path = E.path_edges + ((size_t)b * (QZ_PATH_RECS + 1) + QZ_PATH_RECS) * QZ_PATH_CAP;  // k_select's descent buffer
         for (uint32_t i = (uint32_t)lane; i < plen; i += 64u) {
             uint32_t pe = path[i];
             double val = ((plen - 1u - i) & 1u) ? leaf_value : -leaf_value;
@@ -785,7 +972,50 @@ __device__ __forceinline__ void copy_block(const TreeView& S, uint32_t s_off, co
     for (int k = lane; k < ne; k += 64) {
         Edge ed = S.pool[sb + (uint32_t)k];
         ed.pedge = pedge;
+        ed.spare = QZ_NONE;
         D.pool[db + (uint32_t)k] = ed;
+        S.pool[sb + (uint32_t)k].spare = db + (uint32_t)k;  // forwarding address: where this edge lives now (translate_records)
+    }
+}
+
+// k_select's descent records across a re-root.  The subtree below root edge `edge` has just been copied and every copied
+// edge left a forwarding address behind (Edge::spare of the OLD record).  A record that went through `edge` stays valid
+// one level shorter: its entries are shifted up by one and renamed through the forwarding addresses; it is cut where
+// the copy was (pool exhausted).  Every other record described a subtree that is gone.  edge == QZ_NONE: all gone.
+__device__ __forceinline__ void translate_records(EngineDev& E, int b, int lane, uint32_t edge) {
+    constexpr uint32_t R = QZ_PATH_RECS, CAP = QZ_PATH_CAP;
+    const Edge* pool = E.edge_pool;
+    wave_sync();  // the forwarding addresses were stored by other lanes
+    for (uint32_t r = 0; r < R; r++) {
+        const uint32_t len = rfl(E.rec_len[(size_t)b * R + r]);
+        uint32_t* const re = E.path_edges + ((size_t)b * (R + 1u) + r) * CAP;
+        unsigned long long* const rb = E.path_blocks + ((size_t)b * (R + 1u) + r) * CAP;
+        uint32_t newlen = 0u;
+        if (edge != QZ_NONE && len > 1u && rfl(re[0]) == edge) {
+            newlen = len - 1u;
+            for (uint32_t c = 1u; c < len; c += 64u) {
+                const uint32_t i = c + (uint32_t)lane;
+                const bool in = i < len;
+                uint32_t fe = QZ_NONE, fb = QZ_NONE;
+                unsigned long long bo = 0ull;
+                if (in) {
+                    bo = rb[i];
+                    fe = pool[re[i]].spare;
+                    fb = pool[(uint32_t)(bo >> 8)].spare;
+                }
+                const uint64_t bad = __ballot(in && (fe == QZ_NONE || fb == QZ_NONE));
+                const uint32_t nvalid = bad ? (uint32_t)(__ffsll((unsigned long long)bad) - 1) : 64u;
+                if (in && (uint32_t)lane < nvalid) {
+                    re[i - 1u] = fe;
+                    rb[i - 1u] = ((unsigned long long)fb << 8) | (bo & 0xFFull);
+                }
+                if (bad) {
+                    newlen = c - 1u + nvalid;
+                    break;
+                }
+            }
+        }
+        if (lane == 0) E.rec_len[(size_t)b * R + r] = newlen;
     }
 }
 
@@ -855,6 +1085,7 @@ __device__ __forceinline__ void wave_reroot(EngineDev& E, int b, int lane, uint3
             truncated = 1u;
         }
     }
+    translate_records(E, b, lane, flipped ? edge : QZ_NONE);
     if (lane == 0) {
         // successful copy: the old tree (now the other half) goes back to the pool; otherwise the
         // board restarts from a fresh root and its current half is returned
@@ -863,7 +1094,7 @@ __device__ __forceinline__ void wave_reroot(EngineDev& E, int b, int lane, uint3
             E.tree_half[b] = (uint8_t)(half ^ 1u);
             E.tree_npages[tree_slot(E, b, half ^ 1u)] = dnp;
         }
-        E.path_len[b] = 0u;  // the recorded descent belongs to the tree that was just replaced
+        E.path_len[b] = 0u;
         E.n_nodes[b] = new_nodes;
         E.n_edges[b] = new_edges;
         E.root_N[b] = childN;
@@ -885,6 +1116,7 @@ __device__ __forceinline__ void reset_board_state(EngineDev& E, int b) {
     E.root_ne[b] = 0u;
     E.root_eoff[b] = 0u;
     E.path_len[b] = 0u;
+    for (int r = 0; r < QZ_PATH_RECS; r++) E.rec_len[(size_t)b * QZ_PATH_RECS + r] = 0u;
     E.ply[b] = 0u;
     E.status[b] = QZ_PLAYING;
     E.winner[b] = 0;
@@ -910,6 +1142,7 @@ __global__ __launch_bounds__(TPB) void k_reset(EngineDev E, int reset_boards) {
         E.root_ne[b] = 0u;
         E.root_eoff[b] = 0u;
         E.path_len[b] = 0u;
+        for (int r = 0; r < QZ_PATH_RECS; r++) E.rec_len[(size_t)b * QZ_PATH_RECS + r] = 0u;
         E.release[b] = 0;
     }
 }
@@ -1463,6 +1696,11 @@ hipError_t rollout_step(uint64_t* hb, uint64_t* vb, uint64_t* meta, const uint32
                        n_done, seed, step, limit);
     return hipGetLastError();
 }
+#ifdef QZ_SELECT_STAMPS
+extern "C" int qzt_select_stamps_read(void* host_out) {  // [64 launches (playout counter & 63)][4096 boards][8] u32
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_sel_stamps), sizeof(g_sel_stamps));
+}
+#endif
 hipError_t sqrt_table(double* out, int n, hipStream_t s) {
     hipLaunchKernelGGL(k_sqrt_table, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out, n);
     return hipGetLastError();

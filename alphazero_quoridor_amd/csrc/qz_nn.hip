@@ -418,6 +418,93 @@ struct HeadFc {           // lives in the tile memory once the convolutions are 
     float h1[HB][128];
     float logit[HB][144];
 };
+// fc1 + fc2 + tanh and fc3 + softmax of HB leaves whose normalised head features (c * 81 + pos order,
+// FS floats apart) are in LDS: the second half of k_head, and all of k_head_fc
+__device__ __forceinline__ void head_fc_tail(const float* __restrict__ s_f, HeadFc& fc, int nb, long long s0, int tid, int wave, int lane,
+                                             const float* __restrict__ w1t, const float* __restrict__ b1, const float* __restrict__ w2,
+                                             const float* __restrict__ b2, const float* __restrict__ w3t, const float* __restrict__ b3,
+                                             float* __restrict__ p_out, float* __restrict__ v_out) {
+    if (wave < 2) {  // fc1: 324 -> 128, thread = output
+        const int j = tid;
+        float a1[HB];
+#pragma unroll
+        for (int s = 0; s < HB; s++) a1[s] = 0.f;
+        // 12 coalesced weight loads in flight per trip (the loop is latency-bound, not issue-bound)
+        for (int i = 0; i < 4 * PL; i += 12) {
+            float w[12];
+#pragma unroll
+            for (int k = 0; k < 12; k++) w[k] = w1t[(i + k) * 128 + j];
+#pragma unroll
+            for (int s = 0; s < HB; s++) {
+#pragma unroll
+                for (int k4 = 0; k4 < 3; k4++) {
+                    const float4 f = *reinterpret_cast<const float4*>(&s_f[s * FS + i + 4 * k4]);
+                    a1[s] = __builtin_fmaf(w[4 * k4 + 0], f.x, a1[s]);
+                    a1[s] = __builtin_fmaf(w[4 * k4 + 1], f.y, a1[s]);
+                    a1[s] = __builtin_fmaf(w[4 * k4 + 2], f.z, a1[s]);
+                    a1[s] = __builtin_fmaf(w[4 * k4 + 3], f.w, a1[s]);
+                }
+            }
+        }
+        const float bb = b1[j];
+#pragma unroll
+        for (int s = 0; s < HB; s++) fc.h1[s][j] = a1[s] + bb;
+    } else {  // fc3: 162 -> 140 on the third wavefront, thread = outputs j, j + 64, j + 128
+        const int j = tid - 128, j1 = j + 64, j2 = j + 128;
+        const bool three = j2 < 140;
+        float a3[HB], a3b[HB], a3c[HB];
+#pragma unroll
+        for (int s = 0; s < HB; s++) a3[s] = a3b[s] = a3c[s] = 0.f;
+        for (int i = 0; i < 2 * PL; i += 6) {  // 162 = 27 * 6: up to 18 loads in flight per trip
+            float wa[6], wb[6], wc[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                wa[k] = w3t[(i + k) * 140 + j];
+                wb[k] = w3t[(i + k) * 140 + j1];
+                wc[k] = three ? w3t[(i + k) * 140 + j2] : 0.f;
+            }
+#pragma unroll
+            for (int s = 0; s < HB; s++) {
+#pragma unroll
+                for (int k2 = 0; k2 < 3; k2++) {
+                    const float2 f = *reinterpret_cast<const float2*>(&s_f[s * FS + 4 * PL + i + 2 * k2]);
+                    a3[s] = __builtin_fmaf(wa[2 * k2], f.x, a3[s]);
+                    a3[s] = __builtin_fmaf(wa[2 * k2 + 1], f.y, a3[s]);
+                    a3b[s] = __builtin_fmaf(wb[2 * k2], f.x, a3b[s]);
+                    a3b[s] = __builtin_fmaf(wb[2 * k2 + 1], f.y, a3b[s]);
+                    a3c[s] = __builtin_fmaf(wc[2 * k2], f.x, a3c[s]);
+                    a3c[s] = __builtin_fmaf(wc[2 * k2 + 1], f.y, a3c[s]);
+                }
+            }
+        }
+        const float ba = b3[j], bb = b3[j1], bc = three ? b3[j2] : 0.f;
+#pragma unroll
+        for (int s = 0; s < HB; s++) {
+            fc.logit[s][j] = a3[s] + ba;
+            fc.logit[s][j1] = a3b[s] + bb;
+            if (three) fc.logit[s][j2] = a3c[s] + bc;
+        }
+    }
+    __syncthreads();
+    for (int s = wave; s < nb; s += HT / 64) {  // a wavefront finishes a leaf
+        float part = fc.h1[s][lane] * w2[lane] + fc.h1[s][lane + 64] * w2[lane + 64];
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+        if (lane == 0) v_out[s0 + s] = tanhf(part + b2[0]);
+        const float x0 = fc.logit[s][lane], x1 = fc.logit[s][lane + 64];
+        const bool has2 = lane + 128 < 140;
+        const float x2 = has2 ? fc.logit[s][lane + 128] : -INFINITY;
+        float m = fmaxf(fmaxf(x0, x1), x2);
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        float e = expf(x0 - m) + expf(x1 - m) + (has2 ? expf(x2 - m) : 0.f);
+        for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o);
+        const float lse = m + logf(e);
+        float* po = p_out + (size_t)(s0 + s) * 140;
+        po[lane] = expf(x0 - lse);
+        po[lane + 64] = expf(x1 - lse);
+        if (has2) po[lane + 128] = expf(x2 - lse);
+    }
+}
+
 template <bool NORM>
 __global__ __launch_bounds__(HT) void k_head(const float* __restrict__ t, long long n, const float* __restrict__ w6k,
                                               const float* __restrict__ gamma6, const float* __restrict__ beta6,
@@ -569,86 +656,28 @@ __global__ __launch_bounds__(HT) void k_head(const float* __restrict__ t, long l
         }
     }
     __syncthreads();
-    HeadFc& fc = *reinterpret_cast<HeadFc*>(s_x + HB * FS);
-    if (wave < 2) {  // fc1: 324 -> 128, thread = output
-        const int j = tid;
-        float a1[HB];
-#pragma unroll
-        for (int s = 0; s < HB; s++) a1[s] = 0.f;
-        // 12 coalesced weight loads in flight per trip (the loop is latency-bound, not issue-bound)
-        for (int i = 0; i < 4 * PL; i += 12) {
-            float w[12];
-#pragma unroll
-            for (int k = 0; k < 12; k++) w[k] = w1t[(i + k) * 128 + j];
-#pragma unroll
-            for (int s = 0; s < HB; s++) {
-#pragma unroll
-                for (int k4 = 0; k4 < 3; k4++) {
-                    const float4 f = *reinterpret_cast<const float4*>(&s_f[s * FS + i + 4 * k4]);
-                    a1[s] = __builtin_fmaf(w[4 * k4 + 0], f.x, a1[s]);
-                    a1[s] = __builtin_fmaf(w[4 * k4 + 1], f.y, a1[s]);
-                    a1[s] = __builtin_fmaf(w[4 * k4 + 2], f.z, a1[s]);
-                    a1[s] = __builtin_fmaf(w[4 * k4 + 3], f.w, a1[s]);
-                }
-            }
-        }
-        const float bb = b1[j];
-#pragma unroll
-        for (int s = 0; s < HB; s++) fc.h1[s][j] = a1[s] + bb;
-    } else {  // fc3: 162 -> 140 on the third wavefront, thread = outputs j, j + 64, j + 128
-        const int j = tid - 128, j1 = j + 64, j2 = j + 128;
-        const bool three = j2 < 140;
-        float a3[HB], a3b[HB], a3c[HB];
-#pragma unroll
-        for (int s = 0; s < HB; s++) a3[s] = a3b[s] = a3c[s] = 0.f;
-        for (int i = 0; i < 2 * PL; i += 6) {  // 162 = 27 * 6: up to 18 loads in flight per trip
-            float wa[6], wb[6], wc[6];
-#pragma unroll
-            for (int k = 0; k < 6; k++) {
-                wa[k] = w3t[(i + k) * 140 + j];
-                wb[k] = w3t[(i + k) * 140 + j1];
-                wc[k] = three ? w3t[(i + k) * 140 + j2] : 0.f;
-            }
-#pragma unroll
-            for (int s = 0; s < HB; s++) {
-#pragma unroll
-                for (int k2 = 0; k2 < 3; k2++) {
-                    const float2 f = *reinterpret_cast<const float2*>(&s_f[s * FS + 4 * PL + i + 2 * k2]);
-                    a3[s] = __builtin_fmaf(wa[2 * k2], f.x, a3[s]);
-                    a3[s] = __builtin_fmaf(wa[2 * k2 + 1], f.y, a3[s]);
-                    a3b[s] = __builtin_fmaf(wb[2 * k2], f.x, a3b[s]);
-                    a3b[s] = __builtin_fmaf(wb[2 * k2 + 1], f.y, a3b[s]);
-                    a3c[s] = __builtin_fmaf(wc[2 * k2], f.x, a3c[s]);
-                    a3c[s] = __builtin_fmaf(wc[2 * k2 + 1], f.y, a3c[s]);
-                }
-            }
-        }
-        const float ba = b3[j], bb = b3[j1], bc = three ? b3[j2] : 0.f;
-#pragma unroll
-        for (int s = 0; s < HB; s++) {
-            fc.logit[s][j] = a3[s] + ba;
-            fc.logit[s][j1] = a3b[s] + bb;
-            if (three) fc.logit[s][j2] = a3c[s] + bc;
-        }
+    head_fc_tail(s_f, *reinterpret_cast<HeadFc*>(s_x + HB * FS), nb, s0, tid, wave, lane, w1t, b1, w2, b2, w3t, b3, p_out, v_out);
+}
+
+// The fully connected half alone: feat [n][486] = the normalised, rectified head convolution
+// (value channels 0..3, policy 4..5; c * 81 + pos) written by k_trunk's head stage (qz_conv.hip).
+__global__ __launch_bounds__(HT) void k_head_fc(const float* __restrict__ feat, long long n, const float* __restrict__ w1t,
+                                                const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2,
+                                                const float* __restrict__ w3t, const float* __restrict__ b3, float* __restrict__ p_out,
+                                                float* __restrict__ v_out) {
+    __shared__ __attribute__((aligned(16))) float s_f[HB * FS];
+    __shared__ HeadFc fc;
+    const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const long long s0 = (long long)blockIdx.x * HB;
+    const int nb = (int)((n - s0) < HB ? (n - s0) : HB);
+    for (int i = tid; i < HB * 243; i += HT) {  // 486 floats per leaf as 243 float2
+        const int sl = i / 243, k = i - sl * 243;
+        float2 v = make_float2(0.f, 0.f);
+        if (sl < nb) v = reinterpret_cast<const float2*>(feat + (size_t)(s0 + sl) * 486)[k];
+        *reinterpret_cast<float2*>(&s_f[sl * FS + 2 * k]) = v;
     }
     __syncthreads();
-    for (int s = wave; s < nb; s += HT / 64) {  // a wavefront finishes a leaf
-        float part = fc.h1[s][lane] * w2[lane] + fc.h1[s][lane + 64] * w2[lane + 64];
-        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
-        if (lane == 0) v_out[s0 + s] = tanhf(part + b2[0]);
-        const float x0 = fc.logit[s][lane], x1 = fc.logit[s][lane + 64];
-        const bool has2 = lane + 128 < 140;
-        const float x2 = has2 ? fc.logit[s][lane + 128] : -INFINITY;
-        float m = fmaxf(fmaxf(x0, x1), x2);
-        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-        float e = expf(x0 - m) + expf(x1 - m) + (has2 ? expf(x2 - m) : 0.f);
-        for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o);
-        const float lse = m + logf(e);
-        float* po = p_out + (size_t)(s0 + s) * 140;
-        po[lane] = expf(x0 - lse);
-        po[lane + 64] = expf(x1 - lse);
-        if (has2) po[lane + 128] = expf(x2 - lse);
-    }
+    head_fc_tail(s_f, fc, nb, s0, tid, wave, lane, w1t, b1, w2, b2, w3t, b3, p_out, v_out);
 }
 
 }  // namespace
@@ -703,6 +732,12 @@ hipError_t head(const float* t, long long n, const float* w6k, const float* gamm
     dim3 grid((unsigned)((n + HB - 1) / HB)), block(HT);
     if (gamma6) hipLaunchKernelGGL((k_head<true>), grid, block, 0, s, t, n, w6k, gamma6, beta6, w1t, b1, w2, b2, w3t, b3, p_out, v_out, eps);
     else hipLaunchKernelGGL((k_head<false>), grid, block, 0, s, t, n, w6k, gamma6, beta6, w1t, b1, w2, b2, w3t, b3, p_out, v_out, eps);
+    return hipGetLastError();
+}
+hipError_t head_fc(const float* feat, long long n, const float* w1t, const float* b1, const float* w2, const float* b2, const float* w3t,
+                   const float* b3, float* p_out, float* v_out, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_head_fc, dim3((unsigned)((n + HB - 1) / HB)), dim3(HT), 0, s, feat, n, w1t, b1, w2, b2, w3t, b3, p_out, v_out);
     return hipGetLastError();
 }
 }  // namespace qzl

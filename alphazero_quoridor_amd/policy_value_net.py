@@ -94,7 +94,7 @@ class LeafEvaluator:
     """
 
     def __init__(self, net: nn.Module, bn_mode="per_leaf", dtype=torch.float32, channels_last=False, fused_norm=True,
-                 board_input_layer=True, fused_head=True, mfma_trunk=True, fused_trunk=True):
+                 board_input_layer=True, fused_head=True, mfma_trunk=True, fused_trunk=True, fused_heads_stage=True):
         assert bn_mode in ("per_leaf", "batch", "eval")
         self.fused_norm = fused_norm  # per_leaf on the GPU: use the one-pass HIP normalisation kernel
         # first layer straight from the packed boards (qz_nn_input_layer) when the caller hands them
@@ -112,7 +112,9 @@ class LeafEvaluator:
         # matrix cores with split operands (fp32 accuracy; qz_nn_conv3x3_norm): fp32, channels-last, per-leaf
         self.mfma_trunk = mfma_trunk and fused_norm and bn_mode == "per_leaf" and dtype == torch.float32 and channels_last
         self._w16 = None
+        self._w6_16 = None
         self.fused_trunk = fused_trunk  # all ten layers in ONE persistent launch (activations stay on the CU)
+        self.fused_heads_stage = fused_heads_stage  # the head convolution as the last stage of the fused trunk launch
         self.trunk_events = None   # bench.py: a list that receives (start, end) HIP events around trunk-layer launches
         self.net = net
         self.bn_mode = bn_mode
@@ -173,6 +175,16 @@ class LeafEvaluator:
                     o.copy_(t)
                 self._w16 = [(o, sc) for (o, _), (_, sc) in zip(self._w16, w16)]
             self._trunk_args = None  # host-side pointer tables of qz_nn_trunk, rebuilt on the next call
+            if self.fused_head and self.fused_trunk:
+                # the merged head convolution as one more stage of the fused trunk launch (qz_nn_trunk_heads):
+                # the same split-fp16 B operand with 32 output columns, 6 of them real
+                hw = layers[-1][0]
+                w6 = self._split_weight(torch.cat([hw, torch.zeros((26,) + tuple(hw.shape[1:]), dtype=hw.dtype, device=hw.device)], 0))
+                if self._w6_16 is None:
+                    self._w6_16 = w6
+                else:
+                    self._w6_16[0].copy_(w6[0])
+                    self._w6_16 = (self._w6_16[0], w6[1])
         if self.board_input_layer and layers[0][0].is_cuda:
             tabs = self._input_tables(layers[0][0])
             if self._in_tables is None:
@@ -190,13 +202,13 @@ class LeafEvaluator:
 
     @staticmethod
     def _split_weight(w):
-        """conv weight [64,64,3,3] fp32 -> (fp16 [2,9,4,64,16] = [hi|lo][tap][c_in chunk][c_out][c_in in chunk] of
+        """conv weight [c_out,64,3,3] fp32 -> (fp16 [2,9,4,c_out,16] = [hi|lo][tap][c_in chunk][c_out][c_in in chunk] of
         w * scale, 1 / scale): the B operand of qz_nn_conv3x3_norm (include/qz_abi.h).  scale is the power
         of two that brings max |w| into [1, 2), so that the lo parts are fp16 normals."""
         W = w.detach().to(torch.float32).contiguous()
         mx = float(W.abs().max())
         scale = 2.0 ** (-np.floor(np.log2(mx))) if mx > 0 else 1.0
-        ws = (W * scale).permute(2, 3, 1, 0).reshape(9, 4, 16, 64).permute(0, 1, 3, 2).contiguous()  # [tap][chunk][c_out][16 c_in]
+        ws = (W * scale).permute(2, 3, 1, 0).reshape(9, 4, 16, W.shape[0]).permute(0, 1, 3, 2).contiguous()  # [tap][chunk][c_out][16 c_in]
         hi = ws.to(torch.float16)
         lo = (ws - hi.to(torch.float32)).to(torch.float16)
         return torch.stack([hi, lo]).contiguous(), float(1.0 / scale)
@@ -218,17 +230,36 @@ class LeafEvaluator:
             self.trunk_events.append(ev)
         return out
 
-    def _trunk_mfma(self, x):
-        """All ten trunk layers from one library call (qz_nn_trunk); x is updated in place."""
-        import ctypes as C
+    def _trunk_heads_mfma(self, x):
+        """Trunk + both heads from one library call, two launches (qz_nn_trunk_heads): x = the first layer's
+        output -> (p, v); the trunk output never reaches HBM."""
         from . import _cabi
+        w, g, b, sc = self._trunk_tables()
+        hd = self._head
+        B, dev = x.shape[0], x.device
+        p = torch.empty((B, N_ACTIONS), dtype=torch.float32, device=dev)
+        v = torch.empty(B, dtype=torch.float32, device=dev)
+        feat = torch.empty((B, 6 * 81), dtype=torch.float32, device=dev)
+        _cabi.check(_cabi.load().qz_nn_trunk_heads(
+            x.data_ptr(), B, N_RES, w, g, b, sc, self._w6_16[0].data_ptr(), self._w6_16[1], hd[8].data_ptr(), hd[1].data_ptr(),
+            hd[2].data_ptr(), hd[3].data_ptr(), hd[4].data_ptr(), hd[5].data_ptr(), hd[6].data_ptr(), hd[7].data_ptr(),
+            feat.data_ptr(), p.data_ptr(), v.data_ptr(), BN_EPS, torch.cuda.current_stream(dev).cuda_stream))
+        return p, v
+
+    def _trunk_tables(self):
+        import ctypes as C
         if getattr(self, "_trunk_args", None) is None:
             L = 2 * N_RES
             self._trunk_args = ((C.c_void_p * L)(*[self._w16[i][0].data_ptr() for i in range(L)]),
                                 (C.c_void_p * L)(*[self._layers[i + 1][2].data_ptr() for i in range(L)]),
                                 (C.c_void_p * L)(*[self._layers[i + 1][3].data_ptr() for i in range(L)]),
                                 (C.c_float * L)(*[self._w16[i][1] for i in range(L)]))
-        w, g, b, sc = self._trunk_args
+        return self._trunk_args
+
+    def _trunk_mfma(self, x):
+        """All ten trunk layers from one library call (qz_nn_trunk); x is updated in place."""
+        from . import _cabi
+        w, g, b, sc = self._trunk_tables()
         # scratch of the layer-by-layer route: from the caching allocator every time (one evaluator may serve
         # several board groups on different streams at once, so nothing mutable is kept on the object)
         tmp = None if self.fused_trunk else torch.empty_like(x, memory_format=torch.channels_last)
@@ -319,8 +350,12 @@ class LeafEvaluator:
                 x = x.contiguous(memory_format=torch.channels_last)
             x = self._cbn(x, 0)
         li = 1
-        if self.mfma_trunk and self._w16 is not None and self.trunk_events is None and x.is_cuda and x.dtype == torch.float32 \
-                and x.is_contiguous(memory_format=torch.channels_last) and x.shape[1] == WIDTH:
+        mfma_ok = self.mfma_trunk and self._w16 is not None and self.trunk_events is None and x.is_cuda and x.dtype == torch.float32 \
+            and x.is_contiguous(memory_format=torch.channels_last) and x.shape[1] == WIDTH
+        if mfma_ok and self.fused_trunk and self.fused_head and self.fused_heads_stage and self._w6_16 is not None and self._head is not None \
+                and len(self._head) > 8:
+            return self._trunk_heads_mfma(x)
+        if mfma_ok:
             x = self._trunk_mfma(x)  # ten launches, one library call; x (the first layer's output) is updated in place
             li += 2 * N_RES
         else:

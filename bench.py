@@ -579,7 +579,8 @@ def main():
             ],
             "roofline_nn": None,
             "engine_stats": {kk: st1[kk] for kk in ("node_overflow", "games_aborted", "aborted_no_move", "aborted_max_plies", "aborted_pool",
-                                                    "nonfinite_values", "arena_bytes", "max_nodes", "max_edges", "max_depth", "tree_pages_total",
+                                                    "nonfinite_values", "arena_bytes", "max_nodes", "max_edges", "max_depth", "deep_descents", "deep_descents_cold",
+                                                    "deep_levels", "deep_levels_replayed", "tree_pages_total",
                                                     "tree_pages_peak", "traj_pages_total", "traj_pages_peak")},
             "clocks": sampler.summary() if sampler else None,
         }

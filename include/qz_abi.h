@@ -155,6 +155,9 @@ typedef struct {
     int64_t edges_scanned;     /* 32-byte edge records read by the descents (k_select's algorithmic bytes / 32) */
     int64_t edges_expanded;    /* edge records created by expansions                                    */
     int64_t max_depth;         /* deepest descent so far (tree levels); descents beyond 2,048 levels back up by walking parent links */
+    /* the descents of >= 256 levels (the ones that set the select kernel's duration): how many, how many of them
+     * found a descent record shorter than half their length, their levels, and the levels the replay confirmed */
+    int64_t deep_descents, deep_descents_cold, deep_levels, deep_levels_replayed;
 } qz_stats;
 
 /* MCTSPlayer.__init__ / MCTS.__init__ (mcts.py:89-100, 159-161) for n_boards trees +
@@ -293,6 +296,19 @@ int qz_nn_conv3x3_norm(const float* x /*[dev]*/, const void* w16 /*[dev]*/, cons
 int qz_nn_trunk(float* x /*[dev] in/out*/, float* tmp /*[dev] or NULL*/, int64_t n, int n_blocks, const void* const* w16 /*[host]*/,
                 const float* const* gamma /*[host]*/, const float* const* beta /*[host]*/, const float* inv_scale /*[host]*/,
                 float eps, int fused, void* stream);
+/* Trunk + both heads (policy_value_net.py:75-93,155) from ONE call, two launches: the fused trunk
+ * launch of qz_nn_trunk with one more stage -- the merged 64 -> 6 head convolution + bn2 / bn3 per
+ * leaf + ReLU on the last layer's activations while they are still in LDS -- writes 486 features
+ * per leaf into feat (scratch, [n][486] floats, c * 81 + pos, value channels first), then fc1 /
+ * fc2 / tanh and fc3 / softmax read them.  x [n][81][64] (the first layer's output) is only read;
+ * the trunk output never reaches HBM.  w6_16: the merged head weight [6][64][3][3] prepared like
+ * w16 but with 32 output columns: fp16 [2][9][4][32][16], columns 6..31 zero; the other arguments
+ * as in qz_nn_trunk / qz_nn_head.  Per-leaf normalisation only (gamma6 must not be NULL). */
+int qz_nn_trunk_heads(const float* x /*[dev]*/, int64_t n, int n_blocks, const void* const* w16 /*[host]*/, const float* const* gamma /*[host]*/,
+                      const float* const* beta /*[host]*/, const float* inv_scale /*[host]*/, const void* w6_16 /*[dev]*/, float inv_scale6,
+                      const float* gamma6, const float* beta6, const float* w1t, const float* b1, const float* w2, const float* b2,
+                      const float* w3t, const float* b3, float* feat /*[dev] n*486 scratch*/, float* p_out /*[dev] n*140*/,
+                      float* v_out /*[dev] n*/, float eps, void* stream);
 /* the engine's current leaf boards (what qz_mcts_select just produced) and their terminal flags,
  * as device pointers owned by the engine: input of qz_nn_input_layer */
 int qz_engine_leaf_boards(qz_engine* e, qz_boards* boards_out, const uint8_t** terminal_out);

@@ -149,3 +149,34 @@ def test_fused_trunk_equals_layer_by_layer(gpu_device):
     p1, v1 = fused(planes)
     p2, v2 = layered(planes)
     assert (p1 - p2).abs().max().item() < 2e-6 and (v1 - v2).abs().max().item() < 1e-5
+
+
+def test_head_stage_of_the_trunk_launch_equals_the_separate_head_kernel(gpu_device):
+    """qz_nn_trunk_heads: the merged 64 -> 6 head convolution + bn2 / bn3 + ReLU as the last stage of
+    the fused trunk launch (MFMA on the activations still in LDS) and k_head_fc, against the fused
+    trunk followed by the fp32 VALU head kernel (qz_nn_head): same function, p to 2e-6 and v to 1e-5
+    (the tolerance of the evaluator against the reference).  Ragged batch sizes included; the input
+    tensor must not be modified."""
+    from _stubs import det_fill_state_dict
+    from alphazero_quoridor_amd.policy_value_net import LeafEvaluator, PolicyValueNet
+
+    pvn = PolicyValueNet(use_gpu=True, device=gpu_device)
+    pvn.policy_value_net.load_state_dict(det_fill_state_dict(pvn.policy_value_net.state_dict(), 2024))
+    staged = LeafEvaluator(pvn.policy_value_net, "per_leaf", channels_last=True)
+    separate = LeafEvaluator(pvn.policy_value_net, "per_leaf", channels_last=True, fused_heads_stage=False)
+    assert staged._w6_16 is not None and staged.fused_heads_stage
+    g = torch.Generator().manual_seed(12)
+    for B in (1, 5, 6, 7, 64, 1000, 4096):
+        planes = (torch.rand((B, 26, 9, 9), generator=g) > 0.8).float().to(gpu_device)
+        p1, v1 = staged(planes)
+        p2, v2 = separate(planes)
+        assert p1.shape == (B, 140) and v1.shape == (B,)
+        dp, dv = (p1 - p2).abs().max().item(), (v1 - v2).abs().max().item()
+        assert torch.isfinite(p1).all() and torch.isfinite(v1).all() and dp < 2e-6 and dv < 1e-5, (B, dp, dv)
+        assert abs(p1.sum(dim=1) - 1).max().item() < 1e-5
+    x = torch.relu(torch.randn((300, 64, 9, 9), generator=g)).to(gpu_device).contiguous(memory_format=torch.channels_last)
+    x0 = x.clone(memory_format=torch.preserve_format)
+    pa, va = staged._trunk_heads_mfma(x)
+    assert torch.equal(x, x0)
+    pb, vb = staged._trunk_heads_mfma(x)
+    assert torch.equal(pa, pb) and torch.equal(va, vb)   # run to run: bit-identical
