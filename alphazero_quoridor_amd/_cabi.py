@@ -151,6 +151,8 @@ _SIGNATURES = {
     "qz_nn_conv3x3_norm": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, C.c_float, C.c_int, C.c_float, _P]),
     "qz_nn_trunk": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P, _P, _P, _P, C.c_float, C.c_int, _P]),
     "qz_nn_trunk_heads": (C.c_int, [_P, C.c_int64, C.c_int, _P, _P, _P, _P, _P, C.c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, _P]),
+    "qz_nn_evaluate": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P, _P, _P, C.c_int, _P, _P, _P, _P, _P, C.c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                                 _P, C.c_float, _P]),
     "qz_nn_head": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, _P]),
     "qz_selftest_sqrt": (C.c_int, [_P, C.c_int, _P]),
 }

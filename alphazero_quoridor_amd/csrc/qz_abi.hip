@@ -29,8 +29,13 @@ hipError_t pool_init(const EngineDev&, hipStream_t);
 hipError_t harvest(const EngineDev&, uint64_t*, uint64_t*, uint64_t*, float*, float*, int32_t*, long long, hipStream_t);
 hipError_t sqrt_table(double*, int, hipStream_t);
 hipError_t conv3x3_norm(const float*, const void*, const float*, const float*, const float*, float*, long long, float, int, float, hipStream_t);
+struct TrunkInput {  // qz_conv.hip
+    const uint64_t *hb, *vb, *meta;
+    const uint8_t* terminal;
+    const float *hot9, *base0, *wd, *gamma0, *beta0;
+};
 hipError_t trunk(float*, float*, long long, int, const void* const*, const float* const*, const float* const*, const float*, float, int, hipStream_t,
-                 const void*, const float*, const float*, float, float*);
+                 const void*, const float*, const float*, float, float*, const TrunkInput*);
 hipError_t head_fc(const float*, long long, const float*, const float*, const float*, const float*, const float*, const float*, float*, float*, hipStream_t);
 hipError_t rollout_begin(const uint64_t*, const uint64_t*, const uint64_t*, int, uint8_t*, uint8_t*, int8_t*, int*, hipStream_t);
 hipError_t rollout_step(uint64_t*, uint64_t*, uint64_t*, const uint32_t*, int, const uint8_t*, uint8_t*, int8_t*, int*, uint64_t, int, int, hipStream_t);
@@ -681,7 +686,7 @@ int qz_nn_trunk(float* x, float* tmp, int64_t n, int n_blocks, const void* const
     if ((((uintptr_t)x | (uintptr_t)tmp) & 15) != 0) return fail(QZ_E_INVALID, "tensors must be 16-byte aligned");
     for (int l = 0; l < 2 * n_blocks; l++)
         if (!w16[l] || !gamma[l] || !beta[l]) return fail(QZ_E_INVALID, "null layer tensor");
-    HIP_TRY(qzl::trunk(x, tmp, (long long)n, n_blocks, w16, gamma, beta, inv_scale, eps, fused, (hipStream_t)stream, nullptr, nullptr, nullptr, 0.f, nullptr));
+    HIP_TRY(qzl::trunk(x, tmp, (long long)n, n_blocks, w16, gamma, beta, inv_scale, eps, fused, (hipStream_t)stream, nullptr, nullptr, nullptr, 0.f, nullptr, nullptr));
     return 0;
 }
 int qz_nn_trunk_heads(const float* x, int64_t n, int n_blocks, const void* const* w16, const float* const* gamma, const float* const* beta,
@@ -698,7 +703,28 @@ int qz_nn_trunk_heads(const float* x, int64_t n, int n_blocks, const void* const
     for (int l = 0; l < 2 * n_blocks; l++)
         if (!w16[l] || !gamma[l] || !beta[l]) return fail(QZ_E_INVALID, "null layer tensor");
     HIP_TRY(qzl::trunk(const_cast<float*>(x), nullptr, (long long)n, n_blocks, w16, gamma, beta, inv_scale, eps, 1, (hipStream_t)stream, w6_16, gamma6, beta6,
-                       inv_scale6, feat));
+                       inv_scale6, feat, nullptr));
+    HIP_TRY(qzl::head_fc(feat, (long long)n, w1t, b1, w2, b2, w3t, b3, p_out, v_out, (hipStream_t)stream));
+    return 0;
+}
+int qz_nn_evaluate(const qz_boards* boards, const uint8_t* terminal, int64_t n, const float* hot9, const float* base0, const float* wd,
+                   const float* gamma0, const float* beta0, int n_blocks, const void* const* w16, const float* const* gamma,
+                   const float* const* beta, const float* inv_scale, const void* w6_16, float inv_scale6, const float* gamma6,
+                   const float* beta6, const float* w1t, const float* b1, const float* w2, const float* b2, const float* w3t, const float* b3,
+                   float* feat, float* p_out, float* v_out, float eps, void* stream) {
+    int r;
+    if ((r = device_check())) return r;
+    if (n < 0 || n_blocks <= 0 || n_blocks > 8) return fail(QZ_E_INVALID, "n < 0 or n_blocks outside 1..8");
+    if (n == 0) return 0;
+    if (!boards || !boards->hbits || !boards->vbits || !boards->meta || !hot9 || !base0 || !wd || !gamma0 || !beta0 || !w16 || !gamma || !beta ||
+        !inv_scale || !w6_16 || !gamma6 || !beta6 || !w1t || !b1 || !w2 || !b2 || !w3t || !b3 || !feat || !p_out || !v_out)
+        return fail(QZ_E_INVALID, "null argument");
+    if ((((uintptr_t)wd | (uintptr_t)w6_16) & 15) != 0 || ((uintptr_t)feat & 7) != 0) return fail(QZ_E_INVALID, "wd / w6_16 must be 16-byte, feat 8-byte aligned");
+    for (int l = 0; l < 2 * n_blocks; l++)
+        if (!w16[l] || !gamma[l] || !beta[l]) return fail(QZ_E_INVALID, "null layer tensor");
+    const qzl::TrunkInput in = {boards->hbits, boards->vbits, boards->meta, terminal, hot9, base0, wd, gamma0, beta0};
+    HIP_TRY(qzl::trunk(nullptr, nullptr, (long long)n, n_blocks, w16, gamma, beta, inv_scale, eps, 1, (hipStream_t)stream, w6_16, gamma6, beta6, inv_scale6,
+                       feat, &in));
     HIP_TRY(qzl::head_fc(feat, (long long)n, w1t, b1, w2, b2, w3t, b3, p_out, v_out, (hipStream_t)stream));
     return 0;
 }

@@ -258,6 +258,10 @@ struct TrunkShared {
     half8 a_hi[ROWS * RV];  // one leaf: 81 positions + the all-zero row, 144-byte rows
     half8 a_lo[ROWS * RV];
     float red6[2][2][32];   // head stage: [pass][wave][head channel]
+    // input stage: tables and the board's pixel codes (its raw fp32 output [81][64] lies in the image memory)
+    float wd[4 * 9 * 64];
+    float s9[9 * 64];
+    uint8_t code[96];
 };
 // The head stage (optional): the merged 64 -> 6 head convolution (policy_value_net.py:64-65,69-70:
 // conv2 = value channels 0..3, conv3 = policy channels 4..5) + bn2 / bn3 per leaf + ReLU on the
@@ -271,7 +275,18 @@ struct HeadArgs {
     float* feat;          // [n][486] out; nullptr = no head stage
 };
 
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_trunk(const float* __restrict__ x, float* __restrict__ out, TrunkArgs A, int n_layers, float eps, HeadArgs H
+// The input stage (optional): the first layer conv1(state(board)) + bn1 per leaf + ReLU computed from the packed
+// board and three tables instead of being read from HBM -- k_input_layer's arithmetic (qz_nn.hip: <= 3 all-ones planes
+// by border class, the empty wall grid, <= 22 non-zero pixels) in k_trunk's register layout, followed by the ordinary
+// layer epilogue (statistics, ReLU, hand-over into the LDS images).
+struct InputArgs {
+    const uint64_t *hb, *vb, *meta;  // packed boards; hb == nullptr: no input stage, the trunk input is read from x
+    const uint8_t* terminal;         // or nullptr
+    const float *hot9, *base0, *wd;  // [21][9][64], [81][64], [4][9][64] (qz_nn_input_layer)
+    const float *gamma0, *beta0;     // bn1
+};
+template <bool FROM_BOARD>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_trunk(const float* __restrict__ x, float* __restrict__ out, TrunkArgs A, int n_layers, float eps, HeadArgs H, InputArgs I
 #ifdef QZ_TRUNK_STAMPS
                                                , unsigned long long* stamps  // [workgroup][wave][8]: diagnostic build only
 #endif
@@ -283,12 +298,18 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const size_t obase = (size_t)blockIdx.x * NPOS * C + (size_t)co;
 #ifdef QZ_TRUNK_STAMPS
     unsigned long long t_stage = 0, t_loop = 0, t_stat = 0, t_hand = 0, t_mark = __builtin_amdgcn_s_memtime();
-    const unsigned long long t_begin = t_mark;
+    const unsigned long long t_begin = t_mark, r_begin = __builtin_amdgcn_s_memrealtime();
 #define QZ_STAMP(acc_var) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc_var += now_ - t_mark; t_mark = now_; }
 #else
 #define QZ_STAMP(acc_var)
 #endif
-    {   // stage the leaf (fp32 [81][64]) as fp16 hi / lo images
+    constexpr bool from_board = FROM_BOARD;
+    float* const s_wd = sm.wd;
+    float* const s_s9 = sm.s9;
+    uint8_t* const s_code = sm.code;
+    float* const s_raw = reinterpret_cast<float*>(sm.a_hi);  // input stage: conv1 before bn1, fp32 [81][64] (20,736 of the images' 23,616 B)
+    bool term = false;
+    if (!from_board) {   // stage the leaf (fp32 [81][64]) as fp16 hi / lo images
         const float4* x4 = reinterpret_cast<const float4*>(x) + (size_t)blockIdx.x * NPOS * 16;
         _Float16* ih = reinterpret_cast<_Float16*>(sm.a_hi);
         _Float16* il = reinterpret_cast<_Float16*>(sm.a_lo);
@@ -312,6 +333,70 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             z[0] = z[1] = z[2] = z[3] = (_Float16)0.f;
             *reinterpret_cast<half4*>(ih + NPOS * RSTR + tid * 4) = z;
             *reinterpret_cast<half4*>(il + NPOS * RSTR + tid * 4) = z;
+        }
+    } else {
+        // packed board, include/qz_abi.h: meta = p1 i8 | p2 i8 | walls1 u8 | walls2 u8 | current player u8
+        const uint64_t m = I.meta[blockIdx.x], bhb = I.hb[blockIdx.x], bvb = I.vb[blockIdx.x];
+        const int p1 = (int)(int8_t)(m & 0xFF), p2 = (int)(int8_t)((m >> 8) & 0xFF);
+        const int w1 = (int)((m >> 16) & 0xFF), w2 = (int)((m >> 24) & 0xFF), cur = (int)((m >> 32) & 0xFF);
+        term = I.terminal ? (I.terminal[blockIdx.x] != 0) : false;
+        for (int q = tid; q < 576; q += 128) reinterpret_cast<float4*>(s_wd)[q] = reinterpret_cast<const float4*>(I.wd)[q];
+        {
+            const int wm = cur == 1 ? w1 : w2, wo = cur == 1 ? w2 : w1;
+            int im = wm - 1, io = wo - 1;  // Python index -1 -> last plane (quoridor.py:79-80)
+            if (im < 0) im += 10;
+            if (io < 0) io += 10;
+            const int h0 = im, h1 = 10 + io;
+            for (int e = tid; e < 576; e += 128) {
+                const int cls = e >> 6, c = e & 63;
+                float v = I.hot9[(h0 * 9 + cls) * 64 + c] + I.hot9[(h1 * 9 + cls) * 64 + c];
+                if (cur == 2) v += I.hot9[(20 * 9 + cls) * 64 + c];
+                s_s9[e] = v;
+            }
+        }
+        if (tid < 81) {
+            const int rr = tid / 9, cc = tid - 9 * rr;
+            uint32_t code = 0u;
+            if (rr < 8 && cc < 8) {
+                const int ix = 8 * rr + cc;
+                code = (uint32_t)((bhb >> ix) & 1ull) | ((uint32_t)((bvb >> ix) & 1ull) << 1);
+            }
+            int pm = cur == 1 ? p1 : p2, po = cur == 1 ? p2 : p1;
+            if (pm < 0) pm += 81;
+            if (po < 0) po += 81;
+            code |= (tid == pm ? 4u : 0u) | (tid == po ? 8u : 0u);
+            s_code[tid] = (uint8_t)code;
+        }
+        __syncthreads();
+        // thread = (channel quad, positions p = (tid >> 4) + 8 k): the additions in k_input_layer's order
+        const int cq = tid & 15;
+#pragma unroll 1
+        for (int p = tid >> 4; p < NPOS; p += 8) {
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!term) {
+                const int y = p / 9, xx = p - 9 * y;
+                const int cls = (y == 0 ? 0 : (y == 8 ? 2 : 1)) * 3 + (xx == 0 ? 0 : (xx == 8 ? 2 : 1));
+                const float4 s4 = reinterpret_cast<const float4*>(s_s9)[cls * 16 + cq], b4 = reinterpret_cast<const float4*>(I.base0)[p * 16 + cq];
+                a = make_float4(s4.x + b4.x, s4.y + b4.y, s4.z + b4.z, s4.w + b4.w);
+                for (int dy = -1; dy <= 1; dy++) {
+                    const int ny = y + dy;
+                    if (ny < 0 || ny > 8) continue;
+                    for (int dx = -1; dx <= 1; dx++) {
+                        const int nx = xx + dx;
+                        if (nx < 0 || nx > 8) continue;
+                        const uint32_t code = s_code[ny * 9 + nx];
+                        if (code == 0u) continue;
+                        const int tap = (dy + 1) * 3 + (dx + 1);
+#pragma unroll
+                        for (int kind = 0; kind < 4; kind++)
+                            if ((code >> kind) & 1u) {
+                                const float4 w4 = reinterpret_cast<const float4*>(s_wd)[(kind * 9 + tap) * 16 + cq];
+                                a.x += w4.x; a.y += w4.y; a.z += w4.z; a.w += w4.w;
+                            }
+                    }
+                }
+            }
+            reinterpret_cast<float4*>(s_raw)[p * 16 + cq] = a;
         }
     }
     // this lane's A rows per tile (row m = 32 t + r): vector offset of the position and which of the 9 taps
@@ -339,19 +424,28 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int i = 0; i < 16; i++) {
             const int m = 32 * t + 4 * h + (i & 3) + 8 * (i >> 2);
-            resid[t][i] = m < NPOS ? x[obase + (size_t)m * C] : 0.f;
+            resid[t][i] = (m < NPOS && !from_board) ? x[obase + (size_t)m * C] : 0.f;
         }
     __syncthreads();
     QZ_STAMP(t_stage)
 
     constexpr int PARTV = 9 * 4 * C * 2;
 #pragma unroll 1
-    for (int l = 0; l < n_layers; l++) {
+    for (int l = from_board ? -1 : 0; l < n_layers; l++) {  // l = -1: the input stage takes the place of the matrix loop
         floatx16 acc[3];
 #pragma unroll
         for (int t = 0; t < 3; t++)
 #pragma unroll
             for (int i = 0; i < 16; i++) acc[t][i] = 0.f;
+        if (l < 0) {
+#pragma unroll
+            for (int t = 0; t < 3; t++)
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const int m = 32 * t + 4 * h + (i & 3) + 8 * (i >> 2);
+                    if (m < NPOS) acc[t][i] = s_raw[m * 64 + co];
+                }
+        } else {
         const half8* wb = reinterpret_cast<const half8*>(A.w16[l]) + (size_t)(32 * nt + r) * 2 + h;
         // B ring of three register sets, filled two k steps ahead (the loop of k_conv3x3_norm, fully unrolled)
         half8 bh[3], bl[3];
@@ -360,34 +454,48 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             bh[k] = wb[k * (C * 2)];
             bl[k] = wb[PARTV + k * (C * 2)];
         }
+        // A fragments: the reads of the NEXT tile are issued before the MFMAs of this one (two register sets), so the
+        // ~120-cycle LDS latency runs under 96 cycles of matrix work instead of in front of it; the scheduling fences
+        // keep the compiler from folding the two sets back into one
+        int ro[9][3];
 #pragma unroll
         for (int tap = 0; tap < 9; tap++) {
-            int ro[3];
             const int delta = ((tap / 3 - 1) * 9 + (tap % 3 - 1)) * RV;
 #pragma unroll
-            for (int t = 0; t < 3; t++) ro[t] = ((vmask[t] >> tap) & 1u) ? rbase[t] + delta : ZERO_ROW * RV + h;
+            for (int t = 0; t < 3; t++) ro[tap][t] = ((vmask[t] >> tap) & 1u) ? rbase[t] + delta : ZERO_ROW * RV + h;
+        }
+        half8 ah[2], al[2];
+        ah[0] = sm.a_hi[ro[0][0]];
+        al[0] = sm.a_lo[ro[0][0]];
 #pragma unroll
-            for (int kc = 0; kc < 4; kc++) {
-                const int k = 4 * tap + kc;
-                if (k + 2 < 36) {
-                    bh[(k + 2) % 3] = wb[(k + 2) * (C * 2)];
-                    bl[(k + 2) % 3] = wb[PARTV + (k + 2) * (C * 2)];
-                }
-                asm volatile("" ::: "memory");
-                const half8 b_hi = bh[k % 3], b_lo = bl[k % 3];
-#pragma unroll
-                for (int t = 0; t < 3; t++) {
-                    const half8 a_hi = sm.a_hi[ro[t] + 2 * kc];
-                    const half8 a_lo = sm.a_lo[ro[t] + 2 * kc];
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, acc[t], 0, 0, 0);
-                }
+        for (int k = 0; k < 36; k++) {
+            const int tap = k >> 2, kc = k & 3;
+            if (k + 2 < 36) {
+                bh[(k + 2) % 3] = wb[(k + 2) * (C * 2)];
+                bl[(k + 2) % 3] = wb[PARTV + (k + 2) * (C * 2)];
             }
+            const half8 b_hi = bh[k % 3], b_lo = bl[k % 3];
+#pragma unroll
+            for (int t = 0; t < 3; t++) {
+                const int cur = (3 * k + t) & 1, nxt = cur ^ 1;
+                if (t < 2) {
+                    ah[nxt] = sm.a_hi[ro[tap][t + 1] + 2 * kc];
+                    al[nxt] = sm.a_lo[ro[tap][t + 1] + 2 * kc];
+                } else if (k + 1 < 36) {
+                    ah[nxt] = sm.a_hi[ro[(k + 1) >> 2][0] + 2 * ((k + 1) & 3)];
+                    al[nxt] = sm.a_lo[ro[(k + 1) >> 2][0] + 2 * ((k + 1) & 3)];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur], b_hi, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur], b_lo, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur], b_hi, acc[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
         }
         QZ_STAMP(t_loop)
         // ---- per-leaf statistics of channel co over the 81 rows: all of them live in this wave
-        const float inv_scale = A.inv_scale[l];
+        const float inv_scale = l >= 0 ? A.inv_scale[l] : 1.0f;
         float s0 = 0.f;
 #pragma unroll
         for (int t = 0; t < 3; t++)
@@ -410,10 +518,10 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 q0 += m < NPOS ? d * d : 0.f;
             }
         q0 += __shfl_xor(q0, 32, 64);
-        const float bt = A.beta[l][co];
-        const float kn = A.gamma[l][co] / sqrtf(q0 * (1.0f / 81.0f) + eps);
+        const float bt = (l >= 0 ? A.beta[l] : I.beta0)[co];
+        const float kn = (l >= 0 ? A.gamma[l] : I.gamma0)[co] / sqrtf(q0 * (1.0f / 81.0f) + eps);
         QZ_STAMP(t_stat)
-        const bool second = (l & 1) != 0;  // conv2 of a block: + block input, result = next block input
+        const bool second = (l & 1) != 0;  // conv2 of a block: + block input, result = next block input (the input stage: 0 + its output)
         const bool last = l == n_layers - 1;
 #pragma unroll
         for (int t = 0; t < 3; t++)
@@ -438,6 +546,12 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (!H.feat) break;  // else: the trunk output goes to the images once more, for the head stage
         }
         __syncthreads();  // both waves are done reading this layer's input images
+        if (l < 0 && tid < 16) {  // (the input stage kept its raw output where the zero rows belong)
+            half4 z;
+            z[0] = z[1] = z[2] = z[3] = (_Float16)0.f;
+            *reinterpret_cast<half4*>(reinterpret_cast<_Float16*>(sm.a_hi) + NPOS * RSTR + tid * 4) = z;
+            *reinterpret_cast<half4*>(reinterpret_cast<_Float16*>(sm.a_lo) + NPOS * RSTR + tid * 4) = z;
+        }
         // hand-over: v -> (hi, lo) fp16; the lane pair (co even, co + 1) swaps one packed word by DPP, the even
         // lane stores both hi halves into a_hi, the odd lane both lo halves into a_lo: one 32-bit store each
         uint32_t* img = reinterpret_cast<uint32_t*>((lane & 1) ? static_cast<void*>(sm.a_lo) : static_cast<void*>(sm.a_hi));
@@ -553,7 +667,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (lane == 0) {
         unsigned long long* o = stamps + ((size_t)blockIdx.x * 2 + nt) * 8;
         o[0] = t_stage; o[1] = t_loop; o[2] = t_stat; o[3] = t_hand; o[4] = __builtin_amdgcn_s_memtime() - t_begin; o[5] = t_begin;
-        o[6] = __builtin_amdgcn_s_memrealtime(); o[7] = __smid();
+        o[6] = __builtin_amdgcn_s_memrealtime() - r_begin; o[7] = __smid();  // o[4] / o[6] x 100 MHz = the clock this wave ran at
     }
 #endif
 }
@@ -572,14 +686,21 @@ hipError_t conv3x3_norm(const float* x, const void* w16, const float* gamma, con
     else hipLaunchKernelGGL((k_conv3x3_norm<false, false>), grid, dim3(256), 0, s, x, w, gamma, beta, residual, out, n, inv_scale, eps);
     return hipGetLastError();
 }
-// head != nullptr (fused route only): [w6 fp16, gamma6, beta6, feat out] + inv_scale6: the head stage runs in the same
-// launch and the trunk output is NOT written back to x
+// the input stage's arguments as the C ABI hands them over (qz_abi.hip declares the same struct)
+struct TrunkInput {
+    const uint64_t *hb, *vb, *meta;
+    const uint8_t* terminal;
+    const float *hot9, *base0, *wd, *gamma0, *beta0;
+};
+// feat != nullptr (fused route only): [w6 fp16, gamma6, beta6, feat out] + inv_scale6: the head stage runs in the same
+// launch and the trunk output is NOT written back to x.  in != nullptr (fused route only): the first layer is computed
+// from the packed boards in the same launch and x is not read (may be NULL)
 hipError_t trunk(float* x, float* tmp, long long n, int n_blocks, const void* const* w16, const float* const* gamma, const float* const* beta,
                  const float* inv_scale, float eps, int fused, hipStream_t s, const void* w6 = nullptr, const float* gamma6 = nullptr,
-                 const float* beta6 = nullptr, float inv_scale6 = 0.f, float* feat = nullptr) {
+                 const float* beta6 = nullptr, float inv_scale6 = 0.f, float* feat = nullptr, const TrunkInput* in = nullptr) {
     if (n <= 0 || n_blocks <= 0) return hipSuccess;
     const int nl = 2 * n_blocks;
-    if (feat && !(fused && nl <= MAX_TRUNK_LAYERS)) return hipErrorInvalidValue;
+    if ((feat || in) && !(fused && nl <= MAX_TRUNK_LAYERS)) return hipErrorInvalidValue;
     if (fused && nl <= MAX_TRUNK_LAYERS) {  // one persistent launch: activations stay on the CU
         TrunkArgs A;
         for (int l = 0; l < nl; l++) {
@@ -602,7 +723,10 @@ hipError_t trunk(float* x, float* tmp, long long n, int n_blocks, const void* co
         H.beta6 = beta6;
         H.inv_scale6 = inv_scale6;
         H.feat = feat;
-        hipLaunchKernelGGL(k_trunk, dim3((unsigned)n), dim3(128), 0, s, x, feat ? nullptr : x, A, nl, eps, H);
+        InputArgs I = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        if (in) I = InputArgs{in->hb, in->vb, in->meta, in->terminal, in->hot9, in->base0, in->wd, in->gamma0, in->beta0};
+        if (in) hipLaunchKernelGGL(k_trunk<true>, dim3((unsigned)n), dim3(128), 0, s, x, feat ? nullptr : x, A, nl, eps, H, I);
+        else hipLaunchKernelGGL(k_trunk<false>, dim3((unsigned)n), dim3(128), 0, s, x, feat ? nullptr : x, A, nl, eps, H, I);
         return hipGetLastError();
 #endif
     }

@@ -199,11 +199,12 @@ class SelfPlayEngine:
             self._leaf_ref = (st, term.value, self.n_boards)
         return self._leaf_ref
 
-    def playout_step(self, evaluator, events=None, write_planes=None, tree_events=None):
+    def playout_step(self, evaluator, events=None, write_planes=None, tree_events=None, nn_events=None):
         """One playout of every board.  An evaluator that computes its first layer from the leaf
         boards never reads state(), so the rules op then only produces the legal sets
         (write_planes=True forces the planes anyway: bench.py's roofline of the full op).
-        tree_events = ((start, stop) around k_select, (start, stop) around k_expand_backup)."""
+        tree_events = ((start, stop) around k_select, (start, stop) around k_expand_backup);
+        nn_events = (start, stop) around the evaluator's launches."""
         if getattr(evaluator, "takes_leaf_copy", False):  # e.g. pure_mcts.RolloutEvaluator: plays its copy of the leaves out
             leaf = self.select_boards()
             p, v = evaluator.from_boards(leaf, self.leaf_mask)
@@ -212,10 +213,14 @@ class SelfPlayEngine:
         takes_boards = getattr(evaluator, "accepts_leaf_boards", False)
         want_planes = (not takes_boards) if write_planes is None else bool(write_planes) or not takes_boards
         planes = self.select(events=events, want_planes=want_planes, tree_events=None if tree_events is None else tree_events[0])
+        if nn_events is not None:
+            nn_events[0].record()
         if takes_boards:
             p, v = evaluator(planes, leaf=self.leaf_ref())
         else:
             p, v = evaluator(planes)
+        if nn_events is not None:
+            nn_events[1].record()
         self.expand_backup(p, v, events=None if tree_events is None else tree_events[1])
 
     def capture_steps(self, evaluator, steps_per_graph=1, warmup=3):
@@ -362,12 +367,14 @@ class BoardGroups:
             with torch.cuda.stream(self.streams[g]):
                 yield g, self.engines[g], self.evaluators[g]
 
-    def playout_step(self, events=None, write_planes=None, tree_events=None):
+    def playout_step(self, events=None, write_planes=None, tree_events=None, nn_events=None):
         """One playout of every board; `events` = one (start, end) pair per group around the
-        group's rules-op launch, `tree_events` = one pair of pairs per group (select, expand/backup)."""
+        group's rules-op launch, `tree_events` = one pair of pairs per group (select, expand/backup),
+        `nn_events` = one pair per group around the evaluator."""
         for g, eng, ev in self._each():
             eng.playout_step(ev, events=None if events is None else events[g], write_planes=write_planes,
-                             tree_events=None if tree_events is None else tree_events[g])
+                             tree_events=None if tree_events is None else tree_events[g],
+                             nn_events=None if nn_events is None else nn_events[g])
 
     def run_playouts(self, n=None):
         n = self.n_playout if n is None else int(n)

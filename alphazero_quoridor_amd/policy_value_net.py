@@ -31,15 +31,65 @@ N_RES = 5
 BN_EPS = 1e-5
 
 
+class _BatchNormTrainF64Acc(torch.autograd.Function):
+    """Training-mode batch normalisation whose REDUCTIONS run in float64 (the element-wise part stays
+    fp32).  The library's GPU kernels accumulate the batch sums in fp32; the backward's
+    dy - mean(dy) - xhat * mean(dy * xhat) cancels most of dy in this network, so fp32 sums cost
+    three digits of the early layers' gradients after ten blocks (benchmarks/diag_train_grads.py:
+    2e-3 of the largest element, against 2e-6 for PyTorch's CPU kernels -- which accumulate in
+    double, and which the reference runs on).  With float64 sums the GPU's gradients are as close
+    to the float64 values as the reference's CPU ones (tests/test_gpu_train.py)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        xd = x.double()
+        mean = xd.mean(dim=(0, 2, 3))
+        var = xd.var(dim=(0, 2, 3), unbiased=False)
+        invstd = torch.rsqrt(var + eps)
+        scale = (invstd * weight.double())[None, :, None, None]
+        y = ((xd - mean[None, :, None, None]) * scale + bias.double()[None, :, None, None]).to(x.dtype)
+        ctx.save_for_backward(x, weight, mean, invstd)
+        ctx.mark_non_differentiable(mean, var)
+        return y, mean, var
+
+    @staticmethod
+    def backward(ctx, dy, _dmean, _dvar):
+        x, weight, mean, invstd = ctx.saved_tensors
+        n = x.shape[0] * x.shape[2] * x.shape[3]
+        dyd = dy.double()
+        xhat = (x.double() - mean[None, :, None, None]) * invstd[None, :, None, None]
+        dbeta = dyd.sum(dim=(0, 2, 3))
+        dgamma = (dyd * xhat).sum(dim=(0, 2, 3))
+        dx = (weight.double() * invstd)[None, :, None, None] * (dyd - (dbeta / n)[None, :, None, None] - xhat * (dgamma / n)[None, :, None, None])
+        return dx.to(x.dtype), dgamma.to(weight.dtype), dbeta.to(weight.dtype), None
+
+
+class BatchNorm2d(nn.BatchNorm2d):
+    """nn.BatchNorm2d (same parameters, buffers and state_dict keys) whose training-mode pass on the GPU
+    accumulates in float64 (_BatchNormTrainF64Acc); everything else is the parent's."""
+
+    def forward(self, x):
+        if not (self.training and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and self.affine and self.track_running_stats
+                and self.momentum is not None):
+            return super().forward(x)
+        y, mean, var = _BatchNormTrainF64Acc.apply(x, self.weight, self.bias, self.eps)
+        with torch.no_grad():
+            n = x.shape[0] * x.shape[2] * x.shape[3]
+            self.num_batches_tracked += 1
+            self.running_mean.mul_(1.0 - self.momentum).add_(mean.to(self.running_mean.dtype), alpha=self.momentum)
+            self.running_var.mul_(1.0 - self.momentum).add_((var * (n / max(n - 1, 1))).to(self.running_var.dtype), alpha=self.momentum)
+        return y
+
+
 class BasicBlock(nn.Module):
     """conv-bn-relu-conv-bn-(+x)-relu (policy_value_net.py:20-48); names conv1/bn1/conv2/bn2."""
 
     def __init__(self, inplanes, planes, stride=1, downsample=None):
         super().__init__()
         self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
-        self.bn1 = nn.BatchNorm2d(planes)
+        self.bn1 = BatchNorm2d(planes)
         self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
-        self.bn2 = nn.BatchNorm2d(planes)
+        self.bn2 = BatchNorm2d(planes)
         self.relu = nn.ReLU(inplace=True)
         self.downsample = downsample
         self.stride = stride
@@ -57,16 +107,16 @@ class policy_value_net(nn.Module):  # noqa: N801 -- the reference's class name
     def __init__(self, block=BasicBlock, inplanes=IN_PLANES, planes=WIDTH, stride=1):
         super().__init__()
         self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
-        self.bn1 = nn.BatchNorm2d(planes)
+        self.bn1 = BatchNorm2d(planes)
         self.relu = nn.ReLU(inplace=True)
         for i in range(1, N_RES + 1):
             setattr(self, "res%d" % i, block(planes, planes))
         self.conv2 = nn.Conv2d(planes, 4, 3, stride, 1, bias=False)  # value head
-        self.bn2 = nn.BatchNorm2d(4)
+        self.bn2 = BatchNorm2d(4)
         self.fc1 = nn.Linear(4 * 81, 128)
         self.fc2 = nn.Linear(128, 1)
         self.conv3 = nn.Conv2d(planes, 2, 3, stride, 1, bias=False)  # policy head
-        self.bn3 = nn.BatchNorm2d(2)
+        self.bn3 = BatchNorm2d(2)
         self.fc3 = nn.Linear(2 * 81, N_ACTIONS)
 
     def trunk(self, x):
@@ -94,7 +144,7 @@ class LeafEvaluator:
     """
 
     def __init__(self, net: nn.Module, bn_mode="per_leaf", dtype=torch.float32, channels_last=False, fused_norm=True,
-                 board_input_layer=True, fused_head=True, mfma_trunk=True, fused_trunk=True, fused_heads_stage=True):
+                 board_input_layer=True, fused_head=True, mfma_trunk=True, fused_trunk=True, fused_heads_stage=True, fused_input_stage=True):
         assert bn_mode in ("per_leaf", "batch", "eval")
         self.fused_norm = fused_norm  # per_leaf on the GPU: use the one-pass HIP normalisation kernel
         # first layer straight from the packed boards (qz_nn_input_layer) when the caller hands them
@@ -115,6 +165,7 @@ class LeafEvaluator:
         self._w6_16 = None
         self.fused_trunk = fused_trunk  # all ten layers in ONE persistent launch (activations stay on the CU)
         self.fused_heads_stage = fused_heads_stage  # the head convolution as the last stage of the fused trunk launch
+        self.fused_input_stage = fused_input_stage  # ... and the first layer (from the packed boards) as its first
         self.trunk_events = None   # bench.py: a list that receives (start, end) HIP events around trunk-layer launches
         self.net = net
         self.bn_mode = bn_mode
@@ -246,6 +297,27 @@ class LeafEvaluator:
             feat.data_ptr(), p.data_ptr(), v.data_ptr(), BN_EPS, torch.cuda.current_stream(dev).cuda_stream))
         return p, v
 
+    def _evaluate_boards_mfma(self, leaf):
+        """The whole evaluation from the packed leaf boards, two launches (qz_nn_evaluate): first layer from the
+        boards, trunk and head convolution in one persistent launch, then the fully connected layers."""
+        from . import _cabi
+        import ctypes as C
+        st, term_ptr, n = leaf
+        w, g, b, sc = self._trunk_tables()
+        hd = self._head
+        _, _, gamma0, beta0 = self._layers[0]
+        hot9, base0, wd = self._in_tables
+        dev = gamma0.device
+        p = torch.empty((n, N_ACTIONS), dtype=torch.float32, device=dev)
+        v = torch.empty(n, dtype=torch.float32, device=dev)
+        feat = torch.empty((n, 6 * 81), dtype=torch.float32, device=dev)
+        _cabi.check(_cabi.load().qz_nn_evaluate(
+            C.byref(st), term_ptr or 0, n, hot9.data_ptr(), base0.data_ptr(), wd.data_ptr(), gamma0.data_ptr(), beta0.data_ptr(), N_RES,
+            w, g, b, sc, self._w6_16[0].data_ptr(), self._w6_16[1], hd[8].data_ptr(), hd[1].data_ptr(),
+            hd[2].data_ptr(), hd[3].data_ptr(), hd[4].data_ptr(), hd[5].data_ptr(), hd[6].data_ptr(), hd[7].data_ptr(),
+            feat.data_ptr(), p.data_ptr(), v.data_ptr(), BN_EPS, torch.cuda.current_stream(dev).cuda_stream))
+        return p, v
+
     def _trunk_tables(self):
         import ctypes as C
         if getattr(self, "_trunk_args", None) is None:
@@ -343,6 +415,10 @@ class LeafEvaluator:
         was encoded from (SelfPlayEngine.leaf_ref()); with it the first layer is computed from
         the 24-byte boards and `planes` is not read."""
         if leaf is not None and self.board_input_layer and self._in_tables is not None:
+            if self.fused_input_stage and self.bn_mode == "per_leaf" and self.mfma_trunk and self.fused_trunk and self.fused_head \
+                    and self.fused_heads_stage and self._w16 is not None and self._w6_16 is not None and self._head is not None \
+                    and len(self._head) > 8 and self.trunk_events is None:
+                return self._evaluate_boards_mfma(leaf)
             x = self._first_layer_from_boards(leaf)
         else:
             x = planes.to(self.dtype)

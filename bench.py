@@ -447,6 +447,7 @@ def main():
 
     evs = [[ev_pair() for _ in range(args.groups)] for _ in range(n_launch)]
     tevs = [[(ev_pair(), ev_pair()) for _ in range(args.groups)] for _ in range(n_launch)]
+    nevs = [[ev_pair() for _ in range(args.groups)] for _ in range(n_launch)]
     sampler = ClockSampler(local) if rank == 0 else None
     st0 = eng.stats()
     barrier()
@@ -457,13 +458,10 @@ def main():
     k = 0
     step_ms = []
     ev0 = eng.evaluators[0]
-    trunk_evs = []
     for _ in range(args.steps):
         ts = time.perf_counter()
         for _ in range(args.playouts):
-            if hasattr(ev0, "trunk_events"):  # the trunk layers of every 16th playout step are bracketed with HIP events
-                ev0.trunk_events = trunk_evs if (k & 15) == 0 and getattr(ev0, "mfma_trunk", False) else None
-            eng.playout_step(events=evs[k], write_planes=write_planes, tree_events=tevs[k])
+            eng.playout_step(events=evs[k], write_planes=write_planes, tree_events=tevs[k], nn_events=nevs[k])
             k += 1
         games += end_of_ply()  # harvest synchronises with the device (qz_harvest_counts), so this is the ply's wall time
         step_ms.append((time.perf_counter() - ts) * 1e3)
@@ -573,8 +571,10 @@ def main():
                                % (group_boards * bytes_per_board / 1e6)),
             },
             "roofline_tree": [
-                tree_line("k_select", sel_ms, sel_bytes, "dependent-load latency: duration = deepest of %d descents (mean depth %.1f), one "
-                          "HBM/L2 round trip per level; bytes = edge records scanned" % (group_boards, mean_depth)),
+                tree_line("k_select", sel_ms, sel_bytes, "dependent-load latency: duration = the slowest of %d descents (mean depth %.1f, deepest %d levels); "
+                          "recorded descents are re-evaluated 64 levels per round (16 records per board, translated across re-roots), "
+                          "levels never walked before cost one memory round trip each; bytes = edge records scanned"
+                          % (group_boards, mean_depth, st1["max_depth"])),
                 tree_line("k_expand_backup", exp_ms, exp_bytes, "one expansion (<= 131 records) + lane-parallel backup per board"),
             ],
             "roofline_nn": None,
@@ -584,20 +584,31 @@ def main():
                                                     "tree_pages_peak", "traj_pages_total", "traj_pages_peak")},
             "clocks": sampler.summary() if sampler else None,
         }
-        if trunk_evs:
-            conv_ms = sum(a.elapsed_time(b) for a, b in trunk_evs) / len(trunk_evs)
-            flops = 2.0 * group_boards * 81 * 64 * 576  # the convolution's own multiply-adds: what an fp32 kernel would do
+        nn_ms = sum(a.elapsed_time(b) for row in nevs for a, b in row) / n_evs
+        if getattr(ev0, "mfma_trunk", False) and not args.library_trunk:
+            # the convolutions' own multiply-adds (what an fp32 kernel would do): 10 trunk layers 64->64, the merged head
+            # convolution 64->6, the first layer 26->64; + the three fully connected layers
+            conv_flops = 2.0 * group_boards * 81 * 9 * (10 * 64 * 64 + 64 * 6 + 26 * 64)
+            fc_flops = 2.0 * group_boards * (324 * 128 + 128 + 162 * 140)
+            trunk_mfma = 3.0 * (96.0 / 81.0) * 2.0 * group_boards * 81 * 9 * (10 * 64 * 64) + 3.0 * (96.0 / 81.0) * 2.0 * group_boards * 81 * 9 * 64 * 32
             out["roofline_nn"] = {
-                "kernel": "k_conv3x3_norm (one trunk layer: conv3x3 64->64 as implicit GEMM on v_mfma_f32_32x32x16_f16 with split fp16 "
-                          "operands, per-leaf normalisation, residual, ReLU; 10 launches per playout step)",
-                "bound": "mfma", "achieved": flops / (conv_ms * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
-                "frac": flops / (conv_ms * 1e-3) / 1e12 / 2500.0, "traffic": None,
-                "avg_launch_us": conv_ms * 1e3, "launches": len(trunk_evs), "algorithmic_flops_per_launch": flops,
-                "executed_mfma_tflops": 3.0 * (192.0 / 162.0) * flops / (conv_ms * 1e-3) / 1e12,
-                "note": "achieved = fp32-equivalent convolution FLOPs / time; peak = dense fp16 MFMA (MI355X_MICROARCH.md). fp32 accuracy costs "
-                        "three fp16 MFMAs per product (hi*hi + hi*lo + lo*hi) and 162 of 192 tile rows are live, so the matrix pipe executes "
-                        "3.56x the algorithmic FLOPs (executed_mfma_tflops); the f32-input MFMA peak this replaces is 157 TFLOP/s",
+                "kernel": "k_trunk<true> + k_head_fc (the whole leaf evaluation in two launches: first layer from the packed boards, ten "
+                          "conv3x3 64->64 layers as implicit GEMMs on v_mfma_f32_32x32x16_f16 with split fp16 operands, per-leaf "
+                          "normalisation / residual / ReLU, merged head convolution -- activations never leave the CU -- then fc1/fc2/tanh, "
+                          "fc3/softmax)",
+                "bound": "mfma", "achieved": (conv_flops + fc_flops) / (nn_ms * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
+                "frac": (conv_flops + fc_flops) / (nn_ms * 1e-3) / 1e12 / 2500.0, "traffic": None,
+                "avg_launch_us": nn_ms * 1e3, "launches": n_evs, "algorithmic_flops_per_launch": conv_flops + fc_flops,
+                "executed_mfma_tflops": trunk_mfma / (nn_ms * 1e-3) / 1e12,
+                "note": "achieved = fp32-equivalent FLOPs of the network / time of both launches (HIP events on the launch stream, every "
+                        "playout step); peak = dense fp16 MFMA at the 2.4 GHz boost clock (MI355X_MICROARCH.md).  fp32 accuracy costs three "
+                        "fp16 MFMAs per product (hi*hi + hi*lo + lo*hi) and 81 of 96 tile rows are live, so the matrix pipe executes 3.56x "
+                        "the algorithmic FLOPs of the convolutions (executed_mfma_tflops); the f32-input MFMA peak this replaces is 157 "
+                        "TFLOP/s.  Inside this kernel the chip runs at ~1.7 GHz (power), profiles/round2/trunk_stamps.txt",
             }
+        else:
+            out["roofline_nn"] = {"kernel": "evaluator on MIOpen fp32 convolutions (--library-trunk)", "bound": "mfma", "avg_launch_us": nn_ms * 1e3,
+                                  "launches": n_evs, "achieved": None, "peak": None, "unit": "TFLOP/s", "frac": None, "traffic": None}
         if st1["games_aborted"]:
             sys.stderr.write("bench.py: WARNING %d games were dropped (no_move %d, max_plies %d, pool %d)\n"
                              % (st1["games_aborted"], st1["aborted_no_move"], st1["aborted_max_plies"], st1["aborted_pool"]))

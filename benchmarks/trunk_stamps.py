@@ -30,6 +30,9 @@ tot = s[:, :, 4]
 print("waves %d; cycles per wave: total %.0f | staging %.0f | MFMA loops %.0f | statistics %.0f | hand-over %.0f   (10 layers)" %
       (s.shape[0] * 2, tot.mean(), s[:, :, 0].mean(), s[:, :, 1].mean(), s[:, :, 2].mean(), s[:, :, 3].mean()))
 print("per layer: MFMA loop %.0f cycles (324 MFMAs = 10,368 MFMA-pipe cycles), statistics %.0f, hand-over %.0f" % (s[:, :, 1].mean() / 10, s[:, :, 2].mean() / 10, s[:, :, 3].mean() / 9))
+mhz = (s[:, :, 4] / np.maximum(s[:, :, 6], 1.0)) * 100.0
+print("in-kernel clock (s_memtime / s_memrealtime x 100 MHz): median %.0f MHz, p5 %.0f, p95 %.0f -> the dense fp16 MFMA peak at that clock is %.2f PFLOP/s"
+      % (np.median(mhz), np.percentile(mhz, 5), np.percentile(mhz, 95), 2.5 * np.median(mhz) / 2400.0))
 begin = s[:, 0, 5]
 span = (begin.max() - begin.min() + tot.max())
 print("kernel span %.0f cycles; workgroups %d; first-start spread %.0f" % (span, s.shape[0], begin.max() - begin.min()))

@@ -309,6 +309,20 @@ int qz_nn_trunk_heads(const float* x /*[dev]*/, int64_t n, int n_blocks, const v
                       const float* gamma6, const float* beta6, const float* w1t, const float* b1, const float* w2, const float* b2,
                       const float* w3t, const float* b3, float* feat /*[dev] n*486 scratch*/, float* p_out /*[dev] n*140*/,
                       float* v_out /*[dev] n*/, float eps, void* stream);
+/* The whole leaf evaluation policy_value_fn's network part (policy_value_net.py:145-164 without the
+ * host round trips): packed boards -> p [n][140], v [n], two launches.  The fused trunk launch of
+ * qz_nn_trunk_heads with one more stage in front: the first layer conv1(state(board)) + bn1 per leaf +
+ * ReLU is computed from the 24-byte boards and the three tables of qz_nn_input_layer inside the
+ * workgroup that owns the leaf, so no activation tensor is read from or written to HBM at all
+ * (boards in, 486 head features out).  terminal: NULL or the leaf flags (a flagged leaf gets the
+ * all-zero first-layer pre-activation, like qz_nn_input_layer).  The other arguments as in
+ * qz_nn_input_layer / qz_nn_trunk_heads. */
+int qz_nn_evaluate(const qz_boards* boards /*[dev] arrays*/, const uint8_t* terminal /*[dev] or NULL*/, int64_t n, const float* hot9,
+                   const float* base0, const float* wd, const float* gamma0, const float* beta0, int n_blocks,
+                   const void* const* w16 /*[host]*/, const float* const* gamma /*[host]*/, const float* const* beta /*[host]*/,
+                   const float* inv_scale /*[host]*/, const void* w6_16, float inv_scale6, const float* gamma6, const float* beta6,
+                   const float* w1t, const float* b1, const float* w2, const float* b2, const float* w3t, const float* b3,
+                   float* feat /*[dev] n*486 scratch*/, float* p_out /*[dev] n*140*/, float* v_out /*[dev] n*/, float eps, void* stream);
 /* the engine's current leaf boards (what qz_mcts_select just produced) and their terminal flags,
  * as device pointers owned by the engine: input of qz_nn_input_layer */
 int qz_engine_leaf_boards(qz_engine* e, qz_boards* boards_out, const uint8_t** terminal_out);

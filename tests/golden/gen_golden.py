@@ -630,6 +630,16 @@ def gen_train(out_dir):
         out["w_" + k.replace(".", "_")] = sd[k].numpy()
     for k, g in grads0.items():
         out["g0_" + k.replace(".", "_")] = g
+    # the same gradients in float64 (the reference's module, weights and loss expressions, double precision): the yardstick
+    # for how far an fp32 backward -- the reference's own on the CPU, ours on the GPU -- is from the exact value
+    ref64 = fresh()
+    ref64.policy_value_net.double()
+    sb, pb, wb = (torch.from_numpy(np.asarray(x, dtype=np.float64)) for x in (states, pi, z))
+    logp, value = ref64.policy_value_net(sb)
+    (F.mse_loss(value.view(-1), wb) + (-torch.mean(torch.sum(pb * logp, 1)))).backward()
+    named64 = dict(ref64.policy_value_net.named_parameters())
+    for k in grads0:
+        out["g64_" + k.replace(".", "_")] = named64[k].grad.detach().numpy()
     # old/new outputs of policy_value (batch statistics) on the same minibatch after the three steps
     p_after, v_after = ref.policy_value(states)
     out["p_after"], out["v_after"] = p_after, v_after

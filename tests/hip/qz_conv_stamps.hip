@@ -13,6 +13,7 @@ extern "C" int qzt_trunk_stamps(float* x, long long n, int n_layers, const void*
         A.beta[l] = l < n_layers ? beta[l] : nullptr;
         A.inv_scale[l] = l < n_layers ? inv_scale[l] : 0.f;
     }
-    hipLaunchKernelGGL(k_trunk, dim3((unsigned)n), dim3(128), 0, (hipStream_t)stream, x, x, A, n_layers, 1e-5f, HeadArgs{nullptr, nullptr, nullptr, 0.f, nullptr}, stamps);
+    hipLaunchKernelGGL(k_trunk<false>, dim3((unsigned)n), dim3(128), 0, (hipStream_t)stream, x, x, A, n_layers, 1e-5f, HeadArgs{nullptr, nullptr, nullptr, 0.f, nullptr},
+                       InputArgs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, stamps);
     return (int)hipGetLastError();
 }

@@ -2,6 +2,7 @@
 conv3x3 + per-sample (training-mode, batch of one) BatchNorm + residual + ReLU."""
 import numpy as np
 import pytest
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -180,3 +181,33 @@ def test_head_stage_of_the_trunk_launch_equals_the_separate_head_kernel(gpu_devi
     assert torch.equal(x, x0)
     pb, vb = staged._trunk_heads_mfma(x)
     assert torch.equal(pa, pb) and torch.equal(va, vb)   # run to run: bit-identical
+
+
+def test_input_stage_of_the_trunk_launch_equals_the_separate_input_kernel(gpu_device, golden_dir):
+    """qz_nn_evaluate: the first layer computed from the packed boards inside the trunk launch (same
+    additions in the same order as qz_nn_input_layer; the per-leaf statistics are summed in another
+    order) against qz_nn_input_layer + qz_nn_trunk_heads, on fixture positions of all game phases,
+    with terminal flags on some leaves and ragged batch sizes.  p to 2e-6, v to 1e-5."""
+    from _stubs import det_fill_state_dict
+    from alphazero_quoridor_amd.boards import DeviceBoards
+    from alphazero_quoridor_amd.policy_value_net import LeafEvaluator, PolicyValueNet
+
+    pvn = PolicyValueNet(use_gpu=True, device=gpu_device)
+    pvn.policy_value_net.load_state_dict(det_fill_state_dict(pvn.policy_value_net.state_dict(), 2024))
+    staged = LeafEvaluator(pvn.policy_value_net, "per_leaf", channels_last=True)
+    separate = LeafEvaluator(pvn.policy_value_net, "per_leaf", channels_last=True, fused_input_stage=False)
+    assert staged.fused_input_stage and staged.board_input_layer
+    b = np.load(golden_dir + "/rules_positions.npz")["board"]
+    rng = np.random.RandomState(3)
+    for n in (1, 7, 130, 4096):
+        sel = b[rng.randint(0, len(b), size=n)]
+        db = DeviceBoards.from_packed(sel, gpu_device)
+        term = torch.from_numpy((rng.rand(n) < 0.1).astype(np.uint8)).to(gpu_device)
+        for tp in (0, term.data_ptr()):
+            leaf = (db.struct(), tp, n)
+            p1, v1 = staged(None, leaf=leaf)
+            p2, v2 = separate(None, leaf=leaf)
+            dp, dv = (p1 - p2).abs().max().item(), (v1 - v2).abs().max().item()
+            assert torch.isfinite(p1).all() and torch.isfinite(v1).all() and dp < 2e-6 and dv < 1e-5, (n, bool(tp), dp, dv)
+        pa, va = staged(None, leaf=leaf)
+        assert torch.equal(pa, p1) and torch.equal(va, v1)   # run to run: bit-identical

@@ -20,12 +20,13 @@ def test_train_step_on_device_matches_reference_fixture(gpu_device, golden_dir):
     """policy_value_net.py:166-192: three optimiser steps (Adam, weight decay 1e-4, three learning
     rates) on the reference's own 128-tuple minibatch, states re-encoded from the packed boards by
     the HIP encoder.  Step 0 (same weights on both sides) is the tight comparison: loss and entropy
-    to 2e-5, and the GRADIENTS of the reference's own backward() (fixture g0_*) to 1e-4 of each
-    tensor's largest element.  Adam's first steps are +-lr * sign-like, so an element whose gradient
-    is at the rounding-noise level lands lr apart on the two machines (MIOpen backward vs CPU
-    backward) and the later steps drift: 1e-3 / 3e-3 relative on the loss.  Post-step weights: the
-    bulk must agree, no element may move more than 3 lr; the outputs three steps later are close in
-    the bulk (median), not element by element."""
+    to 2e-5, and the GRADIENTS measured against their float64 value (fixture g64_*): no further from it
+    than 4x the reference's own fp32 backward on the CPU is (fixture g0_*).  Adam's first steps are +-lr * sign-like, so an element whose gradient
+    is at the rounding-noise level lands lr apart on the two machines and the later steps drift a
+    little: 5e-5 / 2e-4 relative on the loss.  Post-step weights: the bulk must agree to 5e-5, no
+    element may differ by more than one lr; the outputs three steps later are close, not equal.
+    (The batch-norm reductions of the training pass run in float64 on the GPU, like PyTorch's CPU
+    kernels do: with the library's fp32 sums the early layers' gradients are 2e-3 off.)"""
     from _stubs import det_fill_state_dict
     from alphazero_quoridor_amd import rules
     from alphazero_quoridor_amd.boards import DeviceBoards
@@ -40,28 +41,34 @@ def test_train_step_on_device_matches_reference_fixture(gpu_device, golden_dir):
         loss, ent = pvn.train_step_t(states, pi, z, float(lr))
         assert loss.is_cuda and loss.dim() == 0
         print("step %d: loss %.7f (ref %.7f)  entropy %.7f (ref %.7f)" % (i, float(loss), d["loss"][i], float(ent), d["entropy"][i]))
-        tol = (2e-5, 1e-3, 3e-3)[i]
+        tol = (2e-6, 5e-5, 2e-4)[i]
         assert abs(float(loss) - d["loss"][i]) < tol * abs(d["loss"][i]) and abs(float(ent) - d["entropy"][i]) < tol * 4.5
         if i == 0:
+            # gradients of step 0 against the float64 value (fixture g64_*): the GPU's fp32 backward (MIOpen) may be no further
+            # from it than 4x the reference's own fp32 backward on the CPU is (fixture g0_*), floor 2e-5 of the tensor's largest element
             named = dict(pvn.policy_value_net.named_parameters())
+            worst = []
             for gk in [k for k in d.files if k.startswith("g0_")]:
                 name = [n for n in named if n.replace(".", "_") == gk[3:]][0]
-                g, ref = named[name].grad.cpu().numpy(), d[gk]
-                err = np.abs(g - ref).max() / np.abs(ref).max()
-                print("grad %-20s max |dg| / max |g| = %.2e" % (name, err))
-                assert err < 1e-4, name
+                g, ref, exact = named[name].grad.cpu().numpy().astype(np.float64), d[gk].astype(np.float64), d["g64_" + gk[3:]]
+                sc = np.abs(exact).max()
+                e_gpu, e_ref = np.abs(g - exact).max() / sc, np.abs(ref - exact).max() / sc
+                print("grad %-20s |d|/max|g|: GPU fp32 vs float64 %.2e   reference CPU fp32 vs float64 %.2e" % (name, e_gpu, e_ref))
+                worst.append((name, e_gpu, e_ref))
+            for name, e_gpu, e_ref in worst:
+                assert e_gpu < max(4.0 * e_ref, 2e-5), (name, e_gpu, e_ref)
     sd = pvn.get_policy_param()
     lr_max = float(max(d["lr"]))
     for k in ("fc2.weight", "bn1.weight", "conv3.weight", "conv2.weight"):
         diff = np.abs(sd[k].cpu().numpy() - d["w_" + k.replace(".", "_")]).reshape(-1)
         print(k, "median |dw| %.3g  p99 %.3g  max %.3g" % (np.median(diff), np.percentile(diff, 99), diff.max()))
-        assert np.median(diff) < 1e-4 and diff.max() <= 3.1 * 3 * lr_max, k
+        assert np.median(diff) < 5e-5 and diff.max() <= 1.05 * lr_max, k   # (an element whose gradient is rounding noise moves by +-lr either way)
     p, v = pvn.policy_value_t(states)
     # three sign-like Adam steps later the two machines' nets are close, not equal (v = tanh of a 128-term sum
     # whose weights differ by up to 3 lr each: single leaves move by tenths)
     dp, dv = np.abs(p.cpu().numpy() - d["p_after"]), np.abs(v.cpu().numpy() - d["v_after"])
     print("after 3 steps: |dp| median %.2e max %.2e   |dv| median %.2e max %.2e" % (np.median(dp), dp.max(), np.median(dv), dv.max()))
-    assert dp.max() < 0.05 and np.median(dv) < 0.1 and dv.max() < 1.0
+    assert dp.max() < 0.02 and np.median(dv) < 0.01 and dv.max() < 0.2
 
 
 def test_replay_buffer_samples_reencoded_states_on_the_device(gpu_device, golden_dir, tmp_path):
