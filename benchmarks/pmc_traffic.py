@@ -6,7 +6,8 @@
 Per launch: HBM-side bytes = 2 x FETCH_SIZE + WRITE_SIZE, in units of 1,024 B (MI355X_MICROARCH.md, HBM / rocprofv3
 section: on gfx950 FETCH_SIZE reports half the bytes of wide streaming reads -- an upper bound for the small gathers of these
 kernels --, WRITE_SIZE is exact; Infinity-Cache hits are counted).  Kernels named in --kernels are summed per launch
-(the pooled pipeline is two launches); the first `--skip` launches of every kernel are dropped (warm-up)."""
+(the pooled pipeline is two launches); only the last `--last` launches of every kernel count (the script's timed loop of
+mask + planes calls; what precedes it is warm-up and mask-only calls)."""
 import argparse, csv, glob, json, os, collections
 
 ap = argparse.ArgumentParser()
@@ -17,7 +18,7 @@ ap.add_argument("--boards", type=int, required=True)
 ap.add_argument("--bytes-per-board", type=float, required=True)
 ap.add_argument("--label", required=True)
 ap.add_argument("--planes", type=int, default=1)
-ap.add_argument("--skip", type=int, default=3)
+ap.add_argument("--last", type=int, default=20, help="use the last N launches of every kernel (the timed loop of the bench script; earlier ones are warm-up and mask-only calls)")
 ap.add_argument("--out", required=True)
 ap.add_argument("--rows-out")
 a = ap.parse_args()
@@ -36,8 +37,8 @@ def per_launch(d, counter):
             if sub in r["Kernel_Name"]:
                 by[sub].append(float(r["Counter_Value"]))
                 rows.append((r["Kernel_Name"][:80], counter, r["Counter_Value"]))
-    assert all(len(by[s]) > a.skip for s in subs), {s: len(by[s]) for s in subs}
-    return sum(sum(by[s][a.skip:]) / len(by[s][a.skip:]) for s in subs), rows, {s: len(by[s]) - a.skip for s in subs}
+    assert all(len(by[s]) >= a.last for s in subs), {s: len(by[s]) for s in subs}
+    return sum(sum(by[s][-a.last:]) / a.last for s in subs), rows, {s: a.last for s in subs}
 
 
 f_kb, rows_f, n_f = per_launch(a.fetch, "FETCH_SIZE")
