@@ -125,6 +125,7 @@ QZ_HD void pool_k1(const Board& b, bool terminal, bool want_moves, int p, PoolBo
     none.found = false;
     int len = 0, lj = -1, fj = -1;
     PathEdges pe = none;
+    BB last = bb_zero();
     if (walls) {
         JumpPlan plan = make_jump_plan(b.hb, b.vb, side_opp(b, p));
         out.plan[p - 1] = plan;
@@ -132,12 +133,13 @@ QZ_HD void pool_k1(const Board& b, bool terminal, bool want_moves, int p, PoolBo
         OrderedPath op = find_path_tables(g, side_start(b, p), side_goal(p), POOL_MAX_LAYERS + 1, tab, lj, fj);
         pe = op.e;
         len = op.len;
+        last = op.last;
     }
     out.pe[p - 1] = pe;
     out.len[p - 1] = len;
     out.lastjump[p - 1] = lj;
     out.farjump[p - 1] = fj;
-    out.tiles[p - 1] = len > 0 ? bb_or(tab.suffix[len - 1], bb_bit(side_start(b, p))) : bb_zero();
+    out.tiles[p - 1] = len > 0 ? bb_or(last, bb_bit(side_start(b, p))) : bb_zero();
     // candidates that remove an edge of this path (or, if the path jumps, that sit next to the
     // opponent): only those need a flood for player p
     uint64_t nh = 0, nv = 0;

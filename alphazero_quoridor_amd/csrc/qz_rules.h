@@ -215,7 +215,7 @@ QZ_HD int corner(uint64_t hb, uint64_t vb, int t, int which) {
 #define QZ_TABLE_QUAL static const
 #endif
 #if defined(__HIPCC__)
-QZ_TABLE_QUAL uint8_t g_corner_ref_dev[324] = {
+QZ_TABLE_QUAL __attribute__((aligned(4))) uint8_t g_corner_ref_dev[324] = {
     65, 0, 64, 64, 0, 0, 64, 64, 1, 1, 64, 64, 2, 2, 64, 64, 3, 3, 64, 64, 4, 4, 64, 64,
     5, 5, 64, 64, 6, 6, 64, 64, 7, 7, 65, 64, 65, 8, 0, 65, 8, 9, 1, 0, 9, 10, 2, 1,
     10, 11, 3, 2, 11, 12, 4, 3, 12, 13, 5, 4, 13, 14, 6, 5, 14, 15, 7, 6, 15, 65, 65, 7,
@@ -253,6 +253,16 @@ QZ_HD int corner_ref_tab(int t, int which) {
     return g_corner_ref_dev[4 * t + which];
 #else
     return g_corner_ref_host[4 * t + which];
+#endif
+}
+// the four corner references of tile t in one word: NW | NE << 8 | SE << 16 | SW << 24 (t in 0..80).  ONE load where
+// four byte loads used to wait for each other: on the GPU every table look-up is a round trip of the dependent chain
+QZ_HD uint32_t corner_ref4(int t) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return reinterpret_cast<const uint32_t*>(g_corner_ref_dev)[t];
+#else
+    return (uint32_t)g_corner_ref_host[4 * t] | ((uint32_t)g_corner_ref_host[4 * t + 1] << 8) |
+           ((uint32_t)g_corner_ref_host[4 * t + 2] << 16) | ((uint32_t)g_corner_ref_host[4 * t + 3] << 24);
 #endif
 }
 // branch-free ref_value
@@ -412,8 +422,12 @@ QZ_HD uint32_t pawn_actions(uint64_t hb, uint64_t vb, int loc, int opp, int play
 
 QZ_HD uint32_t pawn_actions_tab(uint64_t hb, uint64_t vb, int loc, int opp, int player) {
     const int H = 1, V = -1;
-    int xnw = corner_tab(hb, vb, loc, 0), xne = corner_tab(hb, vb, loc, 1), xse = corner_tab(hb, vb, loc, 2),
-        xsw = corner_tab(hb, vb, loc, 3);
+    // both tiles' corner references up front: two independent loads, one round trip
+    const uint32_t wl = corner_ref4((unsigned)loc <= 80u ? loc : 0), wo = corner_ref4((unsigned)opp <= 80u ? opp : 0);
+    int xnw = ref_value_fast(hb, vb, (int)(wl & 0xFFu)), xne = ref_value_fast(hb, vb, (int)((wl >> 8) & 0xFFu)),
+        xse = ref_value_fast(hb, vb, (int)((wl >> 16) & 0xFFu)), xsw = ref_value_fast(hb, vb, (int)(wl >> 24));
+    const int onw = ref_value_fast(hb, vb, (int)(wo & 0xFFu)), one = ref_value_fast(hb, vb, (int)((wo >> 8) & 0xFFu)),
+              ose = ref_value_fast(hb, vb, (int)((wo >> 16) & 0xFFu)), osw = ref_value_fast(hb, vb, (int)(wo >> 24));
     bool on = loc == opp - 9, os = loc == opp + 9, oe = loc == opp - 1, ow = loc == opp + 1;
     int row = loc / 9;
     uint32_t m = 0;
@@ -426,22 +440,18 @@ QZ_HD uint32_t pawn_actions_tab(uint64_t hb, uint64_t vb, int loc, int opp, int 
     if (e) m |= 1u << 2;
     if (w) m |= 1u << 3;
     if (on && xne != H && xnw != H) {
-        int onw = corner_tab(hb, vb, opp, 0), one = corner_tab(hb, vb, opp, 1);
         if ((onw != H && one != H) || (row == 7 && player == 1)) m |= 1u << 4;
         if (one != V && xne != V) m |= 1u << 8;
         if (onw != V && xnw != V) m |= 1u << 9;
     } else if (os && xse != H && xsw != H) {
-        int ose = corner_tab(hb, vb, opp, 2), osw = corner_tab(hb, vb, opp, 3);
         if ((osw != H && ose != H) || (row == 1 && player == 2)) m |= 1u << 5;
         if (ose != V && xse != V) m |= 1u << 10;
         if (osw != V && xsw != V) m |= 1u << 11;
     } else if (oe && xse != V && xne != V) {
-        int one = corner_tab(hb, vb, opp, 1), ose = corner_tab(hb, vb, opp, 2);
         if (ose != V && one != V) m |= 1u << 6;
         if (one != H) m |= 1u << 8;
         if (ose != H) m |= 1u << 10;
     } else if (ow && xsw != V && xnw != V) {
-        int onw = corner_tab(hb, vb, opp, 0), osw = corner_tab(hb, vb, opp, 3);
         if (onw != V && osw != V) m |= 1u << 7;
         if (onw != H) m |= 1u << 9;
         if (osw != H) m |= 1u << 11;
@@ -758,12 +768,19 @@ struct JumpPlan {
 QZ_HD JumpPlan make_jump_plan(uint64_t hb, uint64_t vb, int O) {
     JumpPlan p;
     p.O = O;
-    const int tile[12] = {O, O, O, O, O - 9, O - 9, O + 9, O + 9, O - 1, O - 1, O + 1, O + 1};
+    // the five tiles' corner references up front (clamped index, validity applied afterwards): five independent loads, one
+    // round trip of the dependent chain instead of twelve
+    const int tile5[5] = {O, O - 9, O + 9, O - 1, O + 1};
+    uint32_t w5[5];
+    bool ok5[5];
+    for (int k = 0; k < 5; k++) {
+        ok5[k] = tile5[k] >= 0 && tile5[k] <= 80;
+        w5[k] = corner_ref4(ok5[k] ? tile5[k] : 0);
+    }
+    const int grp[12] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4};
     const int which[12] = {0, 1, 2, 3, 0, 1, 2, 3, 2, 1, 3, 0};
     for (int i = 0; i < 12; i++) {
-        int t = tile[i];
-        bool ok = t >= 0 && t <= 80;
-        int rf = ok ? corner_ref_tab(t, which[i]) : 64;
+        int rf = ok5[grp[i]] ? (int)((w5[grp[i]] >> (8 * which[i])) & 0xFFu) : 64;
         p.ref[i] = (int8_t)rf;
         p.val[i] = (int8_t)ref_value_fast(hb, vb, rf);
     }
@@ -894,6 +911,7 @@ QZ_HD bool flood_to(const Graph& g, int start, BB goal_or_safe) { return flood_t
 struct OrderedPath {
     PathEdges e;
     int len;  // number of edges, 0 if !found, -1 if found but longer than the layer store
+    BB last;  // find_path_tables: tab.suffix[len - 1] (every tile of the path but the start), so that nobody reads it back
 };
 QZ_HD OrderedPath find_path_ordered(const Graph& g, int start, BB goal, BB* layers, int stride, int max_layers,
                                     uint8_t* tiles, uint8_t* kinds, int tstride) {
@@ -994,6 +1012,7 @@ QZ_HD OrderedPath find_path_tables(const Graph& g, int start, BB goal, int max_e
     p.e.jump = false;
     p.e.found = false;
     p.len = 0;
+    p.last = bb_zero();
     first_jump_r = -1;
     far_jump_r = -1;  // reverse position of the jump edge closest to the START
     BB R = bb_bit(start);
@@ -1077,6 +1096,7 @@ QZ_HD OrderedPath find_path_tables(const Graph& g, int start, BB goal, int max_e
         t = s;
     }
     p.len = k;
+    p.last = acc;
     return p;
 }
 
