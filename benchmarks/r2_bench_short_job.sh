@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-2 job J: bench with the deep-descent telemetry
+# short bench run (no CPU baseline, no C3 microbench): step time, engine telemetry, tree-kernel durations
 mkdir -p gpurun_out/r2j
 python bench.py --steps ${STEPS:-6} --no-cpu-baseline --no-c3 $EXTRA > gpurun_out/r2j/bench.json 2> gpurun_out/r2j/bench.err
 python - <<PY
