@@ -335,6 +335,10 @@ def steady_state(plies_per_s, length_file):
         "ci95": [plies_per_s / hi, plies_per_s / lo] if lo and hi else None,
         "n_games_in_length_sample": d.get("games_finished"), "n_games_censored": d.get("games_censored"),
         "length_estimator": d.get("estimator"), "length_source": os.path.relpath(length_file, ROOT),
+        # the model-free part: E[min(L, T)] <= E[L], so plies/s / restricted mean is an UPPER bound of games/s.  The hazard of
+        # these games keeps falling with their age (heavy tail), so the exponential tail makes `value` lean high, not low
+        "upper_bound": plies_per_s / float(d["restricted_mean"]) if d.get("restricted_mean") else None,
+        "restricted_mean_plies": d.get("restricted_mean"), "observation_window_plies": d.get("T"), "survival_at_window": d.get("survival_at_T"),
     }
 
 

@@ -7,9 +7,12 @@ timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -6 > $O/pytest_gpu.log
 timeout 900 python bench.py --steps 8 --clock-log $O/clock_log_bench_default.json > $O/bench_default.json 2> $O/bench_default.err
 timeout 600 python bench.py --steps 6 --groups 2 --no-cpu-baseline --no-c3 > $O/bench_groups2.json 2> $O/bench_groups2.err
 timeout 600 python bench.py --steps 2 --library-trunk --no-cpu-baseline --no-c3 > $O/bench_library_trunk.json 2> $O/bench_library_trunk.err
+# the other BASELINE configurations that fit one GPU: configs[1] (n_playout=100) and configs[4] per GPU (n_playout=800)
+timeout 600 python bench.py --steps 12 --playouts 100 --no-cpu-baseline --no-c3 > $O/bench_c2_playouts100.json 2> $O/bench_c2_playouts100.err
+timeout 600 python bench.py --steps 3 --playouts 800 --no-cpu-baseline --no-c3 > $O/bench_c5_playouts800_1gpu.json 2> $O/bench_c5_playouts800_1gpu.err
 python - <<PY
 import json
-for f in ("bench_default", "bench_groups2", "bench_library_trunk"):
+for f in ("bench_default", "bench_groups2", "bench_library_trunk", "bench_c2_playouts100", "bench_c5_playouts800_1gpu"):
     d = json.loads(open("$O/%s.json" % f).read().strip().splitlines()[-1])
     print(f, {k: d[k] for k in ("value", "ms_per_step", "plies_per_s", "playouts_per_s")}, d["games_per_s_steady_state"]["value"] if d.get("games_per_s_steady_state") else None)
     print("   rules %.1f us frac %.3f | select %.1f | expand %.1f | nn %s" % (d["roofline"]["avg_launch_us"], d["roofline"]["frac"], d["roofline_tree"][0]["avg_launch_us"],
