@@ -552,9 +552,10 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             *reinterpret_cast<half4*>(reinterpret_cast<_Float16*>(sm.a_hi) + NPOS * RSTR + tid * 4) = z;
             *reinterpret_cast<half4*>(reinterpret_cast<_Float16*>(sm.a_lo) + NPOS * RSTR + tid * 4) = z;
         }
-#ifdef QZ_HANDOVER_B32
         // hand-over: v -> (hi, lo) fp16; the lane pair (co even, co + 1) swaps one packed word by DPP, the even
         // lane stores both hi halves into a_hi, the odd lane both lo halves into a_lo: one 32-bit store each
+        // (two 16-bit stores per element and no DPP: 4.8 k instead of 5.8 k cycles here, but the MFMA loop of the other wave
+        // gets 0.4 k longer: no gain)
         uint32_t* img = reinterpret_cast<uint32_t*>((lane & 1) ? static_cast<void*>(sm.a_lo) : static_cast<void*>(sm.a_hi));
         const int cpair = (co & ~1) >> 1;
 #pragma unroll
@@ -571,25 +572,6 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const uint32_t word = (lane & 1) ? ((other >> 16) | (mine & 0xFFFF0000u)) : ((mine & 0xFFFFu) | (other << 16));
                 if (m < NPOS) img[m * (RSTR / 2) + cpair] = word;
             }
-#else
-        // hand-over: v -> (hi, lo) fp16 straight into the two images, one 16-bit store each (four VALU instructions per
-        // element; pairing neighbouring channels into 32-bit stores by DPP costs seven more and was measured slower)
-        _Float16* const ih = reinterpret_cast<_Float16*>(sm.a_hi) + co;
-        _Float16* const il = reinterpret_cast<_Float16*>(sm.a_lo) + co;
-#pragma unroll
-        for (int t = 0; t < 3; t++)
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const int m = 32 * t + 4 * h + (i & 3) + 8 * (i >> 2);
-                const float v = acc[t][i];
-                const _Float16 hi = (_Float16)v;
-                const _Float16 lo = (_Float16)(v - (float)hi);
-                if (m < NPOS) {
-                    ih[m * RSTR] = hi;
-                    il[m * RSTR] = lo;
-                }
-            }
-#endif
         __syncthreads();  // the new images are complete before anybody reads them
         QZ_STAMP(t_hand)
     }

@@ -433,8 +433,8 @@ __device__ __forceinline__ uint32_t tree_alloc(const EngineDev& E, TreeView& T, 
 //    the next deep one would walk its hundreds of levels one by one.  Every edge remembers which
 //    record went through it last (Edge::rid); where the path leaves the record it is following,
 //    it goes on in the record of the edge it took, at the same level.  A descent that only extends
-//    its record is appended to it; any other is copied over the least valuable record if it is
-//    longer than that one is worth (its length while it was useful recently, nothing afterwards).
+//    its record is appended to it; any other is copied over the least valuable record (oldest last
+//    use, short before long: stamp + 4 x length; a pure value-by-length rule was measured worse).
 //  * a round costs about five walked levels, so it is only tried where the record has eight more
 //    levels to offer, and after a round that ended early the next eight levels are walked (in
 //    step with the record: the replay can resume at any level);
@@ -694,35 +694,29 @@ __global__ __launch_bounds__(TPB) void k_select(EngineDev E) {
             const uint32_t n = plen < CAP ? plen : CAP;
             const uint32_t clock = rfl(E.rec_clock[b]) + 1u;
             uint32_t dest, from;  // levels [from, n) of this descent go into record dest, and their edges point at it
-            bool keep = true;     // ... unless it is not worth a record
             if (cur != QZ_NONE) {
                 dest = cur;  // the descent is record cur, or extends it
                 from = n > cur_len ? cur_len : n;
             } else {
                 // the descent left its last record at left_at and walked the rest.  In place if the new levels are at least as
-                // many as the recorded ones they replace.  Else it takes the place of the least valuable record -- worth its
-                // length (what losing it costs: a walk of that many levels) while it has been useful within the last 1,024
-                // descents, nothing after that -- but only if it is longer than that record is worth: short paths never evict
-                // a live long line, they simply go unrecorded
+                // many as the recorded ones they replace, else over the least valuable record (oldest last use, short before long)
                 const uint32_t l_left = left_rec != QZ_NONE ? rdl(rlen, (int)left_rec) : 0u;
                 if (left_rec != QZ_NONE && n - left_at >= l_left - left_at) {
                     dest = left_rec;
                     from = left_at;
                 } else {
-                    uint32_t bestv = 0xFFFFFFFFu, best_age = 0u;
-                    dest = src;
-                    from = n;  // (nothing recorded unless a victim is found)
+                    uint32_t bestv = 0xFFFFFFFFu;
+                    dest = 0u;
                     for (uint32_t r = 0; r < R; r++) {
-                        const uint32_t l = rdl(rlen, (int)r), age = clock - rdl(rstamp, (int)r);
-                        const uint32_t v = (l == 0u || age >= 1024u) ? 0u : l;
-                        if (r != left_rec && !((used >> r) & 1u) && (v < bestv || (v == bestv && age > best_age))) {
+                        // (a long record is worth more than its age says: losing it costs a walk of its length)
+                        const uint32_t l = rdl(rlen, (int)r), v = l == 0u ? 0u : rdl(rstamp, (int)r) + 4u * l;
+                        if (v < bestv && r != left_rec && !((used >> r) & 1u)) {
                             bestv = v;
-                            best_age = age;
                             dest = r;
                         }
                     }
-                    if (bestv < n) from = 0u;
-                    else keep = false;
+                    if (bestv == 0xFFFFFFFFu) dest = left_rec != QZ_NONE ? left_rec : 0u;  // every record was useful just now
+                    from = 0u;
                 }
             }
             const uint32_t first = from > 0u ? from : (left_rec != QZ_NONE ? left_at : 0u);
@@ -738,7 +732,7 @@ __global__ __launch_bounds__(TPB) void k_select(EngineDev E) {
                 }
             }
             if (lane < (int)R) {
-                if (keep && (uint32_t)lane == dest) {
+                if ((uint32_t)lane == dest) {
                     if (from < n) rlen = n;
                     rstamp = clock;
                 } else if ((used >> lane) & 1u) rstamp = clock;
@@ -746,7 +740,7 @@ __global__ __launch_bounds__(TPB) void k_select(EngineDev E) {
                 E.rec_stamp[(size_t)b * R + lane] = rstamp;
             }
             if (lane == 0) {
-                if (keep) E.rec_last[b] = dest;
+                E.rec_last[b] = dest;
                 E.rec_clock[b] = clock;
             }
         }
