@@ -13,7 +13,9 @@ extern "C" int qzt_trunk_stamps(float* x, long long n, int n_layers, const void*
         A.beta[l] = l < n_layers ? beta[l] : nullptr;
         A.inv_scale[l] = l < n_layers ? inv_scale[l] : 0.f;
     }
-    hipLaunchKernelGGL(k_trunk<false>, dim3((unsigned)n), dim3(128), 0, (hipStream_t)stream, x, x, A, n_layers, 1e-5f, HeadArgs{nullptr, nullptr, nullptr, 0.f, nullptr},
+    // QZ_STAMPS_PAD_LDS=<bytes>: extra dynamic LDS per workgroup, to measure a wave that has its SIMD for itself (96 KB -> one workgroup per CU)
+    const size_t pad = getenv("QZ_STAMPS_PAD_LDS") ? (size_t)atol(getenv("QZ_STAMPS_PAD_LDS")) : 0;
+    hipLaunchKernelGGL(k_trunk<false>, dim3((unsigned)n), dim3(128), pad, (hipStream_t)stream, x, x, A, n_layers, 1e-5f, HeadArgs{nullptr, nullptr, nullptr, 0.f, nullptr},
                        InputArgs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, stamps);
     return (int)hipGetLastError();
 }
