@@ -128,8 +128,9 @@ typedef struct {
     int32_t traj_pool_pages;   /* 0 = auto: 16 per board (1 MB)                                  */
     int32_t traj_page_dwords;  /* 0 = 16,384 (64 KB); >= 256.  Small pages only make sense in tests */
     qz_rules_opts rules;       /* formulation of the leaf rules op (all zero = defaults)        */
-    int32_t select_opts;       /* A/B switches of the descent kernel (0 = defaults): bit 0 = do not warm the caches along
-                                  the previous descent, bit 1 = no readlane scan for nodes with <= 8 children */
+    int32_t select_opts;       /* A/B switches of the descent kernel (0 = defaults): bit 0 = walk every level (no replay of
+                                  recorded descents; same results, the test partner of the records), bit 1 = no readlane
+                                  scan for nodes with <= 8 children */
 } qz_config;
 
 typedef struct {
