@@ -17,6 +17,10 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
+if os.environ.get("QZ_BENCH_LIB"):  # A/B of a differently built library (benchmarks only): before anything loads it
+    from alphazero_quoridor_amd import _cabi as _c  # noqa: E402
+
+    _c.LIB_PATH = os.environ["QZ_BENCH_LIB"]
 from alphazero_quoridor_amd import rules  # noqa: E402
 from alphazero_quoridor_amd.boards import DeviceBoards, opening_packed  # noqa: E402
 
