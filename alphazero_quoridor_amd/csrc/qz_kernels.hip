@@ -479,7 +479,11 @@ __device__ __forceinline__ bool apply_actions_wave(Board& bd, uint32_t act, int 
 }
 #ifdef QZ_SELECT_STAMPS  // diagnostic build only (tests/hip/Makefile, benchmarks/select_stamps.py): where a descent's time goes
 __device__ unsigned int g_sel_stamps[64][4096][8];
+#if QZ_SELECT_STAMPS >= 2  // light: counters + one stamp at each end (the per-phase stamps slow the walk)
+#define QZ_SEL_MARK(acc)
+#else
 #define QZ_SEL_MARK(acc) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc += (unsigned int)(now_ - t_mark); t_mark = now_; }
+#endif
 #define QZ_SEL_COUNT(x) x
 #else
 #define QZ_SEL_MARK(acc)

@@ -51,3 +51,9 @@ sel = tot > np.percentile(tot, 90)
 X = np.stack([buf[:, :, 3][sel], buf[:, :, 4][sel], buf[:, :, 5][sel], np.ones(sel.sum())], axis=1).astype(np.float64)
 coef, *_ = np.linalg.lstsq(X, tot[sel].astype(np.float64), rcond=None)
 print("ticks ~ %.0f per replay round + %.0f per narrow walk level + %.0f per wide walk level + %.0f" % tuple(coef))
+# the board that is the slowest most often: its 64 consecutive descents (slot = playout counter & 63; the run stopped after
+# playout 320 of a ply, so slots 0..63 are playouts 256..319 in order)
+vals, counts = np.unique(worst, return_counts=True)
+bsel = int(vals[counts.argmax()])
+print("board %d, descents of playouts 256..319: (plen, replayed, rounds, walked narrow)" % bsel)
+print(" ".join("(%d,%d,%d,%d)" % (buf[k, bsel, 6], buf[k, bsel, 7], buf[k, bsel, 3], buf[k, bsel, 4]) for k in range(64)))
