@@ -137,6 +137,7 @@ _SIGNATURES = {
     "qz_mcts_leaf_inputs": (C.c_int, [_P, _P, _P, _P, _P]),
     "qz_mcts_select_boards": (C.c_int, [_P, C.POINTER(qz_boards), _P, _P, _P]),
     "qz_mcts_expand_backup": (C.c_int, [_P, _P, _P, _P]),
+    "qz_mcts_expand_backup_descend": (C.c_int, [_P, _P, _P, _P]),
     "qz_mcts_root_pi": (C.c_int, [_P, _P, _P, _P]),
     "qz_mcts_root_children": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "qz_mcts_update_with_move": (C.c_int, [_P, _P, _P]),

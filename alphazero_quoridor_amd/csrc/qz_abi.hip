@@ -20,6 +20,7 @@ size_t movegen_scratch_bytes(int);
 hipError_t step(uint64_t*, uint64_t*, uint64_t*, const uint8_t*, int, uint8_t*, uint8_t*, hipStream_t);
 hipError_t select(const EngineDev&, hipStream_t);
 hipError_t expand_backup(const EngineDev&, const float*, const float*, hipStream_t);
+hipError_t expand_backup_select(const EngineDev&, const float*, const float*, hipStream_t);
 hipError_t root_pi(const EngineDev&, double*, int32_t*, hipStream_t);
 hipError_t root_children(const EngineDev&, int32_t*, double*, float*, int32_t*, hipStream_t);
 hipError_t update_with_move(const EngineDev&, const uint8_t*, hipStream_t);
@@ -495,6 +496,13 @@ int qz_mcts_expand_backup(qz_engine* e, const float* p, const float* v, void* st
     ENGINE_CHECK(e);
     if (!p || !v) return fail(QZ_E_INVALID, "p/v is null");
     HIP_TRY(qzl::expand_backup(e->dev, p, v, (hipStream_t)stream));
+    return 0;
+}
+
+int qz_mcts_expand_backup_descend(qz_engine* e, const float* p, const float* v, void* stream) {
+    ENGINE_CHECK(e);
+    if (!p || !v) return fail(QZ_E_INVALID, "p/v is null");
+    HIP_TRY(qzl::expand_backup_select(e->dev, p, v, (hipStream_t)stream));
     return 0;
 }
 

@@ -489,10 +489,7 @@ __device__ unsigned int g_sel_stamps[64][4096][8];
 #define QZ_SEL_MARK(acc)
 #define QZ_SEL_COUNT(x)
 #endif
-__global__ __launch_bounds__(TPB) void k_select(EngineDev E) {
-    const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
-    const int b = (int)blockIdx.x * WPB + wave;
-    if (b >= E.n_boards) return;
+__device__ __forceinline__ void select_board(EngineDev& E, const int b, const int lane) {
 #ifdef QZ_SELECT_STAMPS
     unsigned long long t_mark = __builtin_amdgcn_s_memtime();
     const unsigned long long t_begin = t_mark;
@@ -781,11 +778,15 @@ __global__ __launch_bounds__(TPB) void k_select(EngineDev E) {
     }
 }
 
-// TreeNode.expand (mcts.py:27-35) + update_recursive (mcts.py:44-62)
-__global__ __launch_bounds__(TPB) void k_expand_backup(EngineDev E, const float* __restrict__ p, const float* __restrict__ v) {
+__global__ __launch_bounds__(TPB) void k_select(EngineDev E) {
     const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
     const int b = (int)blockIdx.x * WPB + wave;
     if (b >= E.n_boards) return;
+    select_board(E, b, lane);
+}
+
+// TreeNode.expand (mcts.py:27-35) + update_recursive (mcts.py:44-62)
+__device__ __forceinline__ void expand_backup_board(EngineDev& E, const float* __restrict__ p, const float* __restrict__ v, const int b, const int lane) {
     uint32_t term = rfl(E.leaf_term[b]);
     if (term == 3u) return;
     const uint32_t pedge = rfl(E.leaf_pedge[b]);
@@ -885,6 +886,25 @@ __global__ __launch_bounds__(TPB) void k_expand_backup(EngineDev E, const float*
         E.bc_levels[b] += (unsigned long long)plen;
         if (term != 0u) E.bc_terminal[b] += 1u;
     }
+}
+
+__global__ __launch_bounds__(TPB) void k_expand_backup(EngineDev E, const float* __restrict__ p, const float* __restrict__ v) {
+    const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+    const int b = (int)blockIdx.x * WPB + wave;
+    if (b >= E.n_boards) return;
+    expand_backup_board(E, p, v, b, lane);
+}
+// Playout i's expansion + backup and playout i+1's descent of the same board in ONE launch, by the same wavefront: a
+// kernel boundary flushes the eight XCDs' L2s, so a descent launched on its own fetches every edge record of its chain
+// from the Infinity Cache / HBM (~1 us per level); here the records the backup just touched are still in this XCD's L2.
+// Same operations in the same order per board as k_expand_backup followed by k_select.
+__global__ __launch_bounds__(TPB) void k_expand_backup_select(EngineDev E, const float* __restrict__ p, const float* __restrict__ v) {
+    const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+    const int b = (int)blockIdx.x * WPB + wave;
+    if (b >= E.n_boards) return;
+    expand_backup_board(E, p, v, b, lane);
+    wave_sync();  // the backup's stores (other lanes) before the descent's loads
+    select_board(E, b, lane);
 }
 
 // softmax(1/temp * log(visits + 1e-10)) over the root's children (mcts.py:6-9, 141-144).
@@ -1653,6 +1673,10 @@ hipError_t select(const EngineDev& E, hipStream_t s) {
 }
 hipError_t expand_backup(const EngineDev& E, const float* p, const float* v, hipStream_t s) {
     hipLaunchKernelGGL(k_expand_backup, wave_grid(E.n_boards), dim3(TPB), 0, s, E, p, v);
+    return hipGetLastError();
+}
+hipError_t expand_backup_select(const EngineDev& E, const float* p, const float* v, hipStream_t s) {
+    hipLaunchKernelGGL(k_expand_backup_select, wave_grid(E.n_boards), dim3(TPB), 0, s, E, p, v);
     return hipGetLastError();
 }
 hipError_t root_pi(const EngineDev& E, double* pi, int32_t* visits, hipStream_t s) {

@@ -104,6 +104,7 @@ class SelfPlayEngine:
         self._graph = None
         self._graph_steps = 0
         self._leaf_ref = None
+        self._descended = False  # the last expand / backup launch also ran the next playout's descent
 
     @property
     def planes(self):
@@ -129,10 +130,12 @@ class SelfPlayEngine:
             pass
 
     def reset(self):
+        self._descended = False
         _cabi.check(self.L.qz_engine_reset(self.h, self._s()))
 
     def set_boards(self, boards: DeviceBoards, reset_trees=True):
         assert boards.n == self.n_boards
+        self._descended = False
         _cabi.check(self.L.qz_engine_set_boards(self.h, boards.byref(), int(reset_trees), self._s()))
 
     def get_boards(self) -> DeviceBoards:
@@ -157,12 +160,14 @@ class SelfPlayEngine:
         mp = self.leaf_mask.data_ptr() if want_mask else 0
         tp = self.leaf_term.data_ptr() if want_mask else 0
         pp = self.planes.data_ptr() if want_planes else 0
-        if events is None and tree_events is None:
+        descended, self._descended = self._descended, False  # the previous step's fused launch has already walked the trees
+        if events is None and tree_events is None and not descended:
             _cabi.check(self.L.qz_mcts_select(self.h, pp, mp, tp, self._s()))
         else:
             if tree_events is not None:
                 tree_events[0].record()
-            _cabi.check(self.L.qz_mcts_descend(self.h, self._s()))
+            if not descended:
+                _cabi.check(self.L.qz_mcts_descend(self.h, self._s()))
             if tree_events is not None:
                 tree_events[1].record()
             if events is not None:
@@ -179,12 +184,18 @@ class SelfPlayEngine:
                                                  self.leaf_term.data_ptr(), self._s()))
         return out
 
-    def expand_backup(self, p: torch.Tensor, v: torch.Tensor, events=None):
+    def expand_backup(self, p: torch.Tensor, v: torch.Tensor, events=None, then_descend=False):
+        """then_descend: also run the NEXT playout's descent in the same launch (qz_mcts_expand_backup_descend);
+        the next select() then only runs the rules op.  Only between two playouts of the same roots."""
         assert p.dtype == torch.float32 and v.dtype == torch.float32 and p.is_contiguous() and v.is_contiguous()
         assert p.shape == (self.n_boards, 140) and v.numel() == self.n_boards
         if events is not None:
             events[0].record()
-        _cabi.check(self.L.qz_mcts_expand_backup(self.h, p.data_ptr(), v.data_ptr(), self._s()))
+        if then_descend:
+            _cabi.check(self.L.qz_mcts_expand_backup_descend(self.h, p.data_ptr(), v.data_ptr(), self._s()))
+        else:
+            _cabi.check(self.L.qz_mcts_expand_backup(self.h, p.data_ptr(), v.data_ptr(), self._s()))
+        self._descended = bool(then_descend)
         if events is not None:
             events[1].record()
 
@@ -199,13 +210,15 @@ class SelfPlayEngine:
             self._leaf_ref = (st, term.value, self.n_boards)
         return self._leaf_ref
 
-    def playout_step(self, evaluator, events=None, write_planes=None, tree_events=None, nn_events=None):
+    def playout_step(self, evaluator, events=None, write_planes=None, tree_events=None, nn_events=None, more=False):
         """One playout of every board.  An evaluator that computes its first layer from the leaf
         boards never reads state(), so the rules op then only produces the legal sets
         (write_planes=True forces the planes anyway: bench.py's roofline of the full op).
         tree_events = ((start, stop) around k_select, (start, stop) around k_expand_backup);
-        nn_events = (start, stop) around the evaluator's launches."""
+        nn_events = (start, stop) around the evaluator's launches.  more=True: another playout of the same
+        roots follows, so its descent runs in this step's expand / backup launch."""
         if getattr(evaluator, "takes_leaf_copy", False):  # e.g. pure_mcts.RolloutEvaluator: plays its copy of the leaves out
+            assert not self._descended
             leaf = self.select_boards()
             p, v = evaluator.from_boards(leaf, self.leaf_mask)
             self.expand_backup(p, v)
@@ -221,7 +234,7 @@ class SelfPlayEngine:
             p, v = evaluator(planes)
         if nn_events is not None:
             nn_events[1].record()
-        self.expand_backup(p, v, events=None if tree_events is None else tree_events[1])
+        self.expand_backup(p, v, events=None if tree_events is None else tree_events[1], then_descend=more)
 
     def capture_steps(self, evaluator, steps_per_graph=1, warmup=3):
         """Capture `steps_per_graph` playout steps (select -> net -> expand/backup) into one
@@ -235,8 +248,8 @@ class SelfPlayEngine:
         torch.cuda.synchronize(self.device)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            for _ in range(steps_per_graph):
-                self.playout_step(evaluator)
+            for i in range(steps_per_graph):
+                self.playout_step(evaluator, more=i + 1 < steps_per_graph)
         self._graph, self._graph_steps = g, int(steps_per_graph)
         return warmup  # playouts already spent on the current roots
 
@@ -248,12 +261,13 @@ class SelfPlayEngine:
             while n - done >= self._graph_steps:
                 self._graph.replay()
                 done += self._graph_steps
-        for _ in range(n - done):
-            self.playout_step(evaluator)
+        for i in range(n - done):
+            self.playout_step(evaluator, more=i + 1 < n - done)
 
     # ------------------------------------------------------------------ end of a ply
     def finish_move(self, forced=None):
         """-> (moves uint8 [B] (255 = board idle), pi float32 [B,140])."""
+        self._descended = False  # (a descent run ahead of this move would describe the old roots)
         fp = 0
         if forced is not None:
             self._forced = forced.to(device=self.device, dtype=torch.uint8).contiguous()
@@ -267,6 +281,7 @@ class SelfPlayEngine:
         return self.moves, self.pi
 
     def update_with_move(self, moves: torch.Tensor):
+        self._descended = False
         self._upd = moves.to(device=self.device, dtype=torch.uint8).contiguous()
         _cabi.check(self.L.qz_mcts_update_with_move(self.h, self._upd.data_ptr(), self._s()))
 
@@ -367,14 +382,14 @@ class BoardGroups:
             with torch.cuda.stream(self.streams[g]):
                 yield g, self.engines[g], self.evaluators[g]
 
-    def playout_step(self, events=None, write_planes=None, tree_events=None, nn_events=None):
+    def playout_step(self, events=None, write_planes=None, tree_events=None, nn_events=None, more=False):
         """One playout of every board; `events` = one (start, end) pair per group around the
         group's rules-op launch, `tree_events` = one pair of pairs per group (select, expand/backup),
         `nn_events` = one pair per group around the evaluator."""
         for g, eng, ev in self._each():
             eng.playout_step(ev, events=None if events is None else events[g], write_planes=write_planes,
                              tree_events=None if tree_events is None else tree_events[g],
-                             nn_events=None if nn_events is None else nn_events[g])
+                             nn_events=None if nn_events is None else nn_events[g], more=more)
 
     def run_playouts(self, n=None):
         n = self.n_playout if n is None else int(n)
@@ -382,8 +397,8 @@ class BoardGroups:
             for _, eng, ev in self._each():
                 eng.run_playouts(ev, n)
             return
-        for _ in range(n):
-            self.playout_step()
+        for i in range(n):
+            self.playout_step(more=i + 1 < n)
 
     # Results handed to the caller were produced on a group stream: the caller's stream is made to
     # wait for it, and the tensors are marked as used there, before anything is returned.

@@ -369,6 +369,7 @@ def main():
     ap.add_argument("--library-trunk", action="store_true",
                     help="NOT the default: run the trunk convolutions through MIOpen (fp32 implicit GEMM) + the separate normalisation "
                          "kernel instead of the split-fp16 MFMA kernel (qz_nn_conv3x3_norm), for A/B runs")
+    ap.add_argument("--separate-descent", action="store_true", help="A/B: k_select as its own launch (default: fused into the previous playout's expand / backup launch)")
     ap.add_argument("--select-opts", type=int, default=0, help="A/B switches of k_select (qz_config.select_opts)")
     ap.add_argument("--length-file", default=None,
                     help="game-length sample for games_per_s_steady_state (default: newest profiles/round*/game_length_<n>playouts.json)")
@@ -464,8 +465,10 @@ def main():
     ev0 = eng.evaluators[0]
     for _ in range(args.steps):
         ts = time.perf_counter()
-        for _ in range(args.playouts):
-            eng.playout_step(events=evs[k], write_planes=write_planes, tree_events=tevs[k], nn_events=nevs[k])
+        for j in range(args.playouts):
+            # (the expand / backup launch of every playout but the ply's last also runs the next playout's descent)
+            eng.playout_step(events=evs[k], write_planes=write_planes, tree_events=tevs[k], nn_events=nevs[k],
+                             more=(j + 1 < args.playouts) and not args.separate_descent)
             k += 1
         games += end_of_ply()  # harvest synchronises with the device (qz_harvest_counts), so this is the ply's wall time
         step_ms.append((time.perf_counter() - ts) * 1e3)
@@ -574,13 +577,20 @@ def main():
                                "overwritten; `traffic` is what the PMC counters saw at the memory controllers"
                                % (group_boards * bytes_per_board / 1e6)),
             },
-            "roofline_tree": [
+            "roofline_tree": ([
                 tree_line("k_select", sel_ms, sel_bytes, "dependent-load latency: duration = the slowest of %d descents (mean depth %.1f, deepest %d levels); "
                           "recorded descents are re-evaluated 64 levels per round (16 records per board, translated across re-roots), "
                           "levels never walked before cost one memory round trip each; bytes = edge records scanned"
                           % (group_boards, mean_depth, st1["max_depth"])),
                 tree_line("k_expand_backup", exp_ms, exp_bytes, "one expansion (<= 131 records) + lane-parallel backup per board"),
-            ],
+            ] if args.separate_descent else [
+                tree_line("k_expand_backup_select", sel_ms + exp_ms, sel_bytes + exp_bytes,
+                          "playout i's expansion + backup and playout i+1's descent of the same board in one launch, same wavefront (the records the "
+                          "backup touched are still in the XCD's L2 for the descent; the ply's first descent runs alone and is in the average).  "
+                          "Dependent-load latency: duration = the slowest of %d boards (mean depth %.1f, deepest descent %d levels); recorded "
+                          "descents are re-evaluated 64 levels per round (16 records per board, translated across re-roots); bytes = edge records "
+                          "scanned + written" % (group_boards, mean_depth, st1["max_depth"])),
+            ]),
             "roofline_nn": None,
             "engine_stats": {kk: st1[kk] for kk in ("node_overflow", "games_aborted", "aborted_no_move", "aborted_max_plies", "aborted_pool",
                                                     "nonfinite_values", "arena_bytes", "max_nodes", "max_edges", "max_depth", "deep_descents", "deep_descents_cold",

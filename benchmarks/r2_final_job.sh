@@ -15,8 +15,8 @@ import json
 for f in ("bench_default", "bench_groups2", "bench_library_trunk", "bench_c2_playouts100", "bench_c5_playouts800_1gpu"):
     d = json.loads(open("$O/%s.json" % f).read().strip().splitlines()[-1])
     print(f, {k: d[k] for k in ("value", "ms_per_step", "plies_per_s", "playouts_per_s")}, d["games_per_s_steady_state"]["value"] if d.get("games_per_s_steady_state") else None)
-    print("   rules %.1f us frac %.3f | select %.1f | expand %.1f | nn %s" % (d["roofline"]["avg_launch_us"], d["roofline"]["frac"], d["roofline_tree"][0]["avg_launch_us"],
-          d["roofline_tree"][1]["avg_launch_us"], (d.get("roofline_nn") or {}).get("avg_launch_us")))
+    print("   rules %.1f us frac %.3f | tree %s | nn %s" % (d["roofline"]["avg_launch_us"], d["roofline"]["frac"],
+          [(t["kernel"], round(t["avg_launch_us"], 1)) for t in d["roofline_tree"]], (d.get("roofline_nn") or {}).get("avg_launch_us")))
 PY
 timeout 300 python benchmarks/movegen_bench.py > $O/movegen_c3.jsonl 2>/dev/null; cut -c1-150 $O/movegen_c3.jsonl
 timeout 300 python benchmarks/movegen_bench.py --boards 4096 > $O/movegen_b4096.jsonl 2>/dev/null; cut -c1-150 $O/movegen_b4096.jsonl

@@ -200,6 +200,11 @@ int qz_mcts_select_boards(qz_engine* e, const qz_boards* leaf_out, uint32_t* lea
  * ignore p/v and use +-1 (mcts.py:125). */
 int qz_mcts_expand_backup(qz_engine* e, const float* p /*[dev]*/, const float* v /*[dev]*/,
                           void* stream);
+/* qz_mcts_expand_backup of this playout + qz_mcts_descend of the NEXT one in one launch (the loop of
+ * MCTS.get_move_probs, mcts.py:135-139, runs them back to back on the same tree anyway): the edge
+ * records the backup has just touched are still in the cache the descent reads through.  Follow with
+ * qz_mcts_leaf_inputs, exactly as after qz_mcts_descend.  Same results as the two separate calls. */
+int qz_mcts_expand_backup_descend(qz_engine* e, const float* p /*[dev]*/, const float* v /*[dev]*/, void* stream);
 /* MCTS.get_move_probs tail (mcts.py:141-144): pi[n][140] float64 <- softmax(log(N+1e-10)/temp)
  * scattered to action ids (mcts.py:174-177); visits[n][140] int32 (may be NULL) */
 int qz_mcts_root_pi(qz_engine* e, double* pi /*[dev]*/, int32_t* visits /*[dev]*/, void* stream);

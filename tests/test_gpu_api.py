@@ -557,6 +557,6 @@ def test_bench_single_gpu_line_carries_the_contract(gpu_device):
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     assert cb["playouts_per_s_allcores"] >= 0.5 * cb["playouts_per_s_1core"] > 0 and cb["compare_on"].startswith("playouts_per_s")
     assert d["engine_stats"]["node_overflow"] == 0
-    assert [t["kernel"] for t in d["roofline_tree"]] == ["k_select", "k_expand_backup"] and all(t["achieved"] > 0 for t in d["roofline_tree"])
+    assert [t["kernel"] for t in d["roofline_tree"]] == ["k_expand_backup_select"] and all(t["achieved"] > 0 for t in d["roofline_tree"])
     assert "games_per_s_steady_state" in d and "game_lengths_seen" in d and len(d["ms_per_step_series"]) == 2
     assert d["roofline"]["planes_written"] is True and d["roofline"]["planes_consumed_by_evaluator"] is False
