@@ -435,9 +435,11 @@ __device__ __forceinline__ uint32_t tree_alloc(const EngineDev& E, TreeView& T, 
 //    it goes on in the record of the edge it took, at the same level.  A descent that only extends
 //    its record is appended to it; any other is copied over the least valuable record (oldest last
 //    use, short before long: stamp + 4 x length; a pure value-by-length rule was measured worse).
-//  * a round costs about five walked levels, so it is only tried where the record has eight more
-//    levels to offer, and after a round that ended early the next eight levels are walked (in
-//    step with the record: the replay can resume at any level);
+//  * a round costs about two walked levels (1.75 vs 1.0 us, benchmarks/select_stamps.py), so it is
+//    only tried where the record has eight more levels to offer, and after a round that ended early
+//    the next eight levels are walked (in step with the record: the replay can resume at any level);
+//  * records outlive the re-root: translate_records() renames them through the forwarding
+//    addresses the copy leaves behind;
 //  * every lane takes the float64 square root of ITS OWN edge's visit count while the division
 //    is in flight: the winner's is the next level's sqrt(N_parent), off the critical path;
 //  * nodes with <= 8 children (most of a long game: a mover without walls has 2-5 moves) pick
