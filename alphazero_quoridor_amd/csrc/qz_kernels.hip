@@ -137,6 +137,8 @@ struct WaveBoardShared {
     PoolBoard ctx[G];
     PathTab tab[G][2];
     uint16_t items[G * 256];
+    CoopSearch cs[G == 1 ? 2 : 1];  // G == 1: the two base-path searches on nine lanes each (qz_path_rows.h)
+    BB conv[2][5];                  // their pn, ps, pe, pw, last as three-word sets
 };
 template <int NBE, int G>
 union WaveRulesShared {
@@ -147,7 +149,7 @@ union WaveRulesShared {
 // G boards per wavefront: the 2G base-path searches of a wave run side by side on 2G lanes (the
 // search is one long dependent chain, so it costs a wave the same whether 2 or 8 lanes are
 // live), and the work items of the G boards share the flood passes.
-template <int NBE, int G>
+template <int NBE, int G, bool COOP>
 __global__ __launch_bounds__(256) void k_wave_rules(const uint64_t* __restrict__ hb, const uint64_t* __restrict__ vb,
                                                     const uint64_t* __restrict__ meta, int n, const uint8_t* __restrict__ terminal,
                                                     uint32_t* __restrict__ mask5, float* __restrict__ planes, int n_mg_groups,
@@ -173,7 +175,57 @@ __global__ __launch_bounds__(256) void k_wave_rules(const uint64_t* __restrict__
             }
         }
         WaveBoardShared<G>& ws = sm.w[wave];
-        if (lane < 2 * ng) {
+        if (COOP && G == 1) {
+            // base paths on nine lanes per player: lanes 0 / 1 build the board context and the two
+            // graphs, lanes 0..8 / 9..17 search (flood + walk back, a row of the board per lane), all
+            // lanes turn the rows into three-word sets, lanes 0 / 1 derive the need masks
+            const Board bd = unpack(hb[bw], vb[bw], meta[bw]);  // not terminal, mover has walls (short cut above)
+            K1Pre k1;
+            k1.walls = false;
+            if (lane < 2) {
+                Graph g;
+                k1 = pool_k1_pre(bd, false, true, lane + 1, ws.ctx[0], g);
+                CoopSearch& S = ws.cs[lane];
+                S.cn = g.cn;
+                S.cs = g.cs;
+                S.ce = g.ce;
+                S.cw = g.cw;
+                S.notO = g.notO;
+                for (int q = 0; q < 4; q++) {
+                    S.jd[q] = g.j.d[q];
+                    S.ja[q] = g.j.a[q];
+                }
+                S.start = side_start(bd, lane + 1);
+                S.goal_row = k1.walls ? (lane == 0 ? 8 : 0) : -1;
+            }
+            wave_sync();
+            coop_find_path(ws.cs, 2);
+            wave_sync();
+            const int len0 = ws.cs[0].len, len1 = ws.cs[1].len;  // wave-uniform
+            for (int t = lane; t < 30; t += 64) {  // 2 searches x 5 sets x 3 words
+                const int sidx = t / 15, rem = t - 15 * sidx, set = rem / 3, w = rem - 3 * set;
+                reinterpret_cast<uint32_t*>(&ws.conv[sidx][set])[w] = rows_word(ws.cs[sidx].sets[set], w);
+            }
+            const int n0 = (len0 > 0 ? len0 : 0) * 3, n1 = (len1 > 0 ? len1 : 0) * 3;
+            for (int t = lane; t < n0 + n1; t += 64) {
+                const int sidx = t < n0 ? 0 : 1, rem = t < n0 ? t : t - n0, kk = rem / 3, w = rem - 3 * kk;
+                reinterpret_cast<uint32_t*>(&ws.tab[0][sidx].suffix[kk])[w] = rows_word(ws.cs[sidx].sfx[kk], w);
+            }
+            wave_sync();
+            if (lane < 2) {
+                const CoopSearch& S = ws.cs[lane];
+                OrderedPath op;
+                op.e.pn = ws.conv[lane][0];
+                op.e.ps = ws.conv[lane][1];
+                op.e.pe = ws.conv[lane][2];
+                op.e.pw = ws.conv[lane][3];
+                op.last = ws.conv[lane][4];
+                op.e.found = S.found != 0;
+                op.e.jump = S.jump != 0;
+                op.len = S.len;
+                pool_k1_post(bd, lane + 1, ws.ctx[0], k1, op, S.first_jump, S.far_jump, detour_mode);
+            }
+        } else if (lane < 2 * ng) {
             const int g = lane >> 1, b = bw + g;
             Board bd = unpack(hb[b], vb[b], meta[b]);
             const bool term = terminal ? (terminal[b] != 0) : false;
@@ -197,7 +249,9 @@ __global__ __launch_bounds__(256) void k_wave_rules(const uint64_t* __restrict__
             if (j < total) {
                 const uint32_t item = ws.items[j];
                 const int g = (int)(item >> 8), ix = (int)(item & 63u);
-                const bool ok = pool_p3(ws.ctx[g], item, ws.tab[g][(item & 0x80u) ? 1 : 0]);
+                const int side = (item & 0x80u) ? 1 : 0;
+                const bool ok = (COOP && G == 1) ? pool_p3(ws.ctx[0], item, ws.cs[side].srcpos, ws.tab[0][side].suffix)
+                                                 : pool_p3(ws.ctx[g], item, ws.tab[g][side]);
                 if (!ok) atomicOr(&ws.ctx[g].blocked[((item & 0x40u) ? 0 : 2) + (ix >> 5)], 1u << (ix & 31));
             }
         }
@@ -1628,7 +1682,7 @@ hipError_t movegen_encode(const uint64_t* hb, const uint64_t* vb, const uint64_t
     // Small batches are latency-bound: one launch, a wavefront per board, no hand-off through
     // HBM (k_wave_rules).  From ~8k boards on the chip is saturated and the pooled two-launch
     // pipeline, which packs lanes better, wins.
-    if (ro.variant == 2 || ro.variant == 3 || ro.variant == 4 || (ro.variant == 0 && n < 8192)) {
+    if (ro.variant == 2 || ro.variant == 3 || ro.variant == 4 || ro.variant == 5 || (ro.variant == 0 && n < 8192)) {
         const int n_enc_groups = planes ? (n + NBE - 1) / NBE : 0;
         // boards per wavefront: on bench trees (late-game boards, many without walls left) one board per
         // wavefront measured 29.1 us vs 33.0 (two) / 34.6 (four) at 4,096 boards; on the synthetic
@@ -1636,9 +1690,12 @@ hipError_t movegen_encode(const uint64_t* hb, const uint64_t* vb, const uint64_t
         const int G = ro.variant == 2 ? 2 : (ro.variant == 4 ? 4 : 1);
         const int n_mg_groups = mask5 ? (n + WPB * G - 1) / (WPB * G) : 0;
         dim3 grid((unsigned)(n_mg_groups + n_enc_groups));
-        if (G == 1) hipLaunchKernelGGL((k_wave_rules<NBE, 1>), grid, dim3(256), 0, s, hb, vb, meta, n, terminal, mask5, planes, n_mg_groups, ro.detour_wave);
-        else if (G == 4) hipLaunchKernelGGL((k_wave_rules<NBE, 4>), grid, dim3(256), 0, s, hb, vb, meta, n, terminal, mask5, planes, n_mg_groups, ro.detour_wave);
-        else hipLaunchKernelGGL((k_wave_rules<NBE, 2>), grid, dim3(256), 0, s, hb, vb, meta, n, terminal, mask5, planes, n_mg_groups, ro.detour_wave);
+        // one board per wavefront: base paths on nine lanes per player (qz_path_rows.h); variant 5 = the same kernel
+        // with one search per lane, kept as its A/B and parity partner
+        if (G == 1 && ro.variant != 5) hipLaunchKernelGGL((k_wave_rules<NBE, 1, true>), grid, dim3(256), 0, s, hb, vb, meta, n, terminal, mask5, planes, n_mg_groups, ro.detour_wave);
+        else if (G == 1) hipLaunchKernelGGL((k_wave_rules<NBE, 1, false>), grid, dim3(256), 0, s, hb, vb, meta, n, terminal, mask5, planes, n_mg_groups, ro.detour_wave);
+        else if (G == 4) hipLaunchKernelGGL((k_wave_rules<NBE, 4, false>), grid, dim3(256), 0, s, hb, vb, meta, n, terminal, mask5, planes, n_mg_groups, ro.detour_wave);
+        else hipLaunchKernelGGL((k_wave_rules<NBE, 2, false>), grid, dim3(256), 0, s, hb, vb, meta, n, terminal, mask5, planes, n_mg_groups, ro.detour_wave);
         return hipGetLastError();
     }
     PoolBoard* recs = reinterpret_cast<PoolBoard*>(scratch);

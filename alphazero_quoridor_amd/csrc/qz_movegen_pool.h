@@ -19,6 +19,7 @@
 // functions lane by lane on the CPU to check them against the oracle.
 #pragma once
 #include "qz_rules.h"
+#include "qz_path_rows.h"
 
 namespace qz {
 
@@ -101,45 +102,46 @@ QZ_HD void pool_p0(PoolBoard& c, const Board& b, bool terminal, bool want_moves)
 // ---- P0 + P1 as ONE lane task (device launch 1: lane = (board, player)) -------------------
 // Both lanes of a board derive the board context redundantly (cheap, and it keeps every lane
 // busy); lane p == 1 stores the shared part of the record, each lane stores its own path.
-QZ_HD void pool_k1(const Board& b, bool terminal, bool want_moves, int p, PoolBoard& out, PathTab& tab, int detour_mode = 0) {
-    const bool live = !terminal && want_moves;
-    const bool walls = live && ((b.cur == 1 ? b.w1 : b.w2) > 0);
+// Three steps so that a kernel can put its own path finder in the middle (k_wave_rules runs the
+// search on nine lanes per player, qz_path_rows.h): pool_k1_pre -> search -> pool_k1_post.
+struct K1Pre {
     Blk base;
-    base.n = base.s = base.e = base.w = bb_zero();
+    bool walls;  // the mover has walls left: blocked sets, slots, jump plans and paths are needed
+};
+QZ_HD K1Pre pool_k1_pre(const Board& b, bool terminal, bool want_moves, int p, PoolBoard& out, Graph& g) {
+    const bool live = !terminal && want_moves;
+    K1Pre k;
+    k.walls = live && ((b.cur == 1 ? b.w1 : b.w2) > 0);
+    k.base.n = k.base.s = k.base.e = k.base.w = bb_zero();
     // a mover without walls only has pawn moves: no blocked sets, wall slots, jump plans or paths
     // (95 % of the leaf boards of a 400-playout self-play run, benchmarks/insitu_leaf_stats.py)
-    if (walls) base = blk_or(blocked_from(spread8(b.hb), spread8(b.vb)), blocked_borders());
+    if (k.walls) k.base = blk_or(blocked_from(spread8(b.hb), spread8(b.vb)), blocked_borders());
     if (p == 1) {
         out.b = b;
-        out.flags = (terminal ? 2u : 0u) | (walls ? 1u : 0u);
+        out.flags = (terminal ? 2u : 0u) | (k.walls ? 1u : 0u);
         for (int i = 0; i < 4; i++) out.blocked[i] = 0u;
-        out.base = base;
-        out.sh = walls ? static_ok_h(b.hb, b.vb) : 0ull;
-        out.sv = walls ? static_ok_v(b.hb, b.vb) : 0ull;
+        out.base = k.base;
+        out.sh = k.walls ? static_ok_h(b.hb, b.vb) : 0ull;
+        out.sv = k.walls ? static_ok_v(b.hb, b.vb) : 0ull;
         int loc = b.cur == 1 ? b.p1 : b.p2, opp = b.cur == 1 ? b.p2 : b.p1;
         out.pawn = live ? pawn_actions_tab(b.hb, b.vb, loc, opp, b.cur) : 0u;
     }
-    PathEdges none;
-    none.pn = none.ps = none.pe = none.pw = bb_zero();
-    none.jump = false;
-    none.found = false;
-    int len = 0, lj = -1, fj = -1;
-    PathEdges pe = none;
-    BB last = bb_zero();
-    if (walls) {
+    if (k.walls) {
         JumpPlan plan = make_jump_plan(b.hb, b.vb, side_opp(b, p));
         out.plan[p - 1] = plan;
-        Graph g = make_graph_plan(base, plan, -1, false);
-        OrderedPath op = find_path_tables(g, side_start(b, p), side_goal(p), POOL_MAX_LAYERS + 1, tab, lj, fj);
-        pe = op.e;
-        len = op.len;
-        last = op.last;
+        g = make_graph_plan(k.base, plan, -1, false);
     }
+    return k;
+}
+// `op`: the base path of player p (found == false, len == 0 where there was nothing to search)
+QZ_HD void pool_k1_post(const Board& b, int p, PoolBoard& out, const K1Pre& k, const OrderedPath& op, int lj, int fj, int detour_mode) {
+    const PathEdges& pe = op.e;
+    const int len = op.len;
     out.pe[p - 1] = pe;
     out.len[p - 1] = len;
     out.lastjump[p - 1] = lj;
     out.farjump[p - 1] = fj;
-    out.tiles[p - 1] = len > 0 ? bb_or(last, bb_bit(side_start(b, p))) : bb_zero();
+    out.tiles[p - 1] = len > 0 ? bb_or(op.last, bb_bit(side_start(b, p))) : bb_zero();
     // candidates that remove an edge of this path (or, if the path jumps, that sit next to the
     // opponent): only those need a flood for player p
     uint64_t nh = 0, nv = 0;
@@ -157,19 +159,38 @@ QZ_HD void pool_k1(const Board& b, bool terminal, bool want_moves, int p, PoolBo
         if (detour_mode >= 1 && (nh | nv) != 0ull) {
             const int start = side_start(b, p), opp = side_opp(b, p);
             const BB goal = side_goal(p);
-            Graph g2 = make_graph_nojump(blk_or(base, blocked_from(spread8(nh), spread8(nv))), opp);
+            Graph g2 = make_graph_nojump(blk_or(k.base, blocked_from(spread8(nh), spread8(nv))), opp);
             if (flood_to(g2, bb_bit(start), goal)) {
                 nh = nv = 0ull;
             } else if (detour_mode >= 2 && nh != 0ull && nv != 0ull) {
-                g2 = make_graph_nojump(blk_or(base, blocked_from(spread8(nh), bb_zero())), opp);
+                g2 = make_graph_nojump(blk_or(k.base, blocked_from(spread8(nh), bb_zero())), opp);
                 if (flood_to(g2, bb_bit(start), goal)) nh = 0ull;
-                g2 = make_graph_nojump(blk_or(base, blocked_from(bb_zero(), spread8(nv))), opp);
+                g2 = make_graph_nojump(blk_or(k.base, blocked_from(bb_zero(), spread8(nv))), opp);
                 if (flood_to(g2, bb_bit(start), goal)) nv = 0ull;
             }
         }
     }
     out.need[p - 1] = nh;
     out.need[2 + p - 1] = nv;
+}
+// FINDER 0: one search per lane on three-word sets (find_path_tables); 1: the nine-rows formulation in
+// its array form (find_path_rows; what the host check runs in place of the SIMT form of k_wave_rules)
+template <int FINDER = 0>
+QZ_HD void pool_k1(const Board& b, bool terminal, bool want_moves, int p, PoolBoard& out, PathTab& tab, int detour_mode = 0) {
+    Graph g;
+    const K1Pre k = pool_k1_pre(b, terminal, want_moves, p, out, g);
+    OrderedPath op;
+    op.e.pn = op.e.ps = op.e.pe = op.e.pw = bb_zero();
+    op.e.jump = false;
+    op.e.found = false;
+    op.len = 0;
+    op.last = bb_zero();
+    int lj = -1, fj = -1;
+    if (k.walls) {
+        if (FINDER == 0) op = find_path_tables(g, side_start(b, p), side_goal(p), POOL_MAX_LAYERS + 1, tab, lj, fj);
+        else op = find_path_rows(g, side_start(b, p), side_goal(p), POOL_MAX_LAYERS + 1, tab, lj, fj);
+    }
+    pool_k1_post(b, p, out, k, op, lj, fj, detour_mode);
 }
 
 // ---- P2 ---------------------------------------------------------------------------------

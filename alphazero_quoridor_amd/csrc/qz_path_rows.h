@@ -1,0 +1,365 @@
+// qz_path_rows.h -- the base-path search of the rules op with one LANE PER BOARD ROW.
+//
+// find_path_tables() (qz_rules.h) runs one search per lane on 81-bit sets held in three words:
+// ~120-200 instructions per flood layer and per walk-back step, all on one dependent chain, and
+// that chain is what a rules kernel waits for.  Here nine neighbouring lanes share
+// a search, lane r holding row r of every set as 9 bits: a north / south move is a one-lane
+// shift of the whole wavefront (DPP wave_shr / wave_shl; rows 0 and 8 never move outwards, so
+// nothing leaks into the neighbouring group), an east / west move a one-bit shift.  Seven
+// searches fit a wavefront; a layer costs ~45 instructions, a walk-back step ~30.
+//
+//   coop_find_path()   the device form (SIMT, all 64 lanes of a wavefront call it together)
+//   find_path_rows()   the same algorithm written over arrays of nine rows: the host-check build
+//                      runs it in place of find_path_tables() and compares the masks with the
+//                      oracle (tests/hostcheck), so the formulation is checked without a GPU
+//
+// Both produce what find_path_tables() produces -- one concrete shortest path as edge sets, its
+// length, the two lookup tables of the flood phase and the jump positions -- but not necessarily
+// the SAME shortest path (ties are broken by the came-from priority N, S, E, W, jumps in both;
+// the goal tile is the lowest hit in both: in practice they agree).  Path-cut pruning is exact
+// for any concrete path, so the legal sets do not depend on the choice.
+#pragma once
+#include "qz_rules.h"
+
+namespace qz {
+
+// row r (bits 9r .. 9r+8) of an 81-bit set
+QZ_HD uint32_t bb_row(BB a, int r) {
+    const int pos = 9 * r, w = pos >> 5, off = pos & 31;
+    const uint32_t lo = w == 0 ? a.w0 : (w == 1 ? a.w1 : a.w2);
+    const uint32_t hi = w == 0 ? a.w1 : (w == 1 ? a.w2 : 0u);
+    return (uint32_t)(((((uint64_t)hi) << 32) | (uint64_t)lo) >> off) & 0x1FFu;
+}
+// word w (0..2) of the 81-bit set whose rows are rw[0..8]
+template <typename T>
+QZ_HD uint32_t rows_word(const T* rw, int w) {
+    if (w == 0) return (uint32_t)rw[0] | ((uint32_t)rw[1] << 9) | ((uint32_t)rw[2] << 18) | ((uint32_t)rw[3] << 27);
+    if (w == 1)
+        return ((uint32_t)rw[3] >> 5) | ((uint32_t)rw[4] << 4) | ((uint32_t)rw[5] << 13) | ((uint32_t)rw[6] << 22) |
+               ((uint32_t)rw[7] << 31);
+    return ((uint32_t)rw[7] >> 1) | ((uint32_t)rw[8] << 8);
+}
+template <typename T>
+QZ_HD BB bb_from_rows(const T* rw) { return BB{rows_word(rw, 0), rows_word(rw, 1), rows_word(rw, 2)}; }
+
+// ---- array form (host check; also the specification of the SIMT form below) -----------------
+template <typename Tab>
+QZ_HD OrderedPath find_path_rows(const Graph& g, int start, BB goal, int max_edges, Tab& tab, int& first_jump_r, int& far_jump_r) {
+    OrderedPath p;
+    p.e.pn = p.e.ps = p.e.pe = p.e.pw = bb_zero();
+    p.e.jump = false;
+    p.e.found = false;
+    p.len = 0;
+    p.last = bb_zero();
+    first_jump_r = -1;
+    far_jump_r = -1;
+    uint32_t cn[9], cs[9], ce[9], cw[9], nO[9], gl[9], jsrc[9], jb[4][9], jd[4][9];
+    uint32_t R[9], front[9], fN[9], fS[9], fE[9], fW[9], fJ[4][9], fJany[9];
+    for (int r = 0; r < 9; r++) {
+        cn[r] = r == 8 ? 0u : bb_row(g.cn, r);
+        cs[r] = r == 0 ? 0u : bb_row(g.cs, r);
+        ce[r] = bb_row(g.ce, r) & 0xFFu;
+        cw[r] = bb_row(g.cw, r) & 0x1FEu;
+        nO[r] = bb_row(g.notO, r);
+        gl[r] = bb_row(goal, r);
+        jsrc[r] = 0u;
+        for (int k = 0; k < 4; k++) {
+            const int a = g.j.a[k];
+            jb[k][r] = (a >= 0 && a <= 80 && a / 9 == r) ? (1u << (a % 9)) : 0u;
+            jd[k][r] = a >= 0 ? bb_row(g.j.d[k], r) : 0u;
+            jsrc[r] |= jb[k][r];
+            fJ[k][r] = 0u;
+        }
+        R[r] = (start >= 0 && start <= 80 && start / 9 == r) ? (1u << (start % 9)) : 0u;
+        front[r] = R[r];
+        fN[r] = fS[r] = fE[r] = fW[r] = 0u;
+    }
+    uint32_t hit[9];
+    int L = 0;
+    for (int it = 0; it < 81; it++) {
+        uint32_t nx[9], nf[9], aN[9], aS[9], aE[9], aW[9];
+        for (int r = 0; r < 9; r++) {
+            aN[r] = (r > 0 ? (R[r - 1] & cn[r - 1]) : 0u) & nO[r];
+            aS[r] = (r < 8 ? (R[r + 1] & cs[r + 1]) : 0u) & nO[r];
+            aE[r] = ((R[r] & ce[r]) << 1) & nO[r];
+            aW[r] = ((R[r] & cw[r]) >> 1) & nO[r];
+            nx[r] = aN[r] | aS[r] | aE[r] | aW[r];
+            uint32_t fresh = nx[r] & ~R[r];  // first reached by a simple move in this layer
+            fN[r] |= aN[r] & fresh;
+            fresh &= ~aN[r];
+            fS[r] |= aS[r] & fresh;
+            fresh &= ~aS[r];
+            fE[r] |= aE[r] & fresh;
+            fresh &= ~aE[r];
+            fW[r] |= aW[r] & fresh;
+        }
+        // a jump source fires once, in the layer after it joined the reached set (its destinations
+        // are in the reached set from then on, so firing again would add nothing)
+        bool anyj = false;
+        for (int r = 0; r < 9; r++) anyj = anyj || (front[r] & jsrc[r]) != 0u;
+        if (anyj) {
+            uint32_t seen[9];
+            for (int r = 0; r < 9; r++) seen[r] = R[r] | nx[r];
+            for (int k = 0; k < 4; k++) {
+                bool fire = false;
+                for (int r = 0; r < 9; r++) fire = fire || (front[r] & jb[k][r]) != 0u;
+                if (!fire) continue;
+                for (int r = 0; r < 9; r++) {
+                    const uint32_t nj = jd[k][r] & ~seen[r];
+                    fJ[k][r] |= nj;
+                    seen[r] |= nj;
+                    nx[r] |= jd[k][r];
+                }
+            }
+        }
+        bool anyhit = false, anynew = false;
+        for (int r = 0; r < 9; r++) {
+            hit[r] = nx[r] & gl[r];
+            nf[r] = nx[r] & ~R[r];
+            anyhit = anyhit || hit[r] != 0u;
+            anynew = anynew || nf[r] != 0u;
+        }
+        if (anyhit) {
+            p.e.found = true;
+            L = it + 1;
+            break;
+        }
+        if (!anynew) return p;
+        for (int r = 0; r < 9; r++) {
+            R[r] |= nx[r];
+            front[r] = nf[r];
+        }
+    }
+    if (!p.e.found) return p;
+    if (L > max_edges) {  // path longer than the tables: conservative answer (every candidate is re-checked)
+        p.e.pn = p.e.ps = p.e.pe = p.e.pw = bb_not(bb_zero());
+        p.e.jump = true;
+        p.len = -1;
+        return p;
+    }
+    for (int i = 0; i < 21; i++) reinterpret_cast<uint32_t*>(tab.srcpos)[i] = 0xFFFFFFFFu;
+    uint32_t cur[9], acc[9], pn[9], ps[9], pe[9], pw[9];
+    {
+        bool taken = false;  // the lowest hit tile
+        for (int r = 0; r < 9; r++) {
+            cur[r] = (!taken && hit[r]) ? (hit[r] & (0u - hit[r])) : 0u;
+            taken = taken || hit[r] != 0u;
+            acc[r] = pn[r] = ps[r] = pe[r] = pw[r] = 0u;
+            fJany[r] = fJ[0][r] | fJ[1][r] | fJ[2][r] | fJ[3][r];
+        }
+    }
+    int k = 0;
+    for (int guard = 0; guard < 82; guard++) {
+        uint32_t nc[9], sN[9], sS[9], sE[9], sW[9];
+        bool anyj = false, anyc = false;
+        for (int r = 0; r < 9; r++) {
+            sN[r] = r < 8 ? (cur[r + 1] & fN[r + 1]) : 0u;  // reached by a north move: it came from the row below
+            sS[r] = r > 0 ? (cur[r - 1] & fS[r - 1]) : 0u;
+            sE[r] = (cur[r] & fE[r]) >> 1;
+            sW[r] = (cur[r] & fW[r]) << 1;
+            nc[r] = sN[r] | sS[r] | sE[r] | sW[r];
+            anyj = anyj || (cur[r] & fJany[r]) != 0u;
+        }
+        if (anyj) {
+            for (int q = 0; q < 4; q++) {
+                bool via = false;
+                for (int r = 0; r < 9; r++) via = via || (cur[r] & fJ[q][r]) != 0u;
+                if (!via) continue;
+                for (int r = 0; r < 9; r++) nc[r] |= jb[q][r];
+                p.e.jump = true;
+                if (first_jump_r < 0) first_jump_r = k;
+                far_jump_r = k;
+                break;
+            }
+        }
+        for (int r = 0; r < 9; r++) anyc = anyc || nc[r] != 0u;
+        if (!anyc) break;  // cur is the start tile: nothing discovered it
+        for (int r = 0; r < 9; r++) {
+            acc[r] |= cur[r];  // this tile and everything behind it
+            pn[r] |= sN[r];
+            ps[r] |= sS[r];
+            pe[r] |= sE[r];
+            pw[r] |= sW[r];
+            if (nc[r]) {
+                int c = 0;
+                while (!((nc[r] >> c) & 1u)) c++;
+                tab.srcpos[9 * r + c] = (uint8_t)k;
+            }
+            cur[r] = nc[r];
+        }
+        tab.suffix[k] = bb_from_rows(acc);
+        k++;
+    }
+    if (k != L) {  // cannot happen: the came-from sets describe shortest paths of exactly L edges
+        p.e.pn = p.e.ps = p.e.pe = p.e.pw = bb_not(bb_zero());
+        p.e.jump = true;
+        p.len = -1;
+        return p;
+    }
+    p.e.pn = bb_from_rows(pn);
+    p.e.ps = bb_from_rows(ps);
+    p.e.pe = bb_from_rows(pe);
+    p.e.pw = bb_from_rows(pw);
+    p.len = k;
+    p.last = bb_from_rows(acc);
+    return p;
+}
+
+#if defined(__HIPCC__)
+// ---- SIMT form ------------------------------------------------------------------------------
+constexpr int COOP_GROUPS = 7;      // searches per wavefront (lanes 9g .. 9g+8; lane 63 idles)
+constexpr int COOP_MAX_EDGES = 41;  // == POOL_MAX_LAYERS + 1
+// value of the lane below / above in the wavefront (0 beyond its ends)
+__device__ __forceinline__ uint32_t lane_below(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138 /* wave_shr:1 */, 0xF, 0xF, true); }
+__device__ __forceinline__ uint32_t lane_above(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x130 /* wave_shl:1 */, 0xF, 0xF, true); }
+
+// What a search reads (filled by the lane that built the board context) and leaves behind, in LDS.
+struct CoopSearch {
+    // in
+    BB cn, cs, ce, cw, notO;  // the Graph of this player
+    BB jd[4];
+    int32_t ja[4];
+    int32_t start, goal_row;  // goal_row < 0: no search (the group idles)
+    // out
+    int32_t found, jump, len, first_jump, far_jump;
+    uint16_t sets[5][9];                   // rows of pn, ps, pe, pw, last
+    uint16_t sfx[COOP_MAX_EDGES][10];      // rows of suffix[k]; column 9 takes the stores of lanes outside every search
+    uint8_t srcpos[84];  // tiles 0..80; byte 83 takes the stores of lanes that have nothing to say
+};
+// All 64 lanes of a wavefront call this together (full exec mask); group g = lane / 9 runs the search
+// described by s[g] for g < n_searches.  Results are in s[g] when it returns (the caller needs a
+// wave-level LDS fence before reading them from other lanes).
+__device__ __forceinline__ void coop_find_path(CoopSearch* s, int n_searches) {
+    const int lane = (int)(threadIdx.x & 63);
+    const int grp = lane / 9, r = lane - 9 * grp;
+    const uint32_t gbase = (uint32_t)(9 * grp);
+    const bool mine = grp < n_searches && grp < COOP_GROUPS;
+    CoopSearch& S = s[mine ? grp : 0];
+    const int goal_row = mine ? S.goal_row : -1;
+    bool act = goal_row >= 0;
+    uint32_t cn = 0, cs = 0, ce = 0, cw = 0, nO = 0, jsrc = 0, jb0 = 0, jb1 = 0, jb2 = 0, jb3 = 0, jd0 = 0, jd1 = 0, jd2 = 0, jd3 = 0, R = 0;
+    if (act) {
+        cn = r == 8 ? 0u : bb_row(S.cn, r);
+        cs = r == 0 ? 0u : bb_row(S.cs, r);
+        ce = bb_row(S.ce, r) & 0xFFu;
+        cw = bb_row(S.cw, r) & 0x1FEu;
+        nO = bb_row(S.notO, r);
+        const int a0 = S.ja[0], a1 = S.ja[1], a2 = S.ja[2], a3 = S.ja[3];
+        const int t0 = 9 * r;
+        jb0 = (a0 >= t0 && a0 < t0 + 9) ? (1u << (a0 - t0)) : 0u;
+        jb1 = (a1 >= t0 && a1 < t0 + 9) ? (1u << (a1 - t0)) : 0u;
+        jb2 = (a2 >= t0 && a2 < t0 + 9) ? (1u << (a2 - t0)) : 0u;
+        jb3 = (a3 >= t0 && a3 < t0 + 9) ? (1u << (a3 - t0)) : 0u;
+        jd0 = a0 >= 0 ? bb_row(S.jd[0], r) : 0u;
+        jd1 = a1 >= 0 ? bb_row(S.jd[1], r) : 0u;
+        jd2 = a2 >= 0 ? bb_row(S.jd[2], r) : 0u;
+        jd3 = a3 >= 0 ? bb_row(S.jd[3], r) : 0u;
+        jsrc = jb0 | jb1 | jb2 | jb3;
+        const int st = S.start;
+        R = (st >= t0 && st < t0 + 9) ? (1u << (st - t0)) : 0u;
+    }
+    const uint32_t gl = r == goal_row ? 0x1FFu : 0u;
+    uint32_t front = R, fN = 0, fS = 0, fE = 0, fW = 0, fJ0 = 0, fJ1 = 0, fJ2 = 0, fJ3 = 0, hitrow = 0;
+    bool found = false;
+    int L = 0;
+#define QZ_GANY(pred) ((uint32_t)(__ballot(pred) >> gbase) & 0x1FFu)
+    for (int it = 0; it < 81; it++) {
+        const uint32_t aN = lane_below(R & cn) & nO;
+        const uint32_t aS = lane_above(R & cs) & nO;
+        const uint32_t aE = ((R & ce) << 1) & nO;
+        const uint32_t aW = ((R & cw) >> 1) & nO;
+        uint32_t nx = aN | aS | aE | aW;
+        uint32_t fresh = nx & ~R;
+        fN |= aN & fresh;
+        fresh &= ~aN;
+        fS |= aS & fresh;
+        fresh &= ~aS;
+        fE |= aE & fresh;
+        fresh &= ~aE;
+        fW |= aW & fresh;
+        if (__ballot((front & jsrc) != 0u) != 0ull) {  // wave-uniform, rare: the frontier touches a tile next to the opponent
+            uint32_t seen = R | nx;
+            uint32_t nj;
+            if (QZ_GANY((front & jb0) != 0u)) { nj = jd0 & ~seen; fJ0 |= nj; seen |= nj; nx |= jd0; }
+            if (QZ_GANY((front & jb1) != 0u)) { nj = jd1 & ~seen; fJ1 |= nj; seen |= nj; nx |= jd1; }
+            if (QZ_GANY((front & jb2) != 0u)) { nj = jd2 & ~seen; fJ2 |= nj; seen |= nj; nx |= jd2; }
+            if (QZ_GANY((front & jb3) != 0u)) { nj = jd3 & ~seen; fJ3 |= nj; seen |= nj; nx |= jd3; }
+        }
+        const uint32_t hit = nx & gl, nf = nx & ~R;
+        const uint32_t gh = QZ_GANY(hit != 0u), gf = QZ_GANY(nf != 0u);
+        // branch-free bookkeeping (a divergent `if` costs more scalar exec-mask work than the layer itself).  A
+        // finished group keeps R and front, and every update above is idempotent on unchanged inputs, so its
+        // lanes may run on: hitrow = hit stays what it was in the layer that found the goal.
+        const bool hitnow = act && gh != 0u, cont = act && gh == 0u && gf != 0u;
+        L += act ? 1 : 0;
+        found = found || hitnow;
+        hitrow = hit;
+        R = cont ? (R | nx) : R;
+        front = cont ? nf : front;
+        act = cont;
+        if (__ballot(act) == 0ull) break;
+    }
+    const bool toolong = found && L > COOP_MAX_EDGES;
+    // the lowest hit tile (hits are confined to the goal row, i.e. to one lane of the group)
+    uint32_t cur = (found && !toolong) ? (hitrow & (0u - hitrow)) : 0u;
+    if (mine && goal_row >= 0)
+        for (int i = r; i < 21; i += 9) reinterpret_cast<uint32_t*>(S.srcpos)[i] = 0xFFFFFFFFu;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t fJany = fJ0 | fJ1 | fJ2 | fJ3;
+    uint32_t acc = 0, pn = 0, ps = 0, pe = 0, pw = 0;
+    int first_jump = -1, far_jump = -1;
+    bool jump = false;
+    for (int k = 0; k < COOP_MAX_EDGES; k++) {
+        const uint32_t sN = lane_above(cur & fN);  // reached by a north move: it came from the row below
+        const uint32_t sS = lane_below(cur & fS);
+        const uint32_t sE = (cur & fE) >> 1;
+        const uint32_t sW = (cur & fW) << 1;
+        uint32_t nc = sN | sS | sE | sW;
+        if (__ballot((cur & fJany) != 0u) != 0ull) {  // wave-uniform, rare
+            bool via = false;
+            const uint32_t v0 = QZ_GANY((cur & fJ0) != 0u), v1 = QZ_GANY((cur & fJ1) != 0u), v2 = QZ_GANY((cur & fJ2) != 0u),
+                           v3 = QZ_GANY((cur & fJ3) != 0u);
+            if (v0) { nc |= jb0; via = true; }
+            else if (v1) { nc |= jb1; via = true; }
+            else if (v2) { nc |= jb2; via = true; }
+            else if (v3) { nc |= jb3; via = true; }
+            if (via) {
+                jump = true;
+                if (first_jump < 0) first_jump = k;
+                far_jump = k;
+            }
+        }
+        if (__ballot(nc != 0u) == 0ull) break;  // every group is back at its start tile
+        // No branches below.  A group that is back at its start tile has nc == 0 in all of its lanes: it ORs the
+        // start tile into acc (harmless: `last` is only used together with the start tile) and writes entries
+        // k >= len of sfx (never read); lanes without the new tile aim their srcpos byte at the padding.
+        acc |= cur;
+        S.sfx[k][mine ? r : 9] = (uint16_t)acc;
+        S.srcpos[nc != 0u ? 9 * r + (__ffs((int)nc) - 1) : 83] = (uint8_t)k;
+        pn |= sN;
+        ps |= sS;
+        pe |= sE;
+        pw |= sW;
+        cur = nc;
+    }
+#undef QZ_GANY
+    if (mine && goal_row >= 0) {
+        const uint32_t all = 0x1FFu;
+        S.sets[0][r] = (uint16_t)(toolong ? all : pn);
+        S.sets[1][r] = (uint16_t)(toolong ? all : ps);
+        S.sets[2][r] = (uint16_t)(toolong ? all : pe);
+        S.sets[3][r] = (uint16_t)(toolong ? all : pw);
+        S.sets[4][r] = (uint16_t)(toolong ? 0u : acc);
+        if (r == 0) {
+            S.found = found ? 1 : 0;
+            S.jump = (jump || toolong) ? 1 : 0;
+            S.len = !found ? 0 : (toolong ? -1 : L);
+            S.first_jump = first_jump;
+            S.far_jump = far_jump;
+        }
+    }
+}
+#endif  // __HIPCC__
+
+}  // namespace qz

@@ -129,11 +129,16 @@ extern "C" long hc_p2_mismatches() { return g_p2_mismatch; }
 // ---- the pooled kernel's phases (qz_movegen_pool.h), executed lane by lane for tiles of nb boards
 static int g_try_detour = 0;
 extern "C" void hc_set_detour(int on) { g_try_detour = on; }
+static int g_finder = 0;  // 0: find_path_tables, 1: find_path_rows (the nine-rows formulation of k_wave_rules)
+extern "C" void hc_set_finder(int f) { g_finder = f; }
 static void pool_tile(const Board* boards, int nb, uint32_t* mask5, float* planes, int64_t* floods, int64_t* flood_iters) {
     std::vector<PoolBoard> ctx(nb);
     std::vector<PathTab> tabs((size_t)nb * 2);
     for (int i = 0; i < nb; i++)  // launch 1: lane = (board, player)
-        for (int p = 2; p >= 1; p--) pool_k1(boards[i], false, true, p, ctx[i], tabs[(size_t)i * 2 + p - 1], g_try_detour);
+        for (int p = 2; p >= 1; p--) {
+            if (g_finder == 0) pool_k1<0>(boards[i], false, true, p, ctx[i], tabs[(size_t)i * 2 + p - 1], g_try_detour);
+            else pool_k1<1>(boards[i], false, true, p, ctx[i], tabs[(size_t)i * 2 + p - 1], g_try_detour);
+        }
     std::vector<uint32_t> items;
     for (int i = 0; i < nb; i++)
         for (int ix = 0; ix < 64; ix++) {

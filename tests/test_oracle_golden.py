@@ -118,7 +118,8 @@ def hostcheck():
     so = os.path.join(HERE, "hostcheck", "libqz_hostcheck.so")
     hdr = os.path.join(HERE, "..", "alphazero_quoridor_amd", "csrc", "qz_rules.h")
     hdr2 = os.path.join(HERE, "..", "alphazero_quoridor_amd", "csrc", "qz_movegen_pool.h")
-    if not os.path.exists(so) or max(os.path.getmtime(src), os.path.getmtime(hdr), os.path.getmtime(hdr2)) > os.path.getmtime(so):
+    hdr3 = os.path.join(HERE, "..", "alphazero_quoridor_amd", "csrc", "qz_path_rows.h")
+    if not os.path.exists(so) or max(os.path.getmtime(p) for p in (src, hdr, hdr2, hdr3)) > os.path.getmtime(so):
         subprocess.check_call(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-o", so, src])
     return C.CDLL(so)
 
@@ -168,6 +169,17 @@ def test_bitboard_movegen_equals_oracle(hostcheck, positions):
         assert np.array_equal(m, omask), "detour mode %d" % mode
         assert floods.value < base_floods * (0.75 if mode == 1 else 0.5)
     hostcheck.hc_set_detour(0)
+    # the nine-rows formulation of the base-path search (qz_path_rows.h: what k_wave_rules runs on nine
+    # lanes per player) in place of the one-lane search: same masks, with and without group detours
+    for mode in (0, 1):
+        hostcheck.hc_set_finder(1)
+        hostcheck.hc_set_detour(mode)
+        m = np.zeros((n, 5), dtype=np.uint32)
+        hostcheck.hc_movegen_pool(hb.ctypes.data_as(C.c_void_p), vb.ctypes.data_as(C.c_void_p), meta.ctypes.data_as(C.c_void_p),
+                                  n, 16, m.ctypes.data_as(C.c_void_p), None, None)
+        hostcheck.hc_set_finder(0)
+        hostcheck.hc_set_detour(0)
+        assert np.array_equal(m, omask), "rows finder, detour mode %d" % mode
     # ordered list from the mask through order_index (the expand kernel's slot rule)
     out = (C.c_int * 140)()
     for i in range(0, n, 53):
