@@ -132,6 +132,16 @@ __global__ __launch_bounds__(256) void k_pool_paths_enc(const uint64_t* __restri
 // board a wavefront that runs the same phase functions as the pooled pipeline on LDS-resident
 // records (lanes 0/1: base paths; lane = slot: cut tests; lane = work item: floods); encoder
 // groups (encoder_group) run beside them in the same grid.
+#ifdef QZ_RULES_STAMPS  // diagnostic build only (tests/hip/Makefile, benchmarks/rules_stamps.py): where a searching wavefront's time goes
+__device__ unsigned int g_rules_stamps[4096][16];   // per board: s_memtime at the phase boundaries (low 32 bits) + counters
+__device__ unsigned long long g_rules_enc[512][2];  // per encoder tile: s_memrealtime (100 MHz) at its first and after its last instruction
+__device__ unsigned long long g_rules_rt[4096][2];  // per board: s_memrealtime at the wavefront's start and end
+#define QZ_RS_MARK(k) { if (lane == 0 && bw < 4096) g_rules_stamps[bw][k] = (unsigned int)__builtin_amdgcn_s_memtime(); }
+#define QZ_RS_SET(k, v) { if (lane == 0 && bw < 4096) g_rules_stamps[bw][k] = (unsigned int)(v); }
+#else
+#define QZ_RS_MARK(k)
+#define QZ_RS_SET(k, v)
+#endif
 template <int G>
 struct WaveBoardShared {
     PoolBoard ctx[G];
@@ -160,6 +170,11 @@ __global__ __launch_bounds__(256) void k_wave_rules(const uint64_t* __restrict__
         const int bw = ((int)blockIdx.x * WPB + wave) * G;  // first board of this wave
         if (bw >= n) return;  // whole wave leaves; only wave-level synchronisation below
         const int ng = (n - bw) < G ? (n - bw) : G;
+#ifdef QZ_RULES_STAMPS
+        if (lane == 0 && bw < 4096) g_rules_rt[bw][0] = __builtin_amdgcn_s_memrealtime();
+        QZ_RS_SET(15, 0)
+        QZ_RS_MARK(0)
+#endif
         if (G == 1) {
             // wave-uniform short cut: a terminal board has no moves, a mover without walls only pawn
             // moves -- one lane, no records, no work list
@@ -171,6 +186,10 @@ __global__ __launch_bounds__(256) void k_wave_rules(const uint64_t* __restrict__
                     mask5[(size_t)bw * 5] = term ? 0u : pawn_actions_tab(bd.hb, bd.vb, loc, opp, bd.cur);
                 }
                 if (lane >= 1 && lane < 5) mask5[(size_t)bw * 5 + lane] = 0u;
+#ifdef QZ_RULES_STAMPS
+                QZ_RS_MARK(9)
+                if (lane == 0 && bw < 4096) g_rules_rt[bw][1] = __builtin_amdgcn_s_memrealtime();
+#endif
                 return;
             }
         }
@@ -182,6 +201,7 @@ __global__ __launch_bounds__(256) void k_wave_rules(const uint64_t* __restrict__
             const Board bd = unpack(hb[bw], vb[bw], meta[bw]);  // not terminal, mover has walls (short cut above)
             K1Pre k1;
             k1.walls = false;
+            QZ_RS_MARK(1)
             if (lane < 2) {
                 Graph g;
                 k1 = pool_k1_pre(bd, false, true, lane + 1, ws.ctx[0], g);
@@ -199,8 +219,10 @@ __global__ __launch_bounds__(256) void k_wave_rules(const uint64_t* __restrict__
                 S.goal_row = k1.walls ? (lane == 0 ? 8 : 0) : -1;
             }
             wave_sync();
+            QZ_RS_MARK(2)
             coop_find_path(ws.cs, 2);
             wave_sync();
+            QZ_RS_MARK(3)
             const int len0 = ws.cs[0].len, len1 = ws.cs[1].len;  // wave-uniform
             for (int t = lane; t < 30; t += 64) {  // 2 searches x 5 sets x 3 words
                 const int sidx = t / 15, rem = t - 15 * sidx, set = rem / 3, w = rem - 3 * set;
@@ -212,6 +234,9 @@ __global__ __launch_bounds__(256) void k_wave_rules(const uint64_t* __restrict__
                 reinterpret_cast<uint32_t*>(&ws.tab[0][sidx].suffix[kk])[w] = rows_word(ws.cs[sidx].sfx[kk], w);
             }
             wave_sync();
+            QZ_RS_MARK(4)
+            QZ_RS_SET(10, len0)
+            QZ_RS_SET(11, len1)
             if (lane < 2) {
                 const CoopSearch& S = ws.cs[lane];
                 OrderedPath op;
@@ -232,6 +257,7 @@ __global__ __launch_bounds__(256) void k_wave_rules(const uint64_t* __restrict__
             pool_k1(bd, term, true, (lane & 1) + 1, ws.ctx[g], ws.tab[g][lane & 1], detour_mode);
         }
         wave_sync();
+        QZ_RS_MARK(5)
         int total = 0;
         for (int g = 0; g < ng; g++) {  // wave-uniform
             const uint32_t m = pool_p2(ws.ctx[g], lane);
@@ -244,6 +270,8 @@ __global__ __launch_bounds__(256) void k_wave_rules(const uint64_t* __restrict__
             }
         }
         wave_sync();
+        QZ_RS_MARK(6)
+        QZ_RS_SET(12, total)
         for (int base = 0; base < total; base += 64) {  // wave-uniform trip count
             const int j = base + lane;
             if (j < total) {
@@ -256,15 +284,29 @@ __global__ __launch_bounds__(256) void k_wave_rules(const uint64_t* __restrict__
             }
         }
         wave_sync();
+        QZ_RS_MARK(7)
         if (lane < ng) {
             uint32_t m5[5];
             pool_p4(ws.ctx[lane], m5);
 #pragma unroll
             for (int w = 0; w < 5; w++) mask5[(size_t)(bw + lane) * 5 + w] = m5[w];
         }
+#ifdef QZ_RULES_STAMPS
+        QZ_RS_MARK(8)
+        QZ_RS_SET(15, 1)
+        if (lane == 0 && bw < 4096) g_rules_rt[bw][1] = __builtin_amdgcn_s_memrealtime();
+#endif
         return;
     }
+#ifdef QZ_RULES_STAMPS
+    const int et = (int)blockIdx.x - n_mg_groups;
+    if (tid == 0 && et < 512) g_rules_enc[et][0] = __builtin_amdgcn_s_memrealtime();
+#endif
     encoder_group<NBE>(sm.enc, hb, vb, meta, n, terminal, planes, ((int)blockIdx.x - n_mg_groups) * NBE, tid);
+#ifdef QZ_RULES_STAMPS
+    __syncthreads();
+    if (tid == 0 && et < 512) g_rules_enc[et][1] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 template <int NB>
@@ -1784,6 +1826,14 @@ hipError_t rollout_step(uint64_t* hb, uint64_t* vb, uint64_t* meta, const uint32
                        n_done, seed, step, limit);
     return hipGetLastError();
 }
+#ifdef QZ_RULES_STAMPS
+extern "C" int qzt_rules_stamps_read(void* stamps, void* enc, void* rt) {  // [4096][16] u32, [512][2] u64, [4096][2] u64
+    hipError_t e = hipMemcpyFromSymbol(stamps, HIP_SYMBOL(g_rules_stamps), sizeof(g_rules_stamps));
+    if (e == hipSuccess) e = hipMemcpyFromSymbol(enc, HIP_SYMBOL(g_rules_enc), sizeof(g_rules_enc));
+    if (e == hipSuccess) e = hipMemcpyFromSymbol(rt, HIP_SYMBOL(g_rules_rt), sizeof(g_rules_rt));
+    return (int)e;
+}
+#endif
 #ifdef QZ_SELECT_STAMPS
 extern "C" int qzt_select_stamps_read(void* host_out) {  // [64 launches (playout counter & 63)][4096 boards][8] u32
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_sel_stamps), sizeof(g_sel_stamps));
