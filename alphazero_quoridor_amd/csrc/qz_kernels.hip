@@ -67,10 +67,11 @@ struct EncShared {
     uint32_t st[POOL_STREAM_WORDS(NBE) + 1];      // the tile as one bit stream (2,106 bits per board)
     __attribute__((aligned(16))) float tbl[16][4];  // nibble -> four floats
 };
+typedef float v4f __attribute__((ext_vector_type(4)));
 template <int NBE>
 __device__ __forceinline__ void encoder_group(EncShared<NBE>& sm, const uint64_t* __restrict__ hb, const uint64_t* __restrict__ vb,
                                               const uint64_t* __restrict__ meta, int n, const uint8_t* __restrict__ terminal,
-                                              float* __restrict__ planes, int b0, int tid) {
+                                              float* __restrict__ planes, int b0, int tid, bool nt = false) {
     const int nb = (n - b0) < NBE ? (n - b0) : NBE;
     if (tid < nb) {
         Board bd = unpack(hb[b0 + tid], vb[b0 + tid], meta[b0 + tid]);
@@ -96,8 +97,14 @@ __device__ __forceinline__ void encoder_group(EncShared<NBE>& sm, const uint64_t
     const int nf = nb * QZ_PLANES_N, nq = nf >> 2;
     const uint32_t sh = (uint32_t)(tid & 7) << 2;
     const float4* tbl = reinterpret_cast<const float4*>(sm.tbl);
+    if (nt) {  // streaming stores: the planes leave the L2 while the kernel runs instead of in its end-of-kernel write-back
 #pragma unroll 4
-    for (int q = tid; q < nq; q += 256) out[q] = tbl[(sm.st[q >> 3] >> sh) & 15u];
+        for (int q = tid; q < nq; q += 256)
+            __builtin_nontemporal_store(reinterpret_cast<const v4f*>(tbl)[(sm.st[q >> 3] >> sh) & 15u], reinterpret_cast<v4f*>(out) + q);
+    } else {
+#pragma unroll 4
+        for (int q = tid; q < nq; q += 256) out[q] = tbl[(sm.st[q >> 3] >> sh) & 15u];
+    }
     if ((nf & 3) && tid == 0) {  // odd number of boards in the last tile: 2 floats left
         const int bit = nf - 2;
         const uint32_t two = (sm.st[bit >> 5] >> (bit & 31)) & 3u;
@@ -206,11 +213,9 @@ __global__ __launch_bounds__(256) void k_wave_rules(const uint64_t* __restrict__
                 Graph g;
                 k1 = pool_k1_pre(bd, false, true, lane + 1, ws.ctx[0], g);
                 CoopSearch& S = ws.cs[lane];
-                S.cn = g.cn;
-                S.cs = g.cs;
-                S.ce = g.ce;
-                S.cw = g.cw;
-                S.notO = g.notO;
+                S.hb = bd.hb;
+                S.vb = bd.vb;
+                S.opp = side_opp(bd, lane + 1);
                 for (int q = 0; q < 4; q++) {
                     S.jd[q] = g.j.d[q];
                     S.ja[q] = g.j.a[q];
@@ -248,13 +253,16 @@ __global__ __launch_bounds__(256) void k_wave_rules(const uint64_t* __restrict__
                 op.e.found = S.found != 0;
                 op.e.jump = S.jump != 0;
                 op.len = S.len;
-                pool_k1_post(bd, lane + 1, ws.ctx[0], k1, op, S.first_jump, S.far_jump, detour_mode);
+                CutMasks cm;
+                cm.h = *reinterpret_cast<const uint64_t*>(S.cut_h);
+                cm.v = *reinterpret_cast<const uint64_t*>(S.cut_v);
+                pool_k1_post(bd, lane + 1, ws.ctx[0], k1, op, S.first_jump, S.far_jump, detour_mode & 0xFF, &cm);
             }
         } else if (lane < 2 * ng) {
             const int g = lane >> 1, b = bw + g;
             Board bd = unpack(hb[b], vb[b], meta[b]);
             const bool term = terminal ? (terminal[b] != 0) : false;
-            pool_k1(bd, term, true, (lane & 1) + 1, ws.ctx[g], ws.tab[g][lane & 1], detour_mode);
+            pool_k1(bd, term, true, (lane & 1) + 1, ws.ctx[g], ws.tab[g][lane & 1], detour_mode & 0xFF);
         }
         wave_sync();
         QZ_RS_MARK(5)
@@ -302,7 +310,7 @@ __global__ __launch_bounds__(256) void k_wave_rules(const uint64_t* __restrict__
     const int et = (int)blockIdx.x - n_mg_groups;
     if (tid == 0 && et < 512) g_rules_enc[et][0] = __builtin_amdgcn_s_memrealtime();
 #endif
-    encoder_group<NBE>(sm.enc, hb, vb, meta, n, terminal, planes, ((int)blockIdx.x - n_mg_groups) * NBE, tid);
+    encoder_group<NBE>(sm.enc, hb, vb, meta, n, terminal, planes, ((int)blockIdx.x - n_mg_groups) * NBE, tid, (detour_mode & 0x100) != 0);
 #ifdef QZ_RULES_STAMPS
     __syncthreads();
     if (tid == 0 && et < 512) g_rules_enc[et][1] = __builtin_amdgcn_s_memrealtime();
@@ -1724,7 +1732,7 @@ hipError_t movegen_encode(const uint64_t* hb, const uint64_t* vb, const uint64_t
     // Small batches are latency-bound: one launch, a wavefront per board, no hand-off through
     // HBM (k_wave_rules).  From ~8k boards on the chip is saturated and the pooled two-launch
     // pipeline, which packs lanes better, wins.
-    if (ro.variant == 2 || ro.variant == 3 || ro.variant == 4 || ro.variant == 5 || (ro.variant == 0 && n < 8192)) {
+    if ((ro.variant >= 2 && ro.variant <= 6) || (ro.variant == 0 && n < 8192)) {
         const int n_enc_groups = planes ? (n + NBE - 1) / NBE : 0;
         // boards per wavefront: on bench trees (late-game boards, many without walls left) one board per
         // wavefront measured 29.1 us vs 33.0 (two) / 34.6 (four) at 4,096 boards; on the synthetic
@@ -1734,7 +1742,9 @@ hipError_t movegen_encode(const uint64_t* hb, const uint64_t* vb, const uint64_t
         dim3 grid((unsigned)(n_mg_groups + n_enc_groups));
         // one board per wavefront: base paths on nine lanes per player (qz_path_rows.h); variant 5 = the same kernel
         // with one search per lane, kept as its A/B and parity partner
-        if (G == 1 && ro.variant != 5) hipLaunchKernelGGL((k_wave_rules<NBE, 1, true>), grid, dim3(256), 0, s, hb, vb, meta, n, terminal, mask5, planes, n_mg_groups, ro.detour_wave);
+        // the planes go out as streaming (non-temporal) stores: they leave the L2 while the searching wavefronts are still
+        // busy instead of in the end-of-kernel write-back (in situ 23.1 -> 21.8 us); variant 6 = ordinary stores (A/B)
+        if (G == 1 && ro.variant != 5) hipLaunchKernelGGL((k_wave_rules<NBE, 1, true>), grid, dim3(256), 0, s, hb, vb, meta, n, terminal, mask5, planes, n_mg_groups, ro.detour_wave | (ro.variant == 6 ? 0 : 0x100));
         else if (G == 1) hipLaunchKernelGGL((k_wave_rules<NBE, 1, false>), grid, dim3(256), 0, s, hb, vb, meta, n, terminal, mask5, planes, n_mg_groups, ro.detour_wave);
         else if (G == 4) hipLaunchKernelGGL((k_wave_rules<NBE, 4, false>), grid, dim3(256), 0, s, hb, vb, meta, n, terminal, mask5, planes, n_mg_groups, ro.detour_wave);
         else hipLaunchKernelGGL((k_wave_rules<NBE, 2, false>), grid, dim3(256), 0, s, hb, vb, meta, n, terminal, mask5, planes, n_mg_groups, ro.detour_wave);

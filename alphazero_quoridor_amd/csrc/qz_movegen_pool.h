@@ -134,7 +134,9 @@ QZ_HD K1Pre pool_k1_pre(const Board& b, bool terminal, bool want_moves, int p, P
     return k;
 }
 // `op`: the base path of player p (found == false, len == 0 where there was nothing to search)
-QZ_HD void pool_k1_post(const Board& b, int p, PoolBoard& out, const K1Pre& k, const OrderedPath& op, int lj, int fj, int detour_mode) {
+// `cuts`: path_cut_masks(op.e) if the caller has it already (k_wave_rules gets it from the search), else nullptr
+QZ_HD void pool_k1_post(const Board& b, int p, PoolBoard& out, const K1Pre& k, const OrderedPath& op, int lj, int fj, int detour_mode,
+                        const CutMasks* cuts = nullptr) {
     const PathEdges& pe = op.e;
     const int len = op.len;
     out.pe[p - 1] = pe;
@@ -146,7 +148,7 @@ QZ_HD void pool_k1_post(const Board& b, int p, PoolBoard& out, const K1Pre& k, c
     // opponent): only those need a flood for player p
     uint64_t nh = 0, nv = 0;
     if (pe.found) {
-        CutMasks cm = path_cut_masks(pe);
+        const CutMasks cm = cuts ? *cuts : path_cut_masks(pe);
         uint64_t near = pe.jump ? near_opp_mask(side_opp(b, p)) : 0ull;
         nh = static_ok_h(b.hb, b.vb) & (cm.h | near);
         nv = static_ok_v(b.hb, b.vb) & (cm.v | near);

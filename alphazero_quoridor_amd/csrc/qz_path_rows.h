@@ -42,6 +42,32 @@ QZ_HD uint32_t rows_word(const T* rw, int w) {
 template <typename T>
 QZ_HD BB bb_from_rows(const T* rw) { return BB{rows_word(rw, 0), rows_word(rw, 1), rows_word(rw, 2)}; }
 
+// Row r of the four blocked sets (walls + borders) straight from the wall bytes:
+// == bb_row(blk_or(blocked_from(spread8(hb), spread8(vb)), blocked_borders()).n|s|e|w, r), incl. the row-0 quirks
+// (tests/hostcheck compares the two on every test position).
+QZ_HD void blocked_rows(uint64_t hb, uint64_t vb, int r, uint32_t& bn, uint32_t& bs, uint32_t& be, uint32_t& bw) {
+    const uint32_t h = r < 8 ? (uint32_t)(hb >> (8 * (r & 7))) & 0xFFu : 0u;
+    const uint32_t hm = r > 0 ? (uint32_t)(hb >> (8 * ((r - 1) & 7))) & 0xFFu : 0u;
+    const uint32_t v = r < 8 ? (uint32_t)(vb >> (8 * (r & 7))) & 0xFFu : 0u;
+    const uint32_t vm = r > 0 ? (uint32_t)(vb >> (8 * ((r - 1) & 7))) & 0xFFu : 0u;
+    bn = r == 8 ? 0x1FFu : (r == 0 ? ((h << 1) | (h & 1u)) : (h | (h << 1)));
+    bs = r == 0 ? 0x1FFu : (hm | (hm << 1));
+    be = (r == 0 ? (((v << 1) & 0xFEu) | (v & 1u)) : (v | vm)) | 0x100u;
+    bw = (((v | vm) << 1) | 1u) & 0x1FFu;
+}
+
+// Row r (a byte, r < 8) of path_cut_masks(): the slots whose horizontal / vertical wall removes an edge of the path,
+// from row r and row r + 1 (`*_up`) of the path's edge sets
+QZ_HD void cut_row(int r, uint32_t pn, uint32_t ps_up, uint32_t pe, uint32_t pe_up, uint32_t pw, uint32_t pw_up, uint32_t& h, uint32_t& v) {
+    const uint32_t ca = pn & 0xFFu, cb = (pn >> 1) & 0xFFu;
+    h = (r == 0 ? (cb | (ca & 1u)) : (ca | cb)) | (ps_up & 0xFFu) | ((ps_up >> 1) & 0xFFu);
+    const uint32_t e0 = pe & 0xFFu, e1 = (pe >> 1) & 0xFFu, e9 = pe_up & 0xFFu;
+    v = (r == 0 ? (e9 | (e1 & 0x7Fu) | (e0 & 1u)) : (e0 | e9)) | ((pw >> 1) & 0xFFu) | ((pw_up >> 1) & 0xFFu);
+}
+#if !defined(__HIPCC__)
+static long g_cut_row_mismatches = 0;  // host check: cut_row() against path_cut_masks() on every path found
+#endif
+
 // ---- array form (host check; also the specification of the SIMT form below) -----------------
 template <typename Tab>
 QZ_HD OrderedPath find_path_rows(const Graph& g, int start, BB goal, int max_edges, Tab& tab, int& first_jump_r, int& far_jump_r) {
@@ -202,6 +228,19 @@ QZ_HD OrderedPath find_path_rows(const Graph& g, int start, BB goal, int max_edg
     p.e.pw = bb_from_rows(pw);
     p.len = k;
     p.last = bb_from_rows(acc);
+#if !defined(__HIPCC__)
+    {
+        uint64_t ch = 0, cv = 0;
+        for (int r = 0; r < 8; r++) {
+            uint32_t h, v;
+            cut_row(r, pn[r], ps[r + 1], pe[r], pe[r + 1], pw[r], pw[r + 1], h, v);
+            ch |= (uint64_t)h << (8 * r);
+            cv |= (uint64_t)v << (8 * r);
+        }
+        const CutMasks cm = path_cut_masks(p.e);
+        if (cm.h != ch || cm.v != cv) g_cut_row_mismatches++;
+    }
+#endif
     return p;
 }
 
@@ -215,15 +254,16 @@ __device__ __forceinline__ uint32_t lane_above(uint32_t x) { return (uint32_t)__
 
 // What a search reads (filled by the lane that built the board context) and leaves behind, in LDS.
 struct CoopSearch {
-    // in
-    BB cn, cs, ce, cw, notO;  // the Graph of this player
+    // in: the board's walls, the opponent's tile (an obstacle), the jump edges around it, the pawn's tile, the goal row
+    uint64_t hb, vb;
     BB jd[4];
     int32_t ja[4];
-    int32_t start, goal_row;  // goal_row < 0: no search (the group idles)
+    int32_t opp, start, goal_row;  // goal_row < 0: no search (the group idles)
     // out
     int32_t found, jump, len, first_jump, far_jump;
+    uint8_t cut_h[8], cut_v[8];            // path_cut_masks() of the path found, one byte per slot row
     uint16_t sets[5][9];                   // rows of pn, ps, pe, pw, last
-    uint16_t sfx[COOP_MAX_EDGES][10];      // rows of suffix[k]; column 9 takes the stores of lanes outside every search
+    uint16_t sfx[COOP_MAX_EDGES + 1][10];      // rows of suffix[k]; column 9 takes the stores of lanes outside every search
     uint8_t srcpos[84];  // tiles 0..80; byte 83 takes the stores of lanes that have nothing to say
 };
 // All 64 lanes of a wavefront call this together (full exec mask); group g = lane / 9 runs the search
@@ -239,13 +279,15 @@ __device__ __forceinline__ void coop_find_path(CoopSearch* s, int n_searches) {
     bool act = goal_row >= 0;
     uint32_t cn = 0, cs = 0, ce = 0, cw = 0, nO = 0, jsrc = 0, jb0 = 0, jb1 = 0, jb2 = 0, jb3 = 0, jd0 = 0, jd1 = 0, jd2 = 0, jd3 = 0, R = 0;
     if (act) {
-        cn = r == 8 ? 0u : bb_row(S.cn, r);
-        cs = r == 0 ? 0u : bb_row(S.cs, r);
-        ce = bb_row(S.ce, r) & 0xFFu;
-        cw = bb_row(S.cw, r) & 0x1FEu;
-        nO = bb_row(S.notO, r);
+        uint32_t bn, bs, be, bw;  // the simple-move graph straight from the wall bytes: nothing to wait for
+        blocked_rows(S.hb, S.vb, r, bn, bs, be, bw);
+        cn = ~bn & 0x1FFu;
+        cs = ~bs & 0x1FFu;
+        ce = ~be & 0x1FFu;
+        cw = ~bw & 0x1FFu;
         const int a0 = S.ja[0], a1 = S.ja[1], a2 = S.ja[2], a3 = S.ja[3];
-        const int t0 = 9 * r;
+        const int t0 = 9 * r, opp = S.opp;
+        nO = (opp >= t0 && opp < t0 + 9) ? (~(1u << (opp - t0)) & 0x1FFu) : 0x1FFu;
         jb0 = (a0 >= t0 && a0 < t0 + 9) ? (1u << (a0 - t0)) : 0u;
         jb1 = (a1 >= t0 && a1 < t0 + 9) ? (1u << (a1 - t0)) : 0u;
         jb2 = (a2 >= t0 && a2 < t0 + 9) ? (1u << (a2 - t0)) : 0u;
@@ -263,13 +305,14 @@ __device__ __forceinline__ void coop_find_path(CoopSearch* s, int n_searches) {
     bool found = false;
     int L = 0;
 #define QZ_GANY(pred) ((uint32_t)(__ballot(pred) >> gbase) & 0x1FFu)
-    for (int it = 0; it < 81; it++) {
-        const uint32_t aN = lane_below(R & cn) & nO;
-        const uint32_t aS = lane_above(R & cs) & nO;
-        const uint32_t aE = ((R & ce) << 1) & nO;
-        const uint32_t aW = ((R & cw) >> 1) & nO;
+    // one flood layer from the reached set Rin whose newest tiles are fin: came-from bookkeeping, returns the generated set
+    auto layer = [&](const uint32_t Rin, const uint32_t fin) -> uint32_t {
+        const uint32_t aN = lane_below(Rin & cn) & nO;
+        const uint32_t aS = lane_above(Rin & cs) & nO;
+        const uint32_t aE = ((Rin & ce) << 1) & nO;
+        const uint32_t aW = ((Rin & cw) >> 1) & nO;
         uint32_t nx = aN | aS | aE | aW;
-        uint32_t fresh = nx & ~R;
+        uint32_t fresh = nx & ~Rin;
         fN |= aN & fresh;
         fresh &= ~aN;
         fS |= aS & fresh;
@@ -277,27 +320,37 @@ __device__ __forceinline__ void coop_find_path(CoopSearch* s, int n_searches) {
         fE |= aE & fresh;
         fresh &= ~aE;
         fW |= aW & fresh;
-        if (__ballot((front & jsrc) != 0u) != 0ull) {  // wave-uniform, rare: the frontier touches a tile next to the opponent
-            uint32_t seen = R | nx;
+        if (__builtin_expect(__ballot((fin & jsrc) != 0u) != 0ull, 0)) {  // wave-uniform, rare: the frontier touches a tile next to the opponent
+            uint32_t seen = Rin | nx;
             uint32_t nj;
-            if (QZ_GANY((front & jb0) != 0u)) { nj = jd0 & ~seen; fJ0 |= nj; seen |= nj; nx |= jd0; }
-            if (QZ_GANY((front & jb1) != 0u)) { nj = jd1 & ~seen; fJ1 |= nj; seen |= nj; nx |= jd1; }
-            if (QZ_GANY((front & jb2) != 0u)) { nj = jd2 & ~seen; fJ2 |= nj; seen |= nj; nx |= jd2; }
-            if (QZ_GANY((front & jb3) != 0u)) { nj = jd3 & ~seen; fJ3 |= nj; seen |= nj; nx |= jd3; }
+            if (QZ_GANY((fin & jb0) != 0u)) { nj = jd0 & ~seen; fJ0 |= nj; seen |= nj; nx |= jd0; }
+            if (QZ_GANY((fin & jb1) != 0u)) { nj = jd1 & ~seen; fJ1 |= nj; seen |= nj; nx |= jd1; }
+            if (QZ_GANY((fin & jb2) != 0u)) { nj = jd2 & ~seen; fJ2 |= nj; seen |= nj; nx |= jd2; }
+            if (QZ_GANY((fin & jb3) != 0u)) { nj = jd3 & ~seen; fJ3 |= nj; seen |= nj; nx |= jd3; }
         }
-        const uint32_t hit = nx & gl, nf = nx & ~R;
-        const uint32_t gh = QZ_GANY(hit != 0u), gf = QZ_GANY(nf != 0u);
-        // branch-free bookkeeping (a divergent `if` costs more scalar exec-mask work than the layer itself).  A
-        // finished group keeps R and front, and every update above is idempotent on unchanged inputs, so its
-        // lanes may run on: hitrow = hit stays what it was in the layer that found the goal.
-        const bool hitnow = act && gh != 0u, cont = act && gh == 0u && gf != 0u;
-        L += act ? 1 : 0;
+        return nx;
+    };
+    // Two layers per trip: the ballots and the taken branch of a trip cost about as much as a layer.  If the goal is
+    // hit in the first layer of a pair the second one has still run: it only marks tiles that the first did not
+    // reach (every tile gets its came-from mark once, when it is first reached), so the walk back is not affected.
+    for (int it = 0; it < 41; it++) {
+        const uint32_t nx1 = layer(R, front);
+        const uint32_t hit1 = nx1 & gl, nf1 = nx1 & ~R, R1 = R | nx1;
+        const uint32_t nx2 = layer(R1, nf1);
+        const uint32_t hit2 = nx2 & gl, nf2 = nx2 & ~R1;
+        const uint32_t gh1 = QZ_GANY(hit1 != 0u), gh2 = QZ_GANY(hit2 != 0u);
+        // Branch-free bookkeeping (a divergent `if` costs more scalar exec-mask work than the layers).  A finished
+        // group keeps R and front, and everything above is idempotent on unchanged inputs, so its lanes may run on:
+        // hitrow stays what it was in the trip that found the goal.  A group that cannot reach its goal (no legal
+        // position has one) stops generating tiles and idles until the others are done.
+        const bool hitnow = act && (gh1 | gh2) != 0u, cont = act && (gh1 | gh2) == 0u;
+        L += act ? (gh1 != 0u ? 1 : 2) : 0;
         found = found || hitnow;
-        hitrow = hit;
-        R = cont ? (R | nx) : R;
-        front = cont ? nf : front;
+        hitrow = gh1 != 0u ? hit1 : hit2;
+        R = cont ? (R1 | nx2) : R;
+        front = cont ? nf2 : front;
         act = cont;
-        if (__ballot(act) == 0ull) break;
+        if (__ballot(act && (nf1 | nf2) != 0u) == 0ull) break;  // every group is done or stuck
     }
     const bool toolong = found && L > COOP_MAX_EDGES;
     // the lowest hit tile (hits are confined to the goal row, i.e. to one lane of the group)
@@ -310,16 +363,20 @@ __device__ __forceinline__ void coop_find_path(CoopSearch* s, int n_searches) {
     uint32_t acc = 0, pn = 0, ps = 0, pe = 0, pw = 0;
     int first_jump = -1, far_jump = -1;
     bool jump = false;
-    for (int k = 0; k < COOP_MAX_EDGES; k++) {
-        const uint32_t sN = lane_above(cur & fN);  // reached by a north move: it came from the row below
-        const uint32_t sS = lane_below(cur & fS);
-        const uint32_t sE = (cur & fE) >> 1;
-        const uint32_t sW = (cur & fW) << 1;
+    // one step of the walk back: from the tile `c` to the tile it was discovered from (0 everywhere once a group is
+    // back at its start tile: nothing discovered that one).  No branches but the rare jump test.  A group that is
+    // done ORs its start tile into acc (harmless: `last` is only used together with the start tile) and writes
+    // entries k >= len of sfx (never read); lanes without the new tile aim their srcpos byte at the padding.
+    auto step = [&](const uint32_t c, const int k) -> uint32_t {
+        const uint32_t sN = lane_above(c & fN);  // reached by a north move: it came from the row below
+        const uint32_t sS = lane_below(c & fS);
+        const uint32_t sE = (c & fE) >> 1;
+        const uint32_t sW = (c & fW) << 1;
         uint32_t nc = sN | sS | sE | sW;
-        if (__ballot((cur & fJany) != 0u) != 0ull) {  // wave-uniform, rare
+        if (__builtin_expect(__ballot((c & fJany) != 0u) != 0ull, 0)) {  // wave-uniform, rare
             bool via = false;
-            const uint32_t v0 = QZ_GANY((cur & fJ0) != 0u), v1 = QZ_GANY((cur & fJ1) != 0u), v2 = QZ_GANY((cur & fJ2) != 0u),
-                           v3 = QZ_GANY((cur & fJ3) != 0u);
+            const uint32_t v0 = QZ_GANY((c & fJ0) != 0u), v1 = QZ_GANY((c & fJ1) != 0u), v2 = QZ_GANY((c & fJ2) != 0u),
+                           v3 = QZ_GANY((c & fJ3) != 0u);
             if (v0) { nc |= jb0; via = true; }
             else if (v1) { nc |= jb1; via = true; }
             else if (v2) { nc |= jb2; via = true; }
@@ -330,26 +387,38 @@ __device__ __forceinline__ void coop_find_path(CoopSearch* s, int n_searches) {
                 far_jump = k;
             }
         }
-        if (__ballot(nc != 0u) == 0ull) break;  // every group is back at its start tile
-        // No branches below.  A group that is back at its start tile has nc == 0 in all of its lanes: it ORs the
-        // start tile into acc (harmless: `last` is only used together with the start tile) and writes entries
-        // k >= len of sfx (never read); lanes without the new tile aim their srcpos byte at the padding.
-        acc |= cur;
+        acc |= c;
         S.sfx[k][mine ? r : 9] = (uint16_t)acc;
         S.srcpos[nc != 0u ? 9 * r + (__ffs((int)nc) - 1) : 83] = (uint8_t)k;
         pn |= sN;
         ps |= sS;
         pe |= sE;
         pw |= sW;
-        cur = nc;
+        return nc;
+    };
+    for (int k = 0; k < COOP_MAX_EDGES; k += 2) {  // two steps per trip
+        const uint32_t mid = step(cur, k);
+        cur = step(mid, k + 1);
+        if (__ballot(cur != 0u) == 0ull) break;  // every group is back at its start tile
     }
 #undef QZ_GANY
+    // path_cut_masks() in rows: slot (r, c) cuts the path if its wall removes one of the path's edges
+    pn = toolong ? 0x1FFu : pn;
+    ps = toolong ? 0x1FFu : ps;
+    pe = toolong ? 0x1FFu : pe;
+    pw = toolong ? 0x1FFu : pw;
+    const uint32_t ps_up = lane_above(ps), pe_up = lane_above(pe), pw_up = lane_above(pw);  // row r + 1 (lane 8 is not used)
+    uint32_t cut_h, cut_v;
+    cut_row(r, pn, ps_up, pe, pe_up, pw, pw_up, cut_h, cut_v);
     if (mine && goal_row >= 0) {
-        const uint32_t all = 0x1FFu;
-        S.sets[0][r] = (uint16_t)(toolong ? all : pn);
-        S.sets[1][r] = (uint16_t)(toolong ? all : ps);
-        S.sets[2][r] = (uint16_t)(toolong ? all : pe);
-        S.sets[3][r] = (uint16_t)(toolong ? all : pw);
+        if (r < 8) {
+            S.cut_h[r] = (uint8_t)cut_h;
+            S.cut_v[r] = (uint8_t)cut_v;
+        }
+        S.sets[0][r] = (uint16_t)pn;
+        S.sets[1][r] = (uint16_t)ps;
+        S.sets[2][r] = (uint16_t)pe;
+        S.sets[3][r] = (uint16_t)pw;
         S.sets[4][r] = (uint16_t)(toolong ? 0u : acc);
         if (r == 0) {
             S.found = found ? 1 : 0;

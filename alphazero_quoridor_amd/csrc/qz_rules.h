@@ -788,50 +788,37 @@ QZ_HD JumpPlan make_jump_plan(uint64_t hb, uint64_t vb, int O) {
 }
 // jump_dests() for the current walls plus an optional candidate wall (cix < 0: none).  A
 // candidate only changes corners that refer to its own (empty) slot.
+QZ_HD BB bb_if(bool c, BB x) {  // c ? x : empty, without a branch
+    const uint32_t m = c ? 0xFFFFFFFFu : 0u;
+    return BB{x.w0 & m, x.w1 & m, x.w2 & m};
+}
+// Branch-free: this runs once per flood item, on divergent lanes -- four `if` blocks cost more in exec-mask
+// bookkeeping than the selects they save (measured: ~250 -> ~170 instructions per call).
 QZ_HD Jumps plan_jumps(const JumpPlan& p, int cix, bool horizontal) {
     const int H = 1, V = -1;
     int cv[12];
     int cval = horizontal ? 1 : -1;
     for (int i = 0; i < 12; i++) cv[i] = (cix >= 0 && p.ref[i] == cix) ? cval : p.val[i];
     const int O = p.O;
+    const BB dN = dest_bit(O + 9), dS = dest_bit(O - 9), dE = dest_bit(O + 1), dW = dest_bit(O - 1);
+    const int onw = cv[0], one = cv[1], ose = cv[2], osw = cv[3];
     Jumps j;
-    for (int k = 0; k < 4; k++) {
-        j.a[k] = -1;
-        j.d[k] = bb_zero();
-    }
-    int onw = cv[0], one = cv[1], ose = cv[2], osw = cv[3];
-    if (O - 9 >= 0 && cv[5] != H && cv[4] != H) {  // :301-314  (A0: xnw = cv[4], xne = cv[5])
-        j.a[0] = O - 9;
-        BB d = bb_zero();
-        if (onw != H && one != H) d = bb_or(d, dest_bit(O + 9));
-        if (one != V && cv[5] != V) d = bb_or(d, dest_bit(O + 1));
-        if (onw != V && cv[4] != V) d = bb_or(d, dest_bit(O - 1));
-        j.d[0] = d;
-    }
-    if (O + 9 <= 80 && cv[6] != H && cv[7] != H) {  // :317-327  (A1: xse = cv[6], xsw = cv[7])
-        j.a[1] = O + 9;
-        BB d = bb_zero();
-        if (osw != H && ose != H) d = bb_or(d, dest_bit(O - 9));
-        if (ose != V && cv[6] != V) d = bb_or(d, dest_bit(O + 1));
-        if (osw != V && cv[7] != V) d = bb_or(d, dest_bit(O - 1));
-        j.d[1] = d;
-    }
-    if (O - 1 >= 0 && cv[8] != V && cv[9] != V) {  // :330-339  (A2: xse = cv[8], xne = cv[9])
-        j.a[2] = O - 1;
-        BB d = bb_zero();
-        if (ose != V && one != V) d = bb_or(d, dest_bit(O + 1));
-        if (one != H) d = bb_or(d, dest_bit(O + 9));
-        if (ose != H) d = bb_or(d, dest_bit(O - 9));
-        j.d[2] = d;
-    }
-    if (O + 1 <= 80 && cv[10] != V && cv[11] != V) {  // :342-351  (A3: xsw = cv[10], xnw = cv[11])
-        j.a[3] = O + 1;
-        BB d = bb_zero();
-        if (onw != V && osw != V) d = bb_or(d, dest_bit(O - 1));
-        if (onw != H) d = bb_or(d, dest_bit(O + 9));
-        if (osw != H) d = bb_or(d, dest_bit(O - 9));
-        j.d[3] = d;
-    }
+    // :301-314  (A0 = O-9: xnw = cv[4], xne = cv[5])
+    const bool ok0 = O - 9 >= 0 && cv[5] != H && cv[4] != H;
+    j.a[0] = ok0 ? O - 9 : -1;
+    j.d[0] = bb_if(ok0, bb_or(bb_or(bb_if(onw != H && one != H, dN), bb_if(one != V && cv[5] != V, dE)), bb_if(onw != V && cv[4] != V, dW)));
+    // :317-327  (A1 = O+9: xse = cv[6], xsw = cv[7])
+    const bool ok1 = O + 9 <= 80 && cv[6] != H && cv[7] != H;
+    j.a[1] = ok1 ? O + 9 : -1;
+    j.d[1] = bb_if(ok1, bb_or(bb_or(bb_if(osw != H && ose != H, dS), bb_if(ose != V && cv[6] != V, dE)), bb_if(osw != V && cv[7] != V, dW)));
+    // :330-339  (A2 = O-1: xse = cv[8], xne = cv[9])
+    const bool ok2 = O - 1 >= 0 && cv[8] != V && cv[9] != V;
+    j.a[2] = ok2 ? O - 1 : -1;
+    j.d[2] = bb_if(ok2, bb_or(bb_or(bb_if(ose != V && one != V, dE), bb_if(one != H, dN)), bb_if(ose != H, dS)));
+    // :342-351  (A3 = O+1: xsw = cv[10], xnw = cv[11])
+    const bool ok3 = O + 1 <= 80 && cv[10] != V && cv[11] != V;
+    j.a[3] = ok3 ? O + 1 : -1;
+    j.d[3] = bb_if(ok3, bb_or(bb_or(bb_if(onw != V && osw != V, dW), bb_if(onw != H, dN)), bb_if(osw != H, dS)));
     return j;
 }
 QZ_HD Graph make_graph_plan(Blk blocked, const JumpPlan& plan, int cix, bool horizontal) {

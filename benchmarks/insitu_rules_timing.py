@@ -10,7 +10,7 @@ for _ in range(300):
     eng.run_playouts(ev, 4); eng.finish_move(); eng.harvest()
 import ctypes as C
 L = _cabi.load()
-for variant in (0, 5, 2, 0, 5):  # k_wave_rules: default (1 board per wavefront, base paths on nine lanes per player), 5 = one search per lane, 2 = two boards per wavefront
+for variant in (0, 6, 5, 0, 6):  # k_wave_rules: default (1 board per wavefront, base paths on nine lanes per player), 6 = the same with streaming stores, 5 = one search per lane
     L.qz_engine_set_rules_opts(eng.h, C.byref(_cabi.qz_rules_opts(variant, 0, 0, 0)))
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(200)]
     for i in range(200): eng.playout_step(ev, events=evs[i], write_planes=True)  # like bench.py: the full op, planes included

@@ -124,6 +124,24 @@ int hc_ordered(const uint32_t* mask5, int* out) {
 }
 }
 
+// blocked_rows() (qz_path_rows.h) against the three-word blocked sets: number of mismatching (board, row, set) triples
+extern "C" long hc_blocked_rows_mismatches(const uint64_t* hb, const uint64_t* vb, int n) {
+    long bad = 0;
+    for (int i = 0; i < n; i++) {
+        Blk base = blk_or(blocked_from(spread8(hb[i]), spread8(vb[i])), blocked_borders());
+        for (int r = 0; r < 9; r++) {
+            uint32_t bn, bs, be, bw;
+            blocked_rows(hb[i], vb[i], r, bn, bs, be, bw);
+            bad += bn != bb_row(base.n, r);
+            bad += bs != bb_row(base.s, r);
+            bad += be != bb_row(base.e, r);
+            bad += bw != bb_row(base.w, r);
+        }
+    }
+    return bad;
+}
+
+extern "C" long hc_cut_row_mismatches() { return g_cut_row_mismatches; }
 static long g_p2_mismatch = 0;
 extern "C" long hc_p2_mismatches() { return g_p2_mismatch; }
 // ---- the pooled kernel's phases (qz_movegen_pool.h), executed lane by lane for tiles of nb boards

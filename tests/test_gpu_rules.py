@@ -147,7 +147,7 @@ def _first_kernel(db, want_mask=True, want_planes=True):
     return mask, planes
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 8, 12, 16, 24, 32])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 8, 12, 16, 24, 32])
 def test_every_movegen_kernel_variant_matches_the_oracle(gpu_device, golden_dir, variant):
     """The library picks k_wave_rules (3) for small batches and the pooled pipeline (tile sizes
     8..32) for large ones; 1 is the first kernel of round 1 (test-only library).  Force each on

@@ -180,6 +180,10 @@ def test_bitboard_movegen_equals_oracle(hostcheck, positions):
         hostcheck.hc_set_finder(0)
         hostcheck.hc_set_detour(0)
         assert np.array_equal(m, omask), "rows finder, detour mode %d" % mode
+    hostcheck.hc_cut_row_mismatches.restype = C.c_long
+    assert hostcheck.hc_cut_row_mismatches() == 0  # cut masks in rows == path_cut_masks() on every path the rows finder found
+    hostcheck.hc_blocked_rows_mismatches.restype = C.c_long
+    assert hostcheck.hc_blocked_rows_mismatches(hb.ctypes.data_as(C.c_void_p), vb.ctypes.data_as(C.c_void_p), n) == 0
     # ordered list from the mask through order_index (the expand kernel's slot rule)
     out = (C.c_int * 140)()
     for i in range(0, n, 53):
