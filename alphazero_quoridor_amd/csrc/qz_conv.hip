@@ -273,6 +273,7 @@ struct HeadArgs {
     const float* beta6;   // [6]
     float inv_scale6;
     float* feat;          // [n][486] out; nullptr = no head stage
+    int role_shift;       // head stage: workgroups with bit `role_shift` of their index set give the two-tile share to wave 1 (>= 31: never)
 };
 
 // The input stage (optional): the first layer conv1(state(board)) + bn1 per leaf + ReLU computed from the packed
@@ -578,9 +579,12 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (H.feat) {
         // ---- head stage.  M tiles: wave 0 takes rows 0..63 (two tiles), wave 1 rows 64..80 (one); lane (r, h)
         // ends up with head channel r (r < 6 are real) of its tiles' rows
-        const bool two = __builtin_amdgcn_readfirstlane(nt) == 0;
-        const int rb0 = nt ? rbase[2] : rbase[0], rb1 = rbase[1];
-        const uint32_t vm0 = nt ? vmask[2] : vmask[0], vm1 = vmask[1];
+        // (the wave with two tiles has twice the matrix work: alternating that role between the waves from workgroup to
+        // workgroup spreads it over the SIMDs of a CU)
+        const int role = nt ^ (int)((H.role_shift < 31) ? ((blockIdx.x >> H.role_shift) & 1u) : 0u);
+        const bool two = __builtin_amdgcn_readfirstlane(role) == 0;
+        const int rb0 = role ? rbase[2] : rbase[0], rb1 = rbase[1];
+        const uint32_t vm0 = role ? vmask[2] : vmask[0], vm1 = vmask[1];
         constexpr int P6 = 36 * 32 * 2;
         const half8* wb6 = reinterpret_cast<const half8*>(H.w6) + (size_t)r * 2 + h;
         floatx16 ha0, ha1;
@@ -624,7 +628,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         // per-leaf statistics of head channel r over the 81 rows: this wave's rows, the lane halves by shuffle,
         // the two waves through LDS
-        const int row0 = (nt ? 64 : 0) + 4 * h;
+        const int row0 = (role ? 64 : 0) + 4 * h;
         const float is6 = H.inv_scale6;
         float s0 = 0.f;
 #pragma unroll
@@ -636,7 +640,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (two) s0 += ha1[i];  // rows 32..63
         }
         s0 += __shfl_xor(s0, 32, 64);
-        if (h == 0) sm.red6[0][nt][r] = s0;
+        if (h == 0) sm.red6[0][role][r] = s0;
         __syncthreads();  // also: both waves are done reading the images
         const float mean = (sm.red6[0][0][r] + sm.red6[0][1][r]) * (1.0f / 81.0f);
         float q0 = 0.f;
@@ -648,7 +652,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (two) q0 += d1 * d1;
         }
         q0 += __shfl_xor(q0, 32, 64);
-        if (h == 0) sm.red6[1][nt][r] = q0;
+        if (h == 0) sm.red6[1][role][r] = q0;
         __syncthreads();
         float* fb = reinterpret_cast<float*>(sm.a_hi);  // 486 floats; the images are dead
         if (r < 6) {
@@ -725,6 +729,7 @@ hipError_t trunk(float* x, float* tmp, long long n, int n_blocks, const void* co
         H.beta6 = beta6;
         H.inv_scale6 = inv_scale6;
         H.feat = feat;
+        H.role_shift = 0;  // odd workgroups swap the roles: 787 -> 779 us for 4,096 leaves (shifts 1..8 and none measured: 783..791)
         InputArgs I = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         if (in) I = InputArgs{in->hb, in->vb, in->meta, in->terminal, in->hot9, in->base0, in->wd, in->gamma0, in->beta0};
         if (in) hipLaunchKernelGGL(k_trunk<true>, dim3((unsigned)n), dim3(128), 0, s, x, feat ? nullptr : x, A, nl, eps, H, I);

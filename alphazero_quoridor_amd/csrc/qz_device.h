@@ -40,7 +40,9 @@
 #define QZ_PLANES_N 2106
 #define QZ_NONE 0xFFFFFFFFu
 #define QZ_NO_MOVE_U8 255
+#ifndef QZ_PATH_RECS
 #define QZ_PATH_RECS 16    // descent records per board (k_select), a power of two
+#endif
 #define QZ_PATH_CAP 2048   // levels of a descent that are recorded (late-game lines are forced and hundreds of plies deep)
 
 #define QZ_PAGE_SHIFT 11
@@ -84,7 +86,8 @@ static_assert(sizeof(Edge) == 32, "edge record must be 32 bytes");
 
 // Which formulation of the rules op (actions() + state()) a call uses: per engine / per call,
 // never process-global.  variant: 0 = by batch size (k_wave_rules below 8,192 boards, pooled
-// pipeline above), 2 | 3 | 4 = k_wave_rules with 2 | 1 | 4 boards per wavefront, 8 | 12 | 16 |
+// pipeline above), 2 | 3 | 4 = k_wave_rules with 2 | 1 | 4 boards per wavefront, 5 | 6 = 3 with one
+// base-path search per lane | with ordinary stores for the planes (A/B partners of 3), 8 | 12 | 16 |
 // 24 | 32 = pooled pipeline with that many boards per mask workgroup.
 struct RulesOpts {
     int variant = 0;

@@ -429,15 +429,16 @@ __device__ __forceinline__ void head_fc_tail(const float* __restrict__ s_f, Head
         float a1[HB];
 #pragma unroll
         for (int s = 0; s < HB; s++) a1[s] = 0.f;
-        // 12 coalesced weight loads in flight per trip (the loop is latency-bound, not issue-bound)
-        for (int i = 0; i < 4 * PL; i += 12) {
-            float w[12];
+        // 36 coalesced weight loads in flight per trip (the loop is latency-bound, not issue-bound: every trip waits one
+        // L2 round trip; 12 per trip made k_head_fc 25 us for 4,096 leaves)
+        for (int i = 0; i < 4 * PL; i += 36) {
+            float w[36];
 #pragma unroll
-            for (int k = 0; k < 12; k++) w[k] = w1t[(i + k) * 128 + j];
+            for (int k = 0; k < 36; k++) w[k] = w1t[(i + k) * 128 + j];
 #pragma unroll
             for (int s = 0; s < HB; s++) {
 #pragma unroll
-                for (int k4 = 0; k4 < 3; k4++) {
+                for (int k4 = 0; k4 < 9; k4++) {
                     const float4 f = *reinterpret_cast<const float4*>(&s_f[s * FS + i + 4 * k4]);
                     a1[s] = __builtin_fmaf(w[4 * k4 + 0], f.x, a1[s]);
                     a1[s] = __builtin_fmaf(w[4 * k4 + 1], f.y, a1[s]);
@@ -455,10 +456,10 @@ __device__ __forceinline__ void head_fc_tail(const float* __restrict__ s_f, Head
         float a3[HB], a3b[HB], a3c[HB];
 #pragma unroll
         for (int s = 0; s < HB; s++) a3[s] = a3b[s] = a3c[s] = 0.f;
-        for (int i = 0; i < 2 * PL; i += 6) {  // 162 = 27 * 6: up to 18 loads in flight per trip
-            float wa[6], wb[6], wc[6];
+        for (int i = 0; i < 2 * PL; i += 18) {  // 162 = 9 * 18: up to 54 loads in flight per trip
+            float wa[18], wb[18], wc[18];
 #pragma unroll
-            for (int k = 0; k < 6; k++) {
+            for (int k = 0; k < 18; k++) {
                 wa[k] = w3t[(i + k) * 140 + j];
                 wb[k] = w3t[(i + k) * 140 + j1];
                 wc[k] = three ? w3t[(i + k) * 140 + j2] : 0.f;
@@ -466,7 +467,7 @@ __device__ __forceinline__ void head_fc_tail(const float* __restrict__ s_f, Head
 #pragma unroll
             for (int s = 0; s < HB; s++) {
 #pragma unroll
-                for (int k2 = 0; k2 < 3; k2++) {
+                for (int k2 = 0; k2 < 9; k2++) {
                     const float2 f = *reinterpret_cast<const float2*>(&s_f[s * FS + 4 * PL + i + 2 * k2]);
                     a3[s] = __builtin_fmaf(wa[2 * k2], f.x, a3[s]);
                     a3[s] = __builtin_fmaf(wa[2 * k2 + 1], f.y, a3[s]);

@@ -378,6 +378,10 @@ def main():
     if args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and "RANK" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
+    if os.environ.get("QZ_BENCH_LIB"):  # A/B of a differently built library on the same box; never set by the driver
+        from alphazero_quoridor_amd import _cabi
+
+        _cabi.LIB_PATH = os.environ["QZ_BENCH_LIB"]
     from alphazero_quoridor_amd import dist as qdist
     from alphazero_quoridor_amd.engine import BoardGroups
     from alphazero_quoridor_amd.policy_value_net import PolicyValueNet

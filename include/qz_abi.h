@@ -74,8 +74,11 @@ int qz_movegen_encode(const qz_boards* boards, int n, uint32_t* mask5 /*[dev]*/,
 /* Which formulation of the rules op a call / an engine uses (tuning and A/B runs; all zero =
  * the defaults).  Per call and per engine: the library keeps no mutable global state.
  *   variant        0 = pick by batch size (k_wave_rules below 8,192 boards, pooled pipeline from
- *                  there on), 2 | 3 | 4 = k_wave_rules with 2 | 1 | 4 boards per wavefront,
- *                  8 | 12 | 16 | 24 | 32 = pooled pipeline with that many boards per mask workgroup
+ *                  there on), 2 | 3 | 4 = k_wave_rules with 2 | 1 | 4 boards per wavefront (3 = what 0
+ *                  picks for small batches: base paths searched on nine lanes per player, planes as
+ *                  streaming stores), 5 = 3 with one base-path search per lane, 6 = 3 with ordinary
+ *                  stores (parity / A-B partners), 8 | 12 | 16 | 24 | 32 = pooled pipeline with that
+ *                  many boards per mask workgroup
  *   detour_pooled  group-detour mode of the pooled pipeline: 0 = default (one group), else 1 + mode
  *   detour_wave    ... of k_wave_rules: 0 = default (off), else 1 + mode (mode 0 | 1 | 2)
  *   enc_split_pct  0 = default (70): percent of the encoder groups beside the path groups */
