@@ -206,22 +206,46 @@ __global__ __launch_bounds__(256) void k_wave_rules(const uint64_t* __restrict__
             // graphs, lanes 0..8 / 9..17 search (flood + walk back, a row of the board per lane), all
             // lanes turn the rows into three-word sets, lanes 0 / 1 derive the need masks
             const Board bd = unpack(hb[bw], vb[bw], meta[bw]);  // not terminal, mover has walls (short cut above)
-            K1Pre k1;
-            k1.walls = false;
             QZ_RS_MARK(1)
+            // board context on parallel lanes: the 2 x 12 corner values of the jump plans (lane = corner; one table
+            // look-up each, all in flight together), the record's scalar fields on lane 0 in the meantime
+            int c_which = 0;
+            bool c_ok = false;
+            uint32_t c_word = 0u;
+            const int c_p = lane >= 12 ? 1 : 0, c_i = lane - 12 * c_p;
+            if (lane < 24) {
+                const int O = side_opp(bd, c_p + 1);
+                const int grp = (int)((0x443322110000ull >> (4 * c_i)) & 15ull);  // jump_plan_corner(), its load first
+                c_which = (int)((0x36E4E4u >> (2 * c_i)) & 3u);
+                const int tile = O + (grp == 0 ? 0 : (grp == 1 ? -9 : (grp == 2 ? 9 : (grp == 3 ? -1 : 1))));
+                c_ok = tile >= 0 && tile <= 80;
+                c_word = corner_ref4(c_ok ? tile : 0);
+            }
+            if (lane == 0) {
+                PoolBoard& out = ws.ctx[0];
+                out.b = bd;
+                out.flags = 1u;  // the mover has walls, the board is live (short cut above)
+                for (int i = 0; i < 4; i++) out.blocked[i] = 0u;
+                out.sh = static_ok_h(bd.hb, bd.vb);
+                out.sv = static_ok_v(bd.hb, bd.vb);
+                const int loc = bd.cur == 1 ? bd.p1 : bd.p2, opp = bd.cur == 1 ? bd.p2 : bd.p1;
+                out.pawn = pawn_actions_tab(bd.hb, bd.vb, loc, opp, bd.cur);
+            }
+            if (lane < 24) {
+                const int ref = c_ok ? (int)((c_word >> (8 * c_which)) & 0xFFu) : 64;
+                JumpPlan& P = ws.ctx[0].plan[c_p];
+                P.ref[c_i] = (int8_t)ref;
+                P.val[c_i] = (int8_t)ref_value_fast(bd.hb, bd.vb, ref);
+                if (c_i == 0) P.O = side_opp(bd, c_p + 1);
+            }
             if (lane < 2) {
-                Graph g;
-                k1 = pool_k1_pre(bd, false, true, lane + 1, ws.ctx[0], g);
                 CoopSearch& S = ws.cs[lane];
                 S.hb = bd.hb;
                 S.vb = bd.vb;
+                S.plan = &ws.ctx[0].plan[lane];
                 S.opp = side_opp(bd, lane + 1);
-                for (int q = 0; q < 4; q++) {
-                    S.jd[q] = g.j.d[q];
-                    S.ja[q] = g.j.a[q];
-                }
                 S.start = side_start(bd, lane + 1);
-                S.goal_row = k1.walls ? (lane == 0 ? 8 : 0) : -1;
+                S.goal_row = lane == 0 ? 8 : 0;
             }
             wave_sync();
             QZ_RS_MARK(2)
@@ -229,9 +253,14 @@ __global__ __launch_bounds__(256) void k_wave_rules(const uint64_t* __restrict__
             wave_sync();
             QZ_RS_MARK(3)
             const int len0 = ws.cs[0].len, len1 = ws.cs[1].len;  // wave-uniform
-            for (int t = lane; t < 30; t += 64) {  // 2 searches x 5 sets x 3 words
-                const int sidx = t / 15, rem = t - 15 * sidx, set = rem / 3, w = rem - 3 * set;
-                reinterpret_cast<uint32_t*>(&ws.conv[sidx][set])[w] = rows_word(ws.cs[sidx].sets[set], w);
+            for (int t = lane; t < 42; t += 64) {  // 2 searches x 5 sets x 3 words, then the four blocked sets
+                if (t < 30) {
+                    const int sidx = t / 15, rem = t - 15 * sidx, set = rem / 3, w = rem - 3 * set;
+                    reinterpret_cast<uint32_t*>(&ws.conv[sidx][set])[w] = rows_word(ws.cs[sidx].sets[set], w);
+                } else {
+                    const int rem = t - 30, set = rem / 3, w = rem - 3 * set;
+                    reinterpret_cast<uint32_t*>(&ws.ctx[0].base)[rem] = rows_word(ws.cs[0].sets[5 + set], w);
+                }
             }
             const int n0 = (len0 > 0 ? len0 : 0) * 3, n1 = (len1 > 0 ? len1 : 0) * 3;
             for (int t = lane; t < n0 + n1; t += 64) {
@@ -244,6 +273,9 @@ __global__ __launch_bounds__(256) void k_wave_rules(const uint64_t* __restrict__
             QZ_RS_SET(11, len1)
             if (lane < 2) {
                 const CoopSearch& S = ws.cs[lane];
+                K1Pre k1;
+                k1.walls = true;
+                k1.base = ws.ctx[0].base;  // (only the group detours read it)
                 OrderedPath op;
                 op.e.pn = ws.conv[lane][0];
                 op.e.ps = ws.conv[lane][1];

@@ -64,6 +64,39 @@ QZ_HD void cut_row(int r, uint32_t pn, uint32_t ps_up, uint32_t pe, uint32_t pe_
     const uint32_t e0 = pe & 0xFFu, e1 = (pe >> 1) & 0xFFu, e9 = pe_up & 0xFFu;
     v = (r == 0 ? (e9 | (e1 & 0x7Fu) | (e0 & 1u)) : (e0 | e9)) | ((pw >> 1) & 0xFFu) | ((pw_up >> 1) & 0xFFu);
 }
+// make_jump_plan() one corner at a time (i = 0..11): what lane i of a plan's twelve lanes computes in k_wave_rules
+QZ_HD void jump_plan_corner(uint64_t hb, uint64_t vb, int O, int i, int& ref, int& val) {
+    const int grp = (int)((0x443322110000ull >> (4 * i)) & 15ull);  // {0,0,0,0,1,1,2,2,3,3,4,4}
+    const int which = (int)((0x36E4E4u >> (2 * i)) & 3u);             // {0,1,2,3,0,1,2,3,2,1,3,0}
+    const int tile = O + (grp == 0 ? 0 : (grp == 1 ? -9 : (grp == 2 ? 9 : (grp == 3 ? -1 : 1))));
+    const bool ok = tile >= 0 && tile <= 80;
+    const uint32_t w = corner_ref4(ok ? tile : 0);
+    ref = ok ? (int)((w >> (8 * which)) & 0xFFu) : 64;
+    val = ref_value_fast(hb, vb, ref);
+}
+// plan_jumps(plan, no candidate) in rows: row r of the four jump sources (jb) and of their destination sets (jd)
+QZ_HD void plan_jump_rows(const int8_t* cv, int O, int r, uint32_t jb[4], uint32_t jd[4]) {
+    const int H = 1, V = -1;
+    const int t0 = 9 * r;
+    const int tn = O + 9, ts = O - 9, te = O + 1, tw = O - 1;
+    const uint32_t rN = (tn <= 80 && tn >= t0 && tn < t0 + 9) ? (1u << (tn - t0)) : 0u;
+    const uint32_t rS = (ts >= 0 && ts >= t0 && ts < t0 + 9) ? (1u << (ts - t0)) : 0u;
+    const uint32_t rE = (te <= 80 && te >= t0 && te < t0 + 9) ? (1u << (te - t0)) : 0u;
+    const uint32_t rW = (tw >= 0 && tw >= t0 && tw < t0 + 9) ? (1u << (tw - t0)) : 0u;
+    const int onw = cv[0], one = cv[1], ose = cv[2], osw = cv[3];
+    const bool ok0 = O - 9 >= 0 && cv[5] != H && cv[4] != H;
+    const bool ok1 = O + 9 <= 80 && cv[6] != H && cv[7] != H;
+    const bool ok2 = O - 1 >= 0 && cv[8] != V && cv[9] != V;
+    const bool ok3 = O + 1 <= 80 && cv[10] != V && cv[11] != V;
+    jb[0] = ok0 ? rS : 0u;
+    jb[1] = ok1 ? rN : 0u;
+    jb[2] = ok2 ? rW : 0u;
+    jb[3] = ok3 ? rE : 0u;
+    jd[0] = ok0 ? (((onw != H && one != H) ? rN : 0u) | ((one != V && cv[5] != V) ? rE : 0u) | ((onw != V && cv[4] != V) ? rW : 0u)) : 0u;
+    jd[1] = ok1 ? (((osw != H && ose != H) ? rS : 0u) | ((ose != V && cv[6] != V) ? rE : 0u) | ((osw != V && cv[7] != V) ? rW : 0u)) : 0u;
+    jd[2] = ok2 ? (((ose != V && one != V) ? rE : 0u) | ((one != H) ? rN : 0u) | ((ose != H) ? rS : 0u)) : 0u;
+    jd[3] = ok3 ? (((onw != V && osw != V) ? rW : 0u) | ((onw != H) ? rN : 0u) | ((osw != H) ? rS : 0u)) : 0u;
+}
 #if !defined(__HIPCC__)
 static long g_cut_row_mismatches = 0;  // host check: cut_row() against path_cut_masks() on every path found
 #endif
@@ -254,15 +287,15 @@ __device__ __forceinline__ uint32_t lane_above(uint32_t x) { return (uint32_t)__
 
 // What a search reads (filled by the lane that built the board context) and leaves behind, in LDS.
 struct CoopSearch {
-    // in: the board's walls, the opponent's tile (an obstacle), the jump edges around it, the pawn's tile, the goal row
+    // in: the board's walls, the opponent's tile (an obstacle), the corner values around it (make_jump_plan: the jump
+    // edges follow from them, plan_jump_rows), the pawn's tile, the goal row
     uint64_t hb, vb;
-    BB jd[4];
-    int32_t ja[4];
+    const JumpPlan* plan;
     int32_t opp, start, goal_row;  // goal_row < 0: no search (the group idles)
     // out
     int32_t found, jump, len, first_jump, far_jump;
     uint8_t cut_h[8], cut_v[8];            // path_cut_masks() of the path found, one byte per slot row
-    uint16_t sets[5][9];                   // rows of pn, ps, pe, pw, last
+    uint16_t sets[9][9];                   // rows of pn, ps, pe, pw, last; search 0 also leaves the board's blocked sets n, s, e, w
     uint16_t sfx[COOP_MAX_EDGES + 1][10];      // rows of suffix[k]; column 9 takes the stores of lanes outside every search
     uint8_t srcpos[84];  // tiles 0..80; byte 83 takes the stores of lanes that have nothing to say
 };
@@ -285,17 +318,27 @@ __device__ __forceinline__ void coop_find_path(CoopSearch* s, int n_searches) {
         cs = ~bs & 0x1FFu;
         ce = ~be & 0x1FFu;
         cw = ~bw & 0x1FFu;
-        const int a0 = S.ja[0], a1 = S.ja[1], a2 = S.ja[2], a3 = S.ja[3];
+        if (grp == 0) {  // for the board record (the flood phase works on three-word sets)
+            S.sets[5][r] = (uint16_t)bn;
+            S.sets[6][r] = (uint16_t)bs;
+            S.sets[7][r] = (uint16_t)be;
+            S.sets[8][r] = (uint16_t)bw;
+        }
         const int t0 = 9 * r, opp = S.opp;
         nO = (opp >= t0 && opp < t0 + 9) ? (~(1u << (opp - t0)) & 0x1FFu) : 0x1FFu;
-        jb0 = (a0 >= t0 && a0 < t0 + 9) ? (1u << (a0 - t0)) : 0u;
-        jb1 = (a1 >= t0 && a1 < t0 + 9) ? (1u << (a1 - t0)) : 0u;
-        jb2 = (a2 >= t0 && a2 < t0 + 9) ? (1u << (a2 - t0)) : 0u;
-        jb3 = (a3 >= t0 && a3 < t0 + 9) ? (1u << (a3 - t0)) : 0u;
-        jd0 = a0 >= 0 ? bb_row(S.jd[0], r) : 0u;
-        jd1 = a1 >= 0 ? bb_row(S.jd[1], r) : 0u;
-        jd2 = a2 >= 0 ? bb_row(S.jd[2], r) : 0u;
-        jd3 = a3 >= 0 ? bb_row(S.jd[3], r) : 0u;
+        const JumpPlan& P = *S.plan;
+        int8_t cv[12];
+        for (int k = 0; k < 12; k++) cv[k] = P.val[k];
+        uint32_t jb[4], jd[4];
+        plan_jump_rows(cv, P.O, r, jb, jd);
+        jb0 = jb[0];
+        jb1 = jb[1];
+        jb2 = jb[2];
+        jb3 = jb[3];
+        jd0 = jd[0];
+        jd1 = jd[1];
+        jd2 = jd[2];
+        jd3 = jd[3];
         jsrc = jb0 | jb1 | jb2 | jb3;
         const int st = S.start;
         R = (st >= t0 && st < t0 + 9) ? (1u << (st - t0)) : 0u;

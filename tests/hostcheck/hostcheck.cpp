@@ -141,6 +141,39 @@ extern "C" long hc_blocked_rows_mismatches(const uint64_t* hb, const uint64_t* v
     return bad;
 }
 
+// jump_plan_corner() / plan_jump_rows() (qz_path_rows.h: what k_wave_rules computes on parallel lanes) against
+// make_jump_plan() / plan_jumps(): number of mismatches over both players of n boards
+extern "C" long hc_plan_rows_mismatches(const uint64_t* hb, const uint64_t* vb, const uint64_t* meta, int n) {
+    long bad = 0;
+    for (int i = 0; i < n; i++) {
+        Board b = unpack(hb[i], vb[i], meta[i]);
+        if (winner_of(b) != 0) continue;
+        for (int p = 1; p <= 2; p++) {
+            const int O = side_opp(b, p);
+            JumpPlan plan = make_jump_plan(b.hb, b.vb, O);
+            int8_t cv[12];
+            for (int k = 0; k < 12; k++) {
+                int ref, val;
+                jump_plan_corner(b.hb, b.vb, O, k, ref, val);
+                bad += ref != plan.ref[k];
+                bad += val != plan.val[k];
+                cv[k] = (int8_t)val;
+            }
+            Jumps j = plan_jumps(plan, -1, false);
+            for (int r = 0; r < 9; r++) {
+                uint32_t jb[4], jd[4];
+                plan_jump_rows(cv, O, r, jb, jd);
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t eb = (j.a[k] >= 0 && j.a[k] <= 80 && j.a[k] / 9 == r) ? (1u << (j.a[k] % 9)) : 0u;
+                    const uint32_t ed = j.a[k] >= 0 ? bb_row(j.d[k], r) : 0u;
+                    bad += jb[k] != eb;
+                    bad += jd[k] != ed;
+                }
+            }
+        }
+    }
+    return bad;
+}
 extern "C" long hc_cut_row_mismatches() { return g_cut_row_mismatches; }
 static long g_p2_mismatch = 0;
 extern "C" long hc_p2_mismatches() { return g_p2_mismatch; }

@@ -182,6 +182,8 @@ def test_bitboard_movegen_equals_oracle(hostcheck, positions):
         assert np.array_equal(m, omask), "rows finder, detour mode %d" % mode
     hostcheck.hc_cut_row_mismatches.restype = C.c_long
     assert hostcheck.hc_cut_row_mismatches() == 0  # cut masks in rows == path_cut_masks() on every path the rows finder found
+    hostcheck.hc_plan_rows_mismatches.restype = C.c_long
+    assert hostcheck.hc_plan_rows_mismatches(hb.ctypes.data_as(C.c_void_p), vb.ctypes.data_as(C.c_void_p), meta.ctypes.data_as(C.c_void_p), n) == 0
     hostcheck.hc_blocked_rows_mismatches.restype = C.c_long
     assert hostcheck.hc_blocked_rows_mismatches(hb.ctypes.data_as(C.c_void_p), vb.ctypes.data_as(C.c_void_p), n) == 0
     # ordered list from the mask through order_index (the expand kernel's slot rule)
