@@ -23,6 +23,9 @@ timeout 300 python benchmarks/movegen_bench.py --boards 4096 > $O/movegen_b4096.
 timeout 300 python benchmarks/conv_bench.py 2>&1 | grep -v amdgpu.ids > $O/conv_bench.txt; cat $O/conv_bench.txt
 timeout 300 python benchmarks/trunk_stamps.py 2>&1 | grep -v amdgpu.ids > $O/trunk_stamps.txt; cat $O/trunk_stamps.txt
 timeout 600 python benchmarks/select_stamps.py 3 2>&1 | grep -v amdgpu.ids > $O/select_stamps.txt; tail -4 $O/select_stamps.txt
+timeout 300 python benchmarks/rules_stamps.py 3 2>&1 | grep -v -e amdgpu.ids -e Warning > $O/rules_stamps.txt; cat $O/rules_stamps.txt
+timeout 300 python benchmarks/insitu_rules_timing.py 2>&1 | grep variant > $O/insitu_rules_variants.txt; cat $O/insitu_rules_variants.txt
+for v in 3 5 6; do timeout 200 python benchmarks/movegen_bench.py --boards 4096 --variant $v 2>/dev/null | grep '^{' >> $O/movegen_b4096_variants.jsonl; done; cut -c1-150 $O/movegen_b4096_variants.jsonl
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -- /usr/bin/python3 $R/bench.py --steps 2 --warmup 0 --desync-plies 700 --no-cpu-baseline --no-c3 > $O/prof_bench.log 2>&1
 find $O/prof_bench -name '*kernel_trace.csv' -delete
