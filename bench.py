@@ -569,7 +569,7 @@ def main():
             "mean_descent_depth": mean_depth,
             "ms_per_step_series": [round(x, 1) for x in step_ms],
             "roofline": {
-                "kernel": ("k_wave_rules (fused Quoridor.actions() + state() of the leaf batch: one wave per board + encoder groups, one launch)"
+                "kernel": ("k_wave_rules (fused Quoridor.actions() + state() of the leaf batch: one wave per board, base paths on nine lanes per player, + encoder groups with streaming stores, one launch)"
                            if group_boards < 8192 else
                            "k_pool_paths_enc + k_pool_masks_enc (Quoridor.actions() + state() of the leaf batch, pooled, two launches)"),
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
