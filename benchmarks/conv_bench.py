@@ -5,6 +5,9 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 from _stubs import det_fill_state_dict
+if os.environ.get("QZ_BENCH_LIB"):  # A/B of a differently built library: before anything loads it
+    from alphazero_quoridor_amd import _cabi as _c
+    _c.LIB_PATH = os.environ["QZ_BENCH_LIB"]
 from alphazero_quoridor_amd.policy_value_net import LeafEvaluator, PolicyValueNet
 
 ap = argparse.ArgumentParser()
