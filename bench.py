@@ -371,6 +371,8 @@ def main():
                          "kernel instead of the split-fp16 MFMA kernel (qz_nn_conv3x3_norm), for A/B runs")
     ap.add_argument("--separate-descent", action="store_true", help="A/B: k_select as its own launch (default: fused into the previous playout's expand / backup launch)")
     ap.add_argument("--select-opts", type=int, default=0, help="A/B switches of k_select (qz_config.select_opts)")
+    ap.add_argument("--rules-variant", type=int, default=0,
+                    help="A/B: qz_rules_opts.variant of the engines' leaf rules op (0 = the library's choice by batch size; include/qz_abi.h)")
     ap.add_argument("--length-file", default=None,
                     help="game-length sample for games_per_s_steady_state (default: newest profiles/round*/game_length_<n>playouts.json)")
     ap.add_argument("--clock-log", default=None, help="write the clock / power samples of the timed region to this JSON file")
@@ -405,6 +407,11 @@ def main():
                       seed=qdist.shard_seed(args.seed, rank), device=dev,
                       n_playout=args.playouts, c_puct=5, temp=1.0, is_selfplay=1, fix_terminal_sign=args.fix_terminal_sign,
                       select_opts=args.select_opts)
+    if args.rules_variant:
+        from alphazero_quoridor_amd import rules as qrules
+
+        for e in eng.engines:
+            e.set_rules_opts(qrules.rules_opts(args.rules_variant))
     group_boards = args.boards // args.groups
     is_dist = world > 1
     write_planes = not args.no_planes
@@ -570,8 +577,10 @@ def main():
             "ms_per_step_series": [round(x, 1) for x in step_ms],
             "roofline": {
                 "kernel": ("k_wave_rules (fused Quoridor.actions() + state() of the leaf batch: one wave per board, base paths on nine lanes per player, + encoder groups with streaming stores, one launch)"
-                           if group_boards < 8192 else
-                           "k_pool_paths_enc + k_pool_masks_enc (Quoridor.actions() + state() of the leaf batch, pooled, two launches)"),
+                           if (group_boards < 8192 and args.rules_variant in (0, 3, 6)) or args.rules_variant in (3, 6) else
+                           ("k_pool_paths_enc + k_pool_masks_enc (Quoridor.actions() + state() of the leaf batch, pooled, two launches)"
+                            if args.rules_variant in (0,) or args.rules_variant >= 8 else "k_wave_rules, qz_rules_opts.variant %d" % args.rules_variant)),
+                "rules_variant": args.rules_variant,
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "avg_launch_us": kern_ms * 1e3, "launches": n_evs,
