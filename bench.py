@@ -550,9 +550,11 @@ def main():
             "dtype": "u64 bitboards + f64 PUCT (rules/tree kernels); %s policy-value net" % args.nn_dtype,
             "data": "synthetic (random-init policy_value_net, seed %d; self-generated games)" % args.seed,
             "config": {
-                "workload": "BASELINE configs[3] per GPU: %d concurrent boards/GPU, n_playout=%d, 9x9, 10 walls/player, "
+                "workload": "%s: %d concurrent boards/GPU, n_playout=%d, 9x9, 10 walls/player, "
                             "c_puct=5, temp=1.0, leaf batch=%d, finished tuples all-gathered every ply"
-                            % (args.boards, args.playouts, args.boards),
+                            % ("BASELINE configs[2] as an engine run" if args.boards == 32768 else
+                               ("BASELINE configs[1]" if args.playouts == 100 else "BASELINE configs[3] per GPU"),
+                               args.boards, args.playouts, args.boards),
                 "boards_per_gpu": args.boards, "board_groups": args.groups, "fix_terminal_sign": bool(args.fix_terminal_sign),
                 "n_playout": args.playouts, "bn_mode": args.bn,
                 "nn_dtype": args.nn_dtype, "channels_last": bool(args.channels_last),
@@ -586,8 +588,10 @@ def main():
                 "avg_launch_us": kern_ms * 1e3, "launches": n_evs,
                 "algorithmic_bytes_per_launch": group_boards * bytes_per_board,
                 "planes_written": planes_written, "planes_consumed_by_evaluator": bool(planes_consumed),
-                "cache_note": ("%.1f MB written per launch: fits the 256-MiB Infinity Cache, so the stores need not reach HBM before they are "
-                               "overwritten; `traffic` is what the PMC counters saw at the memory controllers"
+                "cache_note": (("%.1f MB written per launch: fits the 256-MiB Infinity Cache, so the stores need not reach HBM before they are "
+                                "overwritten; `traffic` is what the PMC counters saw at the memory controllers"
+                                if group_boards * bytes_per_board < 256 * 2**20 else
+                                "%.1f MB written per launch: larger than the 256-MiB Infinity Cache, the stores reach HBM")
                                % (group_boards * bytes_per_board / 1e6)),
             },
             "roofline_tree": ([
