@@ -6,12 +6,19 @@
 // a search, lane r holding row r of every set as 9 bits: a north / south move is a one-lane
 // shift of the whole wavefront (DPP wave_shr / wave_shl; rows 0 and 8 never move outwards, so
 // nothing leaks into the neighbouring group), an east / west move a one-bit shift.  Seven
-// searches fit a wavefront; a layer costs ~45 instructions, a walk-back step ~30.
+// searches fit a wavefront; two flood layers cost ~88 instructions, two walk-back steps ~64
+// (measured in k_wave_rules: ~95 instructions and ~850 cycles per path edge, against ~300
+// instructions with one search per lane).  It pays where FEW searches decide a launch's duration
+// (k_wave_rules: 4,096 leaf boards, a few hundred of them searching); with a search for every
+// lane of the chip the one-lane form needs a third of the issue slots.
 //
 //   coop_find_path()   the device form (SIMT, all 64 lanes of a wavefront call it together)
 //   find_path_rows()   the same algorithm written over arrays of nine rows: the host-check build
 //                      runs it in place of find_path_tables() and compares the masks with the
 //                      oracle (tests/hostcheck), so the formulation is checked without a GPU
+//   blocked_rows(), cut_row(), jump_plan_corner(), plan_jump_rows()
+//                      the pieces around the search in the same row form (shared by both forms
+//                      and by the host check, which compares them with the three-word functions)
 //
 // Both produce what find_path_tables() produces -- one concrete shortest path as edge sets, its
 // length, the two lookup tables of the flood phase and the jump positions -- but not necessarily
