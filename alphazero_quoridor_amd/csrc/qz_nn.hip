@@ -414,21 +414,26 @@ constexpr int HT = 192;   // threads per workgroup; with 78 KB of LDS two workgr
                           // latency-bound phases (staging, fully connected layers) run under the other's convolution
 constexpr int XS = 36;    // row stride of a staged half tile (32 input channels + 4 pad), floats
 constexpr int FS = 488;   // feature stride per leaf (486 used; 16-byte aligned rows)
-struct HeadFc {           // lives in the tile memory once the convolutions are done
-    float h1[HB][128];
-    float logit[HB][144];
+template <int NL>
+struct HeadFcT {          // lives in the tile memory once the convolutions are done
+    float h1[NL][128];
+    float logit[NL][144];
 };
+using HeadFc = HeadFcT<HB>;
+constexpr int HBF = 3;    // leaves per workgroup of k_head_fc: half the multiply-adds per wavefront of the six-leaf form (the
+                          // kernel is bound by its slowest wavefront's ~3,000 dependent FMAs + nine weight round trips, not by traffic)
 // fc1 + fc2 + tanh and fc3 + softmax of HB leaves whose normalised head features (c * 81 + pos order,
 // FS floats apart) are in LDS: the second half of k_head, and all of k_head_fc
-__device__ __forceinline__ void head_fc_tail(const float* __restrict__ s_f, HeadFc& fc, int nb, long long s0, int tid, int wave, int lane,
+template <int NL>
+__device__ __forceinline__ void head_fc_tail(const float* __restrict__ s_f, HeadFcT<NL>& fc, int nb, long long s0, int tid, int wave, int lane,
                                              const float* __restrict__ w1t, const float* __restrict__ b1, const float* __restrict__ w2,
                                              const float* __restrict__ b2, const float* __restrict__ w3t, const float* __restrict__ b3,
                                              float* __restrict__ p_out, float* __restrict__ v_out) {
     if (wave < 2) {  // fc1: 324 -> 128, thread = output
         const int j = tid;
-        float a1[HB];
+        float a1[NL];
 #pragma unroll
-        for (int s = 0; s < HB; s++) a1[s] = 0.f;
+        for (int s = 0; s < NL; s++) a1[s] = 0.f;
         // 36 coalesced weight loads in flight per trip (the loop is latency-bound, not issue-bound: every trip waits one
         // L2 round trip; 12 per trip made k_head_fc 25 us for 4,096 leaves)
         for (int i = 0; i < 4 * PL; i += 36) {
@@ -436,7 +441,7 @@ __device__ __forceinline__ void head_fc_tail(const float* __restrict__ s_f, Head
 #pragma unroll
             for (int k = 0; k < 36; k++) w[k] = w1t[(i + k) * 128 + j];
 #pragma unroll
-            for (int s = 0; s < HB; s++) {
+            for (int s = 0; s < NL; s++) {
 #pragma unroll
                 for (int k4 = 0; k4 < 9; k4++) {
                     const float4 f = *reinterpret_cast<const float4*>(&s_f[s * FS + i + 4 * k4]);
@@ -449,13 +454,13 @@ __device__ __forceinline__ void head_fc_tail(const float* __restrict__ s_f, Head
         }
         const float bb = b1[j];
 #pragma unroll
-        for (int s = 0; s < HB; s++) fc.h1[s][j] = a1[s] + bb;
+        for (int s = 0; s < NL; s++) fc.h1[s][j] = a1[s] + bb;
     } else {  // fc3: 162 -> 140 on the third wavefront, thread = outputs j, j + 64, j + 128
         const int j = tid - 128, j1 = j + 64, j2 = j + 128;
         const bool three = j2 < 140;
-        float a3[HB], a3b[HB], a3c[HB];
+        float a3[NL], a3b[NL], a3c[NL];
 #pragma unroll
-        for (int s = 0; s < HB; s++) a3[s] = a3b[s] = a3c[s] = 0.f;
+        for (int s = 0; s < NL; s++) a3[s] = a3b[s] = a3c[s] = 0.f;
         for (int i = 0; i < 2 * PL; i += 18) {  // 162 = 9 * 18: up to 54 loads in flight per trip
             float wa[18], wb[18], wc[18];
 #pragma unroll
@@ -465,7 +470,7 @@ __device__ __forceinline__ void head_fc_tail(const float* __restrict__ s_f, Head
                 wc[k] = three ? w3t[(i + k) * 140 + j2] : 0.f;
             }
 #pragma unroll
-            for (int s = 0; s < HB; s++) {
+            for (int s = 0; s < NL; s++) {
 #pragma unroll
                 for (int k2 = 0; k2 < 9; k2++) {
                     const float2 f = *reinterpret_cast<const float2*>(&s_f[s * FS + 4 * PL + i + 2 * k2]);
@@ -480,7 +485,7 @@ __device__ __forceinline__ void head_fc_tail(const float* __restrict__ s_f, Head
         }
         const float ba = b3[j], bb = b3[j1], bc = three ? b3[j2] : 0.f;
 #pragma unroll
-        for (int s = 0; s < HB; s++) {
+        for (int s = 0; s < NL; s++) {
             fc.logit[s][j] = a3[s] + ba;
             fc.logit[s][j1] = a3b[s] + bb;
             if (three) fc.logit[s][j2] = a3c[s] + bc;
@@ -666,12 +671,12 @@ __global__ __launch_bounds__(HT) void k_head_fc(const float* __restrict__ feat, 
                                                 const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2,
                                                 const float* __restrict__ w3t, const float* __restrict__ b3, float* __restrict__ p_out,
                                                 float* __restrict__ v_out) {
-    __shared__ __attribute__((aligned(16))) float s_f[HB * FS];
-    __shared__ HeadFc fc;
+    __shared__ __attribute__((aligned(16))) float s_f[HBF * FS];
+    __shared__ HeadFcT<HBF> fc;
     const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const long long s0 = (long long)blockIdx.x * HB;
-    const int nb = (int)((n - s0) < HB ? (n - s0) : HB);
-    for (int i = tid; i < HB * 243; i += HT) {  // 486 floats per leaf as 243 float2
+    const long long s0 = (long long)blockIdx.x * HBF;
+    const int nb = (int)((n - s0) < HBF ? (n - s0) : HBF);
+    for (int i = tid; i < HBF * 243; i += HT) {  // 486 floats per leaf as 243 float2
         const int sl = i / 243, k = i - sl * 243;
         float2 v = make_float2(0.f, 0.f);
         if (sl < nb) v = reinterpret_cast<const float2*>(feat + (size_t)(s0 + sl) * 486)[k];
@@ -738,7 +743,7 @@ hipError_t head(const float* t, long long n, const float* w6k, const float* gamm
 hipError_t head_fc(const float* feat, long long n, const float* w1t, const float* b1, const float* w2, const float* b2, const float* w3t,
                    const float* b3, float* p_out, float* v_out, hipStream_t s) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_head_fc, dim3((unsigned)((n + HB - 1) / HB)), dim3(HT), 0, s, feat, n, w1t, b1, w2, b2, w3t, b3, p_out, v_out);
+    hipLaunchKernelGGL(k_head_fc, dim3((unsigned)((n + HBF - 1) / HBF)), dim3(HT), 0, s, feat, n, w1t, b1, w2, b2, w3t, b3, p_out, v_out);
     return hipGetLastError();
 }
 }  // namespace qzl
