@@ -92,7 +92,7 @@ static_assert(sizeof(Edge) == 32, "edge record must be 32 bytes");
 struct RulesOpts {
     int variant = 0;
     int detour_pooled = 1, detour_wave = 0;  // pool_k1's detour_mode per kernel family
-    int enc_split_pct = 70;                  // share of the encoder tiles beside the path groups
+    int enc_split_pct = 50;                  // share of the encoder tiles beside the path groups
 };
 
 struct EngineDev {

@@ -1784,10 +1784,11 @@ hipError_t movegen_encode(const uint64_t* hb, const uint64_t* vb, const uint64_t
     }
     PoolBoard* recs = reinterpret_cast<PoolBoard*>(scratch);
     PathTab* tabs = reinterpret_cast<PathTab*>(recs + n);
-    // encoder tiles are split over the two launches: 70 % ride beside the path search (a
-    // latency-bound dependent chain of ~31 us that leaves issue slots and the memory pipe idle),
-    // the rest beside the mask groups (~22 us alone).  Sweep at 32,768 boards, S-mid: 35 % 80 us,
-    // 50 % 80, 60 % 77, 70 % 75, 80 % 78, 100 % 82.
+    // encoder tiles are split over the two launches: half of them ride beside the path search (a
+    // latency-bound dependent chain of ~27 us that leaves issue slots and the memory pipe idle),
+    // the rest beside the mask groups (~22 us alone).  Sweep at 32,768 boards on the final kernels
+    // (S-open / S-mid / S-dense, us): 40 % 67.0 / 74.9 / 79.1, 50 % 66.6 / 72.3 / 76.8, 55 % 67.6 /
+    // 72.4 / 77.3, 60 % 67.5 / 71.9 / 78.6, 70 % 67.8 / 73.7 / 80.5 (70 % was the optimum of round 1's kernels).
     const int enc_total = planes ? (n + NBE - 1) / NBE : 0;
     const int enc_a = mask5 ? (enc_total * ro.enc_split_pct) / 100 : 0;
     if (mask5) {

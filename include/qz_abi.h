@@ -81,7 +81,7 @@ int qz_movegen_encode(const qz_boards* boards, int n, uint32_t* mask5 /*[dev]*/,
  *                  many boards per mask workgroup
  *   detour_pooled  group-detour mode of the pooled pipeline: 0 = default (one group), else 1 + mode
  *   detour_wave    ... of k_wave_rules: 0 = default (off), else 1 + mode (mode 0 | 1 | 2)
- *   enc_split_pct  0 = default (70): percent of the encoder groups beside the path groups */
+ *   enc_split_pct  0 = default (50): percent of the encoder groups beside the path groups */
 typedef struct {
     int32_t variant, detour_pooled, detour_wave, enc_split_pct;
 } qz_rules_opts;
