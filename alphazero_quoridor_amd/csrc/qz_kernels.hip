@@ -1744,7 +1744,10 @@ namespace qzl {
 
 static inline dim3 wave_grid(int n) { return dim3((unsigned)((n + WPB - 1) / WPB)); }
 
-constexpr int NBE = 16;  // boards per encoder group
+#ifndef QZ_NBE
+#define QZ_NBE 16
+#endif
+constexpr int NBE = QZ_NBE;  // boards per encoder group (8 and 32 measured at 32,768 boards: see DESIGN 9.2)
 
 template <int NB>
 static void launch_masks_enc(const PoolBoard* recs, const PathTab* tabs, int n, uint32_t* mask5, const uint64_t* hb,
