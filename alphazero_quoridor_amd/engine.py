@@ -103,6 +103,9 @@ class SelfPlayEngine:
         self.pi = torch.zeros((B, 140), dtype=torch.float32, device=dev)
         self._graph = None
         self._graph_steps = 0
+        # None: the rules op writes state() only when the evaluator reads it (one that takes the leaf boards does not);
+        # True: always (bench.py: every launch of a run then moves the op's full algorithmic bytes, timed or not)
+        self.always_write_planes = None
         self._leaf_ref = None
         self._descended = False  # the last expand / backup launch also ran the next playout's descent
 
@@ -224,6 +227,8 @@ class SelfPlayEngine:
             self.expand_backup(p, v)
             return
         takes_boards = getattr(evaluator, "accepts_leaf_boards", False)
+        if write_planes is None:
+            write_planes = self.always_write_planes
         want_planes = (not takes_boards) if write_planes is None else bool(write_planes) or not takes_boards
         planes = self.select(events=events, want_planes=want_planes, tree_events=None if tree_events is None else tree_events[0])
         if nn_events is not None:

@@ -416,6 +416,9 @@ def main():
     is_dist = world > 1
     write_planes = not args.no_planes
     planes_consumed = not getattr(eng.evaluators[0], "accepts_leaf_boards", False)
+    if write_planes:  # the untimed phases launch the rules op the way the timed region does (a rocprofv3 trace of a run
+        for e in eng.engines:  # then averages over one kind of launch)
+            e.always_write_planes = True
 
     def barrier():
         if is_dist:
