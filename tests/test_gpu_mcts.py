@@ -438,6 +438,25 @@ def test_32768_boards_at_400_playouts_fit_one_gpu(gpu_device):
     st = eng.stats()
     assert st["node_overflow"] == 0 and st["games_aborted"] == 0 and st["plies_played"] == 2 * 32768
     assert st["playouts"] == 32768 * 460 and st["tree_pages_peak"] <= st["tree_pages_total"]
+    # the leaf batch of the next playout, in situ at this size: the rules kernels the library can pick from agree on
+    # every live leaf (pooled pipeline = its choice here, k_wave_rules with base paths on nine lanes per player, the same
+    # with one search per lane), and a sample matches the oracle
+    import oracle
+    from alphazero_quoridor_amd import rules
+    from alphazero_quoridor_amd.boards import DeviceBoards
+
+    eng.run_playouts(ev, 30)
+    leaf = eng.select_boards().to_packed()
+    live = leaf[(leaf["p1"] <= 71) & (leaf["p2"] >= 9)]
+    assert len(live) > 30000
+    db = DeviceBoards.from_packed(live, gpu_device)
+    mask, planes = rules.movegen_encode(db)
+    for variant in (3, 5):
+        m, p = rules.movegen_encode(db, opts=rules.rules_opts(variant))
+        assert torch.equal(m, mask) and torch.equal(p, planes), variant
+    omask, status = oracle.movegen_batch(live[::64])
+    assert (status >= 0).all() and np.array_equal(mask.cpu().numpy().view(np.uint32)[::64], omask)
+    assert np.array_equal(planes.cpu().numpy()[::64], oracle.encode_batch(live[::64]))
     eng.close()
 
 
