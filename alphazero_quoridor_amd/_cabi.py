@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "libqzero_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "qz_abi.h")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 N_ACTIONS = 140
 PLANES = 26 * 81
 MASK_WORDS = 5
@@ -66,6 +66,8 @@ class qz_config(C.Structure):
         ("traj_page_dwords", C.c_int32),
         ("rules", qz_rules_opts),
         ("select_opts", C.c_int32),
+        ("memo_small_log2", C.c_int32),
+        ("memo_big_log2", C.c_int32),
     ]
 
 
@@ -101,6 +103,28 @@ class qz_stats(C.Structure):
         ("deep_descents_cold", C.c_int64),
         ("deep_levels", C.c_int64),
         ("deep_levels_replayed", C.c_int64),
+        ("rounds", C.c_int64),
+        ("memo_hits", C.c_int64),
+        ("nn_evals", C.c_int64),
+        ("memo_inserts", C.c_int64),
+        ("memo_locked", C.c_int64),
+        ("open_rounds", C.c_int64),
+        ("open_plies", C.c_int64),
+        ("waiting_boards", C.c_int64),
+        ("runaway_descents", C.c_int64),
+    ]
+
+
+class qz_nn_weights(C.Structure):
+    _fields_ = [
+        ("hot9", C.c_void_p), ("base0", C.c_void_p), ("wd", C.c_void_p), ("gamma0", C.c_void_p), ("beta0", C.c_void_p),
+        ("n_blocks", C.c_int32),
+        ("w16", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),   # host arrays of device pointers
+        ("inv_scale", C.c_void_p),                                          # device array
+        ("w6_16", C.c_void_p),
+        ("gamma6", C.c_void_p), ("beta6", C.c_void_p), ("w1t", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p),
+        ("w3t", C.c_void_p), ("b3", C.c_void_p),
+        ("eps", C.c_float),
     ]
 
 
@@ -143,17 +167,24 @@ _SIGNATURES = {
     "qz_mcts_update_with_move": (C.c_int, [_P, _P, _P]),
     "qz_mcts_finish_move": (C.c_int, [_P, _P, _P, _P, _P]),
     "qz_harvest_counts": (C.c_int, [_P, C.POINTER(C.c_int64 * 2), _P]),
-    "qz_harvest": (C.c_int, [_P, C.POINTER(qz_boards), _P, _P, _P, C.c_int64, _P]),
+    "qz_harvest": (C.c_int, [_P, C.POINTER(qz_boards), _P, _P, _P, _P, C.c_int64, _P]),
     "qz_engine_stats": (C.c_int, [_P, C.POINTER(qz_stats), _P]),
     "qz_nn_instnorm_act": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_float, _P]),
     "qz_nn_instnorm_act_nhwc": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_float, _P]),
     "qz_nn_input_layer": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P, _P, _P, _P, C.c_float, _P]),
     "qz_engine_leaf_boards": (C.c_int, [_P, _P, _P]),
-    "qz_nn_conv3x3_norm": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, C.c_float, C.c_int, C.c_float, _P]),
+    "qz_nn_conv3x3_norm": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, _P, C.c_int, C.c_float, _P]),
     "qz_nn_trunk": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P, _P, _P, _P, C.c_float, C.c_int, _P]),
-    "qz_nn_trunk_heads": (C.c_int, [_P, C.c_int64, C.c_int, _P, _P, _P, _P, _P, C.c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, _P]),
-    "qz_nn_evaluate": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P, _P, _P, C.c_int, _P, _P, _P, _P, _P, C.c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+    "qz_nn_trunk_heads": (C.c_int, [_P, C.c_int64, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, _P]),
+    "qz_nn_evaluate": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P, _P, _P, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                  _P, C.c_float, _P]),
+    "qz_selfplay_advance": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
+    "qz_selfplay_leaf_rules": (C.c_int, [_P, _P]),
+    "qz_selfplay_evaluate": (C.c_int, [_P, C.POINTER(qz_nn_weights), _P]),
+    "qz_selfplay_round_tail": (C.c_int, [_P, _P]),
+    "qz_selfplay_round": (C.c_int, [_P, C.POINTER(qz_nn_weights), C.c_int, C.c_int, C.c_int, _P]),
+    "qz_selfplay_misses": (C.c_int, [_P, C.POINTER(qz_boards), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
+    "qz_memo_flush": (C.c_int, [_P, _P]),
     "qz_nn_head": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, _P]),
     "qz_selftest_sqrt": (C.c_int, [_P, C.c_int, _P]),
 }

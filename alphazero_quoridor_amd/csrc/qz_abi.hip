@@ -15,7 +15,10 @@
 #include "qz_device.h"
 
 namespace qzl {
-hipError_t movegen_encode(const uint64_t*, const uint64_t*, const uint64_t*, int, uint32_t*, float*, const uint8_t*, void*, const RulesOpts&, hipStream_t);
+hipError_t movegen_encode(const uint64_t*, const uint64_t*, const uint64_t*, int, uint32_t*, float*, const uint8_t*, void*, const RulesOpts&, hipStream_t, const int* n_dev = nullptr);
+hipError_t advance(const EngineDev&, const EngineDev*, int, unsigned int, int, int, hipStream_t);
+hipError_t round_tail(const EngineDev&, int, hipStream_t);
+hipError_t memo_flush(const EngineDev&, hipStream_t);
 size_t movegen_scratch_bytes(int);
 hipError_t step(uint64_t*, uint64_t*, uint64_t*, const uint8_t*, int, uint8_t*, uint8_t*, hipStream_t);
 hipError_t select(const EngineDev&, hipStream_t);
@@ -27,17 +30,18 @@ hipError_t update_with_move(const EngineDev&, const uint8_t*, hipStream_t);
 hipError_t finish_move(const EngineDev&, const uint8_t*, float*, uint8_t*, hipStream_t);
 hipError_t reset(const EngineDev&, int, hipStream_t);
 hipError_t pool_init(const EngineDev&, hipStream_t);
-hipError_t harvest(const EngineDev&, uint64_t*, uint64_t*, uint64_t*, float*, float*, int32_t*, long long, hipStream_t);
+hipError_t harvest(const EngineDev&, uint64_t*, uint64_t*, uint64_t*, float*, float*, int32_t*, int32_t*, long long, hipStream_t);
 hipError_t sqrt_table(double*, int, hipStream_t);
-hipError_t conv3x3_norm(const float*, const void*, const float*, const float*, const float*, float*, long long, float, int, float, hipStream_t);
+hipError_t conv3x3_norm(const float*, const void*, const float*, const float*, const float*, float*, long long, const float*, int, float, hipStream_t);
 struct TrunkInput {  // qz_conv.hip
     const uint64_t *hb, *vb, *meta;
     const uint8_t* terminal;
     const float *hot9, *base0, *wd, *gamma0, *beta0;
 };
 hipError_t trunk(float*, float*, long long, int, const void* const*, const float* const*, const float* const*, const float*, float, int, hipStream_t,
-                 const void*, const float*, const float*, float, float*, const TrunkInput*);
-hipError_t head_fc(const float*, long long, const float*, const float*, const float*, const float*, const float*, const float*, float*, float*, hipStream_t);
+                 const void*, const float*, const float*, float*, const TrunkInput*, const int* n_live = nullptr);
+hipError_t head_fc(const float*, long long, const float*, const float*, const float*, const float*, const float*, const float*, float*, float*, hipStream_t,
+                   const int* n_live = nullptr);
 hipError_t rollout_begin(const uint64_t*, const uint64_t*, const uint64_t*, int, uint8_t*, uint8_t*, int8_t*, int*, hipStream_t);
 hipError_t rollout_step(uint64_t*, uint64_t*, uint64_t*, const uint32_t*, int, const uint8_t*, uint8_t*, int8_t*, int*, uint64_t, int, int, hipStream_t);
 hipError_t instnorm_act(const float*, const float*, const float*, const float*, float*, long long, int, int, float, hipStream_t);
@@ -117,6 +121,11 @@ struct qz_engine {
     EngineDev dev;
     RulesOpts rules;
     void* scratch = nullptr;
+    float* feat = nullptr;     // [B][486] head features of the miss list (qz_selfplay_evaluate)
+    EngineDev* dev_mem = nullptr;  // `dev` once more in device memory (k_advance's rarely-run paths read it from there)
+    int par = 0;               // which of the two miss counters the round in progress uses
+    size_t memo_small_bytes = 0, memo_big_bytes = 0;
+    unsigned flushes = 0;
     std::vector<void*> allocs;
     int64_t bytes = 0;
 };
@@ -292,6 +301,7 @@ int qz_engine_create(const qz_config* cfg, qz_engine** out) {
     d.node_cap = c.node_cap;
     d.edge_cap = c.edge_cap;
     d.max_plies = c.max_plies;
+    d.n_playout = c.n_playout;
     d.tree_pool_pages = c.tree_pool_pages;
     d.traj_pool_pages = c.traj_pool_pages;
     d.traj_page_dwords = (uint32_t)c.traj_page_dwords;
@@ -355,6 +365,38 @@ int qz_engine_create(const qz_config* cfg, qz_engine** out) {
     ALLOC(bc_levels, B);
     ALLOC(bc_scanned, B);
     ALLOC(bc_expanded, B);
+    ALLOC(pl_done, B);
+    ALLOC(pend_slot, B);
+    ALLOC(miss_count, (size_t)2);
+    ALLOC(miss_hb, B);
+    ALLOC(miss_vb, B);
+    ALLOC(miss_meta, B);
+    ALLOC(miss_mask, B * 5);
+    ALLOC(miss_p, B * QZ_N_ACT);
+    ALLOC(miss_v, B);
+    ALLOC(bc_memo_hits, B);
+    ALLOC(bc_evals, B);
+    ALLOC(bc_open_rounds, B);
+    ALLOC(bc_open_plies, B);
+    ALLOC(memo.epoch, (size_t)1);
+    if (!rc) rc = dev_alloc(e, &e->feat, B * 486);
+    if (!rc) rc = dev_alloc(e, &e->dev_mem, (size_t)1);
+    // memo tables: powers of two; auto = 8,192 small + 1,024 big entries per board
+    if (c.memo_small_log2 >= 0 && c.memo_big_log2 >= 0) {
+        auto log2_ceil = [](unsigned long long x) { int l = 0; while ((1ull << l) < x) l++; return l; };
+        if (c.memo_small_log2 == 0) c.memo_small_log2 = log2_ceil((unsigned long long)B * 8192ull / QZ_MEMO_S_WAYS);
+        if (c.memo_big_log2 == 0) c.memo_big_log2 = log2_ceil((unsigned long long)B * 1024ull / QZ_MEMO_B_WAYS);
+        if (c.memo_small_log2 > 31 || c.memo_big_log2 > 31) rc = rc ? rc : fail(QZ_E_INVALID, "memo table too large");
+        const size_t sb = ((size_t)1 << c.memo_small_log2), bb = ((size_t)1 << c.memo_big_log2);
+        e->memo_small_bytes = sb * QZ_MEMO_S_WAYS * QZ_MEMO_S_DW * 4;
+        e->memo_big_bytes = bb * QZ_MEMO_B_WAYS * QZ_MEMO_B_DW * 4;
+        ALLOC(memo.small, sb * QZ_MEMO_S_WAYS * QZ_MEMO_S_DW);
+        ALLOC(memo.big, bb * QZ_MEMO_B_WAYS * QZ_MEMO_B_DW);
+        d.memo.small_mask = (uint32_t)(sb - 1);
+        d.memo.big_mask = (uint32_t)(bb - 1);
+    } else {
+        c.memo_small_log2 = c.memo_big_log2 = -1;
+    }
 #undef ALLOC
     if (!rc) {
         uint8_t* sc = nullptr;
@@ -388,7 +430,19 @@ int qz_engine_create(const qz_config* cfg, qz_engine** out) {
     if (he == hipSuccess) he = hipMemset(d.bc_scanned, 0, B * sizeof(unsigned long long));
     if (he == hipSuccess) he = hipMemset(d.bc_expanded, 0, B * sizeof(unsigned long long));
     if (he == hipSuccess) he = hipMemset(d.leaf_mask, 0, B * 5 * sizeof(uint32_t));
+    if (he == hipSuccess) he = hipMemset(d.miss_count, 0, 2 * sizeof(int));
+    if (he == hipSuccess) he = hipMemset(d.bc_memo_hits, 0, B * sizeof(uint32_t));
+    if (he == hipSuccess) he = hipMemset(d.bc_evals, 0, B * sizeof(uint32_t));
+    if (he == hipSuccess) he = hipMemset(d.bc_open_rounds, 0, B * sizeof(uint32_t));
+    if (he == hipSuccess) he = hipMemset(d.bc_open_plies, 0, B * sizeof(uint32_t));
+    if (he == hipSuccess) {
+        const uint32_t one = 1u;  // epoch 0 never matches: an all-zero entry is dead
+        he = hipMemcpy(d.memo.epoch, &one, sizeof(one), hipMemcpyHostToDevice);
+    }
+    if (he == hipSuccess && d.memo.small) he = hipMemset(d.memo.small, 0, e->memo_small_bytes);
+    if (he == hipSuccess && d.memo.big) he = hipMemset(d.memo.big, 0, e->memo_big_bytes);
     if (he == hipSuccess) he = qzl::reset(d, 1, nullptr);
+    if (he == hipSuccess) he = hipMemcpy(e->dev_mem, &d, sizeof(d), hipMemcpyHostToDevice);
     if (he == hipSuccess) he = hipDeviceSynchronize();
     if (he != hipSuccess) {
         qz_engine_destroy(e);
@@ -440,6 +494,8 @@ int qz_engine_set_temp(qz_engine* e, float temp) {
     if (!(temp > 0.f)) return fail(QZ_E_INVALID, "temp must be > 0");
     e->cfg.temp = temp;
     e->dev.temp = temp;
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    HIP_TRY(hipMemcpy(e->dev_mem, &e->dev, sizeof(e->dev), hipMemcpyHostToDevice));  // (synchronous: the next launch sees it)
     return 0;
 }
 
@@ -544,13 +600,13 @@ int qz_harvest_counts(qz_engine* e, int64_t counts[2], void* stream) {
     return 0;
 }
 
-int qz_harvest(qz_engine* e, const qz_boards* t_boards, float* t_pi, float* t_z, int32_t* t_game, int64_t cap, void* stream) {
+int qz_harvest(qz_engine* e, const qz_boards* t_boards, float* t_pi, float* t_z, int32_t* t_game, int32_t* g_board, int64_t cap, void* stream) {
     ENGINE_CHECK(e);
     if (cap < 0) return fail(QZ_E_INVALID, "cap < 0");
     if (cap > 0 && (!t_boards || !t_boards->hbits || !t_boards->vbits || !t_boards->meta || !t_pi || !t_z))
         return fail(QZ_E_INVALID, "null tuple buffers");
     HIP_TRY(qzl::harvest(e->dev, cap ? t_boards->hbits : nullptr, cap ? t_boards->vbits : nullptr,
-                         cap ? t_boards->meta : nullptr, t_pi, t_z, t_game, (long long)cap, (hipStream_t)stream));
+                         cap ? t_boards->meta : nullptr, t_pi, t_z, t_game, g_board, (long long)cap, (hipStream_t)stream));
     return 0;
 }
 
@@ -560,7 +616,7 @@ int qz_engine_stats(qz_engine* e, qz_stats* out, void* stream) {
     unsigned long long h[QZ_C_COUNT];
     hipStream_t s = (hipStream_t)stream;
     const size_t B = (size_t)e->cfg.n_boards;
-    std::vector<uint32_t> bp(B), bt(B), bo(B), nn(B), ne(B), bf(B), bd(B);
+    std::vector<uint32_t> bp(B), bt(B), bo(B), nn(B), ne(B), bf(B), bd(B), mh(B), me_(B), orr(B), opl(B), ps(B);
     int pw[QZ_P_COUNT];
     std::vector<unsigned long long> bl(B), bs(B), be(B);
     HIP_TRY(hipMemcpyAsync(h, e->dev.counters, sizeof(h), hipMemcpyDeviceToHost, s));
@@ -575,6 +631,11 @@ int qz_engine_stats(qz_engine* e, qz_stats* out, void* stream) {
     HIP_TRY(hipMemcpyAsync(be.data(), e->dev.bc_expanded, B * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(nn.data(), e->dev.n_nodes, B * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(ne.data(), e->dev.n_edges, B * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(mh.data(), e->dev.bc_memo_hits, B * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(me_.data(), e->dev.bc_evals, B * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(orr.data(), e->dev.bc_open_rounds, B * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(opl.data(), e->dev.bc_open_plies, B * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(ps.data(), e->dev.pend_slot, B * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     // per-board counters wrap at 2^32 playouts per board (years); sums are 64-bit
     unsigned long long sp = 0, st = 0, so = 0, sl = 0, sf = 0, ss = 0, se = 0;
@@ -622,6 +683,23 @@ int qz_engine_stats(qz_engine* e, qz_stats* out, void* stream) {
     out->arena_bytes = e->bytes;
     out->max_nodes = (int64_t)mn;
     out->max_edges = (int64_t)me;
+    unsigned long long smh = 0, sme = 0, sor = 0, sop = 0, sw = 0;
+    for (size_t i = 0; i < B; i++) {
+        smh += mh[i];
+        sme += me_[i];
+        sor += orr[i];
+        sop += opl[i];
+        sw += ps[i] != QZ_NONE;
+    }
+    out->rounds = (int64_t)h[QZ_C_ROUNDS];
+    out->memo_hits = (int64_t)smh;
+    out->nn_evals = (int64_t)sme;
+    out->memo_inserts = (int64_t)h[QZ_C_MEMO_INSERTS];
+    out->memo_locked = (int64_t)h[QZ_C_MEMO_LOCKED];
+    out->open_rounds = (int64_t)sor;
+    out->open_plies = (int64_t)sop;
+    out->waiting_boards = (int64_t)sw;
+    out->runaway_descents = (int64_t)h[QZ_C_RUNAWAY];
     return 0;
 }
 
@@ -674,12 +752,12 @@ int qz_nn_head(const float* t, int64_t n, const float* w6k, const float* gamma6,
     return 0;
 }
 int qz_nn_conv3x3_norm(const float* x, const void* w16, const float* gamma, const float* beta, const float* residual, float* out, int64_t n,
-                       float inv_scale, int relu, float eps, void* stream) {
+                       const float* inv_scale, int relu, float eps, void* stream) {
     int r;
     if ((r = device_check())) return r;
     if (n < 0) return fail(QZ_E_INVALID, "n < 0");
     if (n == 0) return 0;
-    if (!x || !w16 || !gamma || !beta || !out) return fail(QZ_E_INVALID, "null tensor");
+    if (!x || !w16 || !gamma || !beta || !out || !inv_scale) return fail(QZ_E_INVALID, "null tensor");
     if ((((uintptr_t)x | (uintptr_t)w16 | (uintptr_t)out | (uintptr_t)residual) & 15) != 0) return fail(QZ_E_INVALID, "tensors must be 16-byte aligned");
     HIP_TRY(qzl::conv3x3_norm(x, w16, gamma, beta, residual, out, (long long)n, inv_scale, relu, eps, (hipStream_t)stream));
     return 0;
@@ -690,15 +768,16 @@ int qz_nn_trunk(float* x, float* tmp, int64_t n, int n_blocks, const void* const
     if ((r = device_check())) return r;
     if (n < 0 || n_blocks < 0) return fail(QZ_E_INVALID, "n < 0 or n_blocks < 0");
     if (n == 0 || n_blocks == 0) return 0;
-    if (!x || !w16 || !gamma || !beta || !inv_scale || (!fused && !tmp)) return fail(QZ_E_INVALID, "null argument");
+    if (!x || !w16 || !gamma || !beta || !inv_scale || ((!fused || n_blocks > 8) && !tmp))
+        return fail(QZ_E_INVALID, "null argument (tmp is needed unless fused with n_blocks <= 8)");
     if ((((uintptr_t)x | (uintptr_t)tmp) & 15) != 0) return fail(QZ_E_INVALID, "tensors must be 16-byte aligned");
     for (int l = 0; l < 2 * n_blocks; l++)
         if (!w16[l] || !gamma[l] || !beta[l]) return fail(QZ_E_INVALID, "null layer tensor");
-    HIP_TRY(qzl::trunk(x, tmp, (long long)n, n_blocks, w16, gamma, beta, inv_scale, eps, fused, (hipStream_t)stream, nullptr, nullptr, nullptr, 0.f, nullptr, nullptr));
+    HIP_TRY(qzl::trunk(x, tmp, (long long)n, n_blocks, w16, gamma, beta, inv_scale, eps, fused, (hipStream_t)stream, nullptr, nullptr, nullptr, nullptr, nullptr));
     return 0;
 }
 int qz_nn_trunk_heads(const float* x, int64_t n, int n_blocks, const void* const* w16, const float* const* gamma, const float* const* beta,
-                      const float* inv_scale, const void* w6_16, float inv_scale6, const float* gamma6, const float* beta6, const float* w1t,
+                      const float* inv_scale, const void* w6_16, const float* gamma6, const float* beta6, const float* w1t,
                       const float* b1, const float* w2, const float* b2, const float* w3t, const float* b3, float* feat, float* p_out,
                       float* v_out, float eps, void* stream) {
     int r;
@@ -711,30 +790,44 @@ int qz_nn_trunk_heads(const float* x, int64_t n, int n_blocks, const void* const
     for (int l = 0; l < 2 * n_blocks; l++)
         if (!w16[l] || !gamma[l] || !beta[l]) return fail(QZ_E_INVALID, "null layer tensor");
     HIP_TRY(qzl::trunk(const_cast<float*>(x), nullptr, (long long)n, n_blocks, w16, gamma, beta, inv_scale, eps, 1, (hipStream_t)stream, w6_16, gamma6, beta6,
-                       inv_scale6, feat, nullptr));
+                       feat, nullptr));
     HIP_TRY(qzl::head_fc(feat, (long long)n, w1t, b1, w2, b2, w3t, b3, p_out, v_out, (hipStream_t)stream));
+    return 0;
+}
+static int nn_weights_check(const qz_nn_weights* w) {
+    if (!w) return fail(QZ_E_INVALID, "null weights");
+    if (w->n_blocks <= 0 || w->n_blocks > 8) return fail(QZ_E_INVALID, "n_blocks outside 1..8");
+    if (!w->hot9 || !w->base0 || !w->wd || !w->gamma0 || !w->beta0 || !w->w16 || !w->gamma || !w->beta || !w->inv_scale || !w->w6_16 || !w->gamma6 ||
+        !w->beta6 || !w->w1t || !w->b1 || !w->w2 || !w->b2 || !w->w3t || !w->b3)
+        return fail(QZ_E_INVALID, "null argument");
+    if ((((uintptr_t)w->wd | (uintptr_t)w->w6_16) & 15) != 0) return fail(QZ_E_INVALID, "wd / w6_16 must be 16-byte aligned");
+    for (int l = 0; l < 2 * w->n_blocks; l++)
+        if (!w->w16[l] || !w->gamma[l] || !w->beta[l]) return fail(QZ_E_INVALID, "null layer tensor");
+    return 0;
+}
+// boards -> (p, v) for the first n (or *n_live) boards: the fused trunk launch + the fully connected launch
+static int nn_evaluate(const uint64_t* hb, const uint64_t* vb, const uint64_t* meta, const uint8_t* terminal, int64_t n, const qz_nn_weights* w, float* feat,
+                       float* p_out, float* v_out, const int* n_live, hipStream_t s) {
+    const qzl::TrunkInput in = {hb, vb, meta, terminal, w->hot9, w->base0, w->wd, w->gamma0, w->beta0};
+    HIP_TRY(qzl::trunk(nullptr, nullptr, (long long)n, w->n_blocks, w->w16, w->gamma, w->beta, w->inv_scale, w->eps, 1, s, w->w6_16, w->gamma6, w->beta6, feat, &in,
+                       n_live));
+    HIP_TRY(qzl::head_fc(feat, (long long)n, w->w1t, w->b1, w->w2, w->b2, w->w3t, w->b3, p_out, v_out, s, n_live));
     return 0;
 }
 int qz_nn_evaluate(const qz_boards* boards, const uint8_t* terminal, int64_t n, const float* hot9, const float* base0, const float* wd,
                    const float* gamma0, const float* beta0, int n_blocks, const void* const* w16, const float* const* gamma,
-                   const float* const* beta, const float* inv_scale, const void* w6_16, float inv_scale6, const float* gamma6,
+                   const float* const* beta, const float* inv_scale, const void* w6_16, const float* gamma6,
                    const float* beta6, const float* w1t, const float* b1, const float* w2, const float* b2, const float* w3t, const float* b3,
                    float* feat, float* p_out, float* v_out, float eps, void* stream) {
     int r;
     if ((r = device_check())) return r;
-    if (n < 0 || n_blocks <= 0 || n_blocks > 8) return fail(QZ_E_INVALID, "n < 0 or n_blocks outside 1..8");
+    if (n < 0) return fail(QZ_E_INVALID, "n < 0");
+    const qz_nn_weights w = {hot9, base0, wd, gamma0, beta0, n_blocks, w16, gamma, beta, inv_scale, w6_16, gamma6, beta6, w1t, b1, w2, b2, w3t, b3, eps};
+    if ((r = nn_weights_check(&w))) return r;
     if (n == 0) return 0;
-    if (!boards || !boards->hbits || !boards->vbits || !boards->meta || !hot9 || !base0 || !wd || !gamma0 || !beta0 || !w16 || !gamma || !beta ||
-        !inv_scale || !w6_16 || !gamma6 || !beta6 || !w1t || !b1 || !w2 || !b2 || !w3t || !b3 || !feat || !p_out || !v_out)
-        return fail(QZ_E_INVALID, "null argument");
-    if ((((uintptr_t)wd | (uintptr_t)w6_16) & 15) != 0 || ((uintptr_t)feat & 7) != 0) return fail(QZ_E_INVALID, "wd / w6_16 must be 16-byte, feat 8-byte aligned");
-    for (int l = 0; l < 2 * n_blocks; l++)
-        if (!w16[l] || !gamma[l] || !beta[l]) return fail(QZ_E_INVALID, "null layer tensor");
-    const qzl::TrunkInput in = {boards->hbits, boards->vbits, boards->meta, terminal, hot9, base0, wd, gamma0, beta0};
-    HIP_TRY(qzl::trunk(nullptr, nullptr, (long long)n, n_blocks, w16, gamma, beta, inv_scale, eps, 1, (hipStream_t)stream, w6_16, gamma6, beta6, inv_scale6,
-                       feat, &in));
-    HIP_TRY(qzl::head_fc(feat, (long long)n, w1t, b1, w2, b2, w3t, b3, p_out, v_out, (hipStream_t)stream));
-    return 0;
+    if (!boards || !boards->hbits || !boards->vbits || !boards->meta || !feat || !p_out || !v_out) return fail(QZ_E_INVALID, "null argument");
+    if (((uintptr_t)feat & 7) != 0) return fail(QZ_E_INVALID, "feat must be 8-byte aligned");
+    return nn_evaluate(boards->hbits, boards->vbits, boards->meta, terminal, n, &w, feat, p_out, v_out, nullptr, (hipStream_t)stream);
 }
 int qz_engine_leaf_boards(qz_engine* e, qz_boards* boards_out, const uint8_t** terminal_out) {
     if (!e || !boards_out) return fail(QZ_E_INVALID, "null argument");
@@ -742,6 +835,70 @@ int qz_engine_leaf_boards(qz_engine* e, qz_boards* boards_out, const uint8_t** t
     boards_out->vbits = e->dev.leaf_vb;
     boards_out->meta = e->dev.leaf_meta;
     if (terminal_out) *terminal_out = e->dev.leaf_term;
+    return 0;
+}
+
+// ------------------------------------------------------------------ asynchronous self-play
+int qz_selfplay_advance(qz_engine* e, int max_playouts, int budget_us, int auto_finish, void* stream) {
+    ENGINE_CHECK(e);
+    if (max_playouts <= 0) return fail(QZ_E_INVALID, "max_playouts must be > 0");
+    const unsigned int ticks = budget_us > 0 ? (unsigned int)budget_us * 100u : 0xFFFFFFFFu;  // s_memrealtime: 100 MHz
+    HIP_TRY(qzl::advance(e->dev, e->dev_mem, max_playouts, ticks, auto_finish, e->par, (hipStream_t)stream));
+    return 0;
+}
+int qz_selfplay_leaf_rules(qz_engine* e, void* stream) {
+    ENGINE_CHECK(e);
+    const EngineDev& d = e->dev;
+    HIP_TRY(qzl::movegen_encode(d.miss_hb, d.miss_vb, d.miss_meta, d.n_boards, d.miss_mask, nullptr, nullptr, e->scratch, e->rules, (hipStream_t)stream,
+                                d.miss_count + e->par));
+    return 0;
+}
+int qz_selfplay_evaluate(qz_engine* e, const qz_nn_weights* w, void* stream) {
+    ENGINE_CHECK(e);
+    int r;
+    if ((r = nn_weights_check(w))) return r;
+    const EngineDev& d = e->dev;
+    return nn_evaluate(d.miss_hb, d.miss_vb, d.miss_meta, nullptr, d.n_boards, w, e->feat, d.miss_p, d.miss_v, d.miss_count + e->par, (hipStream_t)stream);
+}
+int qz_selfplay_round_tail(qz_engine* e, void* stream) {
+    ENGINE_CHECK(e);
+    HIP_TRY(qzl::round_tail(e->dev, e->par, (hipStream_t)stream));
+    e->par ^= 1;
+    return 0;
+}
+int qz_selfplay_round(qz_engine* e, const qz_nn_weights* w, int max_playouts, int budget_us, int auto_finish, void* stream) {
+    int r;
+    if ((r = qz_selfplay_advance(e, max_playouts, budget_us, auto_finish, stream))) return r;
+    if ((r = qz_selfplay_leaf_rules(e, stream))) return r;
+    if ((r = qz_selfplay_evaluate(e, w, stream))) return r;
+    return qz_selfplay_round_tail(e, stream);
+}
+int qz_selfplay_misses(qz_engine* e, qz_boards* boards_out, const int32_t** n_dev_out, uint32_t** mask5_out, float** p_out, float** v_out) {
+    if (!e) return fail(QZ_E_INVALID, "null engine");
+    if (boards_out) {
+        boards_out->hbits = e->dev.miss_hb;
+        boards_out->vbits = e->dev.miss_vb;
+        boards_out->meta = e->dev.miss_meta;
+    }
+    if (n_dev_out) *n_dev_out = e->dev.miss_count + e->par;
+    if (mask5_out) *mask5_out = e->dev.miss_mask;
+    if (p_out) *p_out = e->dev.miss_p;
+    if (v_out) *v_out = e->dev.miss_v;
+    return 0;
+}
+int qz_memo_flush(qz_engine* e, void* stream) {
+    ENGINE_CHECK(e);
+    if (!e->dev.memo.small) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (++e->flushes >= 0xFFF0u) {  // the 16-bit epoch is about to wrap: really clear the tables and start over
+        const uint32_t zero = 0u;
+        HIP_TRY(hipMemsetAsync(e->dev.memo.small, 0, e->memo_small_bytes, s));
+        HIP_TRY(hipMemsetAsync(e->dev.memo.big, 0, e->memo_big_bytes, s));
+        HIP_TRY(hipMemcpyAsync(e->dev.memo.epoch, &zero, sizeof(zero), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        e->flushes = 1;
+    }
+    HIP_TRY(qzl::memo_flush(e->dev, s));
     return 0;
 }
 

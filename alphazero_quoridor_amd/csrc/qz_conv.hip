@@ -87,8 +87,9 @@ template <bool RES, bool RELU>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_conv3x3_norm(const float* __restrict__ x, const _Float16* __restrict__ w16,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       const float* __restrict__ residual, float* __restrict__ out, long long n,
-                                                      float inv_scale, float eps) {
+                                                      const float* __restrict__ inv_scale_p, float eps) {
     __shared__ ConvShared sm;
+    const float inv_scale = *inv_scale_p;  // device memory: a captured launch follows the weights (LeafEvaluator.refresh)
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int nt = wave & 1, mg = wave >> 1;
@@ -252,7 +253,7 @@ struct TrunkArgs {
     const _Float16* w16[MAX_TRUNK_LAYERS];
     const float* gamma[MAX_TRUNK_LAYERS];
     const float* beta[MAX_TRUNK_LAYERS];
-    float inv_scale[MAX_TRUNK_LAYERS];
+    const float* inv_scale;  // [dev] [n_layers] (+ the head stage's at [n_layers]): 1 / the power-of-two scale of each layer's weight image
 };
 struct TrunkShared {
     half8 a_hi[ROWS * RV];  // one leaf: 81 positions + the all-zero row, 144-byte rows
@@ -271,8 +272,7 @@ struct HeadArgs {
     const _Float16* w6;   // [2][9][4][32][16] fp16 hi | lo of W6 * scale, columns 6..31 zero
     const float* gamma6;  // [6]
     const float* beta6;   // [6]
-    float inv_scale6;
-    float* feat;          // [n][486] out; nullptr = no head stage
+    float* feat;          // [n][486] out; nullptr = no head stage (its 1 / scale is TrunkArgs.inv_scale[n_layers])
     int role_shift;       // head stage: workgroups with bit `role_shift` of their index set give the two-tile share to wave 1 (>= 31: never)
 };
 
@@ -287,12 +287,14 @@ struct InputArgs {
     const float *gamma0, *beta0;     // bn1
 };
 template <bool FROM_BOARD>
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_trunk(const float* __restrict__ x, float* __restrict__ out, TrunkArgs A, int n_layers, float eps, HeadArgs H, InputArgs I
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_trunk(const float* __restrict__ x, float* __restrict__ out, TrunkArgs A, int n_layers, float eps, HeadArgs H, InputArgs I,
+                                               const int* __restrict__ n_live  // or nullptr: only the first *n_live leaves are evaluated (the engine's miss list)
 #ifdef QZ_TRUNK_STAMPS
                                                , unsigned long long* stamps  // [workgroup][wave][8]: diagnostic build only
 #endif
                                                ) {
     __shared__ TrunkShared sm;
+    if (n_live && (int)blockIdx.x >= __builtin_amdgcn_readfirstlane(*n_live)) return;
     const int tid = (int)threadIdx.x, lane = tid & 63, nt = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int co = 32 * nt + r;
@@ -629,7 +631,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // per-leaf statistics of head channel r over the 81 rows: this wave's rows, the lane halves by shuffle,
         // the two waves through LDS
         const int row0 = (role ? 64 : 0) + 4 * h;
-        const float is6 = H.inv_scale6;
+        const float is6 = A.inv_scale[n_layers];
         float s0 = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; i++) {
@@ -682,7 +684,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 namespace qzl {
 hipError_t conv3x3_norm(const float* x, const void* w16, const float* gamma, const float* beta, const float* residual, float* out,
-                        long long n, float inv_scale, int relu, float eps, hipStream_t s) {
+                        long long n, const float* inv_scale, int relu, float eps, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     const dim3 grid((unsigned)((n + CS - 1) / CS));
     const _Float16* w = reinterpret_cast<const _Float16*>(w16);
@@ -702,24 +704,23 @@ struct TrunkInput {
 // launch and the trunk output is NOT written back to x.  in != nullptr (fused route only): the first layer is computed
 // from the packed boards in the same launch and x is not read (may be NULL)
 hipError_t trunk(float* x, float* tmp, long long n, int n_blocks, const void* const* w16, const float* const* gamma, const float* const* beta,
-                 const float* inv_scale, float eps, int fused, hipStream_t s, const void* w6 = nullptr, const float* gamma6 = nullptr,
-                 const float* beta6 = nullptr, float inv_scale6 = 0.f, float* feat = nullptr, const TrunkInput* in = nullptr) {
+                 const float* inv_scale /*[dev]*/, float eps, int fused, hipStream_t s, const void* w6 = nullptr, const float* gamma6 = nullptr,
+                 const float* beta6 = nullptr, float* feat = nullptr, const TrunkInput* in = nullptr, const int* n_live = nullptr) {
     if (n <= 0 || n_blocks <= 0) return hipSuccess;
     const int nl = 2 * n_blocks;
-    if ((feat || in) && !(fused && nl <= MAX_TRUNK_LAYERS)) return hipErrorInvalidValue;
+    if ((feat || in || n_live) && !(fused && nl <= MAX_TRUNK_LAYERS)) return hipErrorInvalidValue;
     if (fused && nl <= MAX_TRUNK_LAYERS) {  // one persistent launch: activations stay on the CU
         TrunkArgs A;
         for (int l = 0; l < nl; l++) {
             A.w16[l] = reinterpret_cast<const _Float16*>(w16[l]);
             A.gamma[l] = gamma[l];
             A.beta[l] = beta[l];
-            A.inv_scale[l] = inv_scale[l];
         }
         for (int l = nl; l < MAX_TRUNK_LAYERS; l++) {
             A.w16[l] = nullptr;
             A.gamma[l] = A.beta[l] = nullptr;
-            A.inv_scale[l] = 0.f;
         }
+        A.inv_scale = inv_scale;
 #ifdef QZ_TRUNK_STAMPS
         return hipErrorNotSupported;  // the diagnostic build launches the kernel itself (tests/hip/qz_conv_stamps.hip)
 #else
@@ -727,21 +728,20 @@ hipError_t trunk(float* x, float* tmp, long long n, int n_blocks, const void* co
         H.w6 = reinterpret_cast<const _Float16*>(w6);
         H.gamma6 = gamma6;
         H.beta6 = beta6;
-        H.inv_scale6 = inv_scale6;
         H.feat = feat;
         H.role_shift = 0;  // odd workgroups swap the roles: 787 -> 779 us for 4,096 leaves (shifts 1..8 and none measured: 783..791)
         InputArgs I = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         if (in) I = InputArgs{in->hb, in->vb, in->meta, in->terminal, in->hot9, in->base0, in->wd, in->gamma0, in->beta0};
-        if (in) hipLaunchKernelGGL(k_trunk<true>, dim3((unsigned)n), dim3(128), 0, s, x, feat ? nullptr : x, A, nl, eps, H, I);
-        else hipLaunchKernelGGL(k_trunk<false>, dim3((unsigned)n), dim3(128), 0, s, x, feat ? nullptr : x, A, nl, eps, H, I);
+        if (in) hipLaunchKernelGGL(k_trunk<true>, dim3((unsigned)n), dim3(128), 0, s, x, feat ? nullptr : x, A, nl, eps, H, I, n_live);
+        else hipLaunchKernelGGL(k_trunk<false>, dim3((unsigned)n), dim3(128), 0, s, x, feat ? nullptr : x, A, nl, eps, H, I, n_live);
         return hipGetLastError();
 #endif
     }
     for (int b = 0; b < n_blocks; b++) {
         // y = relu(bn1(conv1(x)));  x = relu(bn2(conv2(y)) + x)   (policy_value_net.py:33-48)
-        hipError_t e = conv3x3_norm(x, w16[2 * b], gamma[2 * b], beta[2 * b], nullptr, tmp, n, inv_scale[2 * b], 1, eps, s);
+        hipError_t e = conv3x3_norm(x, w16[2 * b], gamma[2 * b], beta[2 * b], nullptr, tmp, n, inv_scale + 2 * b, 1, eps, s);
         if (e != hipSuccess) return e;
-        e = conv3x3_norm(tmp, w16[2 * b + 1], gamma[2 * b + 1], beta[2 * b + 1], x, x, n, inv_scale[2 * b + 1], 1, eps, s);
+        e = conv3x3_norm(tmp, w16[2 * b + 1], gamma[2 * b + 1], beta[2 * b + 1], x, x, n, inv_scale + 2 * b + 1, 1, eps, s);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;

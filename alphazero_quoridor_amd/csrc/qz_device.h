@@ -67,6 +67,10 @@ enum {
     QZ_C_DEEP_COLD,         // ... whose board's previous descent record was shorter than half of that
     QZ_C_DEEP_LEVELS,       // ... their levels
     QZ_C_DEEP_REPLAYED,     // ... of which the replay of the recorded descent confirmed this many
+    QZ_C_ROUNDS,            // k_advance launches (asynchronous self-play)
+    QZ_C_MEMO_INSERTS,      // evaluations stored in the memo
+    QZ_C_MEMO_LOCKED,       // ... skipped because another wave held the bucket's lock
+    QZ_C_RUNAWAY,           // descents cut off because they were deeper than a tree can be (corrupted storage; must stay 0)
     QZ_C_COUNT
 };
 // pool bookkeeping words (int): free-stack tops and low-water marks
@@ -95,8 +99,33 @@ struct RulesOpts {
     int enc_split_pct = 50;                  // share of the encoder tiles beside the path groups
 };
 
+// Leaf-evaluation memo.  policy_value_fn on a batch of one (policy_value_net.py:145-164, BatchNorm in training mode)
+// is a pure function of the 24-byte board, and a long game revisits the same few thousand boards millions of times
+// (profiles/round3/leaf_duplicates_*.json), so (legal set, priors at the pawn moves / all moves, value) are kept per
+// board, keyed on ALL 24 bytes + the weight epoch: a hit returns exactly the bits the evaluation would produce.
+//   small table: leaves whose mover has no wall left (<= 12 pawn moves): buckets of 4 entries x 32 dwords (512 B, one
+//                coalesced load per probe):  [0..5] hb, vb, meta | epoch << 48   [6] v   [7] legal pawn bits
+//                [8..19] p of pawn codes 0..11   [31] of entry 0: the bucket's insert lock
+//   big table:   every other live leaf: buckets of 2 entries x 160 dwords (640 B): [0..5] key  [6] v  [8..12] mask5
+//                [15] of entry 0: lock   [16..155] p[140]
+// Probes (k_advance) and inserts (k_round_tail) never run at the same time (same stream, different launches), so
+// readers need no protocol; concurrent inserters of one bucket exclude each other through the lock word (the loser
+// skips its insert: the memo is a cache).
+#define QZ_MEMO_S_DW 32
+#define QZ_MEMO_S_WAYS 4
+#define QZ_MEMO_B_DW 160
+#define QZ_MEMO_B_WAYS 2
+struct MemoDev {
+    uint32_t* small;      // [small_buckets][4][32]
+    uint32_t* big;        // [big_buckets][2][160]
+    uint32_t small_mask;  // buckets - 1 (a power of two); tables == nullptr: memo off
+    uint32_t big_mask;
+    uint32_t* epoch;      // [1] device word: entries of other epochs are dead (qz_memo_flush: the weights changed)
+};
+
 struct EngineDev {
     int n_boards, node_cap, edge_cap, max_plies;
+    int n_playout;
     int tree_pool_pages, traj_pool_pages;
     uint32_t traj_page_dwords;
     float c_puct, temp, dirichlet_alpha, noise_frac;
@@ -136,6 +165,18 @@ struct EngineDev {
     // boards of a step on one address (~88 atomics/us on MI355X); summed by qz_engine_stats
     uint32_t *bc_playouts, *bc_terminal, *bc_overflow, *bc_nonfinite, *bc_maxdepth;
     unsigned long long *bc_levels, *bc_scanned, *bc_expanded;  // tree levels walked, edge records read by k_select, edges created
+    // asynchronous self-play (k_advance): every board runs playouts on its own until it meets a leaf that needs the
+    // network (a memo miss); those leaves are compacted into the miss list, evaluated as one batch, and consumed by the
+    // next launch.  A board that has done n_playout playouts plays its move in the same launch.
+    MemoDev memo;
+    uint32_t* pl_done;        // [B] playouts done on the current root
+    uint32_t* pend_slot;      // [B] miss-list slot of the leaf this board waits for, QZ_NONE = none
+    int* miss_count;          // [1] slots used by this round's misses
+    uint64_t *miss_hb, *miss_vb, *miss_meta;  // [B] the leaves awaiting evaluation, compacted
+    uint32_t* miss_mask;      // [B][5] their legal sets (rules op on the miss list)
+    float *miss_p, *miss_v;   // [B][140], [B] the network's output per slot
+    uint32_t *bc_memo_hits, *bc_evals;  // [B] leaves answered by the memo / sent to the network
+    uint32_t *bc_open_rounds, *bc_open_plies;  // [B] launches / plies with a root whose mover still has walls
 };
 
 #if defined(__HIPCC__)

@@ -170,9 +170,13 @@ template <int NBE, int G, bool COOP>
 __global__ __launch_bounds__(256) void k_wave_rules(const uint64_t* __restrict__ hb, const uint64_t* __restrict__ vb,
                                                     const uint64_t* __restrict__ meta, int n, const uint8_t* __restrict__ terminal,
                                                     uint32_t* __restrict__ mask5, float* __restrict__ planes, int n_mg_groups,
-                                                    int detour_mode) {
+                                                    int detour_mode, const int* __restrict__ n_dev) {
     __shared__ WaveRulesShared<NBE, G> sm;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (n_dev) {  // the batch is the first *n_dev boards (the engine's miss list: its length is only known on the device)
+        const int nd = __builtin_amdgcn_readfirstlane(*n_dev);
+        n = nd < n ? nd : n;
+    }
     if ((int)blockIdx.x < n_mg_groups) {
         const int bw = ((int)blockIdx.x * WPB + wave) * G;  // first board of this wave
         if (bw >= n) return;  // whole wave leaves; only wave-level synchronisation below
@@ -627,7 +631,7 @@ __device__ unsigned int g_sel_stamps[64][4096][8];
 #define QZ_SEL_MARK(acc)
 #define QZ_SEL_COUNT(x)
 #endif
-__device__ __forceinline__ void select_board(EngineDev& E, const int b, const int lane) {
+__device__ __forceinline__ void select_board(EngineDev& E, const int b, const int lane, Board* leaf_out = nullptr, uint32_t* term_out = nullptr) {
 #ifdef QZ_SELECT_STAMPS
     unsigned long long t_mark = __builtin_amdgcn_s_memtime();
     const unsigned long long t_begin = t_mark;
@@ -824,6 +828,10 @@ __device__ __forceinline__ void select_board(EngineDev& E, const int b, const in
             plen++;
             const int cne = (int)((misc >> 8) & 0xFFu);
             if (cne == 0) break;  // TreeNode.is_leaf(): never expanded (or terminal)
+            if (plen > (uint32_t)QZ_TREE_PT * QZ_PAGE_EDGES) {  // deeper than a tree has edges: a cycle, i.e. corrupted storage.  Never hang the GPU
+                if (lane == 0) atomicAdd(&E.counters[QZ_C_RUNAWAY], 1ull);
+                break;
+            }
             sq = rdl_f64(mSq, wl);
             base = tree_phys(T, rdl(mCOff, wl));
             ne = cne;
@@ -892,17 +900,19 @@ __device__ __forceinline__ void select_board(EngineDev& E, const int b, const in
         o[4] = n_narrow; o[5] = n_wide; o[6] = plen; o[7] = replayed;
     }
 #endif
+    // 0 live leaf; 1 terminal & winner == current_player; 2 terminal & winner != current_player;
+    // 3 board not playing (finished, waiting for harvest): ignored by expand_backup
+    uint8_t t = 0;
+    if (!live) t = 3;
+    else if (done) t = (winner_of(bd) == bd.cur) ? 1 : 2;
+    if (leaf_out) *leaf_out = bd;
+    if (term_out) *term_out = (uint32_t)t;
     if (lane == 0) {
         E.leaf_hb[b] = bd.hb;
         E.leaf_vb[b] = bd.vb;
         E.leaf_meta[b] = pack_meta(bd);
         E.leaf_pedge[b] = pedge;
         E.path_len[b] = plen;
-        // 0 live leaf; 1 terminal & winner == current_player; 2 terminal & winner != current_player;
-        // 3 board not playing (finished, waiting for harvest): ignored by expand_backup
-        uint8_t t = 0;
-        if (!live) t = 3;
-        else if (done) t = (winner_of(bd) == bd.cur) ? 1 : 2;
         E.leaf_term[b] = t;
         if (nonfinite) E.bc_nonfinite[b] += 1u;
         E.bc_scanned[b] += (unsigned long long)scanned;
@@ -923,75 +933,66 @@ __global__ __launch_bounds__(TPB) void k_select(EngineDev E) {
     select_board(E, b, lane);
 }
 
-// TreeNode.expand (mcts.py:27-35) + update_recursive (mcts.py:44-62)
-__device__ __forceinline__ void expand_backup_board(EngineDev& E, const float* __restrict__ p, const float* __restrict__ v, const int b, const int lane) {
-    uint32_t term = rfl(E.leaf_term[b]);
-    if (term == 3u) return;
-    const uint32_t pedge = rfl(E.leaf_pedge[b]);
-    double leaf_value;
-    if (term == 0u) {
-        leaf_value = (double)v[b];
-        uint32_t m0 = rfl(E.leaf_mask[(size_t)b * 5 + 0]), m1 = rfl(E.leaf_mask[(size_t)b * 5 + 1]),
-                 m2 = rfl(E.leaf_mask[(size_t)b * 5 + 2]), m3 = rfl(E.leaf_mask[(size_t)b * 5 + 3]),
-                 m4 = rfl(E.leaf_mask[(size_t)b * 5 + 4]);
-        uint32_t pawn = m0 & 0xFFFu;
-        uint64_t lh = ((uint64_t)m0 >> 12) | ((uint64_t)m1 << 20) | ((uint64_t)(m2 & 0xFFFu) << 52);
-        uint64_t lv = ((uint64_t)m2 >> 12) | ((uint64_t)m3 << 20) | ((uint64_t)(m4 & 0xFFFu) << 52);
-        int k = __popc(pawn) + __popcll(lh) + __popcll(lv);
-        if (k > 0) {
-            const uint32_t half = rfl(E.tree_half[b]);
-            const size_t slot = tree_slot(E, b, half);
-            TreeView T = tree_view(E, b, half, lane);
-            uint32_t nn = rfl(E.n_nodes[b]), neu = rfl(E.n_edges[b]), np = rfl(E.tree_npages[slot]);
-            uint32_t off = QZ_NONE;
-            if (E.node_cap <= 0 || nn < (uint32_t)E.node_cap) off = tree_alloc(E, T, neu, np, k, lane, false);
-            if (off != QZ_NONE) {
-                const uint32_t base = tree_phys(T, off);
-                for (int a = lane; a < QZ_N_ACT; a += 64) {
-                    uint32_t w = a < 32 ? m0 : (a < 64 ? m1 : (a < 96 ? m2 : (a < 128 ? m3 : m4)));
-                    if ((w >> (a & 31)) & 1u) {
-                        uint32_t e = base + (uint32_t)order_index(pawn, lh, lv, a);
-                        Edge ed;
-                        ed.Q = 0.0;
-                        ed.N = 0u;
-                        ed.P = p[(size_t)b * QZ_N_ACT + a];
-                        ed.pedge = pedge;
-                        ed.coff = 0u;
-                        ed.act = (uint8_t)a;
-                        ed.cne = 0;
-                        ed.rid = 0;
-                        ed.spare = QZ_NONE;
-                        T.pool[e] = ed;
-                    }
+// TreeNode.expand (mcts.py:27-35): a block of k edges in actions() order under physical edge `pedge` (QZ_NONE: the
+// root), priors from prior(a) -- called by the lane that owns action a (a = lane, lane + 64, lane + 128).
+template <typename PriorFn>
+__device__ __forceinline__ void expand_node(EngineDev& E, const int b, const int lane, const uint32_t pedge, const uint32_t m0,
+                                            const uint32_t m1, const uint32_t m2, const uint32_t m3, const uint32_t m4, PriorFn prior) {
+    uint32_t pawn = m0 & 0xFFFu;
+    uint64_t lh = ((uint64_t)m0 >> 12) | ((uint64_t)m1 << 20) | ((uint64_t)(m2 & 0xFFFu) << 52);
+    uint64_t lv = ((uint64_t)m2 >> 12) | ((uint64_t)m3 << 20) | ((uint64_t)(m4 & 0xFFFu) << 52);
+    int k = __popc(pawn) + __popcll(lh) + __popcll(lv);
+    if (k > 0) {
+        const uint32_t half = rfl(E.tree_half[b]);
+        const size_t slot = tree_slot(E, b, half);
+        TreeView T = tree_view(E, b, half, lane);
+        uint32_t nn = rfl(E.n_nodes[b]), neu = rfl(E.n_edges[b]), np = rfl(E.tree_npages[slot]);
+        uint32_t off = QZ_NONE;
+        if (E.node_cap <= 0 || nn < (uint32_t)E.node_cap) off = tree_alloc(E, T, neu, np, k, lane, false);
+        if (off != QZ_NONE) {
+            const uint32_t base = tree_phys(T, off);
+            for (int a = lane; a < QZ_N_ACT; a += 64) {
+                uint32_t w = a < 32 ? m0 : (a < 64 ? m1 : (a < 96 ? m2 : (a < 128 ? m3 : m4)));
+                if ((w >> (a & 31)) & 1u) {
+                    uint32_t e = base + (uint32_t)order_index(pawn, lh, lv, a);
+                    Edge ed;
+                    ed.Q = 0.0;
+                    ed.N = 0u;
+                    ed.P = prior(a);
+                    ed.pedge = pedge;
+                    ed.coff = 0u;
+                    ed.act = (uint8_t)a;
+                    ed.cne = 0;
+                    ed.rid = 0;
+                    ed.spare = QZ_NONE;
+                    T.pool[e] = ed;
                 }
-                if (lane == 0) {
-                    if (pedge != QZ_NONE) {
-                        T.pool[pedge].coff = off;
-                        T.pool[pedge].cne = (uint8_t)k;
-                    } else {
-                        E.root_eoff[b] = off;
-                        E.root_ne[b] = (uint32_t)k;
-                    }
-                    E.n_nodes[b] = nn + 1u;
-                    E.n_edges[b] = neu;
-                    E.tree_npages[slot] = np;
-                    E.bc_expanded[b] += (unsigned long long)k;
-                }
-            } else if (lane == 0) {
-                E.bc_overflow[b] += 1u;
-                E.tree_npages[slot] = np;
             }
+            if (lane == 0) {
+                if (pedge != QZ_NONE) {
+                    T.pool[pedge].coff = off;
+                    T.pool[pedge].cne = (uint8_t)k;
+                } else {
+                    E.root_eoff[b] = off;
+                    E.root_ne[b] = (uint32_t)k;
+                }
+                E.n_nodes[b] = nn + 1u;
+                E.n_edges[b] = neu;
+                E.tree_npages[slot] = np;
+                E.bc_expanded[b] += (unsigned long long)k;
+            }
+        } else if (lane == 0) {
+            E.bc_overflow[b] += 1u;
+            E.tree_npages[slot] = np;
         }
-    } else {
-        // mcts.py:125: +1 if winner == current_player else -1 (always +1 in practice: the
-        // reference does not rotate players on a terminal move)
-        leaf_value = (term == 1u) ? 1.0 : -1.0;
-        if (E.fix_terminal_sign) leaf_value = -leaf_value;
     }
-    // node.update_recursive(-leaf_value) (mcts.py:44-62, 127): the leaf edge gets -leaf_value, its
-    // parent +leaf_value, ... up to the root.  The descent recorded its edges, so all levels are
-    // updated in parallel (lane = level); a path longer than the record falls back to walking
-    // the parent links.
+}
+// node.update_recursive(-leaf_value) (mcts.py:44-62, 127): the leaf edge gets -leaf_value, its
+// parent +leaf_value, ... up to the root.  The descent recorded its edges, so all levels are
+// updated in parallel (lane = level); a path longer than the record falls back to walking
+// the parent links.  term: the leaf's E.leaf_term code (statistics only).
+__device__ __forceinline__ void backup_leaf(EngineDev& E, const int b, const int lane, const double leaf_value, const uint32_t pedge,
+                                            const uint32_t term) {
     Edge* pool = E.edge_pool;
     const uint32_t plen = rfl(E.path_len[b]);
     if (plen <= (uint32_t)QZ_PATH_CAP) {
@@ -1024,6 +1025,34 @@ __device__ __forceinline__ void expand_backup_board(EngineDev& E, const float* _
         E.bc_levels[b] += (unsigned long long)plen;
         if (term != 0u) E.bc_terminal[b] += 1u;
     }
+}
+// mcts.py:125: +1 if winner == current_player else -1 (always +1 in practice: the reference does not rotate players
+// on a terminal move); term = 1 | 2 (E.leaf_term)
+__device__ __forceinline__ double terminal_value(const EngineDev& E, const uint32_t term) {
+    double leaf_value = (term == 1u) ? 1.0 : -1.0;
+    if (E.fix_terminal_sign) leaf_value = -leaf_value;
+    return leaf_value;
+}
+// TreeNode.expand + update_recursive of board b's current leaf with the network's output row `prow` / value `vval` and
+// the legal set `mask` (5 words); terminal leaves ignore all three
+__device__ __forceinline__ void expand_backup_with(EngineDev& E, const uint32_t* __restrict__ mask, const float* __restrict__ prow,
+                                                   const float vval, const int b, const int lane) {
+    uint32_t term = rfl(E.leaf_term[b]);
+    if (term == 3u) return;
+    const uint32_t pedge = rfl(E.leaf_pedge[b]);
+    double leaf_value;
+    if (term == 0u) {
+        leaf_value = (double)vval;
+        expand_node(E, b, lane, pedge, rfl(mask[0]), rfl(mask[1]), rfl(mask[2]), rfl(mask[3]), rfl(mask[4]),
+                    [&](int a) { return prow[a]; });
+    } else {
+        leaf_value = terminal_value(E, term);
+    }
+    backup_leaf(E, b, lane, leaf_value, pedge, term);
+}
+__device__ __forceinline__ void expand_backup_board(EngineDev& E, const float* __restrict__ p, const float* __restrict__ v, const int b, const int lane) {
+    if (rfl(E.leaf_term[b]) == 3u) return;
+    expand_backup_with(E, E.leaf_mask + (size_t)b * 5, p + (size_t)b * QZ_N_ACT, v[b], b, lane);
 }
 
 __global__ __launch_bounds__(TPB) void k_expand_backup(EngineDev E, const float* __restrict__ p, const float* __restrict__ v) {
@@ -1258,6 +1287,7 @@ __device__ __forceinline__ void wave_reroot(EngineDev& E, int b, int lane, uint3
             E.tree_npages[tree_slot(E, b, half ^ 1u)] = dnp;
         }
         E.path_len[b] = 0u;
+        E.pl_done[b] = 0u;  // (asynchronous self-play: playouts on the new root)
         E.n_nodes[b] = new_nodes;
         E.n_edges[b] = new_edges;
         E.root_N[b] = childN;
@@ -1284,6 +1314,8 @@ __device__ __forceinline__ void reset_board_state(EngineDev& E, int b) {
     E.status[b] = QZ_PLAYING;
     E.winner[b] = 0;
     E.release[b] = 0;
+    E.pl_done[b] = 0u;
+    E.pend_slot[b] = QZ_NONE;
     E.game_serial[b] = E.game_serial[b] + 1u;
 }
 
@@ -1307,6 +1339,8 @@ __global__ __launch_bounds__(TPB) void k_reset(EngineDev E, int reset_boards) {
         E.path_len[b] = 0u;
         for (int r = 0; r < QZ_PATH_RECS; r++) E.rec_len[(size_t)b * QZ_PATH_RECS + r] = 0u;
         E.release[b] = 0;
+        E.pl_done[b] = 0u;
+        E.pend_slot[b] = QZ_NONE;
     }
 }
 
@@ -1396,11 +1430,8 @@ __device__ double gamma_small(const Philox& ph, uint32_t c0, uint32_t c1, uint32
 
 // MCTSPlayer.choose_action tail + one iteration of start_self_play (mcts.py:174-187,
 // quoridor.py:585-602).  POP-ONLY (trajectory page, pages of the re-rooted tree).
-__global__ __launch_bounds__(TPB) void k_finish_move(EngineDev E, const uint8_t* __restrict__ forced, float* __restrict__ pi_out,
-                                                     uint8_t* __restrict__ move_out) {
-    const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
-    const int b = (int)blockIdx.x * WPB + wave;
-    if (b >= E.n_boards) return;
+__device__ __forceinline__ void finish_move_board(EngineDev& E, const int b, const int lane, const uint8_t* __restrict__ forced,
+                                                  float* __restrict__ pi_out, uint8_t* __restrict__ move_out) {
     if (move_out && lane == 0) move_out[b] = QZ_NO_MOVE_U8;
     if (pi_out)
         for (int a = lane; a < QZ_N_ACT; a += 64) pi_out[(size_t)b * QZ_N_ACT + a] = 0.f;
@@ -1560,6 +1591,293 @@ __global__ __launch_bounds__(TPB) void k_finish_move(EngineDev E, const uint8_t*
         }
     }
 }
+// the same as a real call (k_advance: inlined there it would set the whole kernel's register count -- 223 VGPRs, two waves
+// per SIMD -- for code that runs once per n_playout playouts).  Ed: the engine's EngineDev in device memory.
+__device__ __forceinline__ void finish_move_call(const EngineDev* __restrict__ Ed, const int b, const int lane) {
+    EngineDev E = *Ed;
+    finish_move_board(E, b, lane, nullptr, nullptr, nullptr);
+}
+__global__ __launch_bounds__(TPB) void k_finish_move(EngineDev E, const uint8_t* __restrict__ forced, float* __restrict__ pi_out,
+                                                     uint8_t* __restrict__ move_out) {
+    const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+    const int b = (int)blockIdx.x * WPB + wave;
+    if (b >= E.n_boards) return;
+    finish_move_board(E, b, lane, forced, pi_out, move_out);
+}
+
+// ---------------------------------------------------------------------------- leaf-evaluation memo
+// (layout: qz_device.h, MemoDev)
+__device__ __forceinline__ uint64_t memo_hash(uint64_t hb, uint64_t vb, uint64_t meta) {
+    uint64_t x = (hb * 0x9E3779B97F4A7C15ull) ^ ((vb + 0xD1B54A32D192ED03ull) * 0xC2B2AE3D27D4EB4Full) ^ (meta * 0x165667B19E3779F9ull);
+    x ^= x >> 32;
+    x *= 0xD6E8FEB86659FD93ull;
+    x ^= x >> 32;
+    x *= 0xD6E8FEB86659FD93ull;
+    x ^= x >> 32;
+    return x;
+}
+// the key dword a lane compares its loaded dword with: entry dwords 0..5 = hb, vb, meta | epoch << 48
+__device__ __forceinline__ uint32_t memo_key_dword(int pos, uint64_t hb, uint64_t vb, uint64_t mk) {
+    return pos == 0 ? (uint32_t)hb : (pos == 1 ? (uint32_t)(hb >> 32) : (pos == 2 ? (uint32_t)vb : (pos == 3 ? (uint32_t)(vb >> 32) : (pos == 4 ? (uint32_t)mk : (uint32_t)(mk >> 32)))));
+}
+__device__ __forceinline__ bool memo_is_small(const Board& bd) { return (bd.cur == 1 ? bd.w1 : bd.w2) <= 0; }
+struct MemoHit {
+    uint32_t m0, m1, m2, m3, m4;  // the legal set
+    float v;
+    float p_lane;        // small table: the prior of pawn code `lane` (lane < 12)
+    const float* p_row;  // big table: p[140]; nullptr for a small-table hit
+};
+// one coalesced load of the bucket, key compare by ballot.  All lanes must call.
+__device__ __forceinline__ bool memo_probe(const EngineDev& E, const Board& bd, const int lane, MemoHit& H) {
+    if (!E.memo.small) return false;
+    const uint64_t hb = bd.hb, vb = bd.vb, mk = pack_meta(bd) | ((uint64_t)rfl(*E.memo.epoch) << 48);
+    const uint64_t h = memo_hash(hb, vb, pack_meta(bd));
+    const int pos = lane & 31;
+    const uint32_t kd = memo_key_dword(pos, hb, vb, mk);
+    if (memo_is_small(bd)) {
+        const uint32_t* B = E.memo.small + (size_t)((uint32_t)h & E.memo.small_mask) * (QZ_MEMO_S_WAYS * QZ_MEMO_S_DW);
+        const uint32_t d0 = B[lane], d1 = B[lane + 64];
+        const uint64_t e0 = __ballot(pos >= 6 || d0 == kd), e1 = __ballot(pos >= 6 || d1 == kd);
+        int e = -1;
+        if ((uint32_t)e0 == 0xFFFFFFFFu) e = 0;
+        else if ((uint32_t)(e0 >> 32) == 0xFFFFFFFFu) e = 1;
+        else if ((uint32_t)e1 == 0xFFFFFFFFu) e = 2;
+        else if ((uint32_t)(e1 >> 32) == 0xFFFFFFFFu) e = 3;
+        if (e < 0) return false;
+        const uint32_t d = (e & 2) ? d1 : d0;
+        const int base = (e & 1) * 32;
+        H.v = __uint_as_float(rdl(d, base + 6));
+        H.m0 = rdl(d, base + 7);
+        H.m1 = H.m2 = H.m3 = H.m4 = 0u;
+        H.p_lane = __uint_as_float((uint32_t)__shfl((int)d, base + 8 + (lane < 12 ? lane : 0), 64));
+        H.p_row = nullptr;
+        return true;
+    }
+    const uint32_t* B = E.memo.big + (size_t)((uint32_t)h & E.memo.big_mask) * (QZ_MEMO_B_WAYS * QZ_MEMO_B_DW);
+    const bool in = pos < 16;
+    const uint32_t d = in ? B[(lane >> 5) * QZ_MEMO_B_DW + pos] : 0u;
+    const uint64_t e0 = __ballot(pos >= 6 || d == kd);
+    int e = -1;
+    if ((uint32_t)e0 == 0xFFFFFFFFu) e = 0;
+    else if ((uint32_t)(e0 >> 32) == 0xFFFFFFFFu) e = 1;
+    if (e < 0) return false;
+    const int base = e * 32;
+    H.v = __uint_as_float(rdl(d, base + 6));
+    H.m0 = rdl(d, base + 8);
+    H.m1 = rdl(d, base + 9);
+    H.m2 = rdl(d, base + 10);
+    H.m3 = rdl(d, base + 11);
+    H.m4 = rdl(d, base + 12);
+    H.p_lane = 0.f;
+    H.p_row = reinterpret_cast<const float*>(B + e * QZ_MEMO_B_DW + 16);
+    return true;
+}
+// store one evaluation (wave-cooperative; k_round_tail only: no probe runs at the same time)
+__device__ __forceinline__ void memo_insert(const EngineDev& E, const uint64_t hb, const uint64_t vb, const uint64_t meta, const uint32_t* __restrict__ mask,
+                                            const float* __restrict__ prow, const float v, const int lane) {
+    if (!E.memo.small) return;
+    const uint32_t epoch = rfl(*E.memo.epoch);
+    const uint64_t mk = meta | ((uint64_t)epoch << 48);
+    const uint64_t h = memo_hash(hb, vb, meta);
+    const int pos = lane & 31;
+    const uint32_t kd = memo_key_dword(pos, hb, vb, mk);
+    const Board bd = unpack(hb, vb, meta);
+    uint32_t* B;
+    int way;
+    uint32_t* lock;
+    if (memo_is_small(bd)) {
+        B = E.memo.small + (size_t)((uint32_t)h & E.memo.small_mask) * (QZ_MEMO_S_WAYS * QZ_MEMO_S_DW);
+        const uint32_t d0 = B[lane], d1 = B[lane + 64];
+        const uint64_t e0 = __ballot(pos >= 6 || d0 == kd), e1 = __ballot(pos >= 6 || d1 == kd);
+        if ((uint32_t)e0 == 0xFFFFFFFFu || (uint32_t)(e0 >> 32) == 0xFFFFFFFFu || (uint32_t)e1 == 0xFFFFFFFFu || (uint32_t)(e1 >> 32) == 0xFFFFFFFFu) return;
+        // first way of another epoch (empty / flushed), else a way picked by the hash
+        const uint64_t l0 = __ballot(pos == 5 && (d0 >> 16) == epoch), l1 = __ballot(pos == 5 && (d1 >> 16) == epoch);
+        const uint32_t livem = (uint32_t)((l0 >> 5) & 1ull) | ((uint32_t)((l0 >> 37) & 1ull) << 1) | ((uint32_t)((l1 >> 5) & 1ull) << 2) | ((uint32_t)((l1 >> 37) & 1ull) << 3);
+        way = livem == 0xFu ? (int)((h >> 40) & 3ull) : (__ffs((int)(~livem & 0xFu)) - 1);
+        lock = B + 31;
+    } else {
+        B = E.memo.big + (size_t)((uint32_t)h & E.memo.big_mask) * (QZ_MEMO_B_WAYS * QZ_MEMO_B_DW);
+        const bool in = pos < 16;
+        const uint32_t d = in ? B[(lane >> 5) * QZ_MEMO_B_DW + pos] : 0u;
+        const uint64_t e0 = __ballot(pos >= 6 || d == kd);
+        if ((uint32_t)e0 == 0xFFFFFFFFu || (uint32_t)(e0 >> 32) == 0xFFFFFFFFu) return;
+        const uint64_t l0 = __ballot(pos == 5 && (d >> 16) == epoch);
+        const uint32_t livem = (uint32_t)((l0 >> 5) & 1ull) | ((uint32_t)((l0 >> 37) & 1ull) << 1);
+        way = livem == 0x3u ? (int)((h >> 40) & 1ull) : (__ffs((int)(~livem & 0x3u)) - 1);
+        lock = B + 15;
+    }
+    uint32_t got = 0u;
+    if (lane == 0) got = atomicCAS(lock, 0u, 1u) == 0u ? 1u : 0u;
+    if (rfl(got) == 0u) {  // another wave is writing this bucket: skip (the memo is a cache)
+        if (lane == 0) atomicAdd(&E.counters[QZ_C_MEMO_LOCKED], 1ull);
+        return;
+    }
+    if (memo_is_small(bd)) {
+        uint32_t* W = B + way * QZ_MEMO_S_DW;
+        if (lane < 20) {
+            uint32_t val;
+            if (lane < 6) val = kd;
+            else if (lane == 6) val = __float_as_uint(v);
+            else if (lane == 7) val = mask[0];
+            else val = __float_as_uint(prow[lane - 8]);
+            W[lane] = val;
+        }
+    } else {
+        uint32_t* W = B + way * QZ_MEMO_B_DW;
+        for (int i = lane; i < 16 + QZ_N_ACT; i += 64) {
+            uint32_t val = 0u;
+            if (i < 6) val = memo_key_dword(i, hb, vb, mk);
+            else if (i == 6) val = __float_as_uint(v);
+            else if (i >= 8 && i < 13) val = mask[i - 8];
+            else if (i >= 16) val = __float_as_uint(prow[i - 16]);
+            if (!(way == 0 && i == 15)) W[i] = val;  // (dword 15 of way 0 is the lock)
+        }
+    }
+    __threadfence();
+    wave_sync();
+    if (lane == 0) {
+        atomicExch(lock, 0u);
+        atomicAdd(&E.counters[QZ_C_MEMO_INSERTS], 1ull);
+    }
+}
+
+// ---------------------------------------------------------------------------- asynchronous self-play
+// k_advance: every board (a wavefront each) runs the loop of MCTS.get_move_probs (mcts.py:135-139) ON ITS OWN for as
+// long as it can: descend -> leaf; a terminal leaf is backed up at once; a leaf whose evaluation is in the memo is
+// expanded from the memo and backed up; any other leaf goes into the miss list (compacted by one atomic) and the
+// board waits for the next launch, which starts by consuming the network's answer (expand + backup, exactly
+// k_expand_backup's code).  After n_playout playouts the board plays its move in the same launch (finish_move_board:
+// pi, noisy sampling, trajectory record, re-root, real step) and goes on searching from the new root; a second move
+// in one launch waits for k_round_tail to hand the replaced tree's pages back (release flag).  Per board the sequence
+// of operations is exactly the lock-step engine's (k_select / k_expand_backup / k_finish_move): trees, pi, sampled
+// moves and harvested tuples are bit-identical; only the interleaving BETWEEN boards differs.
+//   max_iters   playouts a board may start per launch (1 = one playout per launch, the lock-step cadence)
+//   budget      wall-clock limit in s_memrealtime ticks (100 MHz) after which a board starts no new playout
+//   auto_finish 0: boards stop at n_playout (the host calls qz_mcts_finish_move)
+//   par         which of the two miss counters this round uses (rounds alternate: the tail of round r clears the
+//               counter of round r + 1 while nobody reads it)
+__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_advance(EngineDev E, const EngineDev* __restrict__ Ed, int max_iters, unsigned int budget, int auto_finish, int par) {
+    const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+    const int b = __builtin_amdgcn_readfirstlane((int)blockIdx.x * WPB + wave);  // in an SGPR: every per-board address below is scalar arithmetic
+    if (b >= E.n_boards) return;
+    if (b == 0 && lane == 0) atomicAdd(&E.counters[QZ_C_ROUNDS], 1ull);
+    if (rfl(E.status[b]) != QZ_PLAYING) return;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    uint32_t done = rfl(E.pl_done[b]);
+    {
+        const Board rb = unpack(0ull, 0ull, rfl64(E.root_meta[b]));
+        if ((rb.cur == 1 ? rb.w1 : rb.w2) > 0 && lane == 0) E.bc_open_rounds[b] += 1u;
+    }
+    // One resolved leaf at a time: (legal set, priors, value) of the leaf the last descent found -- from the network
+    // (the evaluation this board was waiting for), from the memo, or a terminal leaf's +-1 -- is applied at the top of
+    // the loop by the one copy of TreeNode.expand + update_recursive.
+    const uint32_t slot = rfl(E.pend_slot[b]);
+    bool have = slot != QZ_NONE, waiting = false;
+    uint32_t m0 = 0u, m1 = 0u, m2 = 0u, m3 = 0u, m4 = 0u, term = 0u;
+    const float* prow = nullptr;  // priors as a row of 140 floats, or (nullptr) this lane's prior in pl (small-table hit)
+    float pl = 0.f;
+    double value = 0.0;
+    if (have) {
+        const uint32_t* mk = E.miss_mask + (size_t)slot * 5;
+        m0 = rfl(mk[0]); m1 = rfl(mk[1]); m2 = rfl(mk[2]); m3 = rfl(mk[3]); m4 = rfl(mk[4]);
+        prow = E.miss_p + (size_t)slot * QZ_N_ACT;
+        value = (double)E.miss_v[slot];
+    }
+    for (int it = 0;; it++) {
+        if (have) {
+            const uint32_t pedge = rfl(E.leaf_pedge[b]);
+            if (term == 0u) expand_node(E, b, lane, pedge, m0, m1, m2, m3, m4, [&](int a) { return prow ? prow[a] : pl; });
+            backup_leaf(E, b, lane, value, pedge, term);
+            done++;
+            have = false;
+            wave_sync();
+        }
+        if (it >= max_iters) break;
+        if (done >= (uint32_t)E.n_playout) {
+            if (!auto_finish || rfl((uint32_t)E.release[b]) != 0u) break;
+            const Board rb = unpack(0ull, 0ull, rfl64(E.root_meta[b]));
+            if ((rb.cur == 1 ? rb.w1 : rb.w2) > 0 && lane == 0) E.bc_open_plies[b] += 1u;
+            finish_move_call(Ed, b, lane);
+            done = 0u;
+            wave_sync();
+            if (rfl(E.status[b]) != QZ_PLAYING) break;  // the game is over (or was dropped): wait for the harvest
+            // the move's child had no subtree (or the copy found the pool empty): the board restarts from a fresh root in
+            // the SAME table half, whose pages k_round_tail is about to hand back -- nothing may be built there before
+            if (rfl((uint32_t)E.release[b]) & 2u) break;
+        }
+        if (it > 0 && (unsigned int)(__builtin_amdgcn_s_memrealtime() - t0) > budget) break;
+        Board leaf;
+        select_board(E, b, lane, &leaf, &term);
+        wave_sync();  // the descent buffer (lane 0 / other lanes) before the backup reads it
+        if (term != 0u) {
+            value = terminal_value(E, term);
+            have = true;
+            continue;
+        }
+        MemoHit H;
+        if (memo_probe(E, leaf, lane, H)) {
+            m0 = H.m0; m1 = H.m1; m2 = H.m2; m3 = H.m3; m4 = H.m4;
+            prow = H.p_row;
+            pl = H.p_lane;
+            value = (double)H.v;
+            have = true;
+            if (lane == 0) E.bc_memo_hits[b] += 1u;
+            continue;
+        }
+        // ---- a leaf for the network
+        uint32_t s = 0u;
+        if (lane == 0) s = (uint32_t)atomicAdd(E.miss_count + par, 1);
+        s = rfl(s);
+        if (lane == 0) {
+            E.miss_hb[s] = leaf.hb;
+            E.miss_vb[s] = leaf.vb;
+            E.miss_meta[s] = pack_meta(leaf);
+            E.pend_slot[b] = s;
+            E.bc_evals[b] += 1u;
+        }
+        waiting = true;
+        break;
+    }
+    if (lane == 0) {
+        E.pl_done[b] = done;
+        if (!waiting && slot != QZ_NONE) E.pend_slot[b] = QZ_NONE;
+    }
+}
+
+// After the network: (a) every evaluated leaf goes into the memo, (b) the OTHER miss counter is cleared for the next
+// round, (c) k_release's work: trees replaced by a re-root go back to the pool, dropped games restart.  PUSH-ONLY.
+// Grid: n_boards waves for the slots, then n_boards waves for the boards.
+__global__ __launch_bounds__(TPB) void k_round_tail(EngineDev E, int par) {
+    const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+    const int w = (int)blockIdx.x * WPB + wave;
+    if (w < E.n_boards) {
+        const int n = (int)rfl((uint32_t)E.miss_count[par]);
+        if (w < n) memo_insert(E, rfl64(E.miss_hb[w]), rfl64(E.miss_vb[w]), rfl64(E.miss_meta[w]), E.miss_mask + (size_t)w * 5,
+                               E.miss_p + (size_t)w * QZ_N_ACT, E.miss_v[w], lane);
+        if (w == 0 && lane == 0) E.miss_count[par ^ 1] = 0;
+        return;
+    }
+    const int b = w - E.n_boards;
+    if (b >= E.n_boards) return;
+    const uint32_t rel = rfl((uint32_t)E.release[b]);
+    const uint32_t half = rfl(E.tree_half[b]);
+    if (rfl((uint32_t)E.status[b]) == QZ_ABORTED) {
+        wave_free_tree_half(E, b, 0u, lane);
+        wave_free_tree_half(E, b, 1u, lane);
+        wave_free_traj(E, b, lane);
+        if (lane == 0) reset_board_state(E, b);
+        return;
+    }
+    if (rel & 1u) wave_free_tree_half(E, b, half ^ 1u, lane);
+    if (rel & 2u) wave_free_tree_half(E, b, half, lane);
+    if (rel && lane == 0) E.release[b] = 0;
+}
+// qz_memo_flush: the weights changed, every stored evaluation is dead
+__global__ void k_memo_flush(EngineDev E) {
+    uint32_t e = *E.memo.epoch + 1u;
+    if (e >= 0xFFFFu) e = 0xFFFFu;  // (the host re-zeroes the tables before the epoch could wrap: qz_memo_flush)
+    *E.memo.epoch = e;
+}
 
 // ---------------------------------------------------------------------------- random rollouts
 // MCTS._evaluate_rollout (pure_mcts.py:81-103) for a batch of boards, one launch per iteration.
@@ -1676,13 +1994,14 @@ __global__ __launch_bounds__(1024) void k_harvest_scan(EngineDev E) {
 // PUSH-ONLY: the finished game's tree and trajectory pages go back to the pools.
 __global__ __launch_bounds__(TPB) void k_harvest_copy(EngineDev E, uint64_t* t_hb, uint64_t* t_vb, uint64_t* t_meta,
                                                       float* __restrict__ t_pi, float* __restrict__ t_z,
-                                                      int32_t* __restrict__ t_game, long long cap) {
+                                                      int32_t* __restrict__ t_game, int32_t* __restrict__ g_board, long long cap) {
     const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
     const int b = (int)blockIdx.x * WPB + wave;
     if (b >= E.n_boards) return;
     if (rfl(E.status[b]) != QZ_FINISHED) return;
     const uint32_t n = rfl(E.ply[b]), off = rfl(E.harvest_off[b]), gid = rfl(E.harvest_gid[b]);
     const int win = (int)rfl(E.winner[b]);
+    if (g_board && lane == 0) g_board[gid] = (int32_t)b;
     const uint32_t* ptab = E.traj_ptab + (size_t)b * QZ_TRAJ_PT;
     uint32_t pgi = 0u, cur = 0u;
     for (uint32_t i = 0; i < n; i++) {
@@ -1762,27 +2081,28 @@ static void launch_masks_enc(const PoolBoard* recs, const PathTab* tabs, int n, 
 size_t movegen_scratch_bytes(int n) { return (size_t)n * (sizeof(PoolBoard) + 2 * sizeof(PathTab)); }
 
 hipError_t movegen_encode(const uint64_t* hb, const uint64_t* vb, const uint64_t* meta, int n, uint32_t* mask5,
-                          float* planes, const uint8_t* terminal, void* scratch, const RulesOpts& ro, hipStream_t s) {
+                          float* planes, const uint8_t* terminal, void* scratch, const RulesOpts& ro, hipStream_t s, const int* n_dev) {
     if (n <= 0) return hipSuccess;
+    if (n_dev && planes) return hipErrorInvalidValue;  // a device-side count: k_wave_rules, legal sets only (no encoder tiles)
     // Small batches are latency-bound: one launch, a wavefront per board, no hand-off through
     // HBM (k_wave_rules).  From ~8k boards on the chip is saturated and the pooled two-launch
     // pipeline, which packs lanes better, wins.
-    if ((ro.variant >= 2 && ro.variant <= 6) || (ro.variant == 0 && n < 8192)) {
+    if (n_dev || (ro.variant >= 2 && ro.variant <= 6) || (ro.variant == 0 && n < 8192)) {
         const int n_enc_groups = planes ? (n + NBE - 1) / NBE : 0;
         // boards per wavefront: on bench trees (late-game boards, many without walls left) one board per
         // wavefront measured 29.1 us vs 33.0 (two) / 34.6 (four) at 4,096 boards; on the synthetic
         // S-mid set two were slightly ahead (40.4 vs 42.9 us).  The in-situ number decides.
-        const int G = ro.variant == 2 ? 2 : (ro.variant == 4 ? 4 : 1);
+        const int G = n_dev ? 1 : (ro.variant == 2 ? 2 : (ro.variant == 4 ? 4 : 1));
         const int n_mg_groups = mask5 ? (n + WPB * G - 1) / (WPB * G) : 0;
         dim3 grid((unsigned)(n_mg_groups + n_enc_groups));
         // one board per wavefront: base paths on nine lanes per player (qz_path_rows.h); variant 5 = the same kernel
         // with one search per lane, kept as its A/B and parity partner
         // the planes go out as streaming (non-temporal) stores: they leave the L2 while the searching wavefronts are still
         // busy instead of in the end-of-kernel write-back (in situ 23.1 -> 21.8 us); variant 6 = ordinary stores (A/B)
-        if (G == 1 && ro.variant != 5) hipLaunchKernelGGL((k_wave_rules<NBE, 1, true>), grid, dim3(256), 0, s, hb, vb, meta, n, terminal, mask5, planes, n_mg_groups, ro.detour_wave | (ro.variant == 6 ? 0 : 0x100));
-        else if (G == 1) hipLaunchKernelGGL((k_wave_rules<NBE, 1, false>), grid, dim3(256), 0, s, hb, vb, meta, n, terminal, mask5, planes, n_mg_groups, ro.detour_wave);
-        else if (G == 4) hipLaunchKernelGGL((k_wave_rules<NBE, 4, false>), grid, dim3(256), 0, s, hb, vb, meta, n, terminal, mask5, planes, n_mg_groups, ro.detour_wave);
-        else hipLaunchKernelGGL((k_wave_rules<NBE, 2, false>), grid, dim3(256), 0, s, hb, vb, meta, n, terminal, mask5, planes, n_mg_groups, ro.detour_wave);
+        if (G == 1 && ro.variant != 5) hipLaunchKernelGGL((k_wave_rules<NBE, 1, true>), grid, dim3(256), 0, s, hb, vb, meta, n, terminal, mask5, planes, n_mg_groups, ro.detour_wave | (ro.variant == 6 ? 0 : 0x100), n_dev);
+        else if (G == 1) hipLaunchKernelGGL((k_wave_rules<NBE, 1, false>), grid, dim3(256), 0, s, hb, vb, meta, n, terminal, mask5, planes, n_mg_groups, ro.detour_wave, n_dev);
+        else if (G == 4) hipLaunchKernelGGL((k_wave_rules<NBE, 4, false>), grid, dim3(256), 0, s, hb, vb, meta, n, terminal, mask5, planes, n_mg_groups, ro.detour_wave, n_dev);
+        else hipLaunchKernelGGL((k_wave_rules<NBE, 2, false>), grid, dim3(256), 0, s, hb, vb, meta, n, terminal, mask5, planes, n_mg_groups, ro.detour_wave, n_dev);
         return hipGetLastError();
     }
     PoolBoard* recs = reinterpret_cast<PoolBoard*>(scratch);
@@ -1844,6 +2164,18 @@ hipError_t finish_move(const EngineDev& E, const uint8_t* forced, float* pi_out,
     hipLaunchKernelGGL(k_release, wave_grid(E.n_boards), dim3(TPB), 0, s, E);
     return hipGetLastError();
 }
+hipError_t advance(const EngineDev& E, const EngineDev* Ed, int max_iters, unsigned int budget_ticks, int auto_finish, int par, hipStream_t s) {
+    hipLaunchKernelGGL(k_advance, wave_grid(E.n_boards), dim3(TPB), 0, s, E, Ed, max_iters, budget_ticks, auto_finish, par);
+    return hipGetLastError();
+}
+hipError_t round_tail(const EngineDev& E, int par, hipStream_t s) {
+    hipLaunchKernelGGL(k_round_tail, wave_grid(2 * E.n_boards), dim3(TPB), 0, s, E, par);
+    return hipGetLastError();
+}
+hipError_t memo_flush(const EngineDev& E, hipStream_t s) {
+    hipLaunchKernelGGL(k_memo_flush, dim3(1), dim3(1), 0, s, E);
+    return hipGetLastError();
+}
 hipError_t reset(const EngineDev& E, int reset_boards, hipStream_t s) {
     hipLaunchKernelGGL(k_reset, wave_grid(E.n_boards), dim3(TPB), 0, s, E, reset_boards);
     return hipGetLastError();
@@ -1854,9 +2186,9 @@ hipError_t pool_init(const EngineDev& E, hipStream_t s) {
     return hipGetLastError();
 }
 hipError_t harvest(const EngineDev& E, uint64_t* t_hb, uint64_t* t_vb, uint64_t* t_meta, float* t_pi, float* t_z,
-                   int32_t* t_game, long long cap, hipStream_t s) {
+                   int32_t* t_game, int32_t* g_board, long long cap, hipStream_t s) {
     hipLaunchKernelGGL(k_harvest_scan, dim3(1), dim3(1024), 0, s, E);
-    hipLaunchKernelGGL(k_harvest_copy, wave_grid(E.n_boards), dim3(TPB), 0, s, E, t_hb, t_vb, t_meta, t_pi, t_z, t_game, cap);
+    hipLaunchKernelGGL(k_harvest_copy, wave_grid(E.n_boards), dim3(TPB), 0, s, E, t_hb, t_vb, t_meta, t_pi, t_z, t_game, g_board, cap);
     return hipGetLastError();
 }
 hipError_t rollout_begin(const uint64_t* hb, const uint64_t* vb, const uint64_t* meta, int n, uint8_t* player0, uint8_t* done,

@@ -670,11 +670,16 @@ __global__ __launch_bounds__(HT) void k_head(const float* __restrict__ t, long l
 __global__ __launch_bounds__(HT) void k_head_fc(const float* __restrict__ feat, long long n, const float* __restrict__ w1t,
                                                 const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2,
                                                 const float* __restrict__ w3t, const float* __restrict__ b3, float* __restrict__ p_out,
-                                                float* __restrict__ v_out) {
+                                                float* __restrict__ v_out, const int* __restrict__ n_live) {
     __shared__ __attribute__((aligned(16))) float s_f[HBF * FS];
     __shared__ HeadFcT<HBF> fc;
     const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const long long s0 = (long long)blockIdx.x * HBF;
+    if (n_live) {  // only the first *n_live leaves exist (the engine's miss list)
+        const long long nl = (long long)__builtin_amdgcn_readfirstlane(*n_live);
+        n = nl < n ? nl : n;
+        if (s0 >= n) return;
+    }
     const int nb = (int)((n - s0) < HBF ? (n - s0) : HBF);
     for (int i = tid; i < HBF * 243; i += HT) {  // 486 floats per leaf as 243 float2
         const int sl = i / 243, k = i - sl * 243;
@@ -741,9 +746,9 @@ hipError_t head(const float* t, long long n, const float* w6k, const float* gamm
     return hipGetLastError();
 }
 hipError_t head_fc(const float* feat, long long n, const float* w1t, const float* b1, const float* w2, const float* b2, const float* w3t,
-                   const float* b3, float* p_out, float* v_out, hipStream_t s) {
+                   const float* b3, float* p_out, float* v_out, hipStream_t s, const int* n_live) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_head_fc, dim3((unsigned)((n + HBF - 1) / HBF)), dim3(HT), 0, s, feat, n, w1t, b1, w2, b2, w3t, b3, p_out, v_out);
+    hipLaunchKernelGGL(k_head_fc, dim3((unsigned)((n + HBF - 1) / HBF)), dim3(HT), 0, s, feat, n, w1t, b1, w2, b2, w3t, b3, p_out, v_out, n_live);
     return hipGetLastError();
 }
 }  // namespace qzl

@@ -38,6 +38,7 @@ class TupleBatch:
     z: torch.Tensor       # [n] float32 (+1 recorded mover won / -1)
     game: torch.Tensor    # [n] int32, id of the game inside this batch
     n_games: int
+    slot: torch.Tensor = None   # [n_games] int32: the engine's board every game was played on
 
     def __len__(self):
         return int(self.pi.shape[0])
@@ -58,10 +59,25 @@ class TupleBatch:
         return [(st[i], pi[i], z[i]) for i in range(len(self))]
 
 
+_hip = None
+
+
+def _dev_copy(dst: torch.Tensor, src_ptr: int, nbytes: int):
+    """engine-owned device memory -> a torch tensor, on torch's current stream (hipMemcpyAsync, device to device)"""
+    global _hip
+    if _hip is None:
+        _hip = C.CDLL("libamdhip64.so")
+    rc = _hip.hipMemcpyAsync(C.c_void_p(dst.data_ptr()), C.c_void_p(src_ptr), C.c_size_t(nbytes), 3,
+                             C.c_void_p(torch.cuda.current_stream(dst.device).cuda_stream))
+    if rc != 0:
+        raise _cabi.QzError(_cabi.E_HIP, "hipMemcpyAsync failed: %d" % rc)
+
+
 class SelfPlayEngine:
     def __init__(self, n_boards, n_playout=400, c_puct=5.0, temp=1.0, is_selfplay=1, seed=0, device="cuda:0",
                  fix_terminal_sign=False, node_cap=0, edge_cap=0, max_plies=0, dirichlet_alpha=0.3, noise_frac=0.25,
-                 tree_pool_pages=0, traj_pool_pages=0, traj_page_dwords=0, rules_opts=None, select_opts=0):
+                 tree_pool_pages=0, traj_pool_pages=0, traj_page_dwords=0, rules_opts=None, select_opts=0, memo=True,
+                 memo_small_log2=0, memo_big_log2=0):
         if not torch.cuda.is_available():
             raise _cabi.QzError(_cabi.E_NO_DEVICE, "no HIP device: the engine has no CPU path")
         self.L = _cabi.load()
@@ -83,6 +99,9 @@ class SelfPlayEngine:
         cfg.tree_pool_pages, cfg.traj_pool_pages = int(tree_pool_pages), int(traj_pool_pages)
         cfg.traj_page_dwords = int(traj_page_dwords)
         cfg.select_opts = int(select_opts)
+        # leaf-evaluation memo of the asynchronous self-play loop (include/qz_abi.h): log2 of the bucket counts, 0 = auto
+        cfg.memo_small_log2 = int(memo_small_log2) if memo else -1
+        cfg.memo_big_log2 = int(memo_big_log2) if memo else -1
         if rules_opts is not None:
             cfg.rules = rules_opts
         self.cfg = cfg
@@ -108,6 +127,8 @@ class SelfPlayEngine:
         self.always_write_planes = None
         self._leaf_ref = None
         self._descended = False  # the last expand / backup launch also ran the next playout's descent
+        self._memo_version = None   # (evaluator id, evaluator.version) the memo's contents belong to
+        self._round_graph = None    # captured rounds of the asynchronous loop: (graph, rounds, key)
 
     @property
     def planes(self):
@@ -269,6 +290,87 @@ class SelfPlayEngine:
         for i in range(n - done):
             self.playout_step(evaluator, more=i + 1 < n - done)
 
+    # ------------------------------------------------------------------ asynchronous self-play (qz_selfplay_*)
+    def _memo_guard(self, evaluator):
+        """The memo holds evaluations of ONE set of weights: flush it when the evaluator or its weights changed."""
+        evaluator.ensure_fresh()
+        key = (id(evaluator), evaluator.version)
+        if key != self._memo_version:
+            if self._memo_version is not None:
+                _cabi.check(self.L.qz_memo_flush(self.h, self._s()))
+            self._memo_version = key
+
+    def selfplay_round(self, evaluator, max_playouts=64, budget_us=0, auto_finish=True):
+        """One ROUND of the asynchronous loop (include/qz_abi.h): every board runs playouts on its own -- leaves whose
+        evaluation is in the memo and terminal leaves are resolved in place, a board that has done n_playout playouts
+        plays its move and goes on -- until it meets a leaf that needs the network; those leaves are evaluated as one
+        compacted batch and stored in the memo.  Nothing synchronises with the host."""
+        self._memo_guard(evaluator)
+        self._descended = False
+        _cabi.check(self.L.qz_selfplay_round(self.h, C.byref(evaluator.nn_weights()), int(max_playouts), int(budget_us), int(bool(auto_finish)),
+                                             self._s()))
+
+    def capture_rounds(self, evaluator, rounds=16, max_playouts=64, budget_us=0, auto_finish=True, warmup=2):
+        """Capture `rounds` (even: the two miss counters alternate) rounds into one HIP graph for run_rounds."""
+        assert rounds % 2 == 0
+        self._memo_guard(evaluator)
+        s = torch.cuda.Stream(device=self.device)
+        s.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(s):
+            for _ in range(2 * ((warmup + 1) // 2)):
+                self.selfplay_round(evaluator, max_playouts, budget_us, auto_finish)
+        torch.cuda.current_stream(self.device).wait_stream(s)
+        torch.cuda.synchronize(self.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(rounds):
+                self.selfplay_round(evaluator, max_playouts, budget_us, auto_finish)
+        self._round_graph = (g, int(rounds), (id(evaluator), int(max_playouts), int(budget_us), bool(auto_finish)))
+
+    def run_rounds(self, evaluator, n, max_playouts=64, budget_us=0, auto_finish=True):
+        """n rounds; whole multiples of a captured graph (capture_rounds, same arguments) are replayed."""
+        n = int(n)
+        done = 0
+        g = self._round_graph
+        if g is not None and g[2] == (id(evaluator), int(max_playouts), int(budget_us), bool(auto_finish)):
+            self._memo_guard(evaluator)
+            while n - done >= g[1]:
+                g[0].replay()
+                done += g[1]
+        for _ in range(n - done):
+            self.selfplay_round(evaluator, max_playouts, budget_us, auto_finish)
+
+    def run_playouts_memo(self, evaluator, n=None):
+        """MCTS.get_move_probs's loop for every board in the LOCK-STEP cadence of run_playouts (every board starts one
+        playout per round; the host plays the move), but through the asynchronous loop's machinery: the network only
+        sees the leaves the memo does not know.  n + 1 rounds: the last one only consumes evaluations."""
+        n = self.n_playout if n is None else int(n)
+        assert n == self.n_playout, "the device-side playout budget is the engine's n_playout"
+        for _ in range(n + 1):
+            self.selfplay_round(evaluator, max_playouts=1, auto_finish=False)
+
+    def misses(self):
+        """The miss list of the round in progress (between qz_selfplay_advance and qz_selfplay_round_tail; after a
+        complete round: of the round just finished, count already cleared) as host arrays -- test / inspection helper.
+        -> (packed boards [n], mask5 uint32 [n,5], p float32 [n,140], v float32 [n]).  Synchronises."""
+        st = _cabi.qz_boards()
+        n_dev, mk, pp, vv = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _cabi.check(self.L.qz_selfplay_misses(self.h, C.byref(st), C.byref(n_dev), C.byref(mk), C.byref(pp), C.byref(vv)))
+        cnt = torch.zeros(1, dtype=torch.int32, device=self.device)
+        _dev_copy(cnt, n_dev.value, 4)
+        n = int(cnt.item())
+        hb = torch.empty(n, dtype=torch.int64, device=self.device)
+        vb, meta = torch.empty_like(hb), torch.empty_like(hb)
+        mask = torch.empty((n, 5), dtype=torch.int32, device=self.device)
+        p = torch.empty((n, 140), dtype=torch.float32, device=self.device)
+        v = torch.empty(n, dtype=torch.float32, device=self.device)
+        if n:
+            for t, ptr in ((hb, st.hbits), (vb, st.vbits), (meta, st.meta), (mask, mk.value), (p, pp.value), (v, vv.value)):
+                _dev_copy(t, ptr, t.numel() * t.element_size())
+        torch.cuda.synchronize(self.device)
+        return (_cabi.soa_to_packed(hb.cpu().numpy(), vb.cpu().numpy(), meta.cpu().numpy()), mask.cpu().numpy().view(np.uint32),
+                p.cpu().numpy(), v.cpu().numpy())
+
     # ------------------------------------------------------------------ end of a ply
     def finish_move(self, forced=None):
         """-> (moves uint8 [B] (255 = board idle), pi float32 [B,140])."""
@@ -321,8 +423,9 @@ class SelfPlayEngine:
         pi = torch.empty((plies, 140), dtype=torch.float32, device=self.device)
         z = torch.empty(plies, dtype=torch.float32, device=self.device)
         gid = torch.empty(plies, dtype=torch.int32, device=self.device)
-        _cabi.check(self.L.qz_harvest(self.h, tb.byref(), pi.data_ptr(), z.data_ptr(), gid.data_ptr(), plies, self._s()))
-        return TupleBatch(tb, pi, z, gid, games)
+        slot = torch.empty(games, dtype=torch.int32, device=self.device)
+        _cabi.check(self.L.qz_harvest(self.h, tb.byref(), pi.data_ptr(), z.data_ptr(), gid.data_ptr(), slot.data_ptr(), plies, self._s()))
+        return TupleBatch(tb, pi, z, gid, games, slot)
 
     def stats(self) -> dict:
         st = _cabi.qz_stats()

@@ -163,6 +163,11 @@ class LeafEvaluator:
         self.mfma_trunk = mfma_trunk and fused_norm and bn_mode == "per_leaf" and dtype == torch.float32 and channels_last
         self._w16 = None
         self._w6_16 = None
+        self._inv_scale = None
+        self._trunk_args = None
+        self._nn_weights = None
+        self._dirty = False
+        self.version = 0            # bumped by refresh(): engines flush their leaf-evaluation memo when it changes
         self.fused_trunk = fused_trunk  # all ten layers in ONE persistent launch (activations stay on the CU)
         self.fused_heads_stage = fused_heads_stage  # the head convolution as the last stage of the fused trunk launch
         self.fused_input_stage = fused_input_stage  # ... and the first layer (from the packed boards) as its first
@@ -176,7 +181,18 @@ class LeafEvaluator:
 
     # weights may change between self-play rounds (training).  Cached tensors are updated IN
     # PLACE so that a captured HIP graph keeps pointing at live data.
+    def mark_dirty(self):
+        """The module's weights changed; the copies are re-derived before the next use (ensure_fresh), not now: a
+        policy update runs several optimiser steps before self-play resumes."""
+        self._dirty = True
+
+    def ensure_fresh(self):
+        if self._dirty:
+            self.refresh()
+
     def refresh(self):
+        self._dirty = False
+        self.version += 1
         n, dt = self.net, self.dtype
         mf = torch.channels_last if self.channels_last else torch.contiguous_format
 
@@ -218,24 +234,28 @@ class LeafEvaluator:
                 for o, t in zip(self._head, head):
                     o.copy_(t)
         if self.mfma_trunk and layers[0][0].is_cuda:
+            # 1 / scale of every layer's weight image lives in ONE device array (2 N_RES trunk layers + the head stage),
+            # updated in place like the images themselves: kernels read it from memory, so a launch captured in a HIP
+            # graph before a training step runs with the scales of the weights it finds
+            if self._inv_scale is None:
+                self._inv_scale = torch.ones(2 * N_RES + 1, dtype=torch.float32, device=layers[0][0].device)
             w16 = [self._split_weight(layers[i][0]) for i in range(1, 1 + 2 * N_RES)]
             if self._w16 is None:
-                self._w16 = w16
+                self._w16 = [(t, self._inv_scale[i:i + 1]) for i, (t, _) in enumerate(w16)]
             else:
-                for (o, _), (t, sc) in zip(self._w16, w16):
+                for (o, _), (t, _) in zip(self._w16, w16):
                     o.copy_(t)
-                self._w16 = [(o, sc) for (o, _), (_, sc) in zip(self._w16, w16)]
-            self._trunk_args = None  # host-side pointer tables of qz_nn_trunk, rebuilt on the next call
+            self._inv_scale[:2 * N_RES].copy_(torch.cat([sc for _, sc in w16]))
             if self.fused_head and self.fused_trunk:
                 # the merged head convolution as one more stage of the fused trunk launch (qz_nn_trunk_heads):
                 # the same split-fp16 B operand with 32 output columns, 6 of them real
                 hw = layers[-1][0]
                 w6 = self._split_weight(torch.cat([hw, torch.zeros((26,) + tuple(hw.shape[1:]), dtype=hw.dtype, device=hw.device)], 0))
                 if self._w6_16 is None:
-                    self._w6_16 = w6
+                    self._w6_16 = (w6[0], self._inv_scale[2 * N_RES:])
                 else:
                     self._w6_16[0].copy_(w6[0])
-                    self._w6_16 = (self._w6_16[0], w6[1])
+                self._inv_scale[2 * N_RES:].copy_(w6[1])
         if self.board_input_layer and layers[0][0].is_cuda:
             tabs = self._input_tables(layers[0][0])
             if self._in_tables is None:
@@ -254,15 +274,20 @@ class LeafEvaluator:
     @staticmethod
     def _split_weight(w):
         """conv weight [c_out,64,3,3] fp32 -> (fp16 [2,9,4,c_out,16] = [hi|lo][tap][c_in chunk][c_out][c_in in chunk] of
-        w * scale, 1 / scale): the B operand of qz_nn_conv3x3_norm (include/qz_abi.h).  scale is the power
-        of two that brings max |w| into [1, 2), so that the lo parts are fp16 normals."""
+        w * scale, 1 / scale as a one-element DEVICE tensor): the B operand of qz_nn_conv3x3_norm (include/qz_abi.h).
+        scale is the power of two that brings max |w| into [1, 2), so that the lo parts are fp16 normals.  Everything
+        stays on the device (no host synchronisation: this runs after every optimiser step)."""
         W = w.detach().to(torch.float32).contiguous()
-        mx = float(W.abs().max())
-        scale = 2.0 ** (-np.floor(np.log2(mx))) if mx > 0 else 1.0
+        mx = W.abs().max()
+        _, ex = torch.frexp(mx)                      # mx = m * 2^ex, m in [0.5, 1): floor(log2(mx)) = ex - 1, exactly
+        one = torch.ones((), dtype=torch.float32, device=W.device)
+        live = mx > 0
+        scale = torch.where(live, torch.ldexp(one, 1 - ex), one)
+        inv = torch.where(live, torch.ldexp(one, ex - 1), one).reshape(1)
         ws = (W * scale).permute(2, 3, 1, 0).reshape(9, 4, 16, W.shape[0]).permute(0, 1, 3, 2).contiguous()  # [tap][chunk][c_out][16 c_in]
         hi = ws.to(torch.float16)
         lo = (ws - hi.to(torch.float32)).to(torch.float16)
-        return torch.stack([hi, lo]).contiguous(), float(1.0 / scale)
+        return torch.stack([hi, lo]).contiguous(), inv
 
     def _conv_norm_mfma(self, x, i, relu=True, residual=None):
         from . import _cabi
@@ -275,7 +300,7 @@ class LeafEvaluator:
             ev[0].record()
         _cabi.check(_cabi.load().qz_nn_conv3x3_norm(
             x.data_ptr(), w16.data_ptr(), gamma.data_ptr(), beta.data_ptr(), residual.data_ptr() if residual is not None else 0,
-            out.data_ptr(), x.shape[0], inv_scale, int(relu), BN_EPS, torch.cuda.current_stream(x.device).cuda_stream))
+            out.data_ptr(), x.shape[0], inv_scale.data_ptr(), int(relu), BN_EPS, torch.cuda.current_stream(x.device).cuda_stream))
         if ev is not None:
             ev[1].record()
             self.trunk_events.append(ev)
@@ -292,7 +317,7 @@ class LeafEvaluator:
         v = torch.empty(B, dtype=torch.float32, device=dev)
         feat = torch.empty((B, 6 * 81), dtype=torch.float32, device=dev)
         _cabi.check(_cabi.load().qz_nn_trunk_heads(
-            x.data_ptr(), B, N_RES, w, g, b, sc, self._w6_16[0].data_ptr(), self._w6_16[1], hd[8].data_ptr(), hd[1].data_ptr(),
+            x.data_ptr(), B, N_RES, w, g, b, sc, self._w6_16[0].data_ptr(), hd[8].data_ptr(), hd[1].data_ptr(),
             hd[2].data_ptr(), hd[3].data_ptr(), hd[4].data_ptr(), hd[5].data_ptr(), hd[6].data_ptr(), hd[7].data_ptr(),
             feat.data_ptr(), p.data_ptr(), v.data_ptr(), BN_EPS, torch.cuda.current_stream(dev).cuda_stream))
         return p, v
@@ -313,7 +338,7 @@ class LeafEvaluator:
         feat = torch.empty((n, 6 * 81), dtype=torch.float32, device=dev)
         _cabi.check(_cabi.load().qz_nn_evaluate(
             C.byref(st), term_ptr or 0, n, hot9.data_ptr(), base0.data_ptr(), wd.data_ptr(), gamma0.data_ptr(), beta0.data_ptr(), N_RES,
-            w, g, b, sc, self._w6_16[0].data_ptr(), self._w6_16[1], hd[8].data_ptr(), hd[1].data_ptr(),
+            w, g, b, sc, self._w6_16[0].data_ptr(), hd[8].data_ptr(), hd[1].data_ptr(),
             hd[2].data_ptr(), hd[3].data_ptr(), hd[4].data_ptr(), hd[5].data_ptr(), hd[6].data_ptr(), hd[7].data_ptr(),
             feat.data_ptr(), p.data_ptr(), v.data_ptr(), BN_EPS, torch.cuda.current_stream(dev).cuda_stream))
         return p, v
@@ -325,8 +350,38 @@ class LeafEvaluator:
             self._trunk_args = ((C.c_void_p * L)(*[self._w16[i][0].data_ptr() for i in range(L)]),
                                 (C.c_void_p * L)(*[self._layers[i + 1][2].data_ptr() for i in range(L)]),
                                 (C.c_void_p * L)(*[self._layers[i + 1][3].data_ptr() for i in range(L)]),
-                                (C.c_float * L)(*[self._w16[i][1] for i in range(L)]))
+                                self._inv_scale.data_ptr())
         return self._trunk_args
+
+    def engine_route_ok(self):
+        """True if this evaluator is the two-launch HIP evaluation from packed boards (qz_nn_evaluate): the one the
+        asynchronous self-play loop can run on its miss list (qz_selfplay_evaluate)."""
+        return bool(self.board_input_layer and self._in_tables is not None and self.fused_input_stage and self.bn_mode == "per_leaf"
+                    and self.mfma_trunk and self.fused_trunk and self.fused_head and self.fused_heads_stage and self._w16 is not None
+                    and self._w6_16 is not None and self._head is not None and len(self._head) > 8)
+
+    def nn_weights(self):
+        """qz_nn_weights (include/qz_abi.h) over this evaluator's device tensors.  They are updated in place by
+        refresh(), so the struct stays valid for the evaluator's lifetime."""
+        from . import _cabi
+        self.ensure_fresh()
+        if self._nn_weights is None:
+            assert self.engine_route_ok(), "this evaluator configuration has no one-call HIP route"
+            w, g, b, sc = self._trunk_tables()
+            hd = self._head
+            _, _, gamma0, beta0 = self._layers[0]
+            hot9, base0, wd = self._in_tables
+            nw = _cabi.qz_nn_weights()
+            nw.hot9, nw.base0, nw.wd, nw.gamma0, nw.beta0 = hot9.data_ptr(), base0.data_ptr(), wd.data_ptr(), gamma0.data_ptr(), beta0.data_ptr()
+            nw.n_blocks = N_RES
+            nw.w16, nw.gamma, nw.beta = C_addr(w), C_addr(g), C_addr(b)
+            nw.inv_scale = sc
+            nw.w6_16 = self._w6_16[0].data_ptr()
+            nw.gamma6, nw.beta6 = hd[8].data_ptr(), hd[1].data_ptr()
+            nw.w1t, nw.b1, nw.w2, nw.b2, nw.w3t, nw.b3 = (hd[i].data_ptr() for i in (2, 3, 4, 5, 6, 7))
+            nw.eps = BN_EPS
+            self._nn_weights = nw
+        return self._nn_weights
 
     def _trunk_mfma(self, x):
         """All ten trunk layers from one library call (qz_nn_trunk); x is updated in place."""
@@ -414,6 +469,7 @@ class LeafEvaluator:
         """leaf = (qz_boards struct, terminal-flag device pointer or None, n): the boards `planes`
         was encoded from (SelfPlayEngine.leaf_ref()); with it the first layer is computed from
         the 24-byte boards and `planes` is not read."""
+        self.ensure_fresh()
         if leaf is not None and self.board_input_layer and self._in_tables is not None:
             if self.fused_input_stage and self.bn_mode == "per_leaf" and self.mfma_trunk and self.fused_trunk and self.fused_head \
                     and self.fused_heads_stage and self._w16 is not None and self._w6_16 is not None and self._head is not None \
@@ -460,6 +516,11 @@ class LeafEvaluator:
 
 
 # --------------------------------------------------------------------------------------
+def C_addr(arr):
+    import ctypes as C
+    return C.addressof(arr)
+
+
 def set_learning_rate(optimizer, lr):
     for group in optimizer.param_groups:
         group["lr"] = lr
@@ -502,9 +563,10 @@ class PolicyValueNet:
 
     def weights_changed(self):
         """Call after the module's parameters changed (train_step does): every live evaluator
-        re-derives its weight copies in place (captured HIP graphs keep pointing at live data)."""
+        re-derives its weight copies IN PLACE before its next use (captured HIP graphs keep pointing at live data; the
+        per-layer scales live in device memory too), and engines flush their leaf-evaluation memos."""
         for ev in self._evaluators.values():
-            ev.refresh()
+            ev.mark_dirty()
 
     # device-tensor API (what TrainPipeline uses: nothing goes through numpy) ---------------------
     def _as_states(self, state_batch):

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define QZ_ABI_VERSION 2
+#define QZ_ABI_VERSION 3
 #define QZ_N_ACTIONS 140            /* quoridor.py:12  action_space = 140            */
 #define QZ_PLANES (26 * 81)         /* quoridor.py:58-131  26x9x9 state tensor       */
 #define QZ_MASK_WORDS 5             /* 140-bit legal mask, bit a of word a/32        */
@@ -134,6 +134,10 @@ typedef struct {
     int32_t select_opts;       /* A/B switches of the descent kernel (0 = defaults): bit 0 = walk every level (no replay of
                                   recorded descents; same results, the test partner of the records), bit 1 = no readlane
                                   scan for nodes with <= 8 children */
+    /* Leaf-evaluation memo (qz_selfplay_*): log2 of the number of buckets of its two tables; 0 = auto (8,192 small entries
+     * and 1,024 big entries per board, rounded up to a power of two), < 0 = no memo (every leaf goes to the network).
+     * small: leaves whose mover has no wall left, 4 entries of 128 B per bucket; big: all others, 2 x 640 B. */
+    int32_t memo_small_log2, memo_big_log2;
 } qz_config;
 
 typedef struct {
@@ -162,6 +166,17 @@ typedef struct {
     /* the descents of >= 256 levels (the ones that set the select kernel's duration): how many, how many of them
      * found a descent record shorter than half their length, their levels, and the levels the replay confirmed */
     int64_t deep_descents, deep_descents_cold, deep_levels, deep_levels_replayed;
+    /* asynchronous self-play (qz_selfplay_*) */
+    int64_t rounds;            /* qz_selfplay_advance launches                                            */
+    int64_t memo_hits;         /* leaves expanded from the memo (no network evaluation)                   */
+    int64_t nn_evals;          /* leaves sent to the network (memo misses)                                */
+    int64_t memo_inserts;      /* evaluations stored in the memo                                          */
+    int64_t memo_locked;       /* ... not stored because another insert held the bucket                   */
+    int64_t open_rounds;       /* board-launches / plies whose root's mover still had walls (the phase of a game in which  */
+    int64_t open_plies;        /* almost every leaf is new; the rest of a game revisits a few thousand boards)             */
+    int64_t waiting_boards;    /* boards waiting for the network right now                                */
+    int64_t runaway_descents;  /* descents cut off because they were deeper than a tree has edges (a cycle = corrupted tree
+                                  storage): must be 0; the guard exists so that such a bug cannot hang the GPU   */
 } qz_stats;
 
 /* MCTSPlayer.__init__ / MCTS.__init__ (mcts.py:89-100, 159-161) for n_boards trees +
@@ -236,10 +251,11 @@ int qz_harvest_counts(qz_engine* e, int64_t counts[2] /*[host]*/, void* stream);
  *   t_pi      [cap][140] float32
  *   t_z       [cap] float32: +1 if the recorded mover won else -1   (quoridor.py:599-602)
  *   t_game    [cap] int32: running game id local to this call (may be NULL)
+ *   g_board   [counts[0]] int32: the board (slot of the engine) every harvested game was played on (may be NULL)
  * then the boards are reset (quoridor.py:578) with fresh trees (mcts.py:168-169).
  * `cap` must be >= counts[1] from qz_harvest_counts. */
 int qz_harvest(qz_engine* e, const qz_boards* t_boards, float* t_pi /*[dev]*/, float* t_z /*[dev]*/,
-               int32_t* t_game /*[dev]*/, int64_t cap, void* stream);
+               int32_t* t_game /*[dev]*/, int32_t* g_board /*[dev]*/, int64_t cap, void* stream);
 
 int qz_engine_stats(qz_engine* e, qz_stats* out /*[host]*/, void* stream); /* SYNC */
 
@@ -291,19 +307,21 @@ int qz_nn_head(const float* t /*[dev]*/, int64_t n, const float* w6k, const floa
  * pipe by operand splitting (csrc/qz_conv.hip).  w16: the weight prepared by the caller as
  * fp16 [2][9][4][64][16] = [hi | lo part][tap 3 ky + kx][16-channel chunk of c_in][c_out][c_in in chunk]
  * of W * scale (scale = a power of two that makes the lo parts fp16 normals), hi = fp16(W scale),
- * lo = fp16(W scale - hi); inv_scale = 1 / scale. */
+ * lo = fp16(W scale - hi); inv_scale [dev]: ONE float in device memory = 1 / scale (device memory, so that a launch
+ * captured in a HIP graph follows the weights when the caller re-derives them in place after training). */
 int qz_nn_conv3x3_norm(const float* x /*[dev]*/, const void* w16 /*[dev]*/, const float* gamma /*[dev][64]*/,
                        const float* beta /*[dev][64]*/, const float* residual /*[dev] or NULL*/, float* out /*[dev]*/, int64_t n,
-                       float inv_scale, int relu, float eps, void* stream);
+                       const float* inv_scale /*[dev]*/, int relu, float eps, void* stream);
 /* The whole residual trunk (policy_value_net.py:75-83: n_blocks x [conv-bn-relu-conv-bn-(+x)-relu])
  * from ONE call; x is updated in place.  fused != 0 (n_blocks <= 8): ONE persistent launch in which
  * a workgroup keeps its leaves' activations in LDS / registers across all layers -- HBM sees the
  * input once and the output once; tmp is not used (may be NULL).  fused == 0: 2 n_blocks launches
  * of the layer kernel above through the scratch tensor tmp (same size as x).  Same values either
- * way.  w16 / gamma / beta / inv_scale: [2 n_blocks] HOST arrays (of device pointers / of floats),
- * layer order res1.conv1, res1.conv2, res2.conv1, ... */
+ * way.  w16 / gamma / beta: [2 n_blocks] HOST arrays of device pointers, layer order res1.conv1, res1.conv2,
+ * res2.conv1, ...; inv_scale: DEVICE array of 2 n_blocks floats (see qz_nn_conv3x3_norm).  fused != 0 with
+ * n_blocks > 8 runs layer by layer and needs tmp. */
 int qz_nn_trunk(float* x /*[dev] in/out*/, float* tmp /*[dev] or NULL*/, int64_t n, int n_blocks, const void* const* w16 /*[host]*/,
-                const float* const* gamma /*[host]*/, const float* const* beta /*[host]*/, const float* inv_scale /*[host]*/,
+                const float* const* gamma /*[host]*/, const float* const* beta /*[host]*/, const float* inv_scale /*[dev]*/,
                 float eps, int fused, void* stream);
 /* Trunk + both heads (policy_value_net.py:75-93,155) from ONE call, two launches: the fused trunk
  * launch of qz_nn_trunk with one more stage -- the merged 64 -> 6 head convolution + bn2 / bn3 per
@@ -312,9 +330,10 @@ int qz_nn_trunk(float* x /*[dev] in/out*/, float* tmp /*[dev] or NULL*/, int64_t
  * fc2 / tanh and fc3 / softmax read them.  x [n][81][64] (the first layer's output) is only read;
  * the trunk output never reaches HBM.  w6_16: the merged head weight [6][64][3][3] prepared like
  * w16 but with 32 output columns: fp16 [2][9][4][32][16], columns 6..31 zero; the other arguments
- * as in qz_nn_trunk / qz_nn_head.  Per-leaf normalisation only (gamma6 must not be NULL). */
+ * as in qz_nn_trunk / qz_nn_head; inv_scale: DEVICE array of 2 n_blocks + 1 floats, the last one belongs to w6_16.
+ * Per-leaf normalisation only (gamma6 must not be NULL). */
 int qz_nn_trunk_heads(const float* x /*[dev]*/, int64_t n, int n_blocks, const void* const* w16 /*[host]*/, const float* const* gamma /*[host]*/,
-                      const float* const* beta /*[host]*/, const float* inv_scale /*[host]*/, const void* w6_16 /*[dev]*/, float inv_scale6,
+                      const float* const* beta /*[host]*/, const float* inv_scale /*[dev] 2 n_blocks + 1*/, const void* w6_16 /*[dev]*/,
                       const float* gamma6, const float* beta6, const float* w1t, const float* b1, const float* w2, const float* b2,
                       const float* w3t, const float* b3, float* feat /*[dev] n*486 scratch*/, float* p_out /*[dev] n*140*/,
                       float* v_out /*[dev] n*/, float eps, void* stream);
@@ -329,12 +348,58 @@ int qz_nn_trunk_heads(const float* x /*[dev]*/, int64_t n, int n_blocks, const v
 int qz_nn_evaluate(const qz_boards* boards /*[dev] arrays*/, const uint8_t* terminal /*[dev] or NULL*/, int64_t n, const float* hot9,
                    const float* base0, const float* wd, const float* gamma0, const float* beta0, int n_blocks,
                    const void* const* w16 /*[host]*/, const float* const* gamma /*[host]*/, const float* const* beta /*[host]*/,
-                   const float* inv_scale /*[host]*/, const void* w6_16, float inv_scale6, const float* gamma6, const float* beta6,
+                   const float* inv_scale /*[dev] 2 n_blocks + 1*/, const void* w6_16, const float* gamma6, const float* beta6,
                    const float* w1t, const float* b1, const float* w2, const float* b2, const float* w3t, const float* b3,
                    float* feat /*[dev] n*486 scratch*/, float* p_out /*[dev] n*140*/, float* v_out /*[dev] n*/, float eps, void* stream);
+/* The same arguments as one struct: what the asynchronous self-play loop (qz_selfplay_round) needs to evaluate its miss list. */
+typedef struct {
+    const float *hot9, *base0, *wd, *gamma0, *beta0;   /* first layer (qz_nn_input_layer)                */
+    int32_t n_blocks;                                  /* residual blocks (<= 8)                         */
+    const void* const* w16;                            /* [host] 2 n_blocks device pointers              */
+    const float* const* gamma;                         /* [host]                                         */
+    const float* const* beta;                          /* [host]                                         */
+    const float* inv_scale;                            /* [dev] 2 n_blocks + 1 floats                    */
+    const void* w6_16;
+    const float *gamma6, *beta6, *w1t, *b1, *w2, *b2, *w3t, *b3;
+    float eps;
+} qz_nn_weights;
 /* the engine's current leaf boards (what qz_mcts_select just produced) and their terminal flags,
  * as device pointers owned by the engine: input of qz_nn_input_layer */
 int qz_engine_leaf_boards(qz_engine* e, qz_boards* boards_out, const uint8_t** terminal_out);
+
+/* ------------------------------------------------------------- asynchronous self-play
+ * The loop of Quoridor.start_self_play / MCTSPlayer.choose_action / MCTS.get_move_probs (quoridor.py:582-593,
+ * mcts.py:129-144, 172-187) for every board ON ITS OWN CLOCK.  A ROUND is
+ *     qz_selfplay_advance     every board: consume the evaluation it was waiting for (TreeNode.expand +
+ *                             update_recursive, mcts.py:27-62), then playouts (mcts.py:103-127) until one meets a leaf
+ *                             that needs the network; terminal leaves and leaves whose evaluation is in the MEMO
+ *                             (policy_value_fn on a batch of one is a pure function of the 24-byte board:
+ *                             policy_value_net.py:145-164) are resolved in place.  After n_playout playouts the board
+ *                             plays its move (everything qz_mcts_finish_move does) and goes on from the new root.
+ *                             The leaves that need the network are compacted into the engine's MISS LIST.
+ *     qz_selfplay_leaf_rules  Quoridor.actions() of the miss list (the same kernel as qz_mcts_leaf_inputs)
+ *     qz_selfplay_evaluate    the network on the miss list (qz_nn_evaluate on the first *n boards)
+ *     qz_selfplay_round_tail  store the evaluations in the memo; hand replaced trees back to the pool
+ * and qz_selfplay_round is the four in one call.  Nothing synchronises; the whole round can be captured in a HIP
+ * graph (the miss count stays on the device).  Per board the operations and their order are those of the lock-step
+ * entry points above, so trees, pi, sampled moves and harvested tuples are bit-identical to a lock-step run of the
+ * same seed; only the interleaving between boards differs.  Finished games wait for qz_harvest as before.
+ *   max_playouts  playouts a board may START per round (1 = the lock-step cadence: n_playout + 1 rounds per move)
+ *   budget_us     a board starts no new playout once this much wall time of the launch has passed (0 = no limit)
+ *   auto_finish   0: boards stop at n_playout and the host calls qz_mcts_finish_move */
+int qz_selfplay_advance(qz_engine* e, int max_playouts, int budget_us, int auto_finish, void* stream);
+int qz_selfplay_leaf_rules(qz_engine* e, void* stream);
+int qz_selfplay_evaluate(qz_engine* e, const qz_nn_weights* w, void* stream);
+int qz_selfplay_round_tail(qz_engine* e, void* stream);
+int qz_selfplay_round(qz_engine* e, const qz_nn_weights* w, int max_playouts, int budget_us, int auto_finish, void* stream);
+/* the miss list of the round in progress (between qz_selfplay_advance and qz_selfplay_round_tail), engine-owned
+ * device memory: boards, *n_dev = how many, their legal sets / network outputs once the two calls above have run.
+ * For callers that evaluate the list themselves (another network) and for the tests. */
+int qz_selfplay_misses(qz_engine* e, qz_boards* boards_out, const int32_t** n_dev_out, uint32_t** mask5_out /*[n][5]*/,
+                       float** p_out /*[n][140]*/, float** v_out /*[n]*/);
+/* the weights changed (training step, checkpoint load): every stored evaluation is dead.  O(1): bumps the epoch the
+ * memo's keys carry. */
+int qz_memo_flush(qz_engine* e, void* stream);
 
 /* self-test hook for the GPU tests: out[i] <- device sqrt((double)i), i < n.  The PUCT term
  * uses np.sqrt(parent visits) in float64 (mcts.py:69); the test checks the device result is

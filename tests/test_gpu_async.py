@@ -1,0 +1,256 @@
+"""GPU parity of the asynchronous self-play loop (qz_selfplay_*, include/qz_abi.h) and of the
+leaf-evaluation memo.
+
+The loop changes WHEN things happen (every board runs on its own clock, the network only sees
+the leaves the memo does not know), never WHAT happens to a board: per board the operations of
+MCTS.get_move_probs / choose_action / start_self_play (mcts.py:129-187, quoridor.py:582-610) run
+in the lock-step engine's order.  So the tests compare it with the lock-step engine (itself pinned
+on the reference fixtures and the oracle by test_gpu_mcts.py / test_gpu_api.py) BIT FOR BIT: root
+statistics, pi, sampled moves, harvested tuples; and the miss list in situ with the oracle (legal
+sets) and with the full-batch evaluation (p, v)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+
+
+def _net(gpu_device, seed=2024):
+    from _stubs import det_fill_state_dict
+    from alphazero_quoridor_amd.policy_value_net import PolicyValueNet
+
+    net = PolicyValueNet(use_gpu=True, device=gpu_device)
+    net.policy_value_net.load_state_dict(det_fill_state_dict(net.policy_value_net.state_dict(), seed))
+    return net
+
+
+def _engine(boards, n_playout, **kw):
+    from alphazero_quoridor_amd.boards import DeviceBoards
+    from alphazero_quoridor_amd.engine import SelfPlayEngine
+
+    eng = SelfPlayEngine(len(boards), n_playout=n_playout, c_puct=5.0, temp=1.0, device="cuda:0", **kw)
+    eng.set_boards(DeviceBoards.from_packed(boards, eng.device), reset_trees=True)
+    return eng
+
+
+def _mixed_boards(n, seed):
+    """late-game boards (no walls left: the memo's home ground) and boards with walls, half and half"""
+    from synth import synth_positions
+
+    late = synth_positions(n // 2, seed=seed, max_walls=8)
+    late["w1"] = 0
+    late["w2"] = 0
+    early = synth_positions(n - n // 2, seed=seed + 1, max_walls=12, mover_has_walls=True)
+    return np.concatenate([late, early])
+
+
+def test_memo_on_and_off_give_the_same_search(gpu_device):
+    """two engines on the same boards, same seed, real network, lock-step cadence
+    (every board starts one playout per round, the host plays the moves): A = the plain engine (every
+    leaf evaluated, k_select / k_expand_backup), B = the asynchronous loop's kernels with the memo,
+    C = the same without a memo.  Root visits, Q, priors, pi and sampled moves bit-identical for 10
+    plies; B must have answered most late-game leaves from the memo."""
+    boards = _mixed_boards(256, seed=21)
+    NP = 48
+    ev = _net(gpu_device).evaluator("per_leaf")
+    assert ev.engine_route_ok()
+    a = _engine(boards, NP, seed=9)
+    b = _engine(boards, NP, seed=9)
+    c = _engine(boards, NP, seed=9, memo=False)
+    try:
+        for ply in range(10):
+            a.run_playouts(ev, NP)
+            b.run_playouts_memo(ev)
+            c.run_playouts_memo(ev)
+            ra, rb, rc = a.root_children(), b.root_children(), c.root_children()
+            for x, y, z in zip(ra, rb, rc):
+                assert torch.equal(x, y) and torch.equal(x, z), ply
+            (ma, pa), (mb, pb), (mc, pc) = a.finish_move(), b.finish_move(), c.finish_move()
+            assert torch.equal(ma, mb) and torch.equal(pa, pb) and torch.equal(ma, mc) and torch.equal(pa, pc), ply
+            ha, hb, hc = a.harvest(), b.harvest(), c.harvest()
+            assert (ha is None) == (hb is None) == (hc is None)
+            if ha is not None:
+                assert torch.equal(ha.pi, hb.pi) and torch.equal(ha.z, hb.z) and torch.equal(ha.boards.meta, hb.boards.meta)
+        sa, sb, sc = a.stats(), b.stats(), c.stats()
+        for k in ("playouts", "leaf_terminal", "descent_levels", "edges_expanded", "max_depth", "plies_played"):
+            assert sa[k] == sb[k] == sc[k], k
+        assert sb["node_overflow"] == 0 and sb["games_aborted"] == 0 and sb["runaway_descents"] == 0
+        assert sc["memo_hits"] == 0 and sc["nn_evals"] + sc["leaf_terminal"] == sc["playouts"]
+        assert sb["memo_hits"] + sb["nn_evals"] + sb["leaf_terminal"] == sb["playouts"]
+        print("memo: %d hits, %d evaluations, %d inserts (%d skipped on a locked bucket) in %d playouts"
+              % (sb["memo_hits"], sb["nn_evals"], sb["memo_inserts"], sb["memo_locked"], sb["playouts"]))
+        assert sb["memo_hits"] > 0.3 * sb["playouts"], sb
+    finally:
+        a.close()
+        b.close()
+        c.close()
+
+
+def _games_by_slot(batches):
+    """{slot: [game, ...]}, game = (boards packed bytes, pi bytes, z bytes) in the order the slot played them"""
+    out = {}
+    for tb in batches:
+        gid = tb.game.cpu().numpy()
+        slot = tb.slot.cpu().numpy()
+        packed = tb.boards.to_packed()
+        pi = tb.pi.cpu().numpy()
+        z = tb.z.cpu().numpy()
+        for g in range(tb.n_games):
+            sel = gid == g
+            out.setdefault(int(slot[g]), []).append((packed[sel].tobytes(), pi[sel].tobytes(), z[sel].tobytes()))
+    return out
+
+
+def test_asynchronous_games_equal_lockstep_games(gpu_device):
+    """Complete self-play games (Dirichlet noise, sampled moves, subtree reuse, continuous refill) from the
+    asynchronous loop -- boards on their own clocks, several playouts and whole moves per launch, memo on --
+    against the lock-step engine with the same seed: for every board slot the games come out in the same
+    order with identical (board, pi, z) tuples.  Short games (terminal sign fixed, 24 playouts)."""
+    from alphazero_quoridor_amd.engine import SelfPlayEngine
+
+    B, NP = 192, 24
+    ev = _net(gpu_device, 7).evaluator("per_leaf")
+    lock = SelfPlayEngine(B, n_playout=NP, seed=77, device=gpu_device, fix_terminal_sign=True)
+    asyn = SelfPlayEngine(B, n_playout=NP, seed=77, device=gpu_device, fix_terminal_sign=True)
+    try:
+        lb, ab = [], []
+        for _ in range(260):
+            lock.play_ply(ev)
+            tb = lock.harvest()
+            if tb is not None:
+                lb.append(tb)
+        n_lock = sum(t.n_games for t in lb)
+        assert n_lock >= B // 2, n_lock
+        rounds = 0
+        while sum(t.n_games for t in ab) < n_lock and rounds < 40000:
+            asyn.run_rounds(ev, 8, max_playouts=NP + 8, budget_us=0)
+            rounds += 8
+            tb = asyn.harvest()
+            if tb is not None:
+                ab.append(tb)
+        gl, ga = _games_by_slot(lb), _games_by_slot(ab)
+        compared = 0
+        for slot, games in gl.items():
+            other = ga.get(slot, [])
+            k = min(len(games), len(other))
+            for i in range(k):
+                assert games[i] == other[i], (slot, i)
+            compared += k
+        st = asyn.stats()
+        print("%d games compared tuple by tuple; asynchronous run: %d rounds, %d playouts, %d memo hits, %d evaluations"
+              % (compared, st["rounds"], st["playouts"], st["memo_hits"], st["nn_evals"]))
+        assert compared >= n_lock // 2, (compared, n_lock)
+        assert st["node_overflow"] == 0 and st["runaway_descents"] == 0
+    finally:
+        lock.close()
+        asyn.close()
+
+
+def test_miss_list_in_situ_against_oracle_and_full_batch_evaluation(gpu_device):
+    """The pieces of a round, one by one, on a mid-run engine: after qz_selfplay_advance the miss list holds
+    exactly the boards that wait (one slot each, no duplicates of a board slot); qz_selfplay_leaf_rules gives
+    the oracle's legal sets; qz_selfplay_evaluate gives, bit for bit, what the full-batch qz_nn_evaluate
+    computes for the same boards (the evaluation is a pure function of the board: the memo's premise)."""
+    import ctypes as C
+
+    import oracle
+    from alphazero_quoridor_amd import _cabi
+    from alphazero_quoridor_amd.boards import DeviceBoards
+    from alphazero_quoridor_amd.engine import SelfPlayEngine
+
+    B, NP = 1024, 32
+    ev = _net(gpu_device, 11).evaluator("per_leaf")
+    eng = SelfPlayEngine(B, n_playout=NP, seed=4, device=gpu_device)
+    L = eng.L
+    try:
+        eng.run_rounds(ev, 40, max_playouts=8)
+        checked = 0
+        for it in range(6):
+            eng._memo_guard(ev)
+            _cabi.check(L.qz_selfplay_advance(eng.h, 8, 0, 1, eng._s()))
+            _cabi.check(L.qz_selfplay_leaf_rules(eng.h, eng._s()))
+            _cabi.check(L.qz_selfplay_evaluate(eng.h, C.byref(ev.nn_weights()), eng._s()))
+            packed, mask, p, v = eng.misses()
+            n = len(packed)
+            st = eng.stats()
+            assert st["waiting_boards"] == n, (st["waiting_boards"], n)
+            if n:
+                omask, status = oracle.movegen_batch(packed)
+                assert (status >= 0).all() and np.array_equal(mask, omask)
+                db = DeviceBoards.from_packed(packed, gpu_device)
+                pr, vr = ev(None, leaf=(db.struct(), 0, n))
+                assert np.array_equal(p, pr.cpu().numpy()) and np.array_equal(v, vr.cpu().numpy())
+                checked += n
+            _cabi.check(L.qz_selfplay_round_tail(eng.h, eng._s()))
+        print("miss-list leaves checked against the oracle and the full-batch evaluation: %d" % checked)
+        assert checked > 500
+        st = eng.stats()
+        assert st["memo_inserts"] + st["memo_locked"] <= st["nn_evals"] and st["memo_inserts"] > 0
+    finally:
+        eng.close()
+
+
+def test_memo_is_flushed_when_the_weights_change(gpu_device):
+    """Evaluations stored under one set of weights must never answer for another: after a weight change
+    (PolicyValueNet.weights_changed -> LeafEvaluator.refresh -> qz_memo_flush) the memo engine still equals
+    the plain engine evaluated with the NEW weights, also through a captured HIP graph of rounds (the per-layer
+    scales live in device memory: ADVICE r2)."""
+    boards = _mixed_boards(128, seed=5)
+    NP = 32
+    net = _net(gpu_device, 3)
+    ev = net.evaluator("per_leaf")
+    a = _engine(boards, NP, seed=1)
+    b = _engine(boards, NP, seed=1)
+    try:
+        for phase in range(3):
+            if phase:
+                with torch.no_grad():
+                    for prm in net.policy_value_net.parameters():
+                        prm.mul_(1.0 + 0.9 * phase).add_(0.01 * phase)  # crosses powers of two of max |w|
+                net.weights_changed()
+            for ply in range(3):
+                a.run_playouts(ev, NP)
+                b.run_playouts_memo(ev)
+                for x, y in zip(a.root_children(), b.root_children()):
+                    assert torch.equal(x, y), (phase, ply)
+                (ma, pa), (mb, pb) = a.finish_move(), b.finish_move()
+                assert torch.equal(ma, mb) and torch.equal(pa, pb), (phase, ply)
+                a.harvest()
+                b.harvest()
+        assert b.stats()["memo_hits"] > 0
+    finally:
+        a.close()
+        b.close()
+
+
+def test_captured_rounds_follow_the_weights(gpu_device):
+    """capture_rounds -> weight change -> replay: the replayed launches read the new weight images AND the new
+    per-layer scales (device memory), so the graph run equals an eager run after the same change."""
+    boards = _mixed_boards(128, seed=8)
+    NP = 16
+    net = _net(gpu_device, 5)
+    ev = net.evaluator("per_leaf")
+    g = _engine(boards, NP, seed=2)
+    e = _engine(boards, NP, seed=2)
+    try:
+        e.run_rounds(ev, 2, max_playouts=4)   # the same two eager rounds capture_rounds warms up with
+        g.capture_rounds(ev, rounds=4, max_playouts=4, warmup=2)
+        with torch.no_grad():
+            for prm in net.policy_value_net.parameters():
+                prm.mul_(2.7)
+        net.weights_changed()
+        g.run_rounds(ev, 40, max_playouts=4)
+        e.run_rounds(ev, 40, max_playouts=4)  # no graph on this engine: eager
+        for x, y in zip(g.root_children(), e.root_children()):
+            assert torch.equal(x, y)
+        assert torch.equal(g.get_boards().meta, e.get_boards().meta)
+        sg, se = g.stats(), e.stats()
+        assert sg["playouts"] == se["playouts"] and sg["plies_played"] == se["plies_played"] and sg["plies_played"] > 0
+    finally:
+        g.close()
+        e.close()

@@ -29,7 +29,7 @@ def _run(x, w, gamma, beta, res, relu):
     w16, inv_scale = LeafEvaluator._split_weight(w)
     out = torch.empty_like(x, memory_format=torch.channels_last)
     _cabi.check(_cabi.load().qz_nn_conv3x3_norm(x.data_ptr(), w16.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                                                res.data_ptr() if res is not None else 0, out.data_ptr(), x.shape[0], inv_scale,
+                                                res.data_ptr() if res is not None else 0, out.data_ptr(), x.shape[0], inv_scale.data_ptr(),
                                                 int(relu), 1e-5, torch.cuda.current_stream(x.device).cuda_stream))
     return out
 
@@ -88,7 +88,7 @@ def test_trunk_layer_matches_fp32_reference(gpu_device):
     from alphazero_quoridor_amd.policy_value_net import LeafEvaluator
     w16, inv_scale = LeafEvaluator._split_weight(w)
     _cabi.check(_cabi.load().qz_nn_conv3x3_norm(x2.data_ptr(), w16.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 0, x2.data_ptr(),
-                                                x2.shape[0], inv_scale, 1, 1e-5, torch.cuda.current_stream().cuda_stream))
+                                                x2.shape[0], inv_scale.data_ptr(), 1, 1e-5, torch.cuda.current_stream().cuda_stream))
     assert torch.equal(x2, _run(x, w, gamma, beta, None, True))
 
 

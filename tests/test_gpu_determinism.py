@@ -30,7 +30,7 @@ def test_trunk_kernel_is_deterministic_and_stream_safe(gpu_device):
     def run(x, res, stream):
         out = torch.empty_like(x, memory_format=torch.channels_last)
         _cabi.check(L.qz_nn_conv3x3_norm(x.data_ptr(), w16.data_ptr(), gamma.data_ptr(), beta.data_ptr(), res.data_ptr(), out.data_ptr(),
-                                         x.shape[0], inv_scale, 1, 1e-5, stream.cuda_stream))
+                                         x.shape[0], inv_scale.data_ptr(), 1, 1e-5, stream.cuda_stream))
         return out
 
     xs = [torch.randn((n, 64, 9, 9), generator=g).to(gpu_device).contiguous(memory_format=torch.channels_last) for n in (32, 32, 33, 4096)]
