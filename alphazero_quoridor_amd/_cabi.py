@@ -68,6 +68,7 @@ class qz_config(C.Structure):
         ("select_opts", C.c_int32),
         ("memo_small_log2", C.c_int32),
         ("memo_big_log2", C.c_int32),
+        ("compact_edges", C.c_int32),
     ]
 
 

@@ -302,6 +302,14 @@ int qz_engine_create(const qz_config* cfg, qz_engine** out) {
     d.edge_cap = c.edge_cap;
     d.max_plies = c.max_plies;
     d.n_playout = c.n_playout;
+    if (c.compact_edges == 0) {  // a third of a board's share of the page pool (garbage + live tree + the copy's target must fit), 1..24 pages
+        long long pages = (long long)c.tree_pool_pages / c.n_boards / 3;
+        pages = pages < 1 ? 1 : (pages > 24 ? 24 : pages);
+        c.compact_edges = (int)pages * (int)QZ_PAGE_EDGES;
+    }
+    if (c.node_cap > 0 || c.edge_cap < edge_reach) c.compact_edges = -1;  // the caps count live nodes: every move compacts
+    if (c.compact_edges > edge_reach / 2) c.compact_edges = edge_reach / 2;  // (a ply may add 400 x 131 edges on top)
+    d.compact_edges = c.compact_edges;
     d.tree_pool_pages = c.tree_pool_pages;
     d.traj_pool_pages = c.traj_pool_pages;
     d.traj_page_dwords = (uint32_t)c.traj_page_dwords;
@@ -381,11 +389,11 @@ int qz_engine_create(const qz_config* cfg, qz_engine** out) {
     ALLOC(memo.epoch, (size_t)1);
     if (!rc) rc = dev_alloc(e, &e->feat, B * 486);
     if (!rc) rc = dev_alloc(e, &e->dev_mem, (size_t)1);
-    // memo tables: powers of two; auto = 8,192 small + 1,024 big entries per board
+    // memo tables: powers of two; auto = 4,096 small + 512 big entries per board
     if (c.memo_small_log2 >= 0 && c.memo_big_log2 >= 0) {
         auto log2_ceil = [](unsigned long long x) { int l = 0; while ((1ull << l) < x) l++; return l; };
-        if (c.memo_small_log2 == 0) c.memo_small_log2 = log2_ceil((unsigned long long)B * 8192ull / QZ_MEMO_S_WAYS);
-        if (c.memo_big_log2 == 0) c.memo_big_log2 = log2_ceil((unsigned long long)B * 1024ull / QZ_MEMO_B_WAYS);
+        if (c.memo_small_log2 == 0) c.memo_small_log2 = log2_ceil((unsigned long long)B * 4096ull / QZ_MEMO_S_WAYS);
+        if (c.memo_big_log2 == 0) c.memo_big_log2 = log2_ceil((unsigned long long)B * 512ull / QZ_MEMO_B_WAYS);
         if (c.memo_small_log2 > 31 || c.memo_big_log2 > 31) rc = rc ? rc : fail(QZ_E_INVALID, "memo table too large");
         const size_t sb = ((size_t)1 << c.memo_small_log2), bb = ((size_t)1 << c.memo_big_log2);
         e->memo_small_bytes = sb * QZ_MEMO_S_WAYS * QZ_MEMO_S_DW * 4;

@@ -126,6 +126,7 @@ struct MemoDev {
 struct EngineDev {
     int n_boards, node_cap, edge_cap, max_plies;
     int n_playout;
+    int compact_edges;   // asynchronous loop: moves keep the subtree in place while the tree's cursor is below this (<= 0: every move copies)
     int tree_pool_pages, traj_pool_pages;
     uint32_t traj_page_dwords;
     float c_puct, temp, dirichlet_alpha, noise_frac;

@@ -631,24 +631,97 @@ __device__ unsigned int g_sel_stamps[64][4096][8];
 #define QZ_SEL_MARK(acc)
 #define QZ_SEL_COUNT(x)
 #endif
-__device__ __forceinline__ void select_board(EngineDev& E, const int b, const int lane, Board* leaf_out = nullptr, uint32_t* term_out = nullptr) {
+// The per-board state the tree kernels work on, held in registers for a whole launch: a wavefront that runs many
+// playouts of its board in one launch (k_advance) would otherwise pay a dependent memory round trip for every scalar it
+// re-reads and every counter it bumps per playout (measured: 70 % of such a wavefront's cycles were s_waitcnt).
+// regs_load at the start of a launch (and after a move: finish_move_board works on memory), regs_store at its end.
+struct BoardRegs {
+    Board root;
+    uint32_t rootN, root_ne, root_eoff, half;
+    bool live;
+    TreeView T;                       // page table of the current half (two registers per lane)
+    uint32_t nn, neu, np;             // nodes, edge cursor, pages mapped
+    uint32_t rlen, rstamp;            // lane r < QZ_PATH_RECS: descent record r's length / last-use stamp
+    uint32_t rec_last, rec_clock;
+    uint32_t d_playouts, d_terminal, d_overflow, d_nonfinite, maxdepth;   // deltas of the per-board counters
+    unsigned long long d_levels, d_scanned, d_expanded;
+};
+// the first `cap` levels of the current descent once more in LDS (we: chosen edges, wb: blocks); nullptr: none
+struct PathMirror {
+    uint32_t* we;
+    unsigned long long* wb;
+    uint32_t cap;
+};
+__device__ __forceinline__ BoardRegs regs_load(const EngineDev& E, const int b, const int lane) {
+    BoardRegs R;
+    R.root = load_board(E.root_hb, E.root_vb, E.root_meta, b);
+    R.rootN = rfl(E.root_N[b]);
+    R.root_ne = rfl(E.root_ne[b]);
+    R.root_eoff = rfl(E.root_eoff[b]);
+    R.half = rfl(E.tree_half[b]);
+    R.live = rfl(E.status[b]) == QZ_PLAYING;
+    R.T = tree_view(E, b, R.half, lane);
+    R.nn = rfl(E.n_nodes[b]);
+    R.neu = rfl(E.n_edges[b]);
+    R.np = rfl(E.tree_npages[tree_slot(E, b, R.half)]);
+    R.rlen = lane < QZ_PATH_RECS ? E.rec_len[(size_t)b * QZ_PATH_RECS + lane] : 0u;
+    R.rstamp = lane < QZ_PATH_RECS ? E.rec_stamp[(size_t)b * QZ_PATH_RECS + lane] : 0u;
+    R.rec_last = rfl(E.rec_last[b]);
+    R.rec_clock = rfl(E.rec_clock[b]);
+    R.d_playouts = R.d_terminal = R.d_overflow = R.d_nonfinite = 0u;
+    R.maxdepth = rfl(E.bc_maxdepth[b]);
+    R.d_levels = R.d_scanned = R.d_expanded = 0ull;
+    return R;
+}
+__device__ __forceinline__ void regs_store(const EngineDev& E, const int b, const int lane, const BoardRegs& R) {
+    if (lane < QZ_PATH_RECS) {
+        E.rec_len[(size_t)b * QZ_PATH_RECS + lane] = R.rlen;
+        E.rec_stamp[(size_t)b * QZ_PATH_RECS + lane] = R.rstamp;
+    }
+    if (lane == 0) {
+        // the counters: all loads first, then all stores (one round trip, not one per counter)
+        const uint32_t c0 = E.bc_playouts[b], c1 = E.bc_terminal[b], c2 = E.bc_overflow[b], c3 = E.bc_nonfinite[b];
+        const unsigned long long c4 = E.bc_levels[b], c5 = E.bc_scanned[b], c6 = E.bc_expanded[b];
+        E.root_N[b] = R.rootN;
+        E.root_ne[b] = R.root_ne;
+        E.root_eoff[b] = R.root_eoff;
+        E.n_nodes[b] = R.nn;
+        E.n_edges[b] = R.neu;
+        E.tree_npages[tree_slot(E, b, R.half)] = R.np;
+        E.rec_last[b] = R.rec_last;
+        E.rec_clock[b] = R.rec_clock;
+        E.bc_maxdepth[b] = R.maxdepth;
+        E.bc_playouts[b] = c0 + R.d_playouts;
+        E.bc_terminal[b] = c1 + R.d_terminal;
+        E.bc_overflow[b] = c2 + R.d_overflow;
+        E.bc_nonfinite[b] = c3 + R.d_nonfinite;
+        E.bc_levels[b] = c4 + R.d_levels;
+        E.bc_scanned[b] = c5 + R.d_scanned;
+        E.bc_expanded[b] = c6 + R.d_expanded;
+    }
+}
+// the descent of board b (MCTS._playout, mcts.py:107-113) on the register state R: no per-board scalar is read from or
+// written to memory here; the leaf comes back in registers.  term: 0 live leaf; 1 terminal & winner == current_player;
+// 2 terminal & winner != current_player; 3 board not playing (finished, waiting for harvest)
+__device__ __forceinline__ void select_core(EngineDev& E, BoardRegs& S, const int b, const int lane, const PathMirror PM, Board& leaf_out,
+                                            uint32_t& pedge_out, uint32_t& plen_out, uint32_t& term_out) {
 #ifdef QZ_SELECT_STAMPS
     unsigned long long t_mark = __builtin_amdgcn_s_memtime();
     const unsigned long long t_begin = t_mark;
     unsigned int t_replay = 0, t_walk = 0, n_rounds = 0, n_narrow = 0, n_wide = 0;
 #endif
-    Board bd = load_board(E.root_hb, E.root_vb, E.root_meta, b);
+    Board bd = S.root;
     uint32_t pedge = QZ_NONE;
-    const uint32_t rootN = rfl(E.root_N[b]);
-    int ne = (int)rfl(E.root_ne[b]);
+    const uint32_t rootN = S.rootN;
+    int ne = (int)S.root_ne;
     bool done = false, nonfinite = false;
-    const bool live = rfl(E.status[b]) == QZ_PLAYING;
+    const bool live = S.live;
     uint32_t plen = 0u, scanned = 0u, replayed = 0u;
     if (live && ne > 0) {
         constexpr uint32_t R = QZ_PATH_RECS, CAP = QZ_PATH_CAP;
-        const TreeView T = tree_view(E, b, rfl(E.tree_half[b]), lane);
+        const TreeView T = S.T;
         Edge* const pool = T.pool;
-        uint32_t base = tree_phys(T, rfl(E.root_eoff[b]));
+        uint32_t base = tree_phys(T, S.root_eoff);
         double sq = sqrt((double)rootN);  // np.sqrt(self._parent._n_visits), float64
         uint32_t* const pe0 = E.path_edges + (size_t)b * (R + 1u) * CAP;
         unsigned long long* const pb0 = E.path_blocks + (size_t)b * (R + 1u) * CAP;
@@ -656,9 +729,9 @@ __device__ __forceinline__ void select_board(EngineDev& E, const int b, const in
         unsigned long long* const wb = pb0 + (size_t)R * CAP;
         const bool use = (E.select_opts & 1) == 0;
         // lane r < R keeps record r's length and the time it was last useful
-        uint32_t rlen = (use && lane < (int)R) ? E.rec_len[(size_t)b * R + lane] : 0u;
-        uint32_t rstamp = (lane < (int)R) ? E.rec_stamp[(size_t)b * R + lane] : 0u;
-        const uint32_t src = rfl(E.rec_last[b]) & (R - 1u);  // the record of the previous descent
+        uint32_t rlen = use ? S.rlen : 0u;
+        uint32_t rstamp = S.rstamp;
+        const uint32_t src = S.rec_last & (R - 1u);  // the record of the previous descent
         const uint32_t src_len = rdl(rlen, (int)src);
         // the record being followed: its levels below plen are this descent's (records are whole root-to-leaf paths and
         // the path to an edge is unique).  QZ_NONE: none -- then left_rec / left_at say which record was left last, where
@@ -727,6 +800,10 @@ __device__ __forceinline__ void select_board(EngineDev& E, const int b, const in
                     if (lane < nconf && i < CAP) {
                         we[i] = chosen;
                         wb[i] = w;
+                        if (PM.we && i < PM.cap) {
+                            PM.we[i] = chosen;
+                            PM.wb[i] = w;
+                        }
                     }
                     used |= 1u << cur;
                     done = apply_actions_wave(bd, lact, nconf, lane);
@@ -804,8 +881,13 @@ __device__ __forceinline__ void select_board(EngineDev& E, const int b, const in
             const int a = (int)(misc & 0xFFu);
             done = apply_action(bd, a);  // game.step(action), mcts.py:113
             if (lane == 0 && plen < CAP) {
+                const unsigned long long blk = ((unsigned long long)base << 8) | (unsigned long long)(ne > 255 ? 255 : ne);
                 we[plen] = e;
-                wb[plen] = ((unsigned long long)base << 8) | (unsigned long long)(ne > 255 ? 255 : ne);
+                wb[plen] = blk;
+                if (PM.we && plen < PM.cap) {
+                    PM.we[plen] = e;
+                    PM.wb[plen] = blk;
+                }
             }
             if (use && rfl(recorded) != e && !(cur != QZ_NONE && plen >= cur_len)) {  // (beyond the end of the record it follows, a descent extends it)
                 // the path leaves the record it was following (or follows none): go on in the record that took this
@@ -839,7 +921,7 @@ __device__ __forceinline__ void select_board(EngineDev& E, const int b, const in
         // ---- put this descent on record
         if (use) {
             const uint32_t n = plen < CAP ? plen : CAP;
-            const uint32_t clock = rfl(E.rec_clock[b]) + 1u;
+            const uint32_t clock = S.rec_clock + 1u;
             uint32_t dest, from;  // levels [from, n) of this descent go into record dest, and their edges point at it
             if (cur != QZ_NONE) {
                 dest = cur;  // the descent is record cur, or extends it
@@ -872,9 +954,10 @@ __device__ __forceinline__ void select_board(EngineDev& E, const int b, const in
                 uint32_t* const qe = pe0 + (size_t)dest * CAP;
                 unsigned long long* const qb = pb0 + (size_t)dest * CAP;
                 for (uint32_t i = from + (uint32_t)lane; i < n; i += 64u) {
-                    const uint32_t ed = we[i];
+                    const bool m = PM.we && i < PM.cap;
+                    const uint32_t ed = m ? PM.we[i] : we[i];
                     qe[i] = ed;
-                    qb[i] = wb[i];
+                    qb[i] = m ? PM.wb[i] : wb[i];
                     if (i >= first) pool[ed].rid = (uint16_t)(dest + 1u);
                 }
             }
@@ -883,13 +966,11 @@ __device__ __forceinline__ void select_board(EngineDev& E, const int b, const in
                     if (from < n) rlen = n;
                     rstamp = clock;
                 } else if ((used >> lane) & 1u) rstamp = clock;
-                E.rec_len[(size_t)b * R + lane] = rlen;
-                E.rec_stamp[(size_t)b * R + lane] = rstamp;
+                S.rlen = rlen;
+                S.rstamp = rstamp;
             }
-            if (lane == 0) {
-                E.rec_last[b] = dest;
-                E.rec_clock[b] = clock;
-            }
+            S.rec_last = dest;
+            S.rec_clock = clock;
         }
     }
 #ifdef QZ_SELECT_STAMPS
@@ -900,29 +981,36 @@ __device__ __forceinline__ void select_board(EngineDev& E, const int b, const in
         o[4] = n_narrow; o[5] = n_wide; o[6] = plen; o[7] = replayed;
     }
 #endif
-    // 0 live leaf; 1 terminal & winner == current_player; 2 terminal & winner != current_player;
-    // 3 board not playing (finished, waiting for harvest): ignored by expand_backup
-    uint8_t t = 0;
-    if (!live) t = 3;
-    else if (done) t = (winner_of(bd) == bd.cur) ? 1 : 2;
-    if (leaf_out) *leaf_out = bd;
-    if (term_out) *term_out = (uint32_t)t;
+    uint32_t t = 0u;
+    if (!live) t = 3u;
+    else if (done) t = (winner_of(bd) == bd.cur) ? 1u : 2u;
+    leaf_out = bd;
+    pedge_out = pedge;
+    plen_out = plen;
+    term_out = t;
+    S.d_nonfinite += nonfinite ? 1u : 0u;
+    S.d_scanned += (unsigned long long)scanned;
+    if (plen > S.maxdepth) S.maxdepth = plen;
+    if (plen >= 256u && lane == 0) {  // telemetry of the descents that set the kernel's duration (a handful of boards)
+        atomicAdd(&E.counters[QZ_C_DEEP_DESCENTS], 1ull);
+        if (2u * replayed < plen) atomicAdd(&E.counters[QZ_C_DEEP_COLD], 1ull);
+        atomicAdd(&E.counters[QZ_C_DEEP_LEVELS], (unsigned long long)plen);
+        atomicAdd(&E.counters[QZ_C_DEEP_REPLAYED], (unsigned long long)replayed);
+    }
+}
+// the lock-step kernels' descent: state from memory, leaf to memory (E.leaf_*: what the rules op, the evaluator and
+// k_expand_backup read)
+__device__ __forceinline__ void select_board(EngineDev& E, BoardRegs& S, const int b, const int lane) {
+    Board bd;
+    uint32_t pedge, plen, t;
+    select_core(E, S, b, lane, PathMirror{nullptr, nullptr, 0u}, bd, pedge, plen, t);
     if (lane == 0) {
         E.leaf_hb[b] = bd.hb;
         E.leaf_vb[b] = bd.vb;
         E.leaf_meta[b] = pack_meta(bd);
         E.leaf_pedge[b] = pedge;
         E.path_len[b] = plen;
-        E.leaf_term[b] = t;
-        if (nonfinite) E.bc_nonfinite[b] += 1u;
-        E.bc_scanned[b] += (unsigned long long)scanned;
-        if (plen > E.bc_maxdepth[b]) E.bc_maxdepth[b] = plen;
-        if (plen >= 256u) {  // telemetry of the descents that set the kernel's duration (a handful of boards)
-            atomicAdd(&E.counters[QZ_C_DEEP_DESCENTS], 1ull);
-            if (2u * replayed < plen) atomicAdd(&E.counters[QZ_C_DEEP_COLD], 1ull);
-            atomicAdd(&E.counters[QZ_C_DEEP_LEVELS], (unsigned long long)plen);
-            atomicAdd(&E.counters[QZ_C_DEEP_REPLAYED], (unsigned long long)replayed);
-        }
+        E.leaf_term[b] = (uint8_t)t;
     }
 }
 
@@ -930,27 +1018,26 @@ __global__ __launch_bounds__(TPB) void k_select(EngineDev E) {
     const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
     const int b = (int)blockIdx.x * WPB + wave;
     if (b >= E.n_boards) return;
-    select_board(E, b, lane);
+    BoardRegs S = regs_load(E, b, lane);
+    select_board(E, S, b, lane);
+    regs_store(E, b, lane, S);
 }
 
 // TreeNode.expand (mcts.py:27-35): a block of k edges in actions() order under physical edge `pedge` (QZ_NONE: the
 // root), priors from prior(a) -- called by the lane that owns action a (a = lane, lane + 64, lane + 128).
 template <typename PriorFn>
-__device__ __forceinline__ void expand_node(EngineDev& E, const int b, const int lane, const uint32_t pedge, const uint32_t m0,
+__device__ __forceinline__ void expand_node(EngineDev& E, BoardRegs& S, const int lane, const uint32_t pedge, const uint32_t m0,
                                             const uint32_t m1, const uint32_t m2, const uint32_t m3, const uint32_t m4, PriorFn prior) {
     uint32_t pawn = m0 & 0xFFFu;
     uint64_t lh = ((uint64_t)m0 >> 12) | ((uint64_t)m1 << 20) | ((uint64_t)(m2 & 0xFFFu) << 52);
     uint64_t lv = ((uint64_t)m2 >> 12) | ((uint64_t)m3 << 20) | ((uint64_t)(m4 & 0xFFFu) << 52);
     int k = __popc(pawn) + __popcll(lh) + __popcll(lv);
     if (k > 0) {
-        const uint32_t half = rfl(E.tree_half[b]);
-        const size_t slot = tree_slot(E, b, half);
-        TreeView T = tree_view(E, b, half, lane);
-        uint32_t nn = rfl(E.n_nodes[b]), neu = rfl(E.n_edges[b]), np = rfl(E.tree_npages[slot]);
+        uint32_t neu = S.neu, np = S.np;
         uint32_t off = QZ_NONE;
-        if (E.node_cap <= 0 || nn < (uint32_t)E.node_cap) off = tree_alloc(E, T, neu, np, k, lane, false);
+        if (E.node_cap <= 0 || S.nn < (uint32_t)E.node_cap) off = tree_alloc(E, S.T, neu, np, k, lane, false);
         if (off != QZ_NONE) {
-            const uint32_t base = tree_phys(T, off);
+            const uint32_t base = tree_phys(S.T, off);
             for (int a = lane; a < QZ_N_ACT; a += 64) {
                 uint32_t w = a < 32 ? m0 : (a < 64 ? m1 : (a < 96 ? m2 : (a < 128 ? m3 : m4)));
                 if ((w >> (a & 31)) & 1u) {
@@ -965,40 +1052,39 @@ __device__ __forceinline__ void expand_node(EngineDev& E, const int b, const int
                     ed.cne = 0;
                     ed.rid = 0;
                     ed.spare = QZ_NONE;
-                    T.pool[e] = ed;
+                    S.T.pool[e] = ed;
                 }
             }
-            if (lane == 0) {
-                if (pedge != QZ_NONE) {
-                    T.pool[pedge].coff = off;
-                    T.pool[pedge].cne = (uint8_t)k;
-                } else {
-                    E.root_eoff[b] = off;
-                    E.root_ne[b] = (uint32_t)k;
+            if (pedge != QZ_NONE) {
+                if (lane == 0) {
+                    S.T.pool[pedge].coff = off;
+                    S.T.pool[pedge].cne = (uint8_t)k;
                 }
-                E.n_nodes[b] = nn + 1u;
-                E.n_edges[b] = neu;
-                E.tree_npages[slot] = np;
-                E.bc_expanded[b] += (unsigned long long)k;
+            } else {
+                S.root_eoff = off;
+                S.root_ne = (uint32_t)k;
             }
-        } else if (lane == 0) {
-            E.bc_overflow[b] += 1u;
-            E.tree_npages[slot] = np;
+            S.nn += 1u;
+            S.neu = neu;
+            S.np = np;
+            S.d_expanded += (unsigned long long)k;
+        } else {
+            S.d_overflow += 1u;
+            S.np = np;
         }
     }
 }
 // node.update_recursive(-leaf_value) (mcts.py:44-62, 127): the leaf edge gets -leaf_value, its
-// parent +leaf_value, ... up to the root.  The descent recorded its edges, so all levels are
-// updated in parallel (lane = level); a path longer than the record falls back to walking
-// the parent links.  term: the leaf's E.leaf_term code (statistics only).
-__device__ __forceinline__ void backup_leaf(EngineDev& E, const int b, const int lane, const double leaf_value, const uint32_t pedge,
-                                            const uint32_t term) {
+// parent +leaf_value, ... up to the root.  The descent recorded its edges (the descent buffer `path`, its first PM.cap
+// levels once more in LDS), so all levels are updated in parallel (lane = level); a path longer than the record falls
+// back to walking the parent links.  term: the leaf's code (statistics only).
+__device__ __forceinline__ void backup_leaf(EngineDev& E, BoardRegs& S, const int b, const int lane, const PathMirror PM, const double leaf_value,
+                                            const uint32_t pedge, const uint32_t plen, const uint32_t term) {
     Edge* pool = E.edge_pool;
-    const uint32_t plen = rfl(E.path_len[b]);
     if (plen <= (uint32_t)QZ_PATH_CAP) {
-        const uint32_t* path = E.path_edges + ((size_t)b * (QZ_PATH_RECS + 1) + QZ_PATH_RECS) * QZ_PATH_CAP;  // k_select's descent buffer
+        const uint32_t* path = E.path_edges + ((size_t)b * (QZ_PATH_RECS + 1) + QZ_PATH_RECS) * QZ_PATH_CAP;  // the descent buffer
         for (uint32_t i = (uint32_t)lane; i < plen; i += 64u) {
-            uint32_t pe = path[i];
+            uint32_t pe = (PM.we && i < PM.cap) ? PM.we[i] : path[i];
             double val = ((plen - 1u - i) & 1u) ? leaf_value : -leaf_value;
             uint32_t N = pool[pe].N + 1u;  // mcts.py:51
             double Q = pool[pe].Q;
@@ -1019,59 +1105,57 @@ __device__ __forceinline__ void backup_leaf(EngineDev& E, const int b, const int
             pe = pool[pe].pedge;
         }
     }
-    if (lane == 0) {
-        E.root_N[b] = E.root_N[b] + 1u;  // the root is updated too
-        E.bc_playouts[b] += 1u;
-        E.bc_levels[b] += (unsigned long long)plen;
-        if (term != 0u) E.bc_terminal[b] += 1u;
-    }
+    S.rootN += 1u;  // the root is updated too
+    S.d_playouts += 1u;
+    S.d_levels += (unsigned long long)plen;
+    if (term != 0u) S.d_terminal += 1u;
 }
 // mcts.py:125: +1 if winner == current_player else -1 (always +1 in practice: the reference does not rotate players
-// on a terminal move); term = 1 | 2 (E.leaf_term)
+// on a terminal move); term = 1 | 2
 __device__ __forceinline__ double terminal_value(const EngineDev& E, const uint32_t term) {
     double leaf_value = (term == 1u) ? 1.0 : -1.0;
     if (E.fix_terminal_sign) leaf_value = -leaf_value;
     return leaf_value;
 }
-// TreeNode.expand + update_recursive of board b's current leaf with the network's output row `prow` / value `vval` and
-// the legal set `mask` (5 words); terminal leaves ignore all three
-__device__ __forceinline__ void expand_backup_with(EngineDev& E, const uint32_t* __restrict__ mask, const float* __restrict__ prow,
-                                                   const float vval, const int b, const int lane) {
-    uint32_t term = rfl(E.leaf_term[b]);
+// the lock-step kernels' TreeNode.expand + update_recursive of board b's current leaf (E.leaf_*: written by the last
+// descent) with the caller's p [B][140] / v [B] and the legal sets of the rules op (E.leaf_mask)
+__device__ __forceinline__ void expand_backup_board(EngineDev& E, BoardRegs& S, const float* __restrict__ p, const float* __restrict__ v, const int b, const int lane) {
+    const uint32_t term = rfl(E.leaf_term[b]);
     if (term == 3u) return;
-    const uint32_t pedge = rfl(E.leaf_pedge[b]);
+    const uint32_t pedge = rfl(E.leaf_pedge[b]), plen = rfl(E.path_len[b]);
     double leaf_value;
     if (term == 0u) {
-        leaf_value = (double)vval;
-        expand_node(E, b, lane, pedge, rfl(mask[0]), rfl(mask[1]), rfl(mask[2]), rfl(mask[3]), rfl(mask[4]),
-                    [&](int a) { return prow[a]; });
+        leaf_value = (double)v[b];
+        const uint32_t* mask = E.leaf_mask + (size_t)b * 5;
+        const float* prow = p + (size_t)b * QZ_N_ACT;
+        expand_node(E, S, lane, pedge, rfl(mask[0]), rfl(mask[1]), rfl(mask[2]), rfl(mask[3]), rfl(mask[4]), [&](int a) { return prow[a]; });
     } else {
         leaf_value = terminal_value(E, term);
     }
-    backup_leaf(E, b, lane, leaf_value, pedge, term);
-}
-__device__ __forceinline__ void expand_backup_board(EngineDev& E, const float* __restrict__ p, const float* __restrict__ v, const int b, const int lane) {
-    if (rfl(E.leaf_term[b]) == 3u) return;
-    expand_backup_with(E, E.leaf_mask + (size_t)b * 5, p + (size_t)b * QZ_N_ACT, v[b], b, lane);
+    backup_leaf(E, S, b, lane, PathMirror{nullptr, nullptr, 0u}, leaf_value, pedge, plen, term);
 }
 
 __global__ __launch_bounds__(TPB) void k_expand_backup(EngineDev E, const float* __restrict__ p, const float* __restrict__ v) {
     const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
     const int b = (int)blockIdx.x * WPB + wave;
     if (b >= E.n_boards) return;
-    expand_backup_board(E, p, v, b, lane);
+    BoardRegs S = regs_load(E, b, lane);
+    expand_backup_board(E, S, p, v, b, lane);
+    regs_store(E, b, lane, S);
 }
 // Playout i's expansion + backup and playout i+1's descent of the same board in ONE launch, by the same wavefront: a
 // kernel boundary flushes the eight XCDs' L2s, so a descent launched on its own fetches every edge record of its chain
 // from the Infinity Cache / HBM (~1 us per level); here the records the backup just touched are still in this XCD's L2.
 // Same operations in the same order per board as k_expand_backup followed by k_select.
-__global__ __launch_bounds__(TPB) void k_expand_backup_select(EngineDev E, const float* __restrict__ p, const float* __restrict__ v) {
+__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_expand_backup_select(EngineDev E, const float* __restrict__ p, const float* __restrict__ v) {
     const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
     const int b = (int)blockIdx.x * WPB + wave;
     if (b >= E.n_boards) return;
-    expand_backup_board(E, p, v, b, lane);
+    BoardRegs S = regs_load(E, b, lane);
+    expand_backup_board(E, S, p, v, b, lane);
     wave_sync();  // the backup's stores (other lanes) before the descent's loads
-    select_board(E, b, lane);
+    select_board(E, S, b, lane);
+    regs_store(E, b, lane, S);
 }
 
 // softmax(1/temp * log(visits + 1e-10)) over the root's children (mcts.py:6-9, 141-144).
@@ -1174,7 +1258,7 @@ __device__ __forceinline__ void copy_block(const TreeView& S, uint32_t s_off, co
 // edge left a forwarding address behind (Edge::spare of the OLD record).  A record that went through `edge` stays valid
 // one level shorter: its entries are shifted up by one and renamed through the forwarding addresses; it is cut where
 // the copy was (pool exhausted).  Every other record described a subtree that is gone.  edge == QZ_NONE: all gone.
-__device__ __forceinline__ void translate_records(EngineDev& E, int b, int lane, uint32_t edge) {
+__device__ __forceinline__ void translate_records(EngineDev& E, int b, int lane, uint32_t edge, const bool in_place = false) {
     constexpr uint32_t R = QZ_PATH_RECS, CAP = QZ_PATH_CAP;
     const Edge* pool = E.edge_pool;
     wave_sync();  // the forwarding addresses were stored by other lanes
@@ -1192,8 +1276,13 @@ __device__ __forceinline__ void translate_records(EngineDev& E, int b, int lane,
                 unsigned long long bo = 0ull;
                 if (in) {
                     bo = rb[i];
-                    fe = pool[re[i]].spare;
-                    fb = pool[(uint32_t)(bo >> 8)].spare;
+                    if (in_place) {  // the subtree stays where it is: the entries only move up one level
+                        fe = re[i];
+                        fb = (uint32_t)(bo >> 8);
+                    } else {
+                        fe = pool[re[i]].spare;
+                        fb = pool[(uint32_t)(bo >> 8)].spare;
+                    }
                 }
                 const uint64_t bad = __ballot(in && (fe == QZ_NONE || fb == QZ_NONE));
                 const uint32_t nvalid = bad ? (uint32_t)(__ffsll((unsigned long long)bad) - 1) : 64u;
@@ -1217,7 +1306,13 @@ __device__ __forceinline__ void translate_records(EngineDev& E, int b, int lane,
 // copy itself: blocks are appended in discovery order, so scanning the new tree's edges in
 // logical order and expanding every edge with cne > 0 visits the nodes breadth first.  The old
 // pages are handed back by k_release (launched right after every kernel that re-roots).
-__device__ __forceinline__ void wave_reroot(EngineDev& E, int b, int lane, uint32_t edge) {
+// in_place (the asynchronous loop, while the tree's allocation cursor is below qz_config.compact_edges): the kept subtree
+// is NOT copied -- the chosen child's block simply becomes the root's block where it lies (its edges lose their parent
+// link), the rest of the old tree stays behind as garbage until a later move compacts (the copy below), and a child
+// without a subtree makes the whole tree garbage: the cursor goes back to 0 in the pages already mapped.  Same tree as
+// far as any descent, expansion or backup can tell; a move costs a few stores instead of a breadth-first copy whose
+// duration (up to tens of ms for the largest trees) every other board of the launch had to wait for.
+__device__ __forceinline__ void wave_reroot(EngineDev& E, int b, int lane, uint32_t edge, const bool in_place = false) {
     const uint32_t half = rfl(E.tree_half[b]);
     const TreeView S = tree_view(E, b, half, lane);
     uint32_t s_off = 0u, childN = 0u;
@@ -1226,6 +1321,25 @@ __device__ __forceinline__ void wave_reroot(EngineDev& E, int b, int lane, uint3
         s_ne = (int)rfl((uint32_t)S.pool[edge].cne);
         s_off = rfl(S.pool[edge].coff);
         childN = rfl(S.pool[edge].N);
+    }
+    if (in_place) {
+        if (s_ne > 0) {
+            const uint32_t base = tree_phys(S, s_off);
+            for (int k = lane; k < s_ne; k += 64) S.pool[base + (uint32_t)k].pedge = QZ_NONE;
+        }
+        translate_records(E, b, lane, s_ne > 0 ? edge : QZ_NONE, true);
+        if (lane == 0) {
+            E.path_len[b] = 0u;
+            E.pl_done[b] = 0u;
+            E.root_N[b] = childN;
+            E.root_eoff[b] = s_ne > 0 ? s_off : 0u;
+            E.root_ne[b] = (uint32_t)s_ne;
+            if (s_ne == 0) {
+                E.n_nodes[b] = 0u;
+                E.n_edges[b] = 0u;
+            }
+        }
+        return;
     }
     uint32_t new_nodes = 0u, new_edges = 0u, dnp = 0u, root_off = 0u, truncated = 0u;
     int root_ne = 0;
@@ -1431,7 +1545,7 @@ __device__ double gamma_small(const Philox& ph, uint32_t c0, uint32_t c1, uint32
 // MCTSPlayer.choose_action tail + one iteration of start_self_play (mcts.py:174-187,
 // quoridor.py:585-602).  POP-ONLY (trajectory page, pages of the re-rooted tree).
 __device__ __forceinline__ void finish_move_board(EngineDev& E, const int b, const int lane, const uint8_t* __restrict__ forced,
-                                                  float* __restrict__ pi_out, uint8_t* __restrict__ move_out) {
+                                                  float* __restrict__ pi_out, uint8_t* __restrict__ move_out, const bool in_place = false) {
     if (move_out && lane == 0) move_out[b] = QZ_NO_MOVE_U8;
     if (pi_out)
         for (int a = lane; a < QZ_N_ACT; a += 64) pi_out[(size_t)b * QZ_N_ACT + a] = 0.f;
@@ -1573,7 +1687,7 @@ __device__ __forceinline__ void finish_move_board(EngineDev& E, const int b, con
     if (move_out && lane == 0) move_out[b] = (uint8_t)mv;
 
     // update_with_move(move) in self-play, update_with_move(-1) otherwise (mcts.py:182,187)
-    wave_reroot(E, b, lane, E.is_selfplay ? (uint32_t)(re - E.edge_pool) + (uint32_t)chosen_k : QZ_NONE);
+    wave_reroot(E, b, lane, E.is_selfplay ? (uint32_t)(re - E.edge_pool) + (uint32_t)chosen_k : QZ_NONE, in_place);
 
     // self.step(move); has_a_winner() (quoridor.py:593-596)
     bool done = apply_action(bd, mv);
@@ -1593,9 +1707,9 @@ __device__ __forceinline__ void finish_move_board(EngineDev& E, const int b, con
 }
 // the same as a real call (k_advance: inlined there it would set the whole kernel's register count -- 223 VGPRs, two waves
 // per SIMD -- for code that runs once per n_playout playouts).  Ed: the engine's EngineDev in device memory.
-__device__ __forceinline__ void finish_move_call(const EngineDev* __restrict__ Ed, const int b, const int lane) {
+__device__ __forceinline__ void finish_move_call(const EngineDev* __restrict__ Ed, const int b, const int lane, const bool in_place) {
     EngineDev E = *Ed;
-    finish_move_board(E, b, lane, nullptr, nullptr, nullptr);
+    finish_move_board(E, b, lane, nullptr, nullptr, nullptr, in_place);
 }
 __global__ __launch_bounds__(TPB) void k_finish_move(EngineDev E, const uint8_t* __restrict__ forced, float* __restrict__ pi_out,
                                                      uint8_t* __restrict__ move_out) {
@@ -1628,9 +1742,9 @@ struct MemoHit {
     const float* p_row;  // big table: p[140]; nullptr for a small-table hit
 };
 // one coalesced load of the bucket, key compare by ballot.  All lanes must call.
-__device__ __forceinline__ bool memo_probe(const EngineDev& E, const Board& bd, const int lane, MemoHit& H) {
+__device__ __forceinline__ bool memo_probe(const EngineDev& E, const uint32_t epoch, const Board& bd, const int lane, MemoHit& H) {
     if (!E.memo.small) return false;
-    const uint64_t hb = bd.hb, vb = bd.vb, mk = pack_meta(bd) | ((uint64_t)rfl(*E.memo.epoch) << 48);
+    const uint64_t hb = bd.hb, vb = bd.vb, mk = pack_meta(bd) | ((uint64_t)epoch << 48);
     const uint64_t h = memo_hash(hb, vb, pack_meta(bd));
     const int pos = lane & 31;
     const uint32_t kd = memo_key_dword(pos, hb, vb, mk);
@@ -1756,74 +1870,108 @@ __device__ __forceinline__ void memo_insert(const EngineDev& E, const uint64_t h
 //   auto_finish 0: boards stop at n_playout (the host calls qz_mcts_finish_move)
 //   par         which of the two miss counters this round uses (rounds alternate: the tail of round r clears the
 //               counter of round r + 1 while nobody reads it)
+#ifdef QZ_ADV_STAMPS  // diagnostic build only (tests/hip/Makefile, benchmarks/advance_stamps.py): where a wavefront's time goes in k_advance
+__device__ unsigned long long g_adv_stamps[4096][16];  // per board, accumulated over launches: cycles per phase + counts
+#define QZ_AS_MARK(k) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); as_acc[k] += now_ - as_t; if ((k) == 3 && now_ - as_t > as_max[0]) as_max[0] = now_ - as_t; if ((k) == 4 && now_ - as_t > as_max[1]) as_max[1] = now_ - as_t; as_t = now_; }
+#define QZ_AS_COUNT(k, v) { as_acc[k] += (unsigned long long)(v); }
+#else
+#define QZ_AS_MARK(k)
+#define QZ_AS_COUNT(k, v)
+#endif
+constexpr uint32_t ADV_LCAP = 512;  // levels of a descent mirrored in LDS (6 KB per wavefront); deeper levels are read back from memory
 __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_advance(EngineDev E, const EngineDev* __restrict__ Ed, int max_iters, unsigned int budget, int auto_finish, int par) {
+    __shared__ uint32_t s_we[WPB][ADV_LCAP];
+    __shared__ unsigned long long s_wb[WPB][ADV_LCAP];
     const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
     const int b = __builtin_amdgcn_readfirstlane((int)blockIdx.x * WPB + wave);  // in an SGPR: every per-board address below is scalar arithmetic
     if (b >= E.n_boards) return;
     if (b == 0 && lane == 0) atomicAdd(&E.counters[QZ_C_ROUNDS], 1ull);
     if (rfl(E.status[b]) != QZ_PLAYING) return;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    uint32_t done = rfl(E.pl_done[b]);
-    {
-        const Board rb = unpack(0ull, 0ull, rfl64(E.root_meta[b]));
-        if ((rb.cur == 1 ? rb.w1 : rb.w2) > 0 && lane == 0) E.bc_open_rounds[b] += 1u;
-    }
+#ifdef QZ_ADV_STAMPS
+    unsigned long long as_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, as_max[2] = {0, 0}, as_t = __builtin_amdgcn_s_memtime();
+    const unsigned long long as_t0 = as_t;
+#endif
+    const PathMirror PM{s_we[wave], s_wb[wave], ADV_LCAP};
+    const PathMirror NOPM{nullptr, nullptr, 0u};
+    BoardRegs S = regs_load(E, b, lane);
+    const uint32_t epoch = rfl(*E.memo.epoch);
+    uint32_t done = rfl(E.pl_done[b]), hits = 0u, evals = 0u, open_rounds = 0u, open_plies = 0u;
+    if ((S.root.cur == 1 ? S.root.w1 : S.root.w2) > 0) open_rounds = 1u;
     // One resolved leaf at a time: (legal set, priors, value) of the leaf the last descent found -- from the network
     // (the evaluation this board was waiting for), from the memo, or a terminal leaf's +-1 -- is applied at the top of
     // the loop by the one copy of TreeNode.expand + update_recursive.
     const uint32_t slot = rfl(E.pend_slot[b]);
-    bool have = slot != QZ_NONE, waiting = false;
-    uint32_t m0 = 0u, m1 = 0u, m2 = 0u, m3 = 0u, m4 = 0u, term = 0u;
+    bool have = slot != QZ_NONE, waiting = false, from_memory = have;
+    uint32_t m0 = 0u, m1 = 0u, m2 = 0u, m3 = 0u, m4 = 0u, term = 0u, pedge = QZ_NONE, plen = 0u;
     const float* prow = nullptr;  // priors as a row of 140 floats, or (nullptr) this lane's prior in pl (small-table hit)
     float pl = 0.f;
     double value = 0.0;
-    if (have) {
+    if (have) {  // the leaf of the previous launch: its descent buffer is in memory only
         const uint32_t* mk = E.miss_mask + (size_t)slot * 5;
         m0 = rfl(mk[0]); m1 = rfl(mk[1]); m2 = rfl(mk[2]); m3 = rfl(mk[3]); m4 = rfl(mk[4]);
         prow = E.miss_p + (size_t)slot * QZ_N_ACT;
         value = (double)E.miss_v[slot];
+        pedge = rfl(E.leaf_pedge[b]);
+        plen = rfl(E.path_len[b]);
     }
+    QZ_AS_MARK(0)  // 0: launch prologue (state load, pending evaluation's scalars)
     for (int it = 0;; it++) {
         if (have) {
-            const uint32_t pedge = rfl(E.leaf_pedge[b]);
-            if (term == 0u) expand_node(E, b, lane, pedge, m0, m1, m2, m3, m4, [&](int a) { return prow ? prow[a] : pl; });
-            backup_leaf(E, b, lane, value, pedge, term);
+            if (term == 0u) expand_node(E, S, lane, pedge, m0, m1, m2, m3, m4, [&](int a) { return prow ? prow[a] : pl; });
+            QZ_AS_MARK(1)  // 1: expansion
+            backup_leaf(E, S, b, lane, from_memory ? NOPM : PM, value, pedge, plen, term);
             done++;
             have = false;
+            from_memory = false;
             wave_sync();
+            QZ_AS_MARK(2)  // 2: backup
+            QZ_AS_COUNT(8, 1)
         }
         if (it >= max_iters) break;
         if (done >= (uint32_t)E.n_playout) {
             if (!auto_finish || rfl((uint32_t)E.release[b]) != 0u) break;
-            const Board rb = unpack(0ull, 0ull, rfl64(E.root_meta[b]));
-            if ((rb.cur == 1 ? rb.w1 : rb.w2) > 0 && lane == 0) E.bc_open_plies[b] += 1u;
-            finish_move_call(Ed, b, lane);
+            // the move keeps the subtree in place while the tree is small; once its allocation cursor has passed
+            // compact_edges the move compacts (breadth-first copy into fresh pages), and such a move only STARTS a launch:
+            // it then runs beside the other boards' playouts instead of at the end of everybody's budget
+            const bool compact = E.compact_edges <= 0 || S.neu >= (uint32_t)E.compact_edges;
+            if (compact && it > 0) break;
+            if ((S.root.cur == 1 ? S.root.w1 : S.root.w2) > 0) open_plies++;
+            regs_store(E, b, lane, S);  // the move works on the state in memory
+            wave_sync();
+            finish_move_call(Ed, b, lane, !compact);
             done = 0u;
             wave_sync();
-            if (rfl(E.status[b]) != QZ_PLAYING) break;  // the game is over (or was dropped): wait for the harvest
+            S = regs_load(E, b, lane);
+            QZ_AS_MARK(3)  // 3: the move (state store, finish_move_board, state load)
+            if (!S.live) break;  // the game is over (or was dropped): wait for the harvest
             // the move's child had no subtree (or the copy found the pool empty): the board restarts from a fresh root in
             // the SAME table half, whose pages k_round_tail is about to hand back -- nothing may be built there before
             if (rfl((uint32_t)E.release[b]) & 2u) break;
         }
         if (it > 0 && (unsigned int)(__builtin_amdgcn_s_memrealtime() - t0) > budget) break;
         Board leaf;
-        select_board(E, b, lane, &leaf, &term);
+        select_core(E, S, b, lane, PM, leaf, pedge, plen, term);
         wave_sync();  // the descent buffer (lane 0 / other lanes) before the backup reads it
+        QZ_AS_MARK(4)  // 4: descent
+        QZ_AS_COUNT(9, plen)
         if (term != 0u) {
             value = terminal_value(E, term);
             have = true;
             continue;
         }
         MemoHit H;
-        if (memo_probe(E, leaf, lane, H)) {
+        if (memo_probe(E, epoch, leaf, lane, H)) {
             m0 = H.m0; m1 = H.m1; m2 = H.m2; m3 = H.m3; m4 = H.m4;
             prow = H.p_row;
             pl = H.p_lane;
             value = (double)H.v;
             have = true;
-            if (lane == 0) E.bc_memo_hits[b] += 1u;
+            hits++;
+            QZ_AS_MARK(5)  // 5: memo probe (hit)
             continue;
         }
+        QZ_AS_MARK(6)  // 6: memo probe (miss)
         // ---- a leaf for the network
         uint32_t s = 0u;
         if (lane == 0) s = (uint32_t)atomicAdd(E.miss_count + par, 1);
@@ -1833,14 +1981,34 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             E.miss_vb[s] = leaf.vb;
             E.miss_meta[s] = pack_meta(leaf);
             E.pend_slot[b] = s;
-            E.bc_evals[b] += 1u;
+            E.leaf_pedge[b] = pedge;
+            E.path_len[b] = plen;
         }
+        evals++;
         waiting = true;
         break;
     }
+    regs_store(E, b, lane, S);
+#ifdef QZ_ADV_STAMPS
+    QZ_AS_MARK(7)  // 7: epilogue (miss record, state store)
+    if (lane == 0 && b < 4096) {
+        for (int k = 0; k < 10; k++) g_adv_stamps[b][k] += as_acc[k];
+        const unsigned long long whole = __builtin_amdgcn_s_memtime() - as_t0;
+        g_adv_stamps[b][10] += whole;
+        g_adv_stamps[b][11] += 1ull;
+        if (as_max[0] > g_adv_stamps[b][12]) g_adv_stamps[b][12] = as_max[0];  // longest single move
+        if (as_max[1] > g_adv_stamps[b][13]) g_adv_stamps[b][13] = as_max[1];  // longest single descent
+        if (whole > g_adv_stamps[b][14]) g_adv_stamps[b][14] = whole;          // longest launch of this board
+        g_adv_stamps[b][15] += as_max[0] > 0 ? 1ull : 0ull;                      // launches with a move
+    }
+#endif
     if (lane == 0) {
         E.pl_done[b] = done;
         if (!waiting && slot != QZ_NONE) E.pend_slot[b] = QZ_NONE;
+        if (hits) E.bc_memo_hits[b] += hits;
+        if (evals) E.bc_evals[b] += evals;
+        if (open_rounds) E.bc_open_rounds[b] += open_rounds;
+        if (open_plies) E.bc_open_plies[b] += open_plies;
     }
 }
 
@@ -2209,6 +2377,16 @@ extern "C" int qzt_rules_stamps_read(void* stamps, void* enc, void* rt) {  // [4
     hipError_t e = hipMemcpyFromSymbol(stamps, HIP_SYMBOL(g_rules_stamps), sizeof(g_rules_stamps));
     if (e == hipSuccess) e = hipMemcpyFromSymbol(enc, HIP_SYMBOL(g_rules_enc), sizeof(g_rules_enc));
     if (e == hipSuccess) e = hipMemcpyFromSymbol(rt, HIP_SYMBOL(g_rules_rt), sizeof(g_rules_rt));
+    return (int)e;
+}
+#endif
+#ifdef QZ_ADV_STAMPS
+extern "C" int qzt_advance_stamps_read(void* host_out, int clear) {  // [4096 boards][16] u64
+    hipError_t e = hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_adv_stamps), sizeof(g_adv_stamps));
+    if (e == hipSuccess && clear) {
+        static unsigned long long zeros[4096][16];
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_adv_stamps), zeros, sizeof(zeros));
+    }
     return (int)e;
 }
 #endif

@@ -77,7 +77,7 @@ class SelfPlayEngine:
     def __init__(self, n_boards, n_playout=400, c_puct=5.0, temp=1.0, is_selfplay=1, seed=0, device="cuda:0",
                  fix_terminal_sign=False, node_cap=0, edge_cap=0, max_plies=0, dirichlet_alpha=0.3, noise_frac=0.25,
                  tree_pool_pages=0, traj_pool_pages=0, traj_page_dwords=0, rules_opts=None, select_opts=0, memo=True,
-                 memo_small_log2=0, memo_big_log2=0):
+                 memo_small_log2=0, memo_big_log2=0, compact_edges=0):
         if not torch.cuda.is_available():
             raise _cabi.QzError(_cabi.E_NO_DEVICE, "no HIP device: the engine has no CPU path")
         self.L = _cabi.load()
@@ -102,6 +102,7 @@ class SelfPlayEngine:
         # leaf-evaluation memo of the asynchronous self-play loop (include/qz_abi.h): log2 of the bucket counts, 0 = auto
         cfg.memo_small_log2 = int(memo_small_log2) if memo else -1
         cfg.memo_big_log2 = int(memo_big_log2) if memo else -1
+        cfg.compact_edges = int(compact_edges)  # 0 = default; < 0: every move of the asynchronous loop copies its subtree
         if rules_opts is not None:
             cfg.rules = rules_opts
         self.cfg = cfg

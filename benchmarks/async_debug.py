@@ -1,20 +1,37 @@
-"""debug driver of the asynchronous loop: rounds with timing and counters"""
-import os, sys, time, torch
+"""Driver of the asynchronous self-play loop with interval statistics (deltas between prints):
+plies/s, playouts/s, mean descent depth, memo hit rate, evaluations per round, pool peaks."""
+import json, os, sys, time, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from alphazero_quoridor_amd.engine import SelfPlayEngine
 from alphazero_quoridor_amd.policy_value_net import PolicyValueNet
 B = int(os.environ.get("BOARDS", 192)); NP = int(os.environ.get("PLAYOUTS", 24)); MP = int(os.environ.get("MAXP", 32))
 FIX = int(os.environ.get("FIX", 1)); ITERS = int(os.environ.get("ITERS", 200)); R = int(os.environ.get("ROUNDS", 8)); BUD = int(os.environ.get("BUDGET", 0))
+EVERY = int(os.environ.get("EVERY", max(1, ITERS // 20))); GRAPH = int(os.environ.get("GRAPH", 0)); SEL = int(os.environ.get("SELECT_OPTS", 0))
 dev = torch.device("cuda:0"); torch.manual_seed(0)
 ev = PolicyValueNet(use_gpu=True).evaluator("per_leaf")
-eng = SelfPlayEngine(B, n_playout=NP, seed=77, device=dev, fix_terminal_sign=bool(FIX))
-t0 = time.time(); games = 0
+eng = SelfPlayEngine(B, n_playout=NP, seed=77, device=dev, fix_terminal_sign=bool(FIX), select_opts=SEL)
+if GRAPH:
+    eng.capture_rounds(ev, rounds=R, max_playouts=MP, budget_us=BUD)
+t0 = time.time(); games = 0; prev = eng.stats(); tp = t0; glen = []
 for i in range(ITERS):
     eng.run_rounds(ev, R, max_playouts=MP, budget_us=BUD)
-    torch.cuda.synchronize()
     tb = eng.harvest()
-    if tb is not None: games += tb.n_games
-    if i % max(1, ITERS // 20) == 0:
-        st = eng.stats()
-        print("it %d t %.2fs rounds %d playouts %d plies %d games %d hits %d evals %d waiting %d aborted %d ovf %d" % (i, time.time() - t0, st["rounds"], st["playouts"], st["plies_played"], games, st["memo_hits"], st["nn_evals"], st["waiting_boards"], st["games_aborted"], st["node_overflow"]), flush=True)
+    if tb is not None:
+        games += tb.n_games
+        glen += torch.bincount(tb.game.long(), minlength=tb.n_games).tolist()
+    if (i + 1) % EVERY == 0:
+        st = eng.stats(); now = time.time(); dt = now - tp
+        d = {k: st[k] - prev[k] for k in st}
+        po = max(d["playouts"], 1)
+        print(json.dumps({"t": round(now - t0, 2), "rounds": st["rounds"], "ms_per_round": round(1e3 * dt / max(d["rounds"], 1), 3),
+                          "plies_per_s": round(d["plies_played"] / dt), "playouts_per_s": round(d["playouts"] / dt), "games": games,
+                          "mean_depth": round(d["descent_levels"] / po, 1), "edges_scanned_per_playout": round(d["edges_scanned"] / po, 1),
+                          "hit_rate": round(d["memo_hits"] / po, 4), "terminal_rate": round(d["leaf_terminal"] / po, 4),
+                          "evals_per_round": round(d["nn_evals"] / max(d["rounds"], 1)), "waiting": st["waiting_boards"],
+                          "open_plies": d["open_plies"], "open_board_rounds_frac": round(d["open_rounds"] / max(d["rounds"] * B, 1), 4),
+                          "max_depth": st["max_depth"], "deep_replayed_frac": round(d["deep_levels_replayed"] / max(d["deep_levels"], 1), 3),
+                          "tree_pages_peak": st["tree_pages_peak"], "tree_pages_total": st["tree_pages_total"], "tree_pages_in_use": st["tree_pages_in_use"],
+                          "traj_pages_peak": st["traj_pages_peak"], "memo_inserts": d["memo_inserts"], "aborted": st["games_aborted"], "ovf": st["node_overflow"],
+                          "runaway": st["runaway_descents"], "mean_len_finished": round(sum(glen) / max(len(glen), 1))}), flush=True)
+        prev = st; tp = time.time()
 print("done", time.time() - t0, flush=True)

@@ -134,10 +134,16 @@ typedef struct {
     int32_t select_opts;       /* A/B switches of the descent kernel (0 = defaults): bit 0 = walk every level (no replay of
                                   recorded descents; same results, the test partner of the records), bit 1 = no readlane
                                   scan for nodes with <= 8 children */
-    /* Leaf-evaluation memo (qz_selfplay_*): log2 of the number of buckets of its two tables; 0 = auto (8,192 small entries
-     * and 1,024 big entries per board, rounded up to a power of two), < 0 = no memo (every leaf goes to the network).
+    /* Leaf-evaluation memo (qz_selfplay_*): log2 of the number of buckets of its two tables; 0 = auto (4,096 small entries
+     * and 512 big entries per board, rounded up to a power of two), < 0 = no memo (every leaf goes to the network).
      * small: leaves whose mover has no wall left, 4 entries of 128 B per bucket; big: all others, 2 x 640 B. */
     int32_t memo_small_log2, memo_big_log2;
+    /* qz_selfplay_*: update_with_move (mcts.py:146-151) keeps the chosen child's subtree WHERE IT IS while the tree's
+     * allocation cursor is below this many edges (the rest of the old tree stays behind as garbage), and copies it into
+     * fresh pages -- returning the old ones to the pool -- once the cursor has passed it.  0 = a third of a board's share
+     * of the tree pool, at most 49,152 (24 pages of 64 KB); < 0 = every move copies, like qz_mcts_finish_move.  With node_cap / edge_cap set every move copies
+     * (the caps count live nodes).  Same search either way. */
+    int32_t compact_edges;
 } qz_config;
 
 typedef struct {

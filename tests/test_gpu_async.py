@@ -106,17 +106,23 @@ def _games_by_slot(batches):
     return out
 
 
-def test_asynchronous_games_equal_lockstep_games(gpu_device):
+@pytest.mark.parametrize("compact_edges,budget_us,pool_pages", [(0, 0, 0), (-1, 0, 0), (0, 300, 192 * 60)])
+def test_asynchronous_games_equal_lockstep_games(gpu_device, compact_edges, budget_us, pool_pages):
     """Complete self-play games (Dirichlet noise, sampled moves, subtree reuse, continuous refill) from the
     asynchronous loop -- boards on their own clocks, several playouts and whole moves per launch, memo on --
     against the lock-step engine with the same seed: for every board slot the games come out in the same
-    order with identical (board, pi, z) tuples.  Short games (terminal sign fixed, 24 playouts)."""
+    order with identical (board, pi, z) tuples.  Short games (terminal sign fixed, 24 playouts).  The three
+    ways a move treats the kept subtree: the default threshold of this small engine (one page: compacting
+    moves, deferred to the start of a launch, and in-place moves mixed), always copied (-1, what the lock-step
+    engine does), and a large pool whose threshold (20 pages) these trees rarely reach: moves in place, under a
+    wall-clock budget per launch."""
     from alphazero_quoridor_amd.engine import SelfPlayEngine
 
     B, NP = 192, 24
     ev = _net(gpu_device, 7).evaluator("per_leaf")
     lock = SelfPlayEngine(B, n_playout=NP, seed=77, device=gpu_device, fix_terminal_sign=True)
-    asyn = SelfPlayEngine(B, n_playout=NP, seed=77, device=gpu_device, fix_terminal_sign=True)
+    asyn = SelfPlayEngine(B, n_playout=NP, seed=77, device=gpu_device, fix_terminal_sign=True, compact_edges=compact_edges,
+                          tree_pool_pages=pool_pages)
     try:
         lb, ab = [], []
         for _ in range(260):
@@ -128,7 +134,7 @@ def test_asynchronous_games_equal_lockstep_games(gpu_device):
         assert n_lock >= B // 2, n_lock
         rounds = 0
         while sum(t.n_games for t in ab) < n_lock and rounds < 40000:
-            asyn.run_rounds(ev, 8, max_playouts=NP + 8, budget_us=0)
+            asyn.run_rounds(ev, 8, max_playouts=NP + 8, budget_us=budget_us)
             rounds += 8
             tb = asyn.harvest()
             if tb is not None:
