@@ -16,7 +16,7 @@
 
 namespace qzl {
 hipError_t movegen_encode(const uint64_t*, const uint64_t*, const uint64_t*, int, uint32_t*, float*, const uint8_t*, void*, const RulesOpts&, hipStream_t, const int* n_dev = nullptr);
-hipError_t advance(const EngineDev&, const EngineDev*, int, unsigned int, int, int, hipStream_t);
+hipError_t advance(const EngineDev&, int, unsigned int, int, int, hipStream_t);
 hipError_t round_tail(const EngineDev&, int, hipStream_t);
 hipError_t memo_flush(const EngineDev&, hipStream_t);
 size_t movegen_scratch_bytes(int);
@@ -375,6 +375,7 @@ int qz_engine_create(const qz_config* cfg, qz_engine** out) {
     ALLOC(bc_expanded, B);
     ALLOC(pl_done, B);
     ALLOC(pend_slot, B);
+    ALLOC(reroot_pend, B);
     ALLOC(miss_count, (size_t)2);
     ALLOC(miss_hb, B);
     ALLOC(miss_vb, B);
@@ -439,6 +440,7 @@ int qz_engine_create(const qz_config* cfg, qz_engine** out) {
     if (he == hipSuccess) he = hipMemset(d.bc_expanded, 0, B * sizeof(unsigned long long));
     if (he == hipSuccess) he = hipMemset(d.leaf_mask, 0, B * 5 * sizeof(uint32_t));
     if (he == hipSuccess) he = hipMemset(d.miss_count, 0, 2 * sizeof(int));
+    if (he == hipSuccess) he = hipMemset(d.reroot_pend, 0, B * sizeof(uint32_t));
     if (he == hipSuccess) he = hipMemset(d.bc_memo_hits, 0, B * sizeof(uint32_t));
     if (he == hipSuccess) he = hipMemset(d.bc_evals, 0, B * sizeof(uint32_t));
     if (he == hipSuccess) he = hipMemset(d.bc_open_rounds, 0, B * sizeof(uint32_t));
@@ -851,7 +853,7 @@ int qz_selfplay_advance(qz_engine* e, int max_playouts, int budget_us, int auto_
     ENGINE_CHECK(e);
     if (max_playouts <= 0) return fail(QZ_E_INVALID, "max_playouts must be > 0");
     const unsigned int ticks = budget_us > 0 ? (unsigned int)budget_us * 100u : 0xFFFFFFFFu;  // s_memrealtime: 100 MHz
-    HIP_TRY(qzl::advance(e->dev, e->dev_mem, max_playouts, ticks, auto_finish, e->par, (hipStream_t)stream));
+    HIP_TRY(qzl::advance(e->dev, max_playouts, ticks, auto_finish, e->par, (hipStream_t)stream));
     return 0;
 }
 int qz_selfplay_leaf_rules(qz_engine* e, void* stream) {

@@ -172,6 +172,7 @@ struct EngineDev {
     MemoDev memo;
     uint32_t* pl_done;        // [B] playouts done on the current root
     uint32_t* pend_slot;      // [B] miss-list slot of the leaf this board waits for, QZ_NONE = none
+    uint32_t* reroot_pend;    // [B] the subtree copy of the last move, left for the next k_advance launch: 0 none, 1 fresh root, e + 2 keep edge e
     int* miss_count;          // [1] slots used by this round's misses
     uint64_t *miss_hb, *miss_vb, *miss_meta;  // [B] the leaves awaiting evaluation, compacted
     uint32_t* miss_mask;      // [B][5] their legal sets (rules op on the miss list)

@@ -1361,30 +1361,61 @@ __device__ __forceinline__ void wave_reroot(EngineDev& E, int b, int lane, uint3
                 const uint32_t lim = new_edges < wbase + 64u ? new_edges : wbase + 64u;
                 const uint32_t idx = wbase + (uint32_t)lane;
                 const uint32_t pb = tree_phys(D, wbase);
-                uint32_t cne = 0u;
-                if (idx >= q && idx < lim) cne = D.pool[pb + (uint32_t)lane].cne;
+                // lane = one edge of the window of the NEW tree; the expanded ones are nodes whose children's blocks are
+                // still in the old tree.  Blocks are allocated one after the other (discovery order: the layout does not
+                // depend on how the copies are scheduled), then copied side by side: a node with <= 8 children by ITS lane
+                // (64 nodes' loads in flight together; the one-node-at-a-time form spent two memory round trips per node
+                // and made a move of a 10,000-node tree last milliseconds), wider nodes by the whole wavefront.
+                uint32_t cne = 0u, c_src = 0u;
+                if (idx >= q && idx < lim) {
+                    cne = D.pool[pb + (uint32_t)lane].cne;
+                    c_src = D.pool[pb + (uint32_t)lane].coff;
+                }
                 uint64_t m = __ballot(cne > 0u);
+                uint32_t mydoff = QZ_NONE;
                 while (m) {  // the nodes found in this window, in order
                     const int l = __ffsll((unsigned long long)m) - 1;
                     m &= m - 1ull;
-                    const uint32_t pe = pb + (uint32_t)l;
-                    const int c_ne = (int)rfl((uint32_t)D.pool[pe].cne);
-                    const uint32_t c_src = rfl(D.pool[pe].coff);
+                    const int c_ne = (int)rdl(cne, l);
                     uint32_t doff = QZ_NONE;
                     if (!exhausted) doff = tree_alloc(E, D, new_edges, dnp, c_ne, lane, true);
                     if (doff == QZ_NONE) {  // pool empty: the rest of the subtree is cut off (counted)
                         exhausted = true;
                         truncated++;
-                        if (lane == 0) {
-                            D.pool[pe].cne = 0;
-                            D.pool[pe].coff = 0u;
+                        if (lane == l) {
+                            D.pool[pb + (uint32_t)l].cne = 0;
+                            D.pool[pb + (uint32_t)l].coff = 0u;
                         }
                     } else {
-                        copy_block(S, c_src, D, doff, c_ne, pe, lane);
-                        if (lane == 0) D.pool[pe].coff = doff;
+                        if (lane == l) mydoff = doff;
                         new_nodes++;
                     }
                 }
+                const bool mine = cne > 0u && mydoff != QZ_NONE;
+                uint64_t wide = __ballot(mine && cne > 8u);
+                while (wide) {
+                    const int l = __ffsll((unsigned long long)wide) - 1;
+                    wide &= wide - 1ull;
+                    copy_block(S, rdl(c_src, l), D, rdl(mydoff, l), (int)rdl(cne, l), pb + (uint32_t)l, lane);
+                }
+                {
+                    const bool narrow = mine && cne <= 8u;
+                    const uint32_t sp = tree_phys_lanes(S, c_src), dp = tree_phys_lanes(D, mydoff == QZ_NONE ? 0u : mydoff);  // (all lanes: shuffles)
+                    Edge ed[8];  // all loads first (the stores below may alias them as far as the compiler knows)
+#pragma unroll
+                    for (uint32_t k = 0u; k < 8u; k++)
+                        if (narrow && k < cne) ed[k] = S.pool[sp + k];
+#pragma unroll
+                    for (uint32_t k = 0u; k < 8u; k++) {
+                        if (narrow && k < cne) {
+                            ed[k].pedge = pb + (uint32_t)lane;
+                            ed[k].spare = QZ_NONE;
+                            D.pool[dp + k] = ed[k];
+                            S.pool[sp + k].spare = dp + k;  // forwarding address (translate_records)
+                        }
+                    }
+                }
+                if (mine) D.pool[pb + (uint32_t)lane].coff = mydoff;
                 q = lim;
             }
         } else {
@@ -1430,6 +1461,7 @@ __device__ __forceinline__ void reset_board_state(EngineDev& E, int b) {
     E.release[b] = 0;
     E.pl_done[b] = 0u;
     E.pend_slot[b] = QZ_NONE;
+    E.reroot_pend[b] = 0u;
     E.game_serial[b] = E.game_serial[b] + 1u;
 }
 
@@ -1455,6 +1487,7 @@ __global__ __launch_bounds__(TPB) void k_reset(EngineDev E, int reset_boards) {
         E.release[b] = 0;
         E.pl_done[b] = 0u;
         E.pend_slot[b] = QZ_NONE;
+        E.reroot_pend[b] = 0u;
     }
 }
 
@@ -1545,7 +1578,10 @@ __device__ double gamma_small(const Philox& ph, uint32_t c0, uint32_t c1, uint32
 // MCTSPlayer.choose_action tail + one iteration of start_self_play (mcts.py:174-187,
 // quoridor.py:585-602).  POP-ONLY (trajectory page, pages of the re-rooted tree).
 __device__ __forceinline__ void finish_move_board(EngineDev& E, const int b, const int lane, const uint8_t* __restrict__ forced,
-                                                  float* __restrict__ pi_out, uint8_t* __restrict__ move_out, const bool in_place = false) {
+                                                  float* __restrict__ pi_out, uint8_t* __restrict__ move_out, const int reroot_mode = 0) {
+    // reroot_mode: 0 = copy the kept subtree now (the lock-step engine), 1 = keep it in place, 2 = copy it LATER: the
+    // edge is left in E.reroot_pend for the board's next k_advance launch, where the copy runs beside the other boards'
+    // playouts instead of holding up a launch of its own (everything else of the move happens here)
     if (move_out && lane == 0) move_out[b] = QZ_NO_MOVE_U8;
     if (pi_out)
         for (int a = lane; a < QZ_N_ACT; a += 64) pi_out[(size_t)b * QZ_N_ACT + a] = 0.f;
@@ -1687,7 +1723,19 @@ __device__ __forceinline__ void finish_move_board(EngineDev& E, const int b, con
     if (move_out && lane == 0) move_out[b] = (uint8_t)mv;
 
     // update_with_move(move) in self-play, update_with_move(-1) otherwise (mcts.py:182,187)
-    wave_reroot(E, b, lane, E.is_selfplay ? (uint32_t)(re - E.edge_pool) + (uint32_t)chosen_k : QZ_NONE, in_place);
+    {
+        const uint32_t keep = E.is_selfplay ? (uint32_t)(re - E.edge_pool) + (uint32_t)chosen_k : QZ_NONE;
+        // (a child without a subtree makes the whole tree garbage: the cursor goes back to 0 in place, nothing to copy)
+        const bool has_subtree = keep != QZ_NONE && rfl((uint32_t)E.edge_pool[keep].cne) != 0u;
+        if (reroot_mode == 2 && has_subtree) {
+            if (lane == 0) {
+                E.reroot_pend[b] = keep == QZ_NONE ? 1u : keep + 2u;  // 0 = nothing pending, 1 = fresh root, e + 2 = keep edge e
+                E.pl_done[b] = 0u;
+            }
+        } else {
+            wave_reroot(E, b, lane, keep, reroot_mode != 0);
+        }
+    }
 
     // self.step(move); has_a_winner() (quoridor.py:593-596)
     bool done = apply_action(bd, mv);
@@ -1704,12 +1752,6 @@ __device__ __forceinline__ void finish_move_board(EngineDev& E, const int b, con
             atomicAdd((unsigned long long*)&E.counters[QZ_C_PENDING_PLIES], (unsigned long long)(ply + 1u));
         }
     }
-}
-// the same as a real call (k_advance: inlined there it would set the whole kernel's register count -- 223 VGPRs, two waves
-// per SIMD -- for code that runs once per n_playout playouts).  Ed: the engine's EngineDev in device memory.
-__device__ __forceinline__ void finish_move_call(const EngineDev* __restrict__ Ed, const int b, const int lane, const bool in_place) {
-    EngineDev E = *Ed;
-    finish_move_board(E, b, lane, nullptr, nullptr, nullptr, in_place);
 }
 __global__ __launch_bounds__(TPB) void k_finish_move(EngineDev E, const uint8_t* __restrict__ forced, float* __restrict__ pi_out,
                                                      uint8_t* __restrict__ move_out) {
@@ -1860,14 +1902,13 @@ __device__ __forceinline__ void memo_insert(const EngineDev& E, const uint64_t h
 // long as it can: descend -> leaf; a terminal leaf is backed up at once; a leaf whose evaluation is in the memo is
 // expanded from the memo and backed up; any other leaf goes into the miss list (compacted by one atomic) and the
 // board waits for the next launch, which starts by consuming the network's answer (expand + backup, exactly
-// k_expand_backup's code).  After n_playout playouts the board plays its move in the same launch (finish_move_board:
-// pi, noisy sampling, trajectory record, re-root, real step) and goes on searching from the new root; a second move
-// in one launch waits for k_round_tail to hand the replaced tree's pages back (release flag).  Per board the sequence
-// of operations is exactly the lock-step engine's (k_select / k_expand_backup / k_finish_move): trees, pi, sampled
-// moves and harvested tuples are bit-identical; only the interleaving BETWEEN boards differs.
+// k_expand_backup's code).  A board that has done n_playout playouts stops; k_moves (the next round's first launch)
+// plays its move -- kept out of this kernel because finish_move_board inlined here set the register count of the
+// whole kernel (two waves per SIMD, or spills in the descent).  Per board the sequence of operations is exactly the
+// lock-step engine's (k_select / k_expand_backup / k_finish_move): trees, pi, sampled moves and harvested tuples are
+// bit-identical; only the interleaving BETWEEN boards differs.
 //   max_iters   playouts a board may start per launch (1 = one playout per launch, the lock-step cadence)
 //   budget      wall-clock limit in s_memrealtime ticks (100 MHz) after which a board starts no new playout
-//   auto_finish 0: boards stop at n_playout (the host calls qz_mcts_finish_move)
 //   par         which of the two miss counters this round uses (rounds alternate: the tail of round r clears the
 //               counter of round r + 1 while nobody reads it)
 #ifdef QZ_ADV_STAMPS  // diagnostic build only (tests/hip/Makefile, benchmarks/advance_stamps.py): where a wavefront's time goes in k_advance
@@ -1879,7 +1920,10 @@ __device__ unsigned long long g_adv_stamps[4096][16];  // per board, accumulated
 #define QZ_AS_COUNT(k, v)
 #endif
 constexpr uint32_t ADV_LCAP = 512;  // levels of a descent mirrored in LDS (6 KB per wavefront); deeper levels are read back from memory
-__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_advance(EngineDev E, const EngineDev* __restrict__ Ed, int max_iters, unsigned int budget, int auto_finish, int par) {
+#ifndef QZ_ADV_WAVES
+#define QZ_ADV_WAVES 4  // wavefronts per SIMD the register allocation of k_advance aims at (A/B builds: tests/hip/Makefile)
+#endif
+__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(QZ_ADV_WAVES, QZ_ADV_WAVES))) void k_advance(EngineDev E, int max_iters, unsigned int budget, int par) {
     __shared__ uint32_t s_we[WPB][ADV_LCAP];
     __shared__ unsigned long long s_wb[WPB][ADV_LCAP];
     const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
@@ -1894,9 +1938,20 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #endif
     const PathMirror PM{s_we[wave], s_wb[wave], ADV_LCAP};
     const PathMirror NOPM{nullptr, nullptr, 0u};
+    {   // the compacting half of a move k_moves left for this launch (it runs beside the other boards' playouts)
+        const uint32_t rp = rfl(E.reroot_pend[b]);
+        if (rp != 0u) {
+            wave_reroot(E, b, lane, rp == 1u ? QZ_NONE : rp - 2u, false);
+            if (lane == 0) E.reroot_pend[b] = 0u;
+            wave_sync();
+            // (the copy found the pool empty: the board restarts from a fresh root in the SAME table half, whose pages
+            // k_round_tail is about to hand back -- nothing may be built there before)
+            if (rfl((uint32_t)E.release[b]) & 2u) return;
+        }
+    }
     BoardRegs S = regs_load(E, b, lane);
     const uint32_t epoch = rfl(*E.memo.epoch);
-    uint32_t done = rfl(E.pl_done[b]), hits = 0u, evals = 0u, open_rounds = 0u, open_plies = 0u;
+    uint32_t done = rfl(E.pl_done[b]), hits = 0u, evals = 0u, open_rounds = 0u;
     if ((S.root.cur == 1 ? S.root.w1 : S.root.w2) > 0) open_rounds = 1u;
     // One resolved leaf at a time: (legal set, priors, value) of the leaf the last descent found -- from the network
     // (the evaluation this board was waiting for), from the memo, or a terminal leaf's +-1 -- is applied at the top of
@@ -1929,26 +1984,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             QZ_AS_COUNT(8, 1)
         }
         if (it >= max_iters) break;
-        if (done >= (uint32_t)E.n_playout) {
-            if (!auto_finish || rfl((uint32_t)E.release[b]) != 0u) break;
-            // the move keeps the subtree in place while the tree is small; once its allocation cursor has passed
-            // compact_edges the move compacts (breadth-first copy into fresh pages), and such a move only STARTS a launch:
-            // it then runs beside the other boards' playouts instead of at the end of everybody's budget
-            const bool compact = E.compact_edges <= 0 || S.neu >= (uint32_t)E.compact_edges;
-            if (compact && it > 0) break;
-            if ((S.root.cur == 1 ? S.root.w1 : S.root.w2) > 0) open_plies++;
-            regs_store(E, b, lane, S);  // the move works on the state in memory
-            wave_sync();
-            finish_move_call(Ed, b, lane, !compact);
-            done = 0u;
-            wave_sync();
-            S = regs_load(E, b, lane);
-            QZ_AS_MARK(3)  // 3: the move (state store, finish_move_board, state load)
-            if (!S.live) break;  // the game is over (or was dropped): wait for the harvest
-            // the move's child had no subtree (or the copy found the pool empty): the board restarts from a fresh root in
-            // the SAME table half, whose pages k_round_tail is about to hand back -- nothing may be built there before
-            if (rfl((uint32_t)E.release[b]) & 2u) break;
-        }
+        if (done >= (uint32_t)E.n_playout) break;  // the move is k_moves' job (the next round's first launch)
         if (it > 0 && (unsigned int)(__builtin_amdgcn_s_memrealtime() - t0) > budget) break;
         Board leaf;
         select_core(E, S, b, lane, PM, leaf, pedge, plen, term);
@@ -2008,8 +2044,24 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         if (hits) E.bc_memo_hits[b] += hits;
         if (evals) E.bc_evals[b] += evals;
         if (open_rounds) E.bc_open_rounds[b] += open_rounds;
-        if (open_plies) E.bc_open_plies[b] += open_plies;
     }
+}
+
+// k_moves: MCTSPlayer.choose_action's tail + one iteration of start_self_play's loop (finish_move_board) for every
+// board that has done its n_playout playouts.  The move keeps the subtree in place while the tree is small; once the
+// allocation cursor has passed compact_edges it compacts (breadth-first copy into fresh pages; the old half goes back
+// to the pool in k_round_tail).  POP-ONLY.
+__global__ __launch_bounds__(TPB) void k_moves(EngineDev E) {
+    const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+    const int b = __builtin_amdgcn_readfirstlane((int)blockIdx.x * WPB + wave);
+    if (b >= E.n_boards) return;
+    if (rfl(E.status[b]) != QZ_PLAYING || rfl(E.pl_done[b]) < (uint32_t)E.n_playout || rfl((uint32_t)E.release[b]) != 0u ||
+        rfl(E.reroot_pend[b]) != 0u)
+        return;
+    const bool compact = E.compact_edges <= 0 || rfl(E.n_edges[b]) >= (uint32_t)E.compact_edges;
+    const Board rb = unpack(0ull, 0ull, rfl64(E.root_meta[b]));
+    if ((rb.cur == 1 ? rb.w1 : rb.w2) > 0 && lane == 0) E.bc_open_plies[b] += 1u;
+    finish_move_board(E, b, lane, nullptr, nullptr, nullptr, compact ? 2 : 1);
 }
 
 // After the network: (a) every evaluated leaf goes into the memo, (b) the OTHER miss counter is cleared for the next
@@ -2332,8 +2384,9 @@ hipError_t finish_move(const EngineDev& E, const uint8_t* forced, float* pi_out,
     hipLaunchKernelGGL(k_release, wave_grid(E.n_boards), dim3(TPB), 0, s, E);
     return hipGetLastError();
 }
-hipError_t advance(const EngineDev& E, const EngineDev* Ed, int max_iters, unsigned int budget_ticks, int auto_finish, int par, hipStream_t s) {
-    hipLaunchKernelGGL(k_advance, wave_grid(E.n_boards), dim3(TPB), 0, s, E, Ed, max_iters, budget_ticks, auto_finish, par);
+hipError_t advance(const EngineDev& E, int max_iters, unsigned int budget_ticks, int auto_finish, int par, hipStream_t s) {
+    if (auto_finish) hipLaunchKernelGGL(k_moves, wave_grid(E.n_boards), dim3(TPB), 0, s, E);
+    hipLaunchKernelGGL(k_advance, wave_grid(E.n_boards), dim3(TPB), 0, s, E, max_iters, budget_ticks, par);
     return hipGetLastError();
 }
 hipError_t round_tail(const EngineDev& E, int par, hipStream_t s) {

@@ -2,6 +2,9 @@
 plies/s, playouts/s, mean descent depth, memo hit rate, evaluations per round, pool peaks."""
 import json, os, sys, time, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+if os.environ.get("QZ_BENCH_LIB"):  # A/B of a differently built library on the same box
+    from alphazero_quoridor_amd import _cabi
+    _cabi.LIB_PATH = os.environ["QZ_BENCH_LIB"]
 from alphazero_quoridor_amd.engine import SelfPlayEngine
 from alphazero_quoridor_amd.policy_value_net import PolicyValueNet
 B = int(os.environ.get("BOARDS", 192)); NP = int(os.environ.get("PLAYOUTS", 24)); MP = int(os.environ.get("MAXP", 32))
@@ -10,6 +13,9 @@ EVERY = int(os.environ.get("EVERY", max(1, ITERS // 20))); GRAPH = int(os.enviro
 dev = torch.device("cuda:0"); torch.manual_seed(0)
 ev = PolicyValueNet(use_gpu=True).evaluator("per_leaf")
 eng = SelfPlayEngine(B, n_playout=NP, seed=77, device=dev, fix_terminal_sign=bool(FIX), select_opts=SEL)
+SKIP = int(os.environ.get("SKIP_ROUNDS", 0))  # rounds played before the statistics start (from the opening to the late-game regime)
+for _ in range(SKIP // 64):
+    eng.run_rounds(ev, 64, max_playouts=MP, budget_us=BUD); eng.harvest()
 if GRAPH:
     eng.capture_rounds(ev, rounds=R, max_playouts=MP, budget_us=BUD)
 t0 = time.time(); games = 0; prev = eng.stats(); tp = t0; glen = []

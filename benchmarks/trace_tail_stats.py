@@ -11,7 +11,7 @@ t_lo = rows[0][0] + (rows[-1][1] - rows[0][0]) * (1.0 - frac)
 sel = [r for r in rows if r[0] >= t_lo]
 agg = collections.OrderedDict()
 for s, e, k in sel:
-    k = k.split("(")[0][-60:]
+    k = k[k.find("k_"):][:28] if "k_" in k else k[:40]
     a = agg.setdefault(k, [0, 0, 0])
     a[0] += 1; a[1] += e - s; a[2] = max(a[2], e - s)
 span = sel[-1][1] - sel[0][0]
