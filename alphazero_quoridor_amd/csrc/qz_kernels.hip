@@ -643,17 +643,29 @@ struct BoardRegs {
     uint32_t nn, neu, np;             // nodes, edge cursor, pages mapped
     uint32_t rlen, rstamp;            // lane r < QZ_PATH_RECS: descent record r's length / last-use stamp
     uint32_t rec_last, rec_clock;
-    uint32_t d_playouts, d_terminal, d_overflow, d_nonfinite, maxdepth;   // deltas of the per-board counters
-    unsigned long long d_levels, d_scanned, d_expanded;
+    // The per-board counters' deltas of this launch live in LDS (16 dwords per wavefront, bumped by fire-and-forget
+    // ds_add / ds_max): as loop-carried scalars they cost k_advance two dozen SGPRs it does not have -- the compiler
+    // parked them in VGPRs and those in scratch, whose reloads sat in the dependent chain of every playout.
+    uint32_t* lc;
 };
+enum { LC_PLAYOUTS = 0, LC_TERMINAL, LC_OVERFLOW, LC_NONFINITE, LC_MAXDEPTH, LC_HITS, LC_EVALS, LC_SPARE, LC_LEVELS /*u64*/ = 8, LC_SCANNED /*u64*/ = 10,
+       LC_EXPANDED /*u64*/ = 12, LC_WORDS = 16 };
+__device__ __forceinline__ void lc_add(const BoardRegs& S, int i, uint32_t v, int lane) {
+    if (lane == 0) atomicAdd(&S.lc[i], v);
+}
+__device__ __forceinline__ void lc_add64(const BoardRegs& S, int i, unsigned long long v, int lane) {
+    if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(&S.lc[i]), v);
+}
 // the first `cap` levels of the current descent once more in LDS (we: chosen edges, wb: blocks); nullptr: none
 struct PathMirror {
     uint32_t* we;
     unsigned long long* wb;
     uint32_t cap;
 };
-__device__ __forceinline__ BoardRegs regs_load(const EngineDev& E, const int b, const int lane) {
+__device__ __forceinline__ BoardRegs regs_load(const EngineDev& E, const int b, const int lane, uint32_t* lc) {
     BoardRegs R;
+    R.lc = lc;
+    if (lane < LC_WORDS) lc[lane] = 0u;
     R.root = load_board(E.root_hb, E.root_vb, E.root_meta, b);
     R.rootN = rfl(E.root_N[b]);
     R.root_ne = rfl(E.root_ne[b]);
@@ -668,9 +680,7 @@ __device__ __forceinline__ BoardRegs regs_load(const EngineDev& E, const int b, 
     R.rstamp = lane < QZ_PATH_RECS ? E.rec_stamp[(size_t)b * QZ_PATH_RECS + lane] : 0u;
     R.rec_last = rfl(E.rec_last[b]);
     R.rec_clock = rfl(E.rec_clock[b]);
-    R.d_playouts = R.d_terminal = R.d_overflow = R.d_nonfinite = 0u;
-    R.maxdepth = rfl(E.bc_maxdepth[b]);
-    R.d_levels = R.d_scanned = R.d_expanded = 0ull;
+    wave_sync();
     return R;
 }
 __device__ __forceinline__ void regs_store(const EngineDev& E, const int b, const int lane, const BoardRegs& R) {
@@ -678,10 +688,14 @@ __device__ __forceinline__ void regs_store(const EngineDev& E, const int b, cons
         E.rec_len[(size_t)b * QZ_PATH_RECS + lane] = R.rlen;
         E.rec_stamp[(size_t)b * QZ_PATH_RECS + lane] = R.rstamp;
     }
+    wave_sync();
     if (lane == 0) {
         // the counters: all loads first, then all stores (one round trip, not one per counter)
-        const uint32_t c0 = E.bc_playouts[b], c1 = E.bc_terminal[b], c2 = E.bc_overflow[b], c3 = E.bc_nonfinite[b];
+        const uint32_t c0 = E.bc_playouts[b], c1 = E.bc_terminal[b], c2 = E.bc_overflow[b], c3 = E.bc_nonfinite[b], c7 = E.bc_maxdepth[b],
+                       c8 = E.bc_memo_hits[b], c9 = E.bc_evals[b];
         const unsigned long long c4 = E.bc_levels[b], c5 = E.bc_scanned[b], c6 = E.bc_expanded[b];
+        const uint32_t* lc = R.lc;
+        const unsigned long long* lc64 = reinterpret_cast<const unsigned long long*>(R.lc);
         E.root_N[b] = R.rootN;
         E.root_ne[b] = R.root_ne;
         E.root_eoff[b] = R.root_eoff;
@@ -690,14 +704,16 @@ __device__ __forceinline__ void regs_store(const EngineDev& E, const int b, cons
         E.tree_npages[tree_slot(E, b, R.half)] = R.np;
         E.rec_last[b] = R.rec_last;
         E.rec_clock[b] = R.rec_clock;
-        E.bc_maxdepth[b] = R.maxdepth;
-        E.bc_playouts[b] = c0 + R.d_playouts;
-        E.bc_terminal[b] = c1 + R.d_terminal;
-        E.bc_overflow[b] = c2 + R.d_overflow;
-        E.bc_nonfinite[b] = c3 + R.d_nonfinite;
-        E.bc_levels[b] = c4 + R.d_levels;
-        E.bc_scanned[b] = c5 + R.d_scanned;
-        E.bc_expanded[b] = c6 + R.d_expanded;
+        E.bc_maxdepth[b] = lc[LC_MAXDEPTH] > c7 ? lc[LC_MAXDEPTH] : c7;
+        E.bc_playouts[b] = c0 + lc[LC_PLAYOUTS];
+        E.bc_terminal[b] = c1 + lc[LC_TERMINAL];
+        E.bc_overflow[b] = c2 + lc[LC_OVERFLOW];
+        E.bc_nonfinite[b] = c3 + lc[LC_NONFINITE];
+        E.bc_memo_hits[b] = c8 + lc[LC_HITS];
+        E.bc_evals[b] = c9 + lc[LC_EVALS];
+        E.bc_levels[b] = c4 + lc64[LC_LEVELS / 2];
+        E.bc_scanned[b] = c5 + lc64[LC_SCANNED / 2];
+        E.bc_expanded[b] = c6 + lc64[LC_EXPANDED / 2];
     }
 }
 // the descent of board b (MCTS._playout, mcts.py:107-113) on the register state R: no per-board scalar is read from or
@@ -988,9 +1004,11 @@ __device__ __forceinline__ void select_core(EngineDev& E, BoardRegs& S, const in
     pedge_out = pedge;
     plen_out = plen;
     term_out = t;
-    S.d_nonfinite += nonfinite ? 1u : 0u;
-    S.d_scanned += (unsigned long long)scanned;
-    if (plen > S.maxdepth) S.maxdepth = plen;
+    if (lane == 0) {
+        if (nonfinite) atomicAdd(&S.lc[LC_NONFINITE], 1u);
+        atomicAdd(reinterpret_cast<unsigned long long*>(&S.lc[LC_SCANNED]), (unsigned long long)scanned);
+        atomicMax(&S.lc[LC_MAXDEPTH], plen);
+    }
     if (plen >= 256u && lane == 0) {  // telemetry of the descents that set the kernel's duration (a handful of boards)
         atomicAdd(&E.counters[QZ_C_DEEP_DESCENTS], 1ull);
         if (2u * replayed < plen) atomicAdd(&E.counters[QZ_C_DEEP_COLD], 1ull);
@@ -1015,10 +1033,11 @@ __device__ __forceinline__ void select_board(EngineDev& E, BoardRegs& S, const i
 }
 
 __global__ __launch_bounds__(TPB) void k_select(EngineDev E) {
+    __shared__ uint32_t s_lc[WPB][LC_WORDS];
     const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
     const int b = (int)blockIdx.x * WPB + wave;
     if (b >= E.n_boards) return;
-    BoardRegs S = regs_load(E, b, lane);
+    BoardRegs S = regs_load(E, b, lane, s_lc[wave]);
     select_board(E, S, b, lane);
     regs_store(E, b, lane, S);
 }
@@ -1067,9 +1086,9 @@ __device__ __forceinline__ void expand_node(EngineDev& E, BoardRegs& S, const in
             S.nn += 1u;
             S.neu = neu;
             S.np = np;
-            S.d_expanded += (unsigned long long)k;
+            lc_add64(S, LC_EXPANDED, (unsigned long long)k, lane);
         } else {
-            S.d_overflow += 1u;
+            lc_add(S, LC_OVERFLOW, 1u, lane);
             S.np = np;
         }
     }
@@ -1106,9 +1125,11 @@ __device__ __forceinline__ void backup_leaf(EngineDev& E, BoardRegs& S, const in
         }
     }
     S.rootN += 1u;  // the root is updated too
-    S.d_playouts += 1u;
-    S.d_levels += (unsigned long long)plen;
-    if (term != 0u) S.d_terminal += 1u;
+    if (lane == 0) {
+        atomicAdd(&S.lc[LC_PLAYOUTS], 1u);
+        atomicAdd(reinterpret_cast<unsigned long long*>(&S.lc[LC_LEVELS]), (unsigned long long)plen);
+        if (term != 0u) atomicAdd(&S.lc[LC_TERMINAL], 1u);
+    }
 }
 // mcts.py:125: +1 if winner == current_player else -1 (always +1 in practice: the reference does not rotate players
 // on a terminal move); term = 1 | 2
@@ -1136,10 +1157,11 @@ __device__ __forceinline__ void expand_backup_board(EngineDev& E, BoardRegs& S, 
 }
 
 __global__ __launch_bounds__(TPB) void k_expand_backup(EngineDev E, const float* __restrict__ p, const float* __restrict__ v) {
+    __shared__ uint32_t s_lc[WPB][LC_WORDS];
     const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
     const int b = (int)blockIdx.x * WPB + wave;
     if (b >= E.n_boards) return;
-    BoardRegs S = regs_load(E, b, lane);
+    BoardRegs S = regs_load(E, b, lane, s_lc[wave]);
     expand_backup_board(E, S, p, v, b, lane);
     regs_store(E, b, lane, S);
 }
@@ -1148,10 +1170,11 @@ __global__ __launch_bounds__(TPB) void k_expand_backup(EngineDev E, const float*
 // from the Infinity Cache / HBM (~1 us per level); here the records the backup just touched are still in this XCD's L2.
 // Same operations in the same order per board as k_expand_backup followed by k_select.
 __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_expand_backup_select(EngineDev E, const float* __restrict__ p, const float* __restrict__ v) {
+    __shared__ uint32_t s_lc[WPB][LC_WORDS];
     const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
     const int b = (int)blockIdx.x * WPB + wave;
     if (b >= E.n_boards) return;
-    BoardRegs S = regs_load(E, b, lane);
+    BoardRegs S = regs_load(E, b, lane, s_lc[wave]);
     expand_backup_board(E, S, p, v, b, lane);
     wave_sync();  // the backup's stores (other lanes) before the descent's loads
     select_board(E, S, b, lane);
@@ -1926,6 +1949,7 @@ constexpr uint32_t ADV_LCAP = 512;  // levels of a descent mirrored in LDS (6 KB
 __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(QZ_ADV_WAVES, QZ_ADV_WAVES))) void k_advance(EngineDev E, int max_iters, unsigned int budget, int par) {
     __shared__ uint32_t s_we[WPB][ADV_LCAP];
     __shared__ unsigned long long s_wb[WPB][ADV_LCAP];
+    __shared__ uint32_t s_lc[WPB][LC_WORDS];
     const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
     const int b = __builtin_amdgcn_readfirstlane((int)blockIdx.x * WPB + wave);  // in an SGPR: every per-board address below is scalar arithmetic
     if (b >= E.n_boards) return;
@@ -1949,15 +1973,16 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(QZ_ADV_WAVE
             if (rfl((uint32_t)E.release[b]) & 2u) return;
         }
     }
-    BoardRegs S = regs_load(E, b, lane);
+    BoardRegs S = regs_load(E, b, lane, s_lc[wave]);
     const uint32_t epoch = rfl(*E.memo.epoch);
-    uint32_t done = rfl(E.pl_done[b]), hits = 0u, evals = 0u, open_rounds = 0u;
+    uint32_t done = rfl(E.pl_done[b]), open_rounds = 0u;
     if ((S.root.cur == 1 ? S.root.w1 : S.root.w2) > 0) open_rounds = 1u;
     // One resolved leaf at a time: (legal set, priors, value) of the leaf the last descent found -- from the network
     // (the evaluation this board was waiting for), from the memo, or a terminal leaf's +-1 -- is applied at the top of
     // the loop by the one copy of TreeNode.expand + update_recursive.
     const uint32_t slot = rfl(E.pend_slot[b]);
     bool have = slot != QZ_NONE, waiting = false, from_memory = have;
+    Board miss_leaf = S.root;
     uint32_t m0 = 0u, m1 = 0u, m2 = 0u, m3 = 0u, m4 = 0u, term = 0u, pedge = QZ_NONE, plen = 0u;
     const float* prow = nullptr;  // priors as a row of 140 floats, or (nullptr) this lane's prior in pl (small-table hit)
     float pl = 0.f;
@@ -1972,10 +1997,16 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(QZ_ADV_WAVE
     }
     QZ_AS_MARK(0)  // 0: launch prologue (state load, pending evaluation's scalars)
     for (int it = 0;; it++) {
+        // the lane / board indices of THIS iteration, opaque to the optimiser: without this every per-lane and per-board
+        // address of the loop body is hoisted out of the loop as a 64-bit value -- dozens of them, more than there are
+        // registers, so they went to scratch and came back through memory in the dependent chain of every playout
+        int ln = lane, bb = b;
+        asm volatile("" : "+v"(ln));
+        asm volatile("" : "+s"(bb));
         if (have) {
-            if (term == 0u) expand_node(E, S, lane, pedge, m0, m1, m2, m3, m4, [&](int a) { return prow ? prow[a] : pl; });
+            if (term == 0u) expand_node(E, S, ln, pedge, m0, m1, m2, m3, m4, [&](int a) { return prow ? prow[a] : pl; });
             QZ_AS_MARK(1)  // 1: expansion
-            backup_leaf(E, S, b, lane, from_memory ? NOPM : PM, value, pedge, plen, term);
+            backup_leaf(E, S, bb, ln, from_memory ? NOPM : PM, value, pedge, plen, term);
             done++;
             have = false;
             from_memory = false;
@@ -1987,7 +2018,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(QZ_ADV_WAVE
         if (done >= (uint32_t)E.n_playout) break;  // the move is k_moves' job (the next round's first launch)
         if (it > 0 && (unsigned int)(__builtin_amdgcn_s_memrealtime() - t0) > budget) break;
         Board leaf;
-        select_core(E, S, b, lane, PM, leaf, pedge, plen, term);
+        select_core(E, S, bb, ln, PM, leaf, pedge, plen, term);
         wave_sync();  // the descent buffer (lane 0 / other lanes) before the backup reads it
         QZ_AS_MARK(4)  // 4: descent
         QZ_AS_COUNT(9, plen)
@@ -1997,32 +2028,35 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(QZ_ADV_WAVE
             continue;
         }
         MemoHit H;
-        if (memo_probe(E, epoch, leaf, lane, H)) {
+        if (memo_probe(E, epoch, leaf, ln, H)) {
             m0 = H.m0; m1 = H.m1; m2 = H.m2; m3 = H.m3; m4 = H.m4;
             prow = H.p_row;
             pl = H.p_lane;
             value = (double)H.v;
             have = true;
-            hits++;
+            lc_add(S, LC_HITS, 1u, ln);
             QZ_AS_MARK(5)  // 5: memo probe (hit)
             continue;
         }
         QZ_AS_MARK(6)  // 6: memo probe (miss)
-        // ---- a leaf for the network
+        // ---- a leaf for the network: recorded after the loop
+        miss_leaf = leaf;
+        waiting = true;
+        break;
+    }
+    if (waiting) {
         uint32_t s = 0u;
         if (lane == 0) s = (uint32_t)atomicAdd(E.miss_count + par, 1);
         s = rfl(s);
         if (lane == 0) {
-            E.miss_hb[s] = leaf.hb;
-            E.miss_vb[s] = leaf.vb;
-            E.miss_meta[s] = pack_meta(leaf);
+            E.miss_hb[s] = miss_leaf.hb;
+            E.miss_vb[s] = miss_leaf.vb;
+            E.miss_meta[s] = pack_meta(miss_leaf);
             E.pend_slot[b] = s;
             E.leaf_pedge[b] = pedge;
             E.path_len[b] = plen;
         }
-        evals++;
-        waiting = true;
-        break;
+        lc_add(S, LC_EVALS, 1u, lane);
     }
     regs_store(E, b, lane, S);
 #ifdef QZ_ADV_STAMPS
@@ -2041,8 +2075,6 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(QZ_ADV_WAVE
     if (lane == 0) {
         E.pl_done[b] = done;
         if (!waiting && slot != QZ_NONE) E.pend_slot[b] = QZ_NONE;
-        if (hits) E.bc_memo_hits[b] += hits;
-        if (evals) E.bc_evals[b] += evals;
         if (open_rounds) E.bc_open_rounds[b] += open_rounds;
     }
 }
