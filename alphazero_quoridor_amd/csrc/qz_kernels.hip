@@ -635,6 +635,11 @@ __device__ unsigned int g_sel_stamps[64][4096][8];
 // playouts of its board in one launch (k_advance) would otherwise pay a dependent memory round trip for every scalar it
 // re-reads and every counter it bumps per playout (measured: 70 % of such a wavefront's cycles were s_waitcnt).
 // regs_load at the start of a launch (and after a move: finish_move_board works on memory), regs_store at its end.
+// LDS through address-space-3 pointers: through a generic pointer every access is a FLAT instruction, and the wait for a
+// flat load is s_waitcnt vmcnt(0) lgkmcnt(0) -- which on gfx9-class hardware also drains every global STORE issued
+// before it (measured in k_advance: the record commit, all LDS reads, cost 9,000 cycles per playout that way).
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef __attribute__((address_space(3))) unsigned long long lds_u64;
 struct BoardRegs {
     Board root;
     uint32_t rootN, root_ne, root_eoff, half;
@@ -646,25 +651,54 @@ struct BoardRegs {
     // The per-board counters' deltas of this launch live in LDS (16 dwords per wavefront, bumped by fire-and-forget
     // ds_add / ds_max): as loop-carried scalars they cost k_advance two dozen SGPRs it does not have -- the compiler
     // parked them in VGPRs and those in scratch, whose reloads sat in the dependent chain of every playout.
-    uint32_t* lc;
+    lds_u32* lc;
+#ifdef QZ_ADV_STAMPS
+    unsigned long long t_sel[4];  // cycles in: replay rounds, walked levels, record commit, rest of the descent
+#endif
 };
 enum { LC_PLAYOUTS = 0, LC_TERMINAL, LC_OVERFLOW, LC_NONFINITE, LC_MAXDEPTH, LC_HITS, LC_EVALS, LC_SPARE, LC_LEVELS /*u64*/ = 8, LC_SCANNED /*u64*/ = 10,
        LC_EXPANDED /*u64*/ = 12, LC_WORDS = 16 };
 __device__ __forceinline__ void lc_add(const BoardRegs& S, int i, uint32_t v, int lane) {
-    if (lane == 0) atomicAdd(&S.lc[i], v);
+    if (lane == 0) __hip_atomic_fetch_add(S.lc + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 __device__ __forceinline__ void lc_add64(const BoardRegs& S, int i, unsigned long long v, int lane) {
-    if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(&S.lc[i]), v);
+    if (lane == 0) __hip_atomic_fetch_add(reinterpret_cast<lds_u64*>(S.lc + i), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+__device__ __forceinline__ void lc_max(const BoardRegs& S, int i, uint32_t v, int lane) {
+    if (lane == 0) __hip_atomic_fetch_max(S.lc + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 // the first `cap` levels of the current descent once more in LDS (we: chosen edges, wb: blocks); nullptr: none
 struct PathMirror {
-    uint32_t* we;
-    unsigned long long* wb;
-    uint32_t cap;
+    lds_u32* we;
+    lds_u64* wb;
+    uint32_t cap;    // 0: no mirror
+    uint32_t valid;  // levels of the previous descent of THIS launch the mirror still holds (0: none): a replay of that descent's record reads them here
 };
-__device__ __forceinline__ BoardRegs regs_load(const EngineDev& E, const int b, const int lane, uint32_t* lc) {
+// the wave-uniform fields, forced into scalar registers (k_advance's loop: see there)
+__device__ __forceinline__ void regs_uniform(BoardRegs& R) {
+    R.root.hb = rfl64(R.root.hb);
+    R.root.vb = rfl64(R.root.vb);
+    R.root.p1 = (int)rfl((uint32_t)R.root.p1);
+    R.root.p2 = (int)rfl((uint32_t)R.root.p2);
+    R.root.w1 = (int)rfl((uint32_t)R.root.w1);
+    R.root.w2 = (int)rfl((uint32_t)R.root.w2);
+    R.root.cur = (int)rfl((uint32_t)R.root.cur);
+    R.rootN = rfl(R.rootN);
+    R.root_ne = rfl(R.root_ne);
+    R.root_eoff = rfl(R.root_eoff);
+    R.half = rfl(R.half);
+    R.nn = rfl(R.nn);
+    R.neu = rfl(R.neu);
+    R.np = rfl(R.np);
+    R.rec_last = rfl(R.rec_last);
+    R.rec_clock = rfl(R.rec_clock);
+}
+__device__ __forceinline__ BoardRegs regs_load(const EngineDev& E, const int b, const int lane, lds_u32* lc) {
     BoardRegs R;
     R.lc = lc;
+#ifdef QZ_ADV_STAMPS
+    R.t_sel[0] = R.t_sel[1] = R.t_sel[2] = R.t_sel[3] = 0ull;
+#endif
     if (lane < LC_WORDS) lc[lane] = 0u;
     R.root = load_board(E.root_hb, E.root_vb, E.root_meta, b);
     R.rootN = rfl(E.root_N[b]);
@@ -694,8 +728,8 @@ __device__ __forceinline__ void regs_store(const EngineDev& E, const int b, cons
         const uint32_t c0 = E.bc_playouts[b], c1 = E.bc_terminal[b], c2 = E.bc_overflow[b], c3 = E.bc_nonfinite[b], c7 = E.bc_maxdepth[b],
                        c8 = E.bc_memo_hits[b], c9 = E.bc_evals[b];
         const unsigned long long c4 = E.bc_levels[b], c5 = E.bc_scanned[b], c6 = E.bc_expanded[b];
-        const uint32_t* lc = R.lc;
-        const unsigned long long* lc64 = reinterpret_cast<const unsigned long long*>(R.lc);
+        const lds_u32* lc = R.lc;
+        const lds_u64* lc64 = reinterpret_cast<const lds_u64*>(R.lc);
         E.root_N[b] = R.rootN;
         E.root_ne[b] = R.root_ne;
         E.root_eoff[b] = R.root_eoff;
@@ -733,6 +767,13 @@ __device__ __forceinline__ void select_core(EngineDev& E, BoardRegs& S, const in
     bool done = false, nonfinite = false;
     const bool live = S.live;
     uint32_t plen = 0u, scanned = 0u, replayed = 0u;
+#ifdef QZ_ADV_STAMPS
+    uint32_t sel_rounds = 0u, sel_failed = 0u;
+    unsigned long long ts_ = __builtin_amdgcn_s_memtime();
+#define QZ_TS(k) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); S.t_sel[k] += n_ - ts_; ts_ = n_; }
+#else
+#define QZ_TS(k)
+#endif
     if (live && ne > 0) {
         constexpr uint32_t R = QZ_PATH_RECS, CAP = QZ_PATH_CAP;
         const TreeView T = S.T;
@@ -760,36 +801,85 @@ __device__ __forceinline__ void select_core(EngineDev& E, BoardRegs& S, const in
             // ---- replay of record cur from level plen, 64 levels per round
             bool left = false;
             QZ_SEL_MARK(t_walk)
+            QZ_TS(1)
             while (cur != QZ_NONE && walk_credit == 0u && plen + 8u <= cur_len && !left) {
                 QZ_SEL_COUNT(n_rounds++;)
                 const uint32_t* const pe = pe0 + (size_t)cur * CAP;
                 const unsigned long long* const pb = pb0 + (size_t)cur * CAP;
                 const uint32_t i = plen + (uint32_t)lane;
                 bool ok = i < cur_len;
-                uint32_t lbase = 0u, chosen = 0u, pN = 0u, pcoff = 0u;
+                uint32_t lbase = 0u, chosen = 0u, prev = 0u, pN = 0u, pcoff = 0u;
                 unsigned long long w = 0ull;
                 int lne = 0;
+                // the record of the PREVIOUS descent of this launch is still in the LDS mirror (levels below PM.valid, not
+                // yet overwritten above the current level): no memory round trip for its entries
+#ifndef QZ_REPLAY_MIRROR
+#define QZ_REPLAY_MIRROR 1
+#endif
+#ifndef QZ_REPLAY_SPEC
+#define QZ_REPLAY_SPEC 0  // (the edge records requested before the parent-link check: measured no faster, same-box A/B)
+#endif
+                const bool mir = QZ_REPLAY_MIRROR && cur == src && cur_len <= PM.valid;  // wave-uniform (PM.valid = 0 without a mirror)
                 if (ok) {
-                    w = pb[i];
+                    if (mir) {
+                        w = PM.wb[i];
+                        chosen = PM.we[i];
+                        if (lane > 0) prev = PM.we[i - 1u];
+                    } else {
+                        w = pb[i];
+                        chosen = pe[i];
+                        if (lane > 0) prev = pe[i - 1u];
+                    }
                     lbase = (uint32_t)(w >> 8);
                     lne = (int)(w & 0xFFull);
-                    chosen = pe[i];
+                }
+                // ONE round trip for the parent edge (its visit count and child block) AND the node's edge records: the block
+                // address comes from the record, so the loads need not wait for the parent edge; what the record says is only
+                // BELIEVED after the check below (a stale entry points at memory of the pool that now means something else: the
+                // loads are harmless -- lne <= 8 records inside the pool -- and their values are thrown away)
+                ok = ok && lne >= 1 && lne <= 8;
+                // (only the fields the replay needs: Q, N, P, coff, act | cne | rid -- 6 registers per edge record, not 8:
+                // this array is the register peak of the descent)
+                struct EdgeLite {
+                    double Q;
+                    uint32_t N;
+                    float P;
+                    uint32_t coff;
+                    uint8_t act, cne;
+                    uint16_t rid;
+                };
+                EdgeLite ed[8];
+                if (ok) {
                     if (lane > 0) {
-                        const Edge* pv = &pool[pe[i - 1u]];
+                        const Edge* pv = &pool[prev];
                         pN = pv->N;
                         pcoff = pv->coff;
                     }
+#if QZ_REPLAY_SPEC
+#pragma unroll
+                    for (int j = 0; j < 8; j++)
+                        if (j < lne) {
+                            const Edge* src_e = &pool[lbase + (uint32_t)j];
+                            ed[j].Q = src_e->Q; ed[j].N = src_e->N; ed[j].P = src_e->P; ed[j].coff = src_e->coff;
+                            ed[j].act = src_e->act; ed[j].cne = src_e->cne; ed[j].rid = src_e->rid;
+                        }
+#endif
                 }
                 // an entry counts only if its block IS the child block of the entry above (lane 0: the current node)
                 const uint32_t linked = tree_phys_lanes(T, pcoff);
-                ok = ok && lne >= 1 && lne <= 8 && lbase == (lane > 0 ? linked : base);
+                ok = ok && lbase == (lane > 0 ? linked : base);
                 uint32_t lact = 0u, lcne = 0u, lN = 0u, lcoff = 0u;
                 if (ok) {
                     const double lsq = lane > 0 ? sqrt((double)pN) : sq;
-                    Edge ed[8];
+#if !QZ_REPLAY_SPEC
 #pragma unroll
                     for (int j = 0; j < 8; j++)
-                        if (j < lne) ed[j] = pool[lbase + (uint32_t)j];
+                        if (j < lne) {
+                            const Edge* src_e = &pool[lbase + (uint32_t)j];
+                            ed[j].Q = src_e->Q; ed[j].N = src_e->N; ed[j].P = src_e->P; ed[j].coff = src_e->coff;
+                            ed[j].act = src_e->act; ed[j].cne = src_e->cne; ed[j].rid = src_e->rid;
+                        }
+#endif
                     double lbest = 0.0;
                     int arg = 0;
 #pragma unroll
@@ -816,7 +906,7 @@ __device__ __forceinline__ void select_core(EngineDev& E, BoardRegs& S, const in
                     if (lane < nconf && i < CAP) {
                         we[i] = chosen;
                         wb[i] = w;
-                        if (PM.we && i < PM.cap) {
+                        if (i < PM.cap) {
                             PM.we[i] = chosen;
                             PM.wb[i] = w;
                         }
@@ -841,8 +931,13 @@ __device__ __forceinline__ void select_core(EngineDev& E, BoardRegs& S, const in
                 }
                 if (nconf < 64) left = true;
                 if (nconf < 8) walk_credit = 8u;
+#ifdef QZ_ADV_STAMPS
+                sel_rounds++;
+                if (nconf < 8) sel_failed++;
+#endif
             }
             QZ_SEL_MARK(t_replay)
+            QZ_TS(0)
             if (at_leaf) break;
             if (walk_credit > 0u) walk_credit--;
             QZ_SEL_COUNT(if (ne <= 8) n_narrow++; else n_wide++;)
@@ -900,7 +995,7 @@ __device__ __forceinline__ void select_core(EngineDev& E, BoardRegs& S, const in
                 const unsigned long long blk = ((unsigned long long)base << 8) | (unsigned long long)(ne > 255 ? 255 : ne);
                 we[plen] = e;
                 wb[plen] = blk;
-                if (PM.we && plen < PM.cap) {
+                if (plen < PM.cap) {
                     PM.we[plen] = e;
                     PM.wb[plen] = blk;
                 }
@@ -934,10 +1029,19 @@ __device__ __forceinline__ void select_core(EngineDev& E, BoardRegs& S, const in
             base = tree_phys(T, rdl(mCOff, wl));
             ne = cne;
         }
+        QZ_TS(1)
+        // (all wave-uniform by construction; said so explicitly, or the compiler carries them -- and the record bookkeeping
+        // derived from them -- in vector registers it does not have: their scratch reloads each drain the store queue)
+        cur = rfl(cur);
+        cur_len = rfl(cur_len);
+        left_rec = rfl(left_rec);
+        left_at = rfl(left_at);
+        used = rfl(used);
+        plen = rfl(plen);
         // ---- put this descent on record
         if (use) {
             const uint32_t n = plen < CAP ? plen : CAP;
-            const uint32_t clock = S.rec_clock + 1u;
+            const uint32_t clock = rfl(S.rec_clock) + 1u;
             uint32_t dest, from;  // levels [from, n) of this descent go into record dest, and their edges point at it
             if (cur != QZ_NONE) {
                 dest = cur;  // the descent is record cur, or extends it
@@ -964,16 +1068,25 @@ __device__ __forceinline__ void select_core(EngineDev& E, BoardRegs& S, const in
                     from = 0u;
                 }
             }
+            dest = rfl(dest);
+            from = rfl(from);
             const uint32_t first = from > 0u ? from : (left_rec != QZ_NONE ? left_at : 0u);
             if (from < n) {
                 wave_sync();  // lane 0 stored walked levels into the descent buffer, all lanes read it below
                 uint32_t* const qe = pe0 + (size_t)dest * CAP;
                 unsigned long long* const qb = pb0 + (size_t)dest * CAP;
                 for (uint32_t i = from + (uint32_t)lane; i < n; i += 64u) {
-                    const bool m = PM.we && i < PM.cap;
-                    const uint32_t ed = m ? PM.we[i] : we[i];
+                    uint32_t ed;
+                    unsigned long long bk;
+                    if (i < PM.cap) {
+                        ed = PM.we[i];
+                        bk = PM.wb[i];
+                    } else {
+                        ed = we[i];
+                        bk = wb[i];
+                    }
                     qe[i] = ed;
-                    qb[i] = m ? PM.wb[i] : wb[i];
+                    qb[i] = bk;
                     if (i >= first) pool[ed].rid = (uint16_t)(dest + 1u);
                 }
             }
@@ -988,6 +1101,7 @@ __device__ __forceinline__ void select_core(EngineDev& E, BoardRegs& S, const in
             S.rec_last = dest;
             S.rec_clock = clock;
         }
+        QZ_TS(2)
     }
 #ifdef QZ_SELECT_STAMPS
     QZ_SEL_MARK(t_walk)
@@ -1001,14 +1115,17 @@ __device__ __forceinline__ void select_core(EngineDev& E, BoardRegs& S, const in
     if (!live) t = 3u;
     else if (done) t = (winner_of(bd) == bd.cur) ? 1u : 2u;
     leaf_out = bd;
-    pedge_out = pedge;
-    plen_out = plen;
-    term_out = t;
-    if (lane == 0) {
-        if (nonfinite) atomicAdd(&S.lc[LC_NONFINITE], 1u);
-        atomicAdd(reinterpret_cast<unsigned long long*>(&S.lc[LC_SCANNED]), (unsigned long long)scanned);
-        atomicMax(&S.lc[LC_MAXDEPTH], plen);
-    }
+    pedge_out = rfl(pedge);
+    plen_out = rfl(plen);
+    term_out = rfl(t);
+#ifdef QZ_ADV_STAMPS
+    lc_add(S, LC_SPARE, replayed, lane);      // levels confirmed by replay rounds
+    lc_add(S, 14, sel_rounds, lane);          // replay rounds
+    lc_add(S, 15, sel_failed, lane);          // ... that confirmed fewer than 8 levels
+#endif
+    if (nonfinite) lc_add(S, LC_NONFINITE, 1u, lane);
+    lc_add64(S, LC_SCANNED, (unsigned long long)scanned, lane);
+    lc_max(S, LC_MAXDEPTH, plen, lane);
     if (plen >= 256u && lane == 0) {  // telemetry of the descents that set the kernel's duration (a handful of boards)
         atomicAdd(&E.counters[QZ_C_DEEP_DESCENTS], 1ull);
         if (2u * replayed < plen) atomicAdd(&E.counters[QZ_C_DEEP_COLD], 1ull);
@@ -1021,7 +1138,7 @@ __device__ __forceinline__ void select_core(EngineDev& E, BoardRegs& S, const in
 __device__ __forceinline__ void select_board(EngineDev& E, BoardRegs& S, const int b, const int lane) {
     Board bd;
     uint32_t pedge, plen, t;
-    select_core(E, S, b, lane, PathMirror{nullptr, nullptr, 0u}, bd, pedge, plen, t);
+    select_core(E, S, b, lane, PathMirror{(lds_u32*)nullptr, (lds_u64*)nullptr, 0u, 0u}, bd, pedge, plen, t);
     if (lane == 0) {
         E.leaf_hb[b] = bd.hb;
         E.leaf_vb[b] = bd.vb;
@@ -1032,12 +1149,12 @@ __device__ __forceinline__ void select_board(EngineDev& E, BoardRegs& S, const i
     }
 }
 
-__global__ __launch_bounds__(TPB) void k_select(EngineDev E) {
+__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_select(EngineDev E) {
     __shared__ uint32_t s_lc[WPB][LC_WORDS];
     const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
     const int b = (int)blockIdx.x * WPB + wave;
     if (b >= E.n_boards) return;
-    BoardRegs S = regs_load(E, b, lane, s_lc[wave]);
+    BoardRegs S = regs_load(E, b, lane, (lds_u32*)s_lc[wave]);
     select_board(E, S, b, lane);
     regs_store(E, b, lane, S);
 }
@@ -1103,7 +1220,9 @@ __device__ __forceinline__ void backup_leaf(EngineDev& E, BoardRegs& S, const in
     if (plen <= (uint32_t)QZ_PATH_CAP) {
         const uint32_t* path = E.path_edges + ((size_t)b * (QZ_PATH_RECS + 1) + QZ_PATH_RECS) * QZ_PATH_CAP;  // the descent buffer
         for (uint32_t i = (uint32_t)lane; i < plen; i += 64u) {
-            uint32_t pe = (PM.we && i < PM.cap) ? PM.we[i] : path[i];
+            uint32_t pe;
+            if (i < PM.cap) pe = PM.we[i];
+            else pe = path[i];
             double val = ((plen - 1u - i) & 1u) ? leaf_value : -leaf_value;
             uint32_t N = pool[pe].N + 1u;  // mcts.py:51
             double Q = pool[pe].Q;
@@ -1125,11 +1244,9 @@ __device__ __forceinline__ void backup_leaf(EngineDev& E, BoardRegs& S, const in
         }
     }
     S.rootN += 1u;  // the root is updated too
-    if (lane == 0) {
-        atomicAdd(&S.lc[LC_PLAYOUTS], 1u);
-        atomicAdd(reinterpret_cast<unsigned long long*>(&S.lc[LC_LEVELS]), (unsigned long long)plen);
-        if (term != 0u) atomicAdd(&S.lc[LC_TERMINAL], 1u);
-    }
+    lc_add(S, LC_PLAYOUTS, 1u, lane);
+    lc_add64(S, LC_LEVELS, (unsigned long long)plen, lane);
+    if (term != 0u) lc_add(S, LC_TERMINAL, 1u, lane);
 }
 // mcts.py:125: +1 if winner == current_player else -1 (always +1 in practice: the reference does not rotate players
 // on a terminal move); term = 1 | 2
@@ -1153,7 +1270,7 @@ __device__ __forceinline__ void expand_backup_board(EngineDev& E, BoardRegs& S, 
     } else {
         leaf_value = terminal_value(E, term);
     }
-    backup_leaf(E, S, b, lane, PathMirror{nullptr, nullptr, 0u}, leaf_value, pedge, plen, term);
+    backup_leaf(E, S, b, lane, PathMirror{(lds_u32*)nullptr, (lds_u64*)nullptr, 0u, 0u}, leaf_value, pedge, plen, term);
 }
 
 __global__ __launch_bounds__(TPB) void k_expand_backup(EngineDev E, const float* __restrict__ p, const float* __restrict__ v) {
@@ -1161,7 +1278,7 @@ __global__ __launch_bounds__(TPB) void k_expand_backup(EngineDev E, const float*
     const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
     const int b = (int)blockIdx.x * WPB + wave;
     if (b >= E.n_boards) return;
-    BoardRegs S = regs_load(E, b, lane, s_lc[wave]);
+    BoardRegs S = regs_load(E, b, lane, (lds_u32*)s_lc[wave]);
     expand_backup_board(E, S, p, v, b, lane);
     regs_store(E, b, lane, S);
 }
@@ -1174,7 +1291,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
     const int b = (int)blockIdx.x * WPB + wave;
     if (b >= E.n_boards) return;
-    BoardRegs S = regs_load(E, b, lane, s_lc[wave]);
+    BoardRegs S = regs_load(E, b, lane, (lds_u32*)s_lc[wave]);
     expand_backup_board(E, S, p, v, b, lane);
     wave_sync();  // the backup's stores (other lanes) before the descent's loads
     select_board(E, S, b, lane);
@@ -1936,6 +2053,8 @@ __device__ __forceinline__ void memo_insert(const EngineDev& E, const uint64_t h
 //               counter of round r + 1 while nobody reads it)
 #ifdef QZ_ADV_STAMPS  // diagnostic build only (tests/hip/Makefile, benchmarks/advance_stamps.py): where a wavefront's time goes in k_advance
 __device__ unsigned long long g_adv_stamps[4096][16];  // per board, accumulated over launches: cycles per phase + counts
+__device__ unsigned long long g_adv_stamps3[4096][4];  // cycles inside the descents: replay rounds, walked levels (+ set-up), record commit
+__device__ unsigned long long g_adv_stamps2[4096][4];  // levels confirmed by replay, replay rounds, rounds that confirmed < 8 levels
 #define QZ_AS_MARK(k) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); as_acc[k] += now_ - as_t; if ((k) == 3 && now_ - as_t > as_max[0]) as_max[0] = now_ - as_t; if ((k) == 4 && now_ - as_t > as_max[1]) as_max[1] = now_ - as_t; as_t = now_; }
 #define QZ_AS_COUNT(k, v) { as_acc[k] += (unsigned long long)(v); }
 #else
@@ -1960,8 +2079,8 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(QZ_ADV_WAVE
     unsigned long long as_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, as_max[2] = {0, 0}, as_t = __builtin_amdgcn_s_memtime();
     const unsigned long long as_t0 = as_t;
 #endif
-    const PathMirror PM{s_we[wave], s_wb[wave], ADV_LCAP};
-    const PathMirror NOPM{nullptr, nullptr, 0u};
+    PathMirror PM{(lds_u32*)s_we[wave], (lds_u64*)s_wb[wave], ADV_LCAP, 0u};
+    const PathMirror NOPM{(lds_u32*)nullptr, (lds_u64*)nullptr, 0u, 0u};
     {   // the compacting half of a move k_moves left for this launch (it runs beside the other boards' playouts)
         const uint32_t rp = rfl(E.reroot_pend[b]);
         if (rp != 0u) {
@@ -1973,7 +2092,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(QZ_ADV_WAVE
             if (rfl((uint32_t)E.release[b]) & 2u) return;
         }
     }
-    BoardRegs S = regs_load(E, b, lane, s_lc[wave]);
+    BoardRegs S = regs_load(E, b, lane, (lds_u32*)s_lc[wave]);
     const uint32_t epoch = rfl(*E.memo.epoch);
     uint32_t done = rfl(E.pl_done[b]), open_rounds = 0u;
     if ((S.root.cur == 1 ? S.root.w1 : S.root.w2) > 0) open_rounds = 1u;
@@ -2003,6 +2122,17 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(QZ_ADV_WAVE
         int ln = lane, bb = b;
         asm volatile("" : "+v"(ln));
         asm volatile("" : "+s"(bb));
+        // every loop-carried scalar is wave-uniform; said so explicitly at the top of each iteration, or the compiler keeps
+        // them (and everything computed from them) in vector registers it does not have: the copies went to scratch, and a
+        // scratch reload waits for s_waitcnt vmcnt(0), i.e. for every global store issued before it
+        regs_uniform(S);
+        m0 = rfl(m0); m1 = rfl(m1); m2 = rfl(m2); m3 = rfl(m3); m4 = rfl(m4);
+        term = rfl(term); pedge = rfl(pedge); plen = rfl(plen); done = rfl(done);
+        have = rfl((uint32_t)have) != 0u;
+        from_memory = rfl((uint32_t)from_memory) != 0u;
+        value = __longlong_as_double((long long)rfl64((uint64_t)__double_as_longlong(value)));
+        prow = reinterpret_cast<const float*>(rfl64(reinterpret_cast<uint64_t>(prow)));
+        PM.valid = rfl(PM.valid);
         if (have) {
             if (term == 0u) expand_node(E, S, ln, pedge, m0, m1, m2, m3, m4, [&](int a) { return prow ? prow[a] : pl; });
             QZ_AS_MARK(1)  // 1: expansion
@@ -2019,6 +2149,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(QZ_ADV_WAVE
         if (it > 0 && (unsigned int)(__builtin_amdgcn_s_memrealtime() - t0) > budget) break;
         Board leaf;
         select_core(E, S, bb, ln, PM, leaf, pedge, plen, term);
+        PM.valid = plen < ADV_LCAP ? plen : ADV_LCAP;
         wave_sync();  // the descent buffer (lane 0 / other lanes) before the backup reads it
         QZ_AS_MARK(4)  // 4: descent
         QZ_AS_COUNT(9, plen)
@@ -2063,6 +2194,10 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(QZ_ADV_WAVE
     QZ_AS_MARK(7)  // 7: epilogue (miss record, state store)
     if (lane == 0 && b < 4096) {
         for (int k = 0; k < 10; k++) g_adv_stamps[b][k] += as_acc[k];
+        for (int k = 0; k < 3; k++) g_adv_stamps3[b][k] += S.t_sel[k];
+        g_adv_stamps2[b][0] += S.lc[LC_SPARE];
+        g_adv_stamps2[b][1] += S.lc[14];
+        g_adv_stamps2[b][2] += S.lc[15];
         const unsigned long long whole = __builtin_amdgcn_s_memtime() - as_t0;
         g_adv_stamps[b][10] += whole;
         g_adv_stamps[b][11] += 1ull;
@@ -2466,6 +2601,22 @@ extern "C" int qzt_rules_stamps_read(void* stamps, void* enc, void* rt) {  // [4
 }
 #endif
 #ifdef QZ_ADV_STAMPS
+extern "C" int qzt_advance_stamps3_read(void* host_out, int clear) {  // [4096 boards][4] u64
+    hipError_t e = hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_adv_stamps3), sizeof(g_adv_stamps3));
+    if (e == hipSuccess && clear) {
+        static unsigned long long zeros[4096][4];
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_adv_stamps3), zeros, sizeof(zeros));
+    }
+    return (int)e;
+}
+extern "C" int qzt_advance_stamps2_read(void* host_out, int clear) {  // [4096 boards][4] u64
+    hipError_t e = hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_adv_stamps2), sizeof(g_adv_stamps2));
+    if (e == hipSuccess && clear) {
+        static unsigned long long zeros[4096][4];
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_adv_stamps2), zeros, sizeof(zeros));
+    }
+    return (int)e;
+}
 extern "C" int qzt_advance_stamps_read(void* host_out, int clear) {  // [4096 boards][16] u64
     hipError_t e = hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_adv_stamps), sizeof(g_adv_stamps));
     if (e == hipSuccess && clear) {

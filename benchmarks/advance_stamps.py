@@ -19,11 +19,17 @@ for i in range(WARM // 64):
     eng.run_rounds(ev, 64, max_playouts=MP, budget_us=BUD); eng.harvest()
 torch.cuda.synchronize()
 assert L.qzt_advance_stamps_read(buf.ctypes.data_as(C.c_void_p), 1) == 0
+buf2 = np.zeros((4096, 4), dtype=np.uint64)
+assert L.qzt_advance_stamps2_read(buf2.ctypes.data_as(C.c_void_p), 1) == 0
+buf3 = np.zeros((4096, 4), dtype=np.uint64)
+assert L.qzt_advance_stamps3_read(buf3.ctypes.data_as(C.c_void_p), 1) == 0
 st0 = eng.stats(); t0 = time.time()
 for i in range(MEAS // 64):
     eng.run_rounds(ev, 64, max_playouts=MP, budget_us=BUD); eng.harvest()
 torch.cuda.synchronize(); dt = time.time() - t0
 assert L.qzt_advance_stamps_read(buf.ctypes.data_as(C.c_void_p), 0) == 0
+assert L.qzt_advance_stamps2_read(buf2.ctypes.data_as(C.c_void_p), 0) == 0
+assert L.qzt_advance_stamps3_read(buf3.ctypes.data_as(C.c_void_p), 0) == 0
 st1 = eng.stats()
 a = buf[:min(B, 4096)].astype(np.float64)
 tot = a[:, 10].sum()
@@ -34,6 +40,12 @@ out = {"boards": B, "rounds": MEAS, "wall_s": dt, "playouts": int(st1["playouts"
        "cycles_per_launch_per_wave": tot / a[:, 11].sum(), "cycles_per_playout": tot / max(po, 1),
        "share": {n: a[:, k].sum() / tot for k, n in enumerate(names)},
        "cycles_per_playout_by_phase": {n: a[:, k].sum() / max(po, 1) for k, n in enumerate(names)}}
+lv = float(a[:, 9].sum()); r2 = buf2[:min(B, 4096)].astype(np.float64).sum(axis=0)
+out["levels_replayed_frac"] = r2[0] / max(lv, 1); out["replay_rounds_per_playout"] = r2[1] / max(po, 1); out["replay_rounds_failed_frac"] = r2[2] / max(r2[1], 1)
+out["levels_per_replay_round"] = r2[0] / max(r2[1], 1)
+r3 = buf3[:min(B, 4096)].astype(np.float64).sum(axis=0)
+out["descent_cycles_per_playout"] = {"replay_rounds": r3[0] / max(po, 1), "walk_and_setup": r3[1] / max(po, 1), "record_commit": r3[2] / max(po, 1)}
+out["cycles_per_replay_round"] = r3[0] / max(r2[1], 1); out["cycles_per_walked_level"] = r3[1] / max(lv - r2[0], 1)
 q = [0.5, 0.9, 0.99, 1.0]
 out["longest_single_move_cycles_quantiles_over_boards_50_90_99_100"] = np.quantile(a[:, 12], q).tolist()
 out["longest_single_descent_cycles_quantiles"] = np.quantile(a[:, 13], q).tolist()
