@@ -69,6 +69,7 @@ class qz_config(C.Structure):
         ("memo_small_log2", C.c_int32),
         ("memo_big_log2", C.c_int32),
         ("compact_edges", C.c_int32),
+        ("max_depth", C.c_int32),
     ]
 
 
@@ -112,6 +113,7 @@ class qz_stats(C.Structure):
         ("open_rounds", C.c_int64),
         ("open_plies", C.c_int64),
         ("waiting_boards", C.c_int64),
+        ("aborted_depth", C.c_int64),
         ("runaway_descents", C.c_int64),
     ]
 
@@ -156,7 +158,9 @@ _SIGNATURES = {
     "qz_engine_set_boards": (C.c_int, [_P, C.POINTER(qz_boards), C.c_int, _P]),
     "qz_engine_get_boards": (C.c_int, [_P, C.POINTER(qz_boards), _P]),
     "qz_engine_set_temp": (C.c_int, [_P, C.c_float]),
+    "qz_engine_get_plies": (C.c_int, [_P, _P, _P]),
     "qz_engine_set_rules_opts": (C.c_int, [_P, C.POINTER(qz_rules_opts)]),
+    "qz_engine_set_playouts": (C.c_int, [_P, C.c_int]),
     "qz_mcts_select": (C.c_int, [_P, _P, _P, _P, _P]),
     "qz_mcts_descend": (C.c_int, [_P, _P]),
     "qz_mcts_leaf_inputs": (C.c_int, [_P, _P, _P, _P, _P]),

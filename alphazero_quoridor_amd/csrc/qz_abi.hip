@@ -302,6 +302,8 @@ int qz_engine_create(const qz_config* cfg, qz_engine** out) {
     d.edge_cap = c.edge_cap;
     d.max_plies = c.max_plies;
     d.n_playout = c.n_playout;
+    if (c.max_depth < 0) c.max_depth = 0;
+    d.max_depth = c.max_depth;
     if (c.compact_edges == 0) {  // a third of a board's share of the page pool (garbage + live tree + the copy's target must fit), 1..24 pages
         long long pages = (long long)c.tree_pool_pages / c.n_boards / 3;
         pages = pages < 1 ? 1 : (pages > 24 ? 24 : pages);
@@ -376,6 +378,7 @@ int qz_engine_create(const qz_config* cfg, qz_engine** out) {
     ALLOC(pl_done, B);
     ALLOC(pend_slot, B);
     ALLOC(reroot_pend, B);
+    ALLOC(compact_at, B);
     ALLOC(miss_count, (size_t)2);
     ALLOC(miss_hb, B);
     ALLOC(miss_vb, B);
@@ -499,6 +502,13 @@ int qz_engine_get_boards(qz_engine* e, const qz_boards* dst, void* stream) {
     return 0;
 }
 
+int qz_engine_get_plies(qz_engine* e, int32_t* plies, void* stream) {
+    ENGINE_CHECK(e);
+    if (!plies) return fail(QZ_E_INVALID, "plies is null");
+    HIP_TRY(hipMemcpyAsync(plies, e->dev.ply, (size_t)e->cfg.n_boards * sizeof(uint32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
+
 int qz_engine_set_temp(qz_engine* e, float temp) {
     if (!e) return fail(QZ_E_INVALID, "null engine");
     if (!(temp > 0.f)) return fail(QZ_E_INVALID, "temp must be > 0");
@@ -506,6 +516,16 @@ int qz_engine_set_temp(qz_engine* e, float temp) {
     e->dev.temp = temp;
     HIP_TRY(hipSetDevice(e->cfg.device));
     HIP_TRY(hipMemcpy(e->dev_mem, &e->dev, sizeof(e->dev), hipMemcpyHostToDevice));  // (synchronous: the next launch sees it)
+    return 0;
+}
+
+int qz_engine_set_playouts(qz_engine* e, int n_playout) {
+    if (!e) return fail(QZ_E_INVALID, "null engine");
+    if (n_playout < 1) return fail(QZ_E_INVALID, "n_playout must be >= 1");
+    e->cfg.n_playout = n_playout;
+    e->dev.n_playout = n_playout;
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    HIP_TRY(hipMemcpy(e->dev_mem, &e->dev, sizeof(e->dev), hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -671,7 +691,8 @@ int qz_engine_stats(qz_engine* e, qz_stats* out, void* stream) {
     out->aborted_no_move = (int64_t)h[QZ_C_ABORT_NO_MOVE];
     out->aborted_max_plies = (int64_t)h[QZ_C_ABORT_MAX_PLIES];
     out->aborted_pool = (int64_t)h[QZ_C_ABORT_POOL];
-    out->games_aborted = out->aborted_no_move + out->aborted_max_plies + out->aborted_pool;
+    out->aborted_depth = (int64_t)h[QZ_C_ABORT_DEPTH];
+    out->games_aborted = out->aborted_no_move + out->aborted_max_plies + out->aborted_pool + out->aborted_depth;
     out->bad_forced_moves = (int64_t)h[QZ_C_BAD_FORCED];
     out->nonfinite_values = (int64_t)sf;
     out->max_depth = (int64_t)md;

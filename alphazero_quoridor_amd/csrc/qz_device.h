@@ -70,6 +70,7 @@ enum {
     QZ_C_ROUNDS,            // k_advance launches (asynchronous self-play)
     QZ_C_MEMO_INSERTS,      // evaluations stored in the memo
     QZ_C_MEMO_LOCKED,       // ... skipped because another wave held the bucket's lock
+    QZ_C_ABORT_DEPTH,       // games dropped because a descent was deeper than qz_config.max_depth (the reference's RecursionError)
     QZ_C_RUNAWAY,           // descents cut off because they were deeper than a tree can be (corrupted storage; must stay 0)
     QZ_C_COUNT
 };
@@ -126,6 +127,7 @@ struct MemoDev {
 struct EngineDev {
     int n_boards, node_cap, edge_cap, max_plies;
     int n_playout;
+    int max_depth;       // drop a game whose descent is longer than this many levels (0: never)
     int compact_edges;   // asynchronous loop: moves keep the subtree in place while the tree's cursor is below this (<= 0: every move copies)
     int tree_pool_pages, traj_pool_pages;
     uint32_t traj_page_dwords;
@@ -172,6 +174,7 @@ struct EngineDev {
     MemoDev memo;
     uint32_t* pl_done;        // [B] playouts done on the current root
     uint32_t* pend_slot;      // [B] miss-list slot of the leaf this board waits for, QZ_NONE = none
+    uint32_t* compact_at;     // [B] allocation cursor at which the board's next move compacts (compact_edges, or twice the tree's size after its last compaction)
     uint32_t* reroot_pend;    // [B] the subtree copy of the last move, left for the next k_advance launch: 0 none, 1 fresh root, e + 2 keep edge e
     int* miss_count;          // [1] slots used by this round's misses
     uint64_t *miss_hb, *miss_vb, *miss_meta;  // [B] the leaves awaiting evaluation, compacted

@@ -939,6 +939,7 @@ __device__ __forceinline__ void select_core(EngineDev& E, BoardRegs& S, const in
             QZ_SEL_MARK(t_replay)
             QZ_TS(0)
             if (at_leaf) break;
+            if (E.max_depth > 0 && plen > (uint32_t)E.max_depth) break;
             if (walk_credit > 0u) walk_credit--;
             QZ_SEL_COUNT(if (ne <= 8) n_narrow++; else n_wide++;)
             // ---- one level of the walk (all lanes scan this node's children)
@@ -1021,6 +1022,7 @@ __device__ __forceinline__ void select_core(EngineDev& E, BoardRegs& S, const in
             plen++;
             const int cne = (int)((misc >> 8) & 0xFFu);
             if (cne == 0) break;  // TreeNode.is_leaf(): never expanded (or terminal)
+            if (E.max_depth > 0 && plen > (uint32_t)E.max_depth) break;  // the game is about to be dropped (select_core's caller): no point in going on
             if (plen > (uint32_t)QZ_TREE_PT * QZ_PAGE_EDGES) {  // deeper than a tree has edges: a cycle, i.e. corrupted storage.  Never hang the GPU
                 if (lane == 0) atomicAdd(&E.counters[QZ_C_RUNAWAY], 1ull);
                 break;
@@ -1133,12 +1135,26 @@ __device__ __forceinline__ void select_core(EngineDev& E, BoardRegs& S, const in
         atomicAdd(&E.counters[QZ_C_DEEP_REPLAYED], (unsigned long long)replayed);
     }
 }
+// qz_config.max_depth: the reference backs a playout up by RECURSION (TreeNode.update_recursive, mcts.py:55-62: one Python
+// frame per node of the path) and never raises the interpreter's recursion limit of 1,000, so a playout whose path is
+// longer than ~992 levels ends the reference's whole self-play run with a RecursionError.  A board that gets there is
+// dropped (status ABORTED, counted in aborted_depth; restarted by k_release / k_round_tail) -- the one thing a batched
+// engine can do that mirrors "the reference cannot play this game on".  Returns true if the board was dropped.
+__device__ __forceinline__ bool drop_if_too_deep(EngineDev& E, const int b, const int lane, const uint32_t plen) {
+    if (E.max_depth <= 0 || plen <= (uint32_t)E.max_depth) return false;
+    if (lane == 0) {
+        E.status[b] = QZ_ABORTED;
+        atomicAdd(&E.counters[QZ_C_ABORT_DEPTH], 1ull);
+    }
+    return true;
+}
 // the lock-step kernels' descent: state from memory, leaf to memory (E.leaf_*: what the rules op, the evaluator and
 // k_expand_backup read)
 __device__ __forceinline__ void select_board(EngineDev& E, BoardRegs& S, const int b, const int lane) {
     Board bd;
     uint32_t pedge, plen, t;
     select_core(E, S, b, lane, PathMirror{(lds_u32*)nullptr, (lds_u64*)nullptr, 0u, 0u}, bd, pedge, plen, t);
+    if (drop_if_too_deep(E, b, lane, plen)) t = 3u;  // (the board no longer plays: ignored by the rules op, the evaluator's output and expand_backup)
     if (lane == 0) {
         E.leaf_hb[b] = bd.hb;
         E.leaf_vb[b] = bd.vb;
@@ -1477,6 +1493,7 @@ __device__ __forceinline__ void wave_reroot(EngineDev& E, int b, int lane, uint3
             if (s_ne == 0) {
                 E.n_nodes[b] = 0u;
                 E.n_edges[b] = 0u;
+                if (E.compact_edges > 0) E.compact_at[b] = (uint32_t)E.compact_edges;
             }
         }
         return;
@@ -1573,6 +1590,15 @@ __device__ __forceinline__ void wave_reroot(EngineDev& E, int b, int lane, uint3
         }
         E.path_len[b] = 0u;
         E.pl_done[b] = 0u;  // (asynchronous self-play: playouts on the new root)
+        // the next compaction of this board: when its cursor has doubled (a tree whose LIVE part is larger than the
+        // engine-wide threshold would otherwise be copied again at every move; measured: a handful of such boards made
+        // every launch of a 1,024-board engine last 10-20 ms)
+        if (E.compact_edges > 0) {
+            uint32_t next = 2u * new_edges;
+            if (next < (uint32_t)E.compact_edges) next = (uint32_t)E.compact_edges;
+            const uint32_t cap = (uint32_t)QZ_TREE_PT * QZ_PAGE_EDGES * 3u / 4u;
+            E.compact_at[b] = next < cap ? next : cap;
+        }
         E.n_nodes[b] = new_nodes;
         E.n_edges[b] = new_edges;
         E.root_N[b] = childN;
@@ -1602,6 +1628,7 @@ __device__ __forceinline__ void reset_board_state(EngineDev& E, int b) {
     E.pl_done[b] = 0u;
     E.pend_slot[b] = QZ_NONE;
     E.reroot_pend[b] = 0u;
+    E.compact_at[b] = E.compact_edges > 0 ? (uint32_t)E.compact_edges : 0u;
     E.game_serial[b] = E.game_serial[b] + 1u;
 }
 
@@ -1628,6 +1655,7 @@ __global__ __launch_bounds__(TPB) void k_reset(EngineDev E, int reset_boards) {
         E.pl_done[b] = 0u;
         E.pend_slot[b] = QZ_NONE;
         E.reroot_pend[b] = 0u;
+        E.compact_at[b] = E.compact_edges > 0 ? (uint32_t)E.compact_edges : 0u;
     }
 }
 
@@ -2149,6 +2177,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(QZ_ADV_WAVE
         if (it > 0 && (unsigned int)(__builtin_amdgcn_s_memrealtime() - t0) > budget) break;
         Board leaf;
         select_core(E, S, bb, ln, PM, leaf, pedge, plen, term);
+        if (drop_if_too_deep(E, bb, ln, plen)) break;
         PM.valid = plen < ADV_LCAP ? plen : ADV_LCAP;
         wave_sync();  // the descent buffer (lane 0 / other lanes) before the backup reads it
         QZ_AS_MARK(4)  // 4: descent
@@ -2225,7 +2254,7 @@ __global__ __launch_bounds__(TPB) void k_moves(EngineDev E) {
     if (rfl(E.status[b]) != QZ_PLAYING || rfl(E.pl_done[b]) < (uint32_t)E.n_playout || rfl((uint32_t)E.release[b]) != 0u ||
         rfl(E.reroot_pend[b]) != 0u)
         return;
-    const bool compact = E.compact_edges <= 0 || rfl(E.n_edges[b]) >= (uint32_t)E.compact_edges;
+    const bool compact = E.compact_edges <= 0 || rfl(E.n_edges[b]) >= rfl(E.compact_at[b]);
     const Board rb = unpack(0ull, 0ull, rfl64(E.root_meta[b]));
     if ((rb.cur == 1 ? rb.w1 : rb.w2) > 0 && lane == 0) E.bc_open_plies[b] += 1u;
     finish_move_board(E, b, lane, nullptr, nullptr, nullptr, compact ? 2 : 1);

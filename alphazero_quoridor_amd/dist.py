@@ -44,7 +44,9 @@ def init_from_env(device_type="cuda"):
     backend = os.environ.get("QZ_DIST_BACKEND", "nccl" if device_type == "cuda" else "gloo")
     if os.environ.get("QZ_SHARE_DEVICE") == "1":
         local = 0
-    if world > 1 and not dist.is_initialized():
+    # QZ_DIST_FORCE=1: create the process group (and run every collective of this package) even with ONE rank -- the
+    # RCCL code path on a single GPU: init with device_id, uint8 / int64 all_gather_into_tensor, float32 all_reduce
+    if (world > 1 or force_collectives()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if device_type == "cuda":
@@ -56,12 +58,23 @@ def init_from_env(device_type="cuda"):
     return rank, local, world
 
 
+def force_collectives() -> bool:
+    return os.environ.get("QZ_DIST_FORCE") == "1"
+
+
+def collectives_on(group=None) -> bool:
+    """True if the package's collectives should really run: more than one rank, or one rank with QZ_DIST_FORCE=1."""
+    if not dist.is_available() or not dist.is_initialized():
+        return False
+    return dist.get_world_size(group) > 1 or force_collectives()
+
+
 def allgather_tuples(buf: torch.Tensor, group=None, n_games=None):
     """Every rank contributes uint8 [n_r, 588]; every rank gets the concatenation in rank
     order, uint8 [sum n_r, 588].  With `n_games` (this rank's finished games) the call returns
     (tuples, games summed over ranks) -- the same number on every rank, so loops that run
     "until N games" stay in lockstep and issue the same sequence of collectives."""
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not collectives_on(group):
         return buf if n_games is None else (buf, int(n_games))
     world = dist.get_world_size(group)
     dev = buf.device

@@ -59,6 +59,10 @@ class TupleBatch:
         return [(st[i], pi[i], z[i]) for i in range(len(self))]
 
 
+# Under `python train.py` the reference's recursive backup (TreeNode.update_recursive, mcts.py:55-62) overflows Python's
+# default recursion limit of 1,000 when a playout's path has more than 992 levels: the run ends with a RecursionError.
+REFERENCE_MAX_DEPTH = 992
+
 _hip = None
 
 
@@ -77,7 +81,7 @@ class SelfPlayEngine:
     def __init__(self, n_boards, n_playout=400, c_puct=5.0, temp=1.0, is_selfplay=1, seed=0, device="cuda:0",
                  fix_terminal_sign=False, node_cap=0, edge_cap=0, max_plies=0, dirichlet_alpha=0.3, noise_frac=0.25,
                  tree_pool_pages=0, traj_pool_pages=0, traj_page_dwords=0, rules_opts=None, select_opts=0, memo=True,
-                 memo_small_log2=0, memo_big_log2=0, compact_edges=0):
+                 memo_small_log2=0, memo_big_log2=0, compact_edges=0, max_depth=0):
         if not torch.cuda.is_available():
             raise _cabi.QzError(_cabi.E_NO_DEVICE, "no HIP device: the engine has no CPU path")
         self.L = _cabi.load()
@@ -102,6 +106,7 @@ class SelfPlayEngine:
         # leaf-evaluation memo of the asynchronous self-play loop (include/qz_abi.h): log2 of the bucket counts, 0 = auto
         cfg.memo_small_log2 = int(memo_small_log2) if memo else -1
         cfg.memo_big_log2 = int(memo_big_log2) if memo else -1
+        cfg.max_depth = int(max_depth)  # drop a game whose descent exceeds this (0 = never; REFERENCE_MAX_DEPTH mirrors the reference's RecursionError)
         cfg.compact_edges = int(compact_edges)  # 0 = default; < 0: every move of the asynchronous loop copies its subtree
         if rules_opts is not None:
             cfg.rules = rules_opts
@@ -168,8 +173,21 @@ class SelfPlayEngine:
         _cabi.check(self.L.qz_engine_get_boards(self.h, out.byref(), self._s()))
         return out
 
+    def get_plies(self) -> torch.Tensor:
+        """int32 [B]: moves played so far in every board's current game"""
+        out = torch.empty(self.n_boards, dtype=torch.int32, device=self.device)
+        _cabi.check(self.L.qz_engine_get_plies(self.h, out.data_ptr(), self._s()))
+        return out
+
     def set_temp(self, temp: float):
         _cabi.check(self.L.qz_engine_set_temp(self.h, float(temp)))
+
+    def set_playouts(self, n_playout: int):
+        """n_playout for later moves of the asynchronous loop (captured round graphs stay valid: the kernels read it
+        from their arguments at launch... so a captured graph keeps the OLD value: re-capture after changing it)."""
+        _cabi.check(self.L.qz_engine_set_playouts(self.h, int(n_playout)))
+        self.n_playout = int(n_playout)
+        self._round_graph = None
 
     def set_rules_opts(self, opts=None):
         """qz_rules_opts for this engine's leaf rules op (None = library defaults)."""
@@ -274,9 +292,17 @@ class SelfPlayEngine:
         torch.cuda.current_stream(self.device).wait_stream(s)
         torch.cuda.synchronize(self.device)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            for i in range(steps_per_graph):
-                self.playout_step(evaluator, more=i + 1 < steps_per_graph)
+        try:
+            with torch.cuda.graph(g):
+                for i in range(steps_per_graph):
+                    self.playout_step(evaluator, more=i + 1 < steps_per_graph)
+        except Exception:
+            # nothing of the capture has executed: the host-side "the descent already ran" flag must not survive it,
+            # or the next eager select() would skip its descent and expand the warm-up's stale leaf a second time
+            self._graph, self._graph_steps = None, 0
+            raise
+        finally:
+            self._descended = False  # (the last captured step uses more=False; a failed capture ran nothing)
         self._graph, self._graph_steps = g, int(steps_per_graph)
         return warmup  # playouts already spent on the current roots
 
@@ -541,12 +567,33 @@ class BoardGroups:
         self.run_playouts(n_playout)
         return self.finish_move()
 
+    # counters are summed over the groups; these fields are maxima / high-water marks of ONE engine
+    _MAX_FIELDS = ("max_depth", "max_nodes", "max_edges", "rounds")
+
     def stats(self) -> dict:
         tot = {}
         for _, eng, _ in self._each():
             for k, v in eng.stats().items():
-                tot[k] = tot.get(k, 0) + v
+                tot[k] = max(tot.get(k, 0), v) if k in self._MAX_FIELDS else tot.get(k, 0) + v
         return tot
+
+    # ------------------------------------------------------------------ asynchronous self-play
+    def set_playouts(self, n_playout):
+        for eng in self.engines:
+            eng.set_playouts(n_playout)
+        self.n_playout = int(n_playout)
+
+    def capture_rounds(self, rounds=16, **kw):
+        for _, eng, ev in self._each():
+            eng.capture_rounds(ev, rounds=rounds, **kw)
+
+    def run_rounds(self, n, chunk=16, **kw):
+        """n rounds of every group; the groups' launches are issued `chunk` rounds at a time in turn, each on its own
+        stream, so that one group's tree kernel runs under the other's network launches and launch tails."""
+        n, chunk = int(n), int(chunk)
+        for k in range(0, n, chunk):
+            for _, eng, ev in self._each():
+                eng.run_rounds(ev, min(chunk, n - k), **kw)
 
     def synchronize(self):
         for s in self.streams:

@@ -608,9 +608,15 @@ class PolicyValueNet:
 
         return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
+    @staticmethod
+    def _collectives_on():
+        from . import dist as qdist
+
+        return qdist.collectives_on()
+
     def _allreduce_grads(self):
         world = self._world()
-        if world == 1:
+        if not self._collectives_on():
             return
         import torch.distributed as dist
 
@@ -627,7 +633,7 @@ class PolicyValueNet:
     def sync_from_rank0(self):
         """Every rank takes rank 0's weights, BatchNorm buffers and optimiser step count: replicas
         must start identical for the gradient all-reduce to keep them identical."""
-        if self._world() == 1:
+        if not self._collectives_on():
             return
         import torch.distributed as dist
 
@@ -639,7 +645,7 @@ class PolicyValueNet:
     def average_buffers(self):
         """BatchNorm running statistics are fed by each rank's own minibatches: average them."""
         world = self._world()
-        if world == 1:
+        if not self._collectives_on():
             return
         import torch.distributed as dist
 

@@ -24,7 +24,7 @@ import numpy as np
 import torch
 
 from . import dist as qdist
-from .engine import BoardGroups
+from .engine import REFERENCE_MAX_DEPTH, BoardGroups
 from .mcts import MCTSPlayer
 from .policy_value_net import PolicyValueNet
 from .quoridor import Quoridor
@@ -61,6 +61,12 @@ class TrainPipeline(object):
         self.nn_dtype = nn_dtype
         self.use_graph = use_graph
         self.n_groups = n_groups  # board groups on separate HIP streams (engine.BoardGroups)
+        self.async_loop = True        # self-play through the asynchronous loop (False: the lock-step engine, one ply of every board per harvest)
+        self.rounds_per_harvest = 64  # rounds of the loop between two harvests (+ all-gathers)
+        self.budget_us = 1000         # wall-clock budget of a k_advance launch
+        # a game whose search descends deeper than this is dropped (counted in engine stats): the reference's recursive
+        # backup raises RecursionError there (mcts.py:55-62, Python's recursion limit); 0 = play on
+        self.max_depth = REFERENCE_MAX_DEPTH
         self.episode_len = 0
         self._engine = None
         self.shards = ShardWriter(shard_dir, rank=self._rank(), n_playout=self.n_playout) if shard_dir else None
@@ -91,7 +97,7 @@ class TrainPipeline(object):
                 self.data_buffer = ReplayBuffer(self.buffer_size, net.device)  # buffer_size was changed after __init__, like the other knobs
             self._engine = BoardGroups(self.n_boards, self.n_groups, lambda: net.evaluator(self.bn_mode, self.nn_dtype),
                                        seed=qdist.shard_seed(self.seed, self._rank()), device=net.device,
-                                       n_playout=self.n_playout, c_puct=self.c_puct, temp=self.temp, is_selfplay=1)
+                                       n_playout=self.n_playout, c_puct=self.c_puct, temp=self.temp, is_selfplay=1, max_depth=self.max_depth)
             if self.use_graph and self.n_groups == 1:
                 with torch.cuda.stream(self._engine.streams[0]):
                     self._engine.engines[0].capture_steps(self._engine.evaluators[0], 1, warmup=2)
@@ -124,8 +130,14 @@ class TrainPipeline(object):
         eng = self.engine()
         eng.join_main()  # self-play streams start after whatever updated the weights
         got = 0
+        # the asynchronous loop (boards on their own clocks, leaf-evaluation memo: engine.SelfPlayEngine.selfplay_round)
+        # whenever the evaluator is the HIP evaluation it can run on its miss list; the same games either way
+        use_async = self.async_loop and all(getattr(ev, "engine_route_ok", lambda: False)() for ev in eng.evaluators)
         while got < n_games:
-            eng.play_ply()
+            if use_async:
+                eng.run_rounds(self.rounds_per_harvest, max_playouts=4096, budget_us=self.budget_us)
+            else:
+                eng.play_ply()
             tbs = eng.harvest()
             for tb in tbs:
                 last = int(tb.game.max().item())

@@ -10,35 +10,42 @@
 Workload (config.workload): BASELINE.json configs[3] per GPU = 4096 concurrent boards,
 n_playout=400, 9x9, reference defaults (10 walls, c_puct=5, temp=1, Dirichlet 0.3/0.25),
 random-init policy_value_net evaluated in fp32 with the reference's per-leaf BatchNorm
-statistics; weak scaling (4096 boards on every rank), finished tuples all-gathered every ply.
+statistics; weak scaling (4096 boards on every rank), finished tuples all-gathered every step.
 
-A STEP is one ply of every board: 400 playout steps (select -> actions()+state() -> net ->
-expand/backup on the whole 4096-leaf batch) + finish_move + harvest (+ all-gather).  Nothing
-inside a step is skipped or cached.
+DEFAULT ROUTE (--mode async): the asynchronous self-play loop (qz_selfplay_*, include/qz_abi.h).
+Every board runs its 400 playouts per move on its own clock; a leaf whose evaluation is in the
+leaf-evaluation memo (policy_value_fn on a batch of one is a pure function of the 24-byte board)
+is expanded from the memo, every other leaf is evaluated by the network as before, bit for bit
+the same search as the lock-step engine (tests/test_gpu_async.py).  A STEP is --rounds-per-step
+(256) rounds, a round = one pass of the hot path over all boards: k_moves (moves of the boards
+that finished their playouts), k_advance (playouts until every board needs the network),
+Quoridor.actions() + the network on the leaves the memo does not know, memo insert.  Then the
+finished games are harvested (+ all-gathered).  Nothing is skipped: every one of the 400
+playouts of every move descends, expands and backs up exactly as the reference does, every leaf
+gets the reference's evaluation -- from the network the first time, from the memo afterwards.
+--mode lockstep is round 2's route (every leaf through the network), kept for A/B.
 
-games/sec needs finished games, and a reference-faithful 400-playout game lasts thousands of
-plies (hours of wall clock per board), so the boards are first DESYNCHRONISED (untimed): they
-play `--desync-plies` plies with `--desync-playouts` playouts per move so that the population
-is spread over all game phases (continuous refill).
-  value                     = games that finished inside the K timed steps / their wall time
-                              (a small Poisson count on a population that is not yet stationary)
-  games_per_s_steady_state  = plies/s of the timed region / mean length of 400-playout games,
-                              the length distribution being the one measured by the long run
-                              under profiles/ (benchmarks/game_length.py), with its sample size
-                              and a 95 % interval -- the number a long job converges to
-  plies_per_s, playouts_per_s are length-independent and are what GPU and CPU are compared on.
-Game lengths seen here are reported per phase (desync games are 4-playout games, NOT 400-playout games).
+games/sec needs finished games, and a reference-faithful 400-playout game lasts ~20,000 plies
+(the reference backs a won position up with the wrong sign, mcts.py:119-125), so the boards are
+first DESYNCHRONISED (untimed): `--desync-plies` plies at `--desync-playouts` playouts per move
+spread the population over all game phases (continuous refill).
+  value                     = games_per_s_steady_state.value when a length sample of this playout
+                              count is committed under profiles/ (benchmarks/game_length.py), else
+                              the raw count below
+  games_in_timed_region     = games that finished inside the K timed steps (raw count; the population
+                              was desynchronised with short searches and is not yet stationary)
+  games_per_s_steady_state  = what a long job converges to: boards / E[wall time of a game], with the
+                              per-ply cost of the two phases of a game (mover still has walls: almost
+                              every leaf is new and goes to the network; later: almost every leaf is in
+                              the memo) measured in the timed region and the plies per phase from the
+                              committed length sample
+  plies_per_s, playouts_per_s are what GPU and CPU are compared on.
 
-roofline       the rules op of every playout step (qz_mcts_leaf_inputs = Quoridor.actions() +
-               state() of the leaf batch), HIP events around every launch in the timed region on
-               the launch stream; algorithmic bytes = 8,468 B/board (24 B board + 20 B mask +
-               26*81*4 B planes) x boards.  NOTE the default evaluator computes its first layer
-               from the 24-byte boards, so the planes this op writes are not read in this run
-               (they are the reference's state() API output); 34.5 MB per launch also fits the
-               256-MiB Infinity Cache -- `traffic` (PMC, separate rocprofv3 passes) says what
-               reached HBM.
-roofline_tree  k_select and k_expand_backup, same method; bytes from the engine's counters
-               (32-B edge records read by the descents / created by the expansions).
+roofline       the dominant kernel of the route: k_advance (async: every descent, expansion and
+               backup of a round) or the rules op (lockstep), HIP events around every launch in the
+               timed region on the launch stream; algorithmic bytes from the engine's counters.
+roofline_rules the rules op (Quoridor.actions() of the miss list) of every round, same method.
+roofline_nn    the network launches (k_trunk + k_head_fc on the miss list).
 roofline_c3    the rules op on 32,768 mid-game boards (BASELINE configs[2]), timed right after
                the timed region.
 cpu_baseline   the CPU oracle (oracle/, scalar C port of the reference's algorithm, one playout
@@ -342,6 +349,288 @@ def steady_state(plies_per_s, length_file):
     }
 
 
+def steady_state_two_phase(boards_all, open_plies, end_plies, open_board_s, end_board_s, length_file):
+    """Games/s of a stationary population: boards / E[wall time of one game], E = plies of a game in each of its two
+    phases (committed length sample) x board-seconds per ply of that phase (measured in the timed region).  The phases:
+    the root's mover still has walls (131 legal moves, almost every leaf is new: one network round trip per playout)
+    and afterwards (a few thousand positions revisited for the rest of the game: the memo answers).  plies/s alone
+    would weight the phases by the timed region's population, not by a game's."""
+    d = _load_json(length_file or "")
+    if not d or not d.get("mean_plies_per_game") or not d.get("mean_open_plies_per_game") or open_plies <= 0 or end_plies <= 0:
+        return None
+    L, Lo = float(d["mean_plies_per_game"]), float(d["mean_open_plies_per_game"])
+    c_open, c_end = open_board_s / open_plies, end_board_s / end_plies
+    dur = Lo * c_open + (L - Lo) * c_end
+    lo, hi = (d.get("mean_ci95") or [None, None])[:2]
+
+    def rate(length):
+        return boards_all / (Lo * c_open + (length - Lo) * c_end)
+
+    return {
+        "value": boards_all / dur, "unit": "games/s", "estimator": "boards / (open plies x board-seconds per open ply + late plies x board-seconds per late ply)",
+        "mean_plies_per_game": L, "mean_open_plies_per_game": Lo, "board_seconds_per_open_ply": c_open, "board_seconds_per_late_ply": c_end,
+        "seconds_per_game_per_board": dur, "open_phase_share_of_a_game": Lo * c_open / dur,
+        "ci95": [rate(hi), rate(lo)] if lo and hi else None,
+        "n_games_in_length_sample": d.get("games_finished"), "n_games_censored": d.get("games_censored"),
+        "length_estimator": d.get("estimator"), "length_source": os.path.relpath(length_file, ROOT),
+        "upper_bound": rate(float(d["restricted_mean"])) if d.get("restricted_mean") else None,
+        "restricted_mean_plies": d.get("restricted_mean"), "observation_window_plies": d.get("T"), "survival_at_window": d.get("survival_at_T"),
+    }
+
+
+def run_async(args, eng, net, rank, local, world, dev, qdist):
+    """The default route: the asynchronous self-play loop (see the module docstring)."""
+    import ctypes as C
+
+    from alphazero_quoridor_amd import _cabi
+
+    is_dist = world > 1
+    B, G = args.boards, args.groups
+    gb = B // G
+    R = args.rounds_per_step
+    kw = dict(max_playouts=args.max_playouts, budget_us=args.budget_us)
+
+    def barrier():
+        if is_dist:
+            torch.distributed.barrier()
+        torch.cuda.synchronize(dev)
+
+    lengths = {"desync": [], "warmup": [], "timed": []}
+    phase = ["desync"]
+
+    def end_of_step():
+        """harvest every group's finished games (+ the path's only exchange: finished tuples -> every rank's buffer)"""
+        tbs = eng.harvest()
+        n_games = 0
+        for tb in tbs:
+            n_games += tb.n_games
+            gid = tb.game.cpu().numpy()
+            assert gid.size and 0 <= int(gid.min()) and int(gid.max()) < tb.n_games, "corrupt game ids in a harvest"
+            lengths[phase[0]].extend(np.bincount(gid, minlength=tb.n_games).tolist())
+        if is_dist:
+            eng.synchronize()
+            bufs = [qdist.pack_tuples(tb.boards.hbits, tb.boards.vbits, tb.boards.meta, tb.pi, tb.z) for tb in tbs]
+            bufs.append(torch.zeros((0, qdist.TUPLE_BYTES), dtype=torch.uint8, device=dev))
+            qdist.allgather_tuples(torch.cat(bufs))
+        return n_games
+
+    # ---- desynchronise the games (untimed): short searches spread the boards over all game phases
+    t0 = time.time()
+    if args.desync_plies > 0:
+        eng.set_playouts(args.desync_playouts)
+        # a ply of a board costs at most desync_playouts + 1 rounds (every leaf new), fewer once the memo answers
+        for _ in range(0, args.desync_plies * (args.desync_playouts + 1), 64):
+            eng.run_rounds(64, **kw)
+            end_of_step()
+        eng.set_playouts(args.playouts)
+    desync_s = time.time() - t0
+    if args.graph_rounds:
+        eng.capture_rounds(rounds=args.graph_rounds, **kw)
+
+    # ---- warmup steps at the full playout count (untimed)
+    phase[0] = "warmup"
+    for _ in range(args.warmup):
+        eng.run_rounds(R, **kw)
+        end_of_step()
+
+    # ---- timed region.  Every `ev_every`-th round of group 0 is issued as its four pieces with HIP events around them
+    phase[0] = "timed"
+    eng0, ev0, st0_stream = eng.engines[0], eng.evaluators[0], eng.streams[0]
+    L = _cabi.load()
+    ev_every = max(1, args.event_every)
+    names = ("advance", "rules", "nn", "tail")
+    evs = []
+
+    def ev_pair():
+        return (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+
+    def timed_round():
+        """one round of group 0 through the split entry points, each piece bracketed by events on the launch stream"""
+        with torch.cuda.stream(st0_stream):
+            eng0._memo_guard(ev0)
+            s = eng0._s()
+            pairs = [ev_pair() for _ in names]
+            w = ev0.nn_weights()
+            for (a, b), call in zip(pairs, (lambda: L.qz_selfplay_advance(eng0.h, args.max_playouts, args.budget_us, 1, s),
+                                            lambda: L.qz_selfplay_leaf_rules(eng0.h, s),
+                                            lambda: L.qz_selfplay_evaluate(eng0.h, C.byref(w), s),
+                                            lambda: L.qz_selfplay_round_tail(eng0.h, s))):
+                a.record()
+                _cabi.check(call())
+                b.record()
+            evs.append(pairs)
+
+    sampler = ClockSampler(local) if rank == 0 else None
+    st0 = eng.stats()
+    barrier()
+    if sampler:
+        sampler.start()
+    t0 = time.perf_counter()
+    games = 0
+    step_ms = []
+    for _ in range(args.steps):
+        ts = time.perf_counter()
+        done = 0
+        while done < R:
+            if args.graph_rounds == 0 and ev_every <= R:
+                timed_round()                      # group 0, one round, with events
+                for g in range(1, G):              # the other groups' matching round
+                    with torch.cuda.stream(eng.streams[g]):
+                        eng.engines[g].run_rounds(eng.evaluators[g], 1, **kw)
+                done += 1
+            n = min(ev_every - 1 if args.graph_rounds == 0 else R - done, R - done)
+            if n > 0:
+                eng.run_rounds(n, **kw)
+                done += n
+        games += end_of_step()  # harvest synchronises with the device (qz_harvest_counts), so this is the step's wall time
+        step_ms.append((time.perf_counter() - ts) * 1e3)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if sampler:
+        sampler.stop()
+    st1 = eng.stats()
+    d = {k: st1[k] - st0[k] for k in st1}
+
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    tot = torch.tensor([games, d["plies_played"], d["playouts"], d["leaf_terminal"], d["nn_evals"], d["memo_hits"], d["open_plies"], d["open_rounds"]],
+                       dtype=torch.float64, device=dev)
+    if is_dist:
+        torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
+        torch.distributed.all_reduce(tot, op=torch.distributed.ReduceOp.SUM)
+    elapsed = float(el.item())
+    games_all, plies_all, playouts_all, term_all, evals_all, hits_all, open_plies_all, open_rounds_all = (float(x) for x in tot.tolist())
+    if rank != 0:
+        return
+    rounds = args.steps * R
+    round_s = elapsed / rounds
+    # board-seconds per phase: a board is in the open phase in the launches k_advance counted (root's mover has walls)
+    open_board_s = open_rounds_all * round_s
+    end_board_s = max(B * world * rounds - open_rounds_all, 0.0) * round_s
+    length_file = args.length_file or _latest_profile("game_length_%dplayouts.json" % args.playouts)
+    if args.fix_terminal_sign:
+        length_file = args.length_file  # the committed sample is for the reference-faithful sign
+    ss = steady_state_two_phase(B * world, open_plies_all, plies_all - open_plies_all, open_board_s, end_board_s, length_file)
+    ss_simple = steady_state(plies_all / elapsed, length_file)
+
+    def avg_us(i):
+        return sum(p[i][0].elapsed_time(p[i][1]) for p in evs) / max(len(evs), 1) * 1e3
+
+    adv_us, rules_us, nn_us, tail_us = (avg_us(i) for i in range(4)) if evs else (None,) * 4
+    launches = rounds * G * world
+    per_launch = {k: d[k] / (rounds * G) for k in ("edges_scanned", "edges_expanded", "descent_levels", "playouts", "memo_hits", "nn_evals")}
+    # k_advance's algorithmic bytes: every level of a descent reads the node's edge records (32 B each) and its 12-byte
+    # record entry, the backup rewrites 24 B per level, a new leaf probes one 512-byte memo bucket and its expansion
+    # writes 32 B per legal move
+    adv_bytes = (per_launch["edges_scanned"] * 32 + per_launch["descent_levels"] * (12 + 24) + (per_launch["memo_hits"] + per_launch["nn_evals"]) * 512
+                 + per_launch["edges_expanded"] * 32)
+    t_adv = _load_json(_latest_profile("pmc_traffic_advance.json") or "")
+
+    def line(kernel, us, nbytes, note, traffic=None, src=None):
+        if us is None:
+            return None
+        gbs = nbytes / (us * 1e-6) / 1e9
+        return {"kernel": kernel, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_source": src, "avg_launch_us": us, "launches_timed": len(evs), "algorithmic_bytes_per_launch": nbytes, "note": note}
+
+    def len_stats(v):
+        return {"n": len(v), "mean": float(np.mean(v)) if v else None, "median": float(np.median(v)) if v else None}
+
+    miss_per_round = evals_all / max(rounds * G * world, 1)
+    conv_flops = 2.0 * 81 * 9 * (10 * 64 * 64 + 64 * 6 + 26 * 64) + 2.0 * (324 * 128 + 128 + 162 * 140)
+    out = {
+        "metric": "self-play games/sec (9x9, n_playout=%d)" % args.playouts,
+        "value": ss["value"] if ss else games_all / elapsed,
+        "unit": "games/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u64 bitboards + f64 PUCT (rules/tree kernels); %s policy-value net" % args.nn_dtype,
+        "data": "synthetic (random-init policy_value_net, seed %d; self-generated games)" % args.seed,
+        "config": {
+            "workload": "%s: %d concurrent boards/GPU, n_playout=%d, 9x9, 10 walls/player, c_puct=5, temp=1.0, asynchronous self-play loop with "
+                        "leaf-evaluation memo, finished tuples all-gathered every step"
+                        % ("BASELINE configs[2] as an engine run" if B == 32768 else ("BASELINE configs[1]" if args.playouts == 100 else "BASELINE configs[3] per GPU"),
+                           B, args.playouts),
+            "mode": "async", "boards_per_gpu": B, "board_groups": G, "fix_terminal_sign": bool(args.fix_terminal_sign), "n_playout": args.playouts,
+            "bn_mode": args.bn, "nn_dtype": args.nn_dtype,
+            "step": "%d rounds; a round = k_moves + k_advance (every board: playouts until it needs the network, %d us budget) + actions() and "
+                    "network on the leaves the memo does not know + memo insert" % (R, args.budget_us),
+            "max_depth": args.max_depth, "rounds_per_step": R, "budget_us": args.budget_us, "max_playouts_per_round": args.max_playouts, "graph_rounds": args.graph_rounds,
+            "desync": "%d untimed plies at %d playouts/move (%.0fs, %d games finished)" % (args.desync_plies, args.desync_playouts, desync_s, len(lengths["desync"])),
+        },
+        "value_is": ("games_per_s_steady_state.value: boards / E[wall time of a game] (plies per phase from %s, cost per ply of each phase measured in "
+                     "the timed region)" % os.path.relpath(length_file, ROOT)) if ss else
+                    "games finished inside the timed region / wall time (no committed length sample with a phase split for this playout count)",
+        "games_in_timed_region": games_all,
+        "games_in_timed_region_per_s": games_all / elapsed,
+        "games_per_s_steady_state": ss,
+        "games_per_s_plies_over_mean_length": ss_simple,
+        "plies_per_s": plies_all / elapsed,
+        "playouts_per_s": playouts_all / elapsed,
+        "nn_evaluations_per_s": evals_all / elapsed,
+        "memo_hit_rate": hits_all / max(playouts_all, 1.0),
+        "leaf_evals_per_s": evals_all / elapsed,
+        "terminal_leaf_frac": term_all / max(playouts_all, 1.0),
+        "open_phase": {"plies": open_plies_all, "share_of_board_time": open_rounds_all / max(B * world * rounds, 1), "note": "root's mover still has walls"},
+        "game_lengths_seen": {"timed_region_%d_playouts" % args.playouts: len_stats(lengths["timed"] + lengths["warmup"]),
+                              "desync_phase_%d_playouts" % args.desync_playouts: len_stats(lengths["desync"]),
+                              "note": "games finishing in the timed region started in the desync phase; neither is the length of a %d-playout game" % args.playouts},
+        "mean_descent_depth": d["descent_levels"] / max(d["playouts"], 1),
+        "rounds": rounds, "ms_per_round": round_s * 1e3,
+        "ms_per_step_series": [round(x, 1) for x in step_ms],
+        "roofline": line("k_moves + k_advance (one wavefront per board: moves of the boards that finished their playouts, then descents (recorded descents "
+                         "replayed 64 levels per round trip), memo probes, expansions and backups until the board needs the network or the budget is used)",
+                         adv_us, adv_bytes,
+                         "dependent-load latency, not bandwidth: a playout is a chain of ~10 memory round trips (record -> edge blocks -> ... -> memo "
+                         "bucket -> backup) of a single wavefront, four wavefronts per SIMD; %.0f playouts per launch, mean depth %.1f.  The launch lasts "
+                         "its time budget + the slowest board (a subtree compaction); see DESIGN" % (per_launch["playouts"], d["descent_levels"] / max(d["playouts"], 1)),
+                         traffic=(t_adv or {}).get("traffic_bytes_per_launch"), src=("profiles: " + os.path.relpath(_latest_profile("pmc_traffic_advance.json"), ROOT)) if t_adv else None),
+        "roofline_rules": line("k_wave_rules on the miss list (Quoridor.actions() of the leaves the memo does not know; legal sets only)", rules_us, miss_per_round * 44,
+                               "%.0f leaves per launch: a launch lasts as long as one board's dependent chain" % miss_per_round),
+        "roofline_nn": None if nn_us is None else {
+            "kernel": "k_trunk<true> + k_head_fc on the miss list (first layer from the packed boards, ten conv3x3 64->64 layers as implicit GEMMs on "
+                      "v_mfma_f32_32x32x16_f16 with split fp16 operands, per-leaf normalisation, heads)",
+            "bound": "mfma", "achieved": conv_flops * miss_per_round / (nn_us * 1e-6) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
+            "frac": conv_flops * miss_per_round / (nn_us * 1e-6) / 1e12 / 2500.0, "traffic": None, "avg_launch_us": nn_us, "launches_timed": len(evs),
+            "leaves_per_launch": miss_per_round,
+            "note": "one leaf per 2-wave workgroup: with %.0f leaves per launch the launch lasts as long as ONE leaf's eleven layers (latency), the "
+                    "chip is mostly idle; at 4,096 leaves per launch (lock-step mode, the opening phase) the same kernel reaches 0.135" % miss_per_round},
+        "round_tail_us": tail_us,
+        "games_dropped_in_timed_region": {"total": d["games_aborted"], "depth_over_%d_levels" % args.max_depth: d["aborted_depth"], "no_legal_move": d["aborted_no_move"],
+                                          "note": "the reference cannot finish these games either: a path longer than 992 levels overflows its recursive backup "
+                                                  "(RecursionError, mcts.py:55-62), a root without a legal move crashes start_self_play (mcts.py:195-196)"},
+        "engine_stats": {kk: st1[kk] for kk in ("node_overflow", "games_aborted", "aborted_no_move", "aborted_max_plies", "aborted_pool", "aborted_depth", "nonfinite_values",
+                                                "runaway_descents", "arena_bytes", "max_nodes", "max_edges", "max_depth", "tree_pages_total", "tree_pages_peak",
+                                                "traj_pages_total", "traj_pages_peak", "memo_inserts", "memo_locked")},
+        "clocks": sampler.summary() if sampler else None,
+    }
+    if st1["games_aborted"]:
+        sys.stderr.write("bench.py: NOTE %d games were dropped (depth > %d: %d, no legal move: %d, max_plies %d, pool %d)\n"
+                         % (st1["games_aborted"], args.max_depth, st1["aborted_depth"], st1["aborted_no_move"], st1["aborted_max_plies"], st1["aborted_pool"]))
+    assert st1["node_overflow"] == 0 and st1["runaway_descents"] == 0, "tree storage overflowed / corrupted during the run"
+    if args.clock_log and sampler:
+        with open(args.clock_log, "w") as f:
+            json.dump({"step_ms": step_ms, "samples": sampler.samples}, f)
+    if world == 1 and not args.no_c3:
+        out["roofline_c3"] = c3_microbench(dev)
+    if not args.no_cpu_baseline and world == 1:
+        eng.close()
+        torch.cuda.empty_cache()
+        src = ss or ss_simple
+        if src:
+            L_cpu, L_src = src["mean_plies_per_game"], src["length_source"]
+        else:
+            seen = lengths["timed"] + lengths["warmup"] + lengths["desync"]
+            L_cpu = float(np.mean(seen)) if seen else None
+            L_src = "NO length sample for n_playout=%d: mean length of the %d games finished in this run (mostly desync games)" % (args.playouts, len(seen))
+        out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, args.playouts, L_cpu, L_src)
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -351,6 +640,17 @@ def main():
     ap.add_argument("--playouts", type=int, default=400)
     ap.add_argument("--groups", type=int, default=1,
                     help="split the boards of a GPU into this many independent groups on their own HIP streams")
+    ap.add_argument("--mode", default="async", choices=["async", "lockstep"],
+                    help="async (default): the asynchronous self-play loop with the leaf-evaluation memo; lockstep: round 2's route, every leaf through the network")
+    ap.add_argument("--rounds-per-step", type=int, default=256, help="async: rounds of the loop per step")
+    ap.add_argument("--budget-us", type=int, default=1000, help="async: wall-clock budget of a k_advance launch")
+    ap.add_argument("--max-playouts", type=int, default=4096, help="async: playouts a board may start per round")
+    ap.add_argument("--graph-rounds", type=int, default=0, help="async: capture this many (even) rounds per HIP graph (0 = eager launches, per-kernel events)")
+    ap.add_argument("--event-every", type=int, default=4, help="async: every n-th round of group 0 is issued in pieces with HIP events around them")
+    ap.add_argument("--max-depth", type=int, default=992,
+                    help="drop a game whose playout descends more than this many levels (0 = never).  992 = where the reference's recursive backup "
+                         "(mcts.py:55-62) overflows Python's recursion limit under `python train.py` and ends the run with a RecursionError")
+    ap.add_argument("--no-memo", action="store_true", help="async A/B: no leaf-evaluation memo (every leaf goes to the network)")
     ap.add_argument("--bn", default="per_leaf", choices=["per_leaf", "eval", "batch"])
     ap.add_argument("--nn-dtype", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--channels-last", type=int, default=1)
@@ -406,7 +706,14 @@ def main():
     eng = BoardGroups(args.boards, args.groups, make_ev,
                       seed=qdist.shard_seed(args.seed, rank), device=dev,
                       n_playout=args.playouts, c_puct=5, temp=1.0, is_selfplay=1, fix_terminal_sign=args.fix_terminal_sign,
-                      select_opts=args.select_opts)
+                      select_opts=args.select_opts, memo=not args.no_memo, max_depth=args.max_depth)
+    if args.mode == "async":
+        assert args.nn_dtype == "fp32" and args.bn == "per_leaf" and not args.library_trunk, "the asynchronous loop runs the HIP evaluation (fp32, per-leaf BN)"
+        run_async(args, eng, net, rank, local, world, dev, qdist)
+        eng.close()
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
     if args.rules_variant:
         from alphazero_quoridor_amd import rules as qrules
 

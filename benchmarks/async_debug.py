@@ -10,23 +10,54 @@ from alphazero_quoridor_amd.policy_value_net import PolicyValueNet
 B = int(os.environ.get("BOARDS", 192)); NP = int(os.environ.get("PLAYOUTS", 24)); MP = int(os.environ.get("MAXP", 32))
 FIX = int(os.environ.get("FIX", 1)); ITERS = int(os.environ.get("ITERS", 200)); R = int(os.environ.get("ROUNDS", 8)); BUD = int(os.environ.get("BUDGET", 0))
 EVERY = int(os.environ.get("EVERY", max(1, ITERS // 20))); GRAPH = int(os.environ.get("GRAPH", 0)); SEL = int(os.environ.get("SELECT_OPTS", 0))
-dev = torch.device("cuda:0"); torch.manual_seed(0)
+dev = torch.device("cuda:0"); torch.manual_seed(int(os.environ.get("SEED", 0)))
 ev = PolicyValueNet(use_gpu=True).evaluator("per_leaf")
-eng = SelfPlayEngine(B, n_playout=NP, seed=77, device=dev, fix_terminal_sign=bool(FIX), select_opts=SEL)
+G = int(os.environ.get("NGROUPS", 1))  # independent engines of B / G boards, each on its own HIP stream (their launches overlap)
+engs = [SelfPlayEngine(B // G, n_playout=NP, seed=77 + 1000 * g, device=dev, fix_terminal_sign=bool(FIX), select_opts=SEL, max_depth=int(os.environ.get("MAXD", 0))) for g in range(G)]
+streams = [torch.cuda.Stream(device=dev) for _ in range(G)]
 SKIP = int(os.environ.get("SKIP_ROUNDS", 0))  # rounds played before the statistics start (from the opening to the late-game regime)
+
+
+def run(n):
+    for k in range(0, n, 8):  # interleave the groups' launches
+        for g in range(G):
+            with torch.cuda.stream(streams[g]):
+                engs[g].run_rounds(ev, min(8, n - k), max_playouts=MP, budget_us=BUD)
+
+
+def harvest():
+    out = []
+    for g in range(G):
+        with torch.cuda.stream(streams[g]):
+            tb = engs[g].harvest()
+            if tb is not None:
+                out.append((tb.n_games, torch.bincount(tb.game.long(), minlength=tb.n_games).tolist()))  # (.tolist() synchronises this stream)
+    return out
+
+
+def stats():
+    tot = {}
+    for g in range(G):
+        with torch.cuda.stream(streams[g]):
+            for k, v in engs[g].stats().items():
+                tot[k] = max(tot.get(k, 0), v) if k in ("max_depth", "rounds", "max_nodes", "max_edges") else tot.get(k, 0) + v
+    return tot
+
+
 for _ in range(SKIP // 64):
-    eng.run_rounds(ev, 64, max_playouts=MP, budget_us=BUD); eng.harvest()
+    run(64); harvest()
 if GRAPH:
-    eng.capture_rounds(ev, rounds=R, max_playouts=MP, budget_us=BUD)
-t0 = time.time(); games = 0; prev = eng.stats(); tp = t0; glen = []
+    for g in range(G):
+        with torch.cuda.stream(streams[g]):
+            engs[g].capture_rounds(ev, rounds=R, max_playouts=MP, budget_us=BUD)
+t0 = time.time(); games = 0; prev = stats(); tp = t0; glen = []
 for i in range(ITERS):
-    eng.run_rounds(ev, R, max_playouts=MP, budget_us=BUD)
-    tb = eng.harvest()
-    if tb is not None:
-        games += tb.n_games
-        glen += torch.bincount(tb.game.long(), minlength=tb.n_games).tolist()
+    run(R)
+    for n_g, lens in harvest():
+        games += n_g
+        glen += lens
     if (i + 1) % EVERY == 0:
-        st = eng.stats(); now = time.time(); dt = now - tp
+        st = stats(); now = time.time(); dt = now - tp
         d = {k: st[k] - prev[k] for k in st}
         po = max(d["playouts"], 1)
         print(json.dumps({"t": round(now - t0, 2), "rounds": st["rounds"], "ms_per_round": round(1e3 * dt / max(d["rounds"], 1), 3),
@@ -34,7 +65,7 @@ for i in range(ITERS):
                           "mean_depth": round(d["descent_levels"] / po, 1), "edges_scanned_per_playout": round(d["edges_scanned"] / po, 1),
                           "hit_rate": round(d["memo_hits"] / po, 4), "terminal_rate": round(d["leaf_terminal"] / po, 4),
                           "evals_per_round": round(d["nn_evals"] / max(d["rounds"], 1)), "waiting": st["waiting_boards"],
-                          "open_plies": d["open_plies"], "open_board_rounds_frac": round(d["open_rounds"] / max(d["rounds"] * B, 1), 4),
+                          "open_plies": d["open_plies"], "open_board_rounds_frac": round(d["open_rounds"] / max(d["rounds"] * (B // G), 1), 4),
                           "max_depth": st["max_depth"], "deep_replayed_frac": round(d["deep_levels_replayed"] / max(d["deep_levels"], 1), 3),
                           "tree_pages_peak": st["tree_pages_peak"], "tree_pages_total": st["tree_pages_total"], "tree_pages_in_use": st["tree_pages_in_use"],
                           "traj_pages_peak": st["traj_pages_peak"], "memo_inserts": d["memo_inserts"], "aborted": st["games_aborted"], "ovf": st["node_overflow"],

@@ -9,7 +9,7 @@ time T plus S(T)/lambda, lambda = the hazard measured over [T/2, T] (finish even
 risk) -- an exponential tail beyond the observation window; the per-bin hazards are printed so
 the assumption can be checked.  95 % interval: bootstrap over games.
 
-    python benchmarks/game_length.py --boards 512 --playouts 400 --seconds 2400 --out profiles/round2/game_length_400playouts.json
+    python benchmarks/game_length.py --boards 512 --playouts 400 --seconds 900 --out profiles/round3/game_length_400playouts.json
 """
 import argparse
 import json
@@ -60,7 +60,8 @@ def main():
     ap.add_argument("--max-plies", type=int, default=1000000)
     ap.add_argument("--bn", default="per_leaf")
     ap.add_argument("--fix-sign", type=int, default=0)
-    ap.add_argument("--graph", type=int, default=8, help="playout steps per captured HIP graph (0 = eager)")
+    ap.add_argument("--budget-us", type=int, default=1000)
+    ap.add_argument("--max-depth", type=int, default=992, help="drop a game whose search descends deeper (the reference's RecursionError); 0 = never")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -69,31 +70,38 @@ def main():
     net = PolicyValueNet(use_gpu=True)
     ev = net.evaluator(args.bn)
     B = args.boards
-    eng = SelfPlayEngine(B, n_playout=args.playouts, seed=5, device=dev, fix_terminal_sign=bool(args.fix_sign))
-    if args.graph:
-        eng.capture_steps(ev, steps_per_graph=args.graph, warmup=2)
-        eng.reset()
-    age = torch.zeros(B, dtype=torch.int64, device=dev)     # plies of the board's current game
-    finished = []
+    eng = SelfPlayEngine(B, n_playout=args.playouts, seed=5, device=dev, fix_terminal_sign=bool(args.fix_sign), max_depth=args.max_depth)
+    # the asynchronous self-play loop (bit-identical games to the lock-step engine, tests/test_gpu_async.py): boards
+    # restart at once when their game is harvested.  Per finished game: its length and the plies of its OPEN phase (the
+    # mover still has walls: the part of a game whose leaves are almost all new to the memo)
+    finished, finished_open = [], []
     t0 = time.time()
-    ply = 0
-    while ply < args.max_plies and time.time() - t0 < args.seconds:
-        eng.run_playouts(ev)
-        eng.finish_move()
-        ply += 1
-        age += 1
-        bd = eng.get_boards()
-        p1 = ((bd.meta & 0xFF) ^ 0x80) - 0x80            # int8 fields of the meta word
-        p2 = (((bd.meta >> 8) & 0xFF) ^ 0x80) - 0x80
-        done = (p1 >= 72) | (p2 <= 8)                      # has_a_winner (quoridor.py:193-202)
-        if bool(done.any()):
-            finished.extend(age[done].cpu().tolist())
-            age[done] = 0
+    rounds = 0
+    stream = torch.cuda.Stream(device=dev)
+    t_print, p_print = t0, 0
+    with torch.cuda.stream(stream):
+        while time.time() - t0 < args.seconds:
+            eng.run_rounds(ev, 64, max_playouts=4096, budget_us=args.budget_us)
+            rounds += 64
             tb = eng.harvest()
-            assert tb is not None and tb.n_games == int(done.sum())
-    seconds = time.time() - t0
-    st = eng.stats()
-    censored = age[age > 0].cpu().tolist()
+            if tb is not None:
+                gid = tb.game.long()
+                meta = tb.boards.meta
+                cur = (meta >> 32) & 0xFF
+                walls = torch.where(cur == 1, (meta >> 16) & 0xFF, (meta >> 24) & 0xFF)
+                finished.extend(torch.bincount(gid, minlength=tb.n_games).tolist())
+                finished_open.extend(torch.bincount(gid, weights=(walls > 0).double(), minlength=tb.n_games).tolist())
+            if time.time() - t_print > 60:
+                st = eng.stats()
+                sys.stderr.write("t %.0fs rounds %d plies/s %.0f games %d mean depth %.1f max depth %d deep descents %d (levels %d) max edges %d pages in use %d\n"
+                                 % (time.time() - t0, rounds, (st["plies_played"] - p_print) / (time.time() - t_print), len(finished),
+                                    st["descent_levels"] / max(st["playouts"], 1), st["max_depth"], st["deep_descents"], st["deep_levels"], st["max_edges"], st["tree_pages_in_use"]))
+                t_print, p_print = time.time(), st["plies_played"]
+        seconds = time.time() - t0
+        st = eng.stats()
+        ply = int(st["plies_played"] // B)
+        age = eng.get_plies().long()
+        censored = age[age > 0].cpu().tolist()
     times = np.array(finished + censored, dtype=np.float64)
     events = np.array([True] * len(finished) + [False] * len(censored))
     mean, rmst, ST, lam, T = km_mean(times, events)
@@ -112,17 +120,20 @@ def main():
         n_ev = int(np.sum(events & (times > a) & (times <= b)))
         hazards.append({"plies": [float(a), float(b)], "events": n_ev, "plies_at_risk": exposure, "hazard_per_ply": n_ev / exposure if exposure else None})
     out = {
-        "boards": B, "n_playout": args.playouts, "fix_terminal_sign": bool(args.fix_sign), "plies_run": ply, "seconds": seconds,
+        "boards": B, "n_playout": args.playouts, "max_depth": args.max_depth, "fix_terminal_sign": bool(args.fix_sign), "plies_run": ply, "seconds": seconds,
         "plies_per_s": st["plies_played"] / seconds,
         "games_finished": len(finished), "games_censored": len(censored),
         "finished_length_percentiles_10_50_90": [float(x) for x in np.percentile(finished, [10, 50, 90])] if finished else None,
         "finished_mean": float(np.mean(finished)) if finished else None,
+        "mean_open_plies_per_game": float(np.mean(finished_open)) if finished_open else None,
+        "open_plies_percentiles_10_50_90": [float(x) for x in np.percentile(finished_open, [10, 50, 90])] if finished_open else None,
+        "engine": "asynchronous self-play loop (qz_selfplay_*), %d rounds" % rounds,
         "estimator": "Kaplan-Meier restricted mean up to T = %.0f plies (%.0f) + S(T) / lambda with S(T) = %.3f and the hazard over [T/2, T] "
                      "lambda = %s per ply (exponential tail)" % (T, rmst, ST, ("%.3g" % lam) if lam else "n/a"),
         "mean_plies_per_game": mean, "mean_ci95": ci, "restricted_mean": rmst, "survival_at_T": ST, "tail_hazard_per_ply": lam, "T": T,
         "hazard_by_bin": hazards,
         "stats": {k: st[k] for k in ("games_finished", "plies_played", "playouts", "leaf_terminal", "node_overflow", "games_aborted",
-                                     "aborted_no_move", "aborted_max_plies", "aborted_pool", "tree_pages_peak", "tree_pages_total",
+                                     "aborted_no_move", "aborted_max_plies", "aborted_pool", "aborted_depth", "max_depth", "tree_pages_peak", "tree_pages_total",
                                      "traj_pages_peak", "traj_pages_total", "max_edges")},
     }
     text = json.dumps(out)

@@ -144,6 +144,12 @@ typedef struct {
      * of the tree pool, at most 49,152 (24 pages of 64 KB); < 0 = every move copies, like qz_mcts_finish_move.  With node_cap / edge_cap set every move copies
      * (the caps count live nodes).  Same search either way. */
     int32_t compact_edges;
+    /* Drop a game (qz_stats.aborted_depth) as soon as one of its playouts descends more than this many levels; 0 = never.
+     * The reference backs a playout up by recursion (TreeNode.update_recursive, mcts.py:55-62: one Python frame per node
+     * of the path) and never raises the interpreter's recursion limit of 1,000: under `python train.py` a path longer
+     * than 992 levels ends the whole run with a RecursionError.  992 mirrors that envelope; reference-faithful games can
+     * grow forced lines of tens of thousands of levels (the inverted terminal value makes searches avoid winning). */
+    int32_t max_depth;
 } qz_config;
 
 typedef struct {
@@ -152,7 +158,7 @@ typedef struct {
     int64_t playouts;          /* leaf selections                                      */
     int64_t leaf_terminal;     /* playouts that ended on a terminal leaf               */
     int64_t node_overflow;     /* expansions skipped / subtrees truncated: arena full  */
-    int64_t games_aborted;     /* dropped games: sum of the three aborted_* causes below */
+    int64_t games_aborted;     /* dropped games: sum of the aborted_* causes below */
     int64_t pending_games;     /* finished, not yet harvested                          */
     int64_t pending_plies;
     int64_t arena_bytes;       /* device bytes owned by the engine                     */
@@ -181,6 +187,7 @@ typedef struct {
     int64_t open_rounds;       /* board-launches / plies whose root's mover still had walls (the phase of a game in which  */
     int64_t open_plies;        /* almost every leaf is new; the rest of a game revisits a few thousand boards)             */
     int64_t waiting_boards;    /* boards waiting for the network right now                                */
+    int64_t aborted_depth;     /* games dropped because a descent exceeded qz_config.max_depth (the reference's RecursionError) */
     int64_t runaway_descents;  /* descents cut off because they were deeper than a tree has edges (a cycle = corrupted tree
                                   storage): must be 0; the guard exists so that such a bug cannot hang the GPU   */
 } qz_stats;
@@ -195,8 +202,15 @@ int qz_engine_reset(qz_engine* e, void* stream);
  * reset_trees != 0 also drops every search tree. */
 int qz_engine_set_boards(qz_engine* e, const qz_boards* src, int reset_trees, void* stream);
 int qz_engine_get_boards(qz_engine* e, const qz_boards* dst, void* stream);
+/* plies[n_boards] int32 <- moves played so far in every board's current game (inspection: length statistics of games
+ * that are still running) */
+int qz_engine_get_plies(qz_engine* e, int32_t* plies /*[dev]*/, void* stream);
 /* the `temp` argument of get_move_probs / choose_action (mcts.py:129,172) for later calls */
 int qz_engine_set_temp(qz_engine* e, float temp);
+/* the n_playout argument of MCTSPlayer (mcts.py:159) for later moves of the asynchronous loop (qz_selfplay_*): a board
+ * plays its move once it has done this many playouts on its root.  >= 1.  (The lock-step entry points take their
+ * playout count from the number of calls.) */
+int qz_engine_set_playouts(qz_engine* e, int n_playout);
 /* change the formulation of this engine's leaf rules op (qz_config.rules) for later calls */
 int qz_engine_set_rules_opts(qz_engine* e, const qz_rules_opts* opts);
 

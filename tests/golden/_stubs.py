@@ -126,3 +126,36 @@ def det_fill_state_dict(sd, seed=2024):
             fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else shape[0]
             out[k] = torch.from_numpy((rs.standard_normal(shape) * np.sqrt(2.0 / fan_in)).astype(np.float32))
     return out
+
+
+def trained_like_state_dict(sd, seed=4711):
+    """Weights with the spread a trained net shows, for the network parity fixtures: BatchNorm gammas log-uniform in
+    [0.1, 3] and betas ~ N(0, 0.5), convolution / linear weights whose output channels differ in scale by up to 100x
+    inside every layer (10^U(-1, 1) per channel on top of the He fill), biases ~ N(0, 0.2).  Deterministic in `seed`."""
+    import torch
+
+    out = {}
+    for i, (k, v) in enumerate(sd.items()):
+        rs = np.random.RandomState(seed + i)
+        shape = tuple(v.shape)
+        if k.endswith("num_batches_tracked"):
+            out[k] = torch.zeros((), dtype=torch.long)
+        elif k.endswith("running_mean"):
+            out[k] = torch.from_numpy((0.3 * rs.standard_normal(shape)).astype(np.float32))
+        elif k.endswith("running_var"):
+            out[k] = torch.from_numpy((0.5 + np.abs(rs.standard_normal(shape))).astype(np.float32))
+        elif ".bn" in k or k.startswith("bn"):
+            if k.endswith("weight"):
+                out[k] = torch.from_numpy(np.exp(rs.uniform(np.log(0.1), np.log(3.0), shape)).astype(np.float32))
+            else:
+                out[k] = torch.from_numpy((0.5 * rs.standard_normal(shape)).astype(np.float32))
+        elif k.endswith("bias"):
+            out[k] = torch.from_numpy((0.2 * rs.standard_normal(shape)).astype(np.float32))
+        else:
+            fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else shape[0]
+            w = rs.standard_normal(shape) * np.sqrt(2.0 / fan_in)
+            ch = 10.0 ** rs.uniform(-1.0, 1.0, (shape[0],) + (1,) * (len(shape) - 1))
+            if k.startswith("fc"):
+                ch = ch * 0.12  # (nothing normalises the fully connected layers' outputs: keep tanh / softmax out of saturation)
+            out[k] = torch.from_numpy((w * ch).astype(np.float32))
+    return out

@@ -554,6 +554,68 @@ def gen_net(out_dir):
     print("net: 64-state batch, eval + train-batch + 64 per-leaf outputs")
 
 
+def gen_net_more(out_dir):
+    """F8b: the per-leaf outputs of the reference's policy_value_fn (policy_value_net.py:145-164) on the same 64 states
+    for two more weight sets: `trained_like` (_stubs.trained_like_state_dict: BatchNorm gammas in [0.1, 3], output
+    channels of every layer spread over 100x) and `after_steps` (the det-fill weights after the three optimiser steps
+    of the reference's own train_step on F9's minibatch; the full state_dict is stored, it cannot be regenerated
+    without the reference)."""
+    import torch
+    import warnings
+
+    warnings.filterwarnings("ignore")
+    torch.set_num_threads(4)
+    from policy_value_net import PolicyValueNet
+    from _stubs import trained_like_state_dict
+
+    fx = np.load(os.path.join(out_dir, "net_fixture.npz"))
+    boards = fx["board"]
+    games = [game_from_packed(b) for b in boards]
+
+    def per_leaf(pvn):
+        acts, ps, vs = [], [], []
+        for g in games:
+            ap, val = pvn.policy_value_fn(g)
+            ap = list(ap)
+            a = np.full(140, 255, dtype=np.uint8)
+            p = np.zeros(140, dtype=np.float32)
+            a[: len(ap)] = [x[0] for x in ap]
+            p[: len(ap)] = [x[1] for x in ap]
+            acts.append(a)
+            ps.append(p)
+            vs.append(float(val))
+        return np.stack(acts), np.stack(ps), np.array(vs, dtype=np.float32)
+
+    out = {"board": boards}
+    # (1) trained-like
+    pvn = PolicyValueNet(use_gpu=False)
+    pvn.policy_value_net.load_state_dict(trained_like_state_dict(pvn.policy_value_net.state_dict(), seed=4711))
+    out["trained_like_seed"] = np.array(4711)
+    out["trained_like_acts"], out["trained_like_p"], out["trained_like_v"] = per_leaf(pvn)
+    # (2) after the three optimiser steps of F9 (the reference's own train_step; IndexError after optimizer.step())
+    tf = np.load(os.path.join(out_dir, "train_fixture.npz"))
+    tgames = [game_from_packed(b) for b in tf["board"]]
+    states = np.stack([g.state() for g in tgames])
+    pi, z = tf["pi"].astype(np.float64), tf["z"].astype(np.float64)
+    pvn = PolicyValueNet(use_gpu=False)
+    pvn.policy_value_net.load_state_dict(det_fill_state_dict(pvn.policy_value_net.state_dict(), seed=2024))
+    for lr in tf["lr"]:
+        try:
+            pvn.train_step(list(states), list(pi), list(z), float(lr))
+            raise SystemExit("the reference's train_step returned")
+        except IndexError:
+            pass
+    sd = pvn.policy_value_net.state_dict()
+    for k, ref_sum in zip(tf["keys"], tf["sum"]):  # the same weights F9 recorded
+        assert abs(float(sd[str(k)].double().sum()) - float(ref_sum)) <= 1e-9 * max(1.0, abs(float(ref_sum))), k
+    for k, v in sd.items():
+        out["after_steps_w_" + k.replace(".", "__")] = v.numpy()
+    out["after_steps_acts"], out["after_steps_p"], out["after_steps_v"] = per_leaf(pvn)
+    np.savez_compressed(os.path.join(out_dir, "net_fixture_more.npz"), **out)
+    print("net (more weight sets): trained-like + after three optimiser steps, 64 per-leaf outputs each; |v| range",
+          float(np.abs(out["trained_like_v"]).max()), float(np.abs(out["after_steps_v"]).max()))
+
+
 # --------------------------------------------------------------------------- F9
 def gen_train(out_dir):
     """Three consecutive PolicyValueNet.train_step calls of the REAL reference module on a
@@ -684,7 +746,7 @@ def gen_rollouts(out_dir, procs, per_position=320):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="rules,positions,steps,mcts,episodes,net,train,rollouts")
+    ap.add_argument("--only", default="rules,positions,steps,mcts,episodes,net,train,net_more,rollouts")
     ap.add_argument("--procs", type=int, default=8)
     ap.add_argument("--games", type=int, default=160)
     ap.add_argument("--synthetic", type=int, default=120)
@@ -704,6 +766,8 @@ def main():
         gen_net(HERE)
     if "train" in only:
         gen_train(HERE)
+    if "net_more" in only:
+        gen_net_more(HERE)
     if "rollouts" in only:
         gen_rollouts(HERE, args.procs)
 

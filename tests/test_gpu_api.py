@@ -150,10 +150,11 @@ def test_network_outputs_match_reference_fixture(gpu_device, golden_dir):
 
 
 def test_engine_route_evaluator_matches_reference_fixture_directly(gpu_device, golden_dir):
-    """The evaluator configuration bench.py times -- first layer from the packed boards
-    (qz_nn_input_layer), channels-last MIOpen trunk with the fused per-leaf normalisation, both
-    heads in qz_nn_head -- against the outputs of the REAL reference's policy_value_fn
-    (policy_value_net.py:145-164) on all 64 fixture states: 1e-5 on p and v, no intermediate route."""
+    """The evaluator configuration bench.py times -- the two-launch HIP evaluation from the packed boards
+    (qz_nn_evaluate: first layer from the boards, ten trunk layers and the head convolution on the matrix
+    cores with split fp16 operands, then the fully connected layers) -- against the outputs of the REAL
+    reference's policy_value_fn (policy_value_net.py:145-164) on all 64 fixture states: 1e-5 on p and v, no
+    intermediate route."""
     from alphazero_quoridor_amd.boards import DeviceBoards
 
     TOL = 1e-5
@@ -162,6 +163,7 @@ def test_engine_route_evaluator_matches_reference_fixture_directly(gpu_device, g
     pvn = _fixture_net(gpu_device)
     ev = pvn.evaluator("per_leaf", torch.float32, True)
     assert ev.accepts_leaf_boards and ev.board_input_layer and ev.fused_head and ev.fused_norm
+    assert ev.mfma_trunk and ev.engine_route_ok()
     db = DeviceBoards.from_packed(d["board"], gpu_device)
     worst_p = worst_v = 0.0
     for rep in (1, 64):  # the 64 states once, and inside a 4,096-leaf batch (per-leaf statistics are batch-invariant)
@@ -177,6 +179,45 @@ def test_engine_route_evaluator_matches_reference_fixture_directly(gpu_device, g
             worst_v = max(worst_v, float(abs(v[j] - d["leaf_v"][i])))
     print("engine-route evaluator vs reference policy_value_fn: max |dp| %.3g, max |dv| %.3g" % (worst_p, worst_v))
     assert worst_p < TOL and worst_v < TOL, (worst_p, worst_v)
+
+
+def test_engine_route_evaluator_on_two_more_weight_sets(gpu_device, golden_dir):
+    """one deterministic fill pinned a18-a20 with a 1.7x margin.  Two more weight sets against the REAL
+    reference's policy_value_fn on the same 64 states (tests/golden/gen_golden.py:gen_net_more): `trained_like`
+    (BatchNorm gammas in [0.1, 3], output channels of every layer spread over 100x: small channels push the lo halves
+    of the split operands towards fp16 subnormals) and `after_steps` (the weights after the three optimiser steps of
+    the reference's own train_step).  1e-5 on p and v through qz_nn_evaluate, the worst differences printed."""
+    from _stubs import trained_like_state_dict
+    from alphazero_quoridor_amd.boards import DeviceBoards
+    from alphazero_quoridor_amd.policy_value_net import PolicyValueNet
+
+    TOL = 1e-5
+    d = np.load(golden_dir + "/net_fixture_more.npz")
+    db = DeviceBoards.from_packed(d["board"], gpu_device)
+    for name in ("trained_like", "after_steps"):
+        pvn = PolicyValueNet(use_gpu=True, device=gpu_device)
+        sd = pvn.policy_value_net.state_dict()
+        if name == "trained_like":
+            new = trained_like_state_dict(sd, seed=int(d["trained_like_seed"]))
+        else:
+            new = {k: torch.from_numpy(d["after_steps_w_" + k.replace(".", "__")]) for k in sd}
+        pvn.policy_value_net.load_state_dict(new)
+        ev = pvn.evaluator("per_leaf", torch.float32, True)
+        assert ev.mfma_trunk and ev.engine_route_ok()
+        worst_p = worst_v = 0.0
+        for rep in (1, 16):
+            big = DeviceBoards(64 * rep, gpu_device)
+            big.hbits, big.vbits, big.meta = db.hbits.repeat(rep), db.vbits.repeat(rep), db.meta.repeat(rep)
+            p, v = ev(None, leaf=(big.struct(), 0, big.n))
+            p, v = p.cpu().numpy(), v.cpu().numpy()
+            for j in range(big.n):
+                i = j % 64
+                acts = d[name + "_acts"][i]
+                k = int((acts != 255).sum())
+                worst_p = max(worst_p, float(np.abs(p[j][acts[:k]] - d[name + "_p"][i][:k]).max()))
+                worst_v = max(worst_v, float(abs(v[j] - d[name + "_v"][i])))
+        print("%s weights, engine-route evaluator vs reference policy_value_fn: max |dp| %.3g, max |dv| %.3g" % (name, worst_p, worst_v))
+        assert worst_p < TOL and worst_v < TOL, (name, worst_p, worst_v)
 
 
 def test_config1_4096_boards_100_playouts_real_net_with_insitu_oracle_samples(gpu_device):

@@ -260,3 +260,179 @@ def test_captured_rounds_follow_the_weights(gpu_device):
     finally:
         g.close()
         e.close()
+
+
+def test_configs4_800_playouts_per_move(gpu_device):
+    """BASELINE configs[4] per GPU: n_playout=800 (the reference's README goal; train.py:20 defaults to 400).  Tree
+    pools, descent records and the memo are sized from n_playout: 1,024 boards, real net.  Two plies in the lock-step
+    cadence on two routes -- the plain engine (every leaf through the network) and the asynchronous loop's kernels with
+    the memo -- must agree bit for bit on root visits, Q, priors, pi and sampled moves; 256 of the leaf boards in situ
+    against the oracle; then the free-running asynchronous loop at
+    this playout count keeps the tree invariants (nothing overflows, nothing is dropped, no runaway descent)."""
+    import oracle
+    from alphazero_quoridor_amd.engine import SelfPlayEngine
+
+    B, NP = 1024, 800
+    ev = _net(gpu_device, 12).evaluator("per_leaf")
+    a = SelfPlayEngine(B, n_playout=NP, seed=31, device=gpu_device)
+    b = SelfPlayEngine(B, n_playout=NP, seed=31, device=gpu_device)
+    try:
+        rng = np.random.RandomState(5)
+        for ply in range(2):
+            a.run_playouts(ev, NP)
+            b.run_playouts_memo(ev)
+            ra, rb = a.root_children(), b.root_children()
+            for x, y in zip(ra, rb):
+                assert torch.equal(x, y), ply
+            visits, _, _, root_n = ra
+            assert int(root_n.min()) >= NP and bool((visits.clamp(min=0).sum(dim=1) == root_n - 1).all())
+            if ply == 1:  # in situ: the leaves of the next playout against the oracle (legal sets, terminal flags)
+                leaf = a.select_boards().to_packed()
+                mask = a.leaf_mask.cpu().numpy().view(np.uint32)
+                term = a.leaf_term.cpu().numpy()
+                idx = rng.choice(B, 256, replace=False)
+                won = (leaf["p1"] >= 72) | (leaf["p2"] <= 8)
+                assert np.array_equal(term[idx] != 0, won[idx])
+                live = idx[term[idx] == 0]
+                omask, status = oracle.movegen_batch(leaf[live])
+                assert (status >= 0).all() and np.array_equal(mask[live], omask)
+            (ma, pa), (mb, pb) = a.finish_move(), b.finish_move()
+            assert torch.equal(ma, mb) and torch.equal(pa, pb), ply
+            a.harvest()
+            b.harvest()
+        sa, sb = a.stats(), b.stats()
+        for st in (sa, sb):
+            assert st["node_overflow"] == 0 and st["games_aborted"] == 0 and st["nonfinite_values"] == 0 and st["runaway_descents"] == 0
+        assert sa["playouts"] == sb["playouts"] == 2 * B * NP and sa["max_depth"] == sb["max_depth"]
+        # the free-running loop: whole moves inside the launches, in-place re-roots, budget
+        b.run_rounds(ev, 1200, max_playouts=256, budget_us=500)
+        st = b.stats()
+        assert st["node_overflow"] == 0 and st["games_aborted"] == 0 and st["runaway_descents"] == 0 and st["plies_played"] > 2 * B
+        assert st["memo_hits"] + st["nn_evals"] + st["leaf_terminal"] >= st["playouts"]  # (leaves waiting for the network are counted at the miss)
+        print("n_playout=800: %d plies, deepest descent %d levels, %d evaluations, %d memo hits, tree pages peak %d of %d"
+              % (st["plies_played"], st["max_depth"], st["nn_evals"], st["memo_hits"], st["tree_pages_peak"], st["tree_pages_total"]))
+    finally:
+        a.close()
+        b.close()
+
+
+_RCCL_ONE_RANK = r'''
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.environ["QZ_ROOT"]); sys.path.insert(0, os.path.join(os.environ["QZ_ROOT"], "tests", "golden"))
+import torch.distributed as dist
+from alphazero_quoridor_amd import dist as qdist
+from alphazero_quoridor_amd.engine import SelfPlayEngine
+from alphazero_quoridor_amd.policy_value_net import PolicyValueNet
+rank, local, world = qdist.init_from_env("cuda")
+assert world == 1 and dist.is_initialized() and dist.get_backend() == "nccl", (world, dist.is_initialized())
+dev = torch.device("cuda", local)
+torch.manual_seed(0)
+net = PolicyValueNet(use_gpu=True, device=dev)
+ev = net.evaluator("per_leaf")
+# (1) the path's only exchange on RCCL: a real harvested batch, uint8 payload + int64 counts
+eng = SelfPlayEngine(256, n_playout=8, seed=3, device=dev, fix_terminal_sign=True)
+tbs = []
+for _ in range(400):
+    eng.run_rounds(ev, 8, max_playouts=16)
+    tb = eng.harvest()
+    if tb is not None:
+        tbs.append(tb)
+    if sum(t.n_games for t in tbs) >= 4:
+        break
+assert tbs, "no game finished"
+buf = torch.cat([qdist.pack_tuples(t.boards.hbits, t.boards.vbits, t.boards.meta, t.pi, t.z) for t in tbs])
+out, games = qdist.allgather_tuples(buf, n_games=sum(t.n_games for t in tbs))
+assert out.dtype == torch.uint8 and out.shape == buf.shape and torch.equal(out, buf) and games == sum(t.n_games for t in tbs)
+hb, vb, meta, pi, z = qdist.unpack_tuples(out)
+assert torch.equal(pi, torch.cat([t.pi for t in tbs])) and torch.equal(meta, torch.cat([t.boards.meta for t in tbs]))
+# (2) the training-side collectives: gradient all-reduce (flat float32 bucket), weight broadcast, buffer averaging
+st = tbs[0].states()[:32]
+n = st.shape[0]
+pi_t = tbs[0].pi[:n]
+z_t = tbs[0].z[:n]
+net.optimizer.zero_grad(set_to_none=False)
+logp, v = net.policy_value_net(st)
+loss = torch.nn.functional.mse_loss(v.view(-1), z_t) - torch.mean(torch.sum(pi_t * logp, 1))
+loss.backward()
+before = [p.grad.clone() for p in net.policy_value_net.parameters() if p.grad is not None]
+net._allreduce_grads()
+after = [p.grad for p in net.policy_value_net.parameters() if p.grad is not None]
+assert all(torch.equal(x, y) for x, y in zip(before, after)), "a 1-rank all-reduce + division by 1 changed a gradient"
+w0 = [p.detach().clone() for p in net.policy_value_net.parameters()]
+b0 = [b.detach().clone() for b in net.policy_value_net.buffers()]
+net.sync_from_rank0()
+net.average_buffers()
+assert all(torch.equal(x, y) for x, y in zip(w0, net.policy_value_net.parameters()))
+assert all(torch.equal(x, y) for x, y in zip(b0, net.policy_value_net.buffers()))
+torch.cuda.synchronize()
+dist.barrier()
+dist.destroy_process_group()
+print("RCCL one-rank ok: %d tuples all-gathered, %d gradient tensors all-reduced" % (out.shape[0], len(after)))
+'''
+
+
+def test_collectives_on_rccl_with_one_rank(gpu_device):
+    """Every collective of the package on the backend the multi-GPU job uses ("nccl" = RCCL on ROCm), with the ONE rank a
+    1-GPU box allows (QZ_DIST_FORCE=1 makes the package create the process group and run the collectives at world size
+    1): process-group init with device_id, uint8 / int64 all_gather_into_tensor of a really harvested tuple batch
+    (byte-equal to the input), float32 all_reduce of the gradient bucket (gradients unchanged), broadcast of weights and
+    averaging of buffers (unchanged).  In a child process: the test session itself never creates a process group."""
+    import socket
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, QZ_ROOT=root, QZ_DIST_FORCE="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("QZ_DIST_BACKEND", None)
+    r = subprocess.run([sys.executable, "-c", _RCCL_ONE_RANK], env=env, capture_output=True, text=True, timeout=600)
+    sys.stdout.write(r.stdout[-2000:])
+    assert r.returncode == 0, r.stderr[-4000:]
+    assert "RCCL one-rank ok" in r.stdout
+
+
+def test_games_deeper_than_the_reference_can_recurse_are_dropped_and_counted(gpu_device):
+    """qz_config.max_depth: the reference's recursive backup (mcts.py:55-62) ends the run with a RecursionError once a
+    path has more than ~992 levels; the engine drops such a game and counts it.  With a small limit on late-game boards
+    (deep forced lines) both engines -- lock-step and asynchronous -- drop games, count them under aborted_depth, restart
+    the boards and keep going; no descent is ever longer than limit + 1 levels; and a limit that is never reached
+    changes nothing (same harvested tuples as without a limit)."""
+    from alphazero_quoridor_amd.engine import SelfPlayEngine
+    from synth import synth_positions
+
+    boards = synth_positions(256, seed=9, max_walls=8)
+    boards["w1"] = 0
+    boards["w2"] = 0
+    ev = _net(gpu_device, 4).evaluator("per_leaf")
+    NP, LIMIT = 48, 10
+    lock = _engine(boards, NP, seed=2, max_depth=LIMIT)
+    asyn = _engine(boards, NP, seed=2, max_depth=LIMIT)
+    free = _engine(boards, NP, seed=2, max_depth=0)
+    big = _engine(boards, NP, seed=2, max_depth=100000)
+    try:
+        for _ in range(30):
+            lock.play_ply(ev)
+            lock.harvest()
+        asyn.run_rounds(ev, 400, max_playouts=NP, budget_us=0)
+        asyn.harvest()
+        for eng in (lock, asyn):
+            st = eng.stats()
+            assert st["aborted_depth"] > 0 and st["games_aborted"] >= st["aborted_depth"] and st["max_depth"] <= LIMIT + 1, st
+            assert st["node_overflow"] == 0 and st["runaway_descents"] == 0 and st["plies_played"] > 0
+        fb, bb = [], []
+        for _ in range(60):
+            for eng, acc in ((free, fb), (big, bb)):
+                eng.run_rounds(ev, 8, max_playouts=NP)
+                tb = eng.harvest()
+                if tb is not None:
+                    acc.append(tb)
+        assert free.stats()["aborted_depth"] == 0 == big.stats()["aborted_depth"]
+        gf, gb = _games_by_slot(fb), _games_by_slot(bb)
+        assert gf.keys() == gb.keys() and all(gf[k] == gb[k] for k in gf)
+        print("depth limit %d: lock-step dropped %d games, asynchronous %d" % (LIMIT, lock.stats()["aborted_depth"], asyn.stats()["aborted_depth"]))
+    finally:
+        for eng in (lock, asyn, free, big):
+            eng.close()
