@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--bn", default="per_leaf")
     ap.add_argument("--fix-sign", type=int, default=0)
     ap.add_argument("--budget-us", type=int, default=1000)
+    ap.add_argument("--traj-pages-per-board", type=int, default=200, help="trajectory pool (64-KB pages): games of > 100,000 plies must not be dropped for want of room")
     ap.add_argument("--max-depth", type=int, default=992, help="drop a game whose search descends deeper (the reference's RecursionError); 0 = never")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
@@ -70,7 +71,8 @@ def main():
     net = PolicyValueNet(use_gpu=True)
     ev = net.evaluator(args.bn)
     B = args.boards
-    eng = SelfPlayEngine(B, n_playout=args.playouts, seed=5, device=dev, fix_terminal_sign=bool(args.fix_sign), max_depth=args.max_depth)
+    eng = SelfPlayEngine(B, n_playout=args.playouts, seed=5, device=dev, fix_terminal_sign=bool(args.fix_sign), max_depth=args.max_depth,
+                         traj_pool_pages=args.traj_pages_per_board * B)
     # the asynchronous self-play loop (bit-identical games to the lock-step engine, tests/test_gpu_async.py): boards
     # restart at once when their game is harvested.  Per finished game: its length and the plies of its OPEN phase (the
     # mover still has walls: the part of a game whose leaves are almost all new to the memo)

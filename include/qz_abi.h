@@ -128,7 +128,7 @@ typedef struct {
     int32_t edge_cap;          /* most edges per tree (0 = the page table's reach: 262,144)      */
     int32_t max_plies;         /* drop a game after this many plies (0 = no limit; the reference has none) */
     int32_t tree_pool_pages;   /* 0 = auto: n_boards x max(4, ceil(250 x n_playout / 2,048)), >= 264 */
-    int32_t traj_pool_pages;   /* 0 = auto: 16 per board (1 MB)                                  */
+    int32_t traj_pool_pages;   /* 0 = auto: 64 per board (4 MB) up to 8,192 boards, 16 beyond    */
     int32_t traj_page_dwords;  /* 0 = 16,384 (64 KB); >= 256.  Small pages only make sense in tests */
     qz_rules_opts rules;       /* formulation of the leaf rules op (all zero = defaults)        */
     int32_t select_opts;       /* A/B switches of the descent kernel (0 = defaults): bit 0 = walk every level (no replay of
