@@ -128,6 +128,7 @@ class qz_nn_weights(C.Structure):
         ("gamma6", C.c_void_p), ("beta6", C.c_void_p), ("w1t", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p),
         ("w3t", C.c_void_p), ("b3", C.c_void_p),
         ("eps", C.c_float),
+        ("precision", C.c_int32),
     ]
 
 
@@ -183,6 +184,7 @@ _SIGNATURES = {
     "qz_nn_trunk_heads": (C.c_int, [_P, C.c_int64, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, _P]),
     "qz_nn_evaluate": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P, _P, _P, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                  _P, C.c_float, _P]),
+    "qz_nn_evaluate_w": (C.c_int, [_P, _P, C.c_int64, C.POINTER(qz_nn_weights), _P, _P, _P, _P]),
     "qz_selfplay_advance": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
     "qz_selfplay_leaf_rules": (C.c_int, [_P, _P]),
     "qz_selfplay_evaluate": (C.c_int, [_P, C.POINTER(qz_nn_weights), _P]),

@@ -39,7 +39,7 @@ struct TrunkInput {  // qz_conv.hip
     const float *hot9, *base0, *wd, *gamma0, *beta0;
 };
 hipError_t trunk(float*, float*, long long, int, const void* const*, const float* const*, const float* const*, const float*, float, int, hipStream_t,
-                 const void*, const float*, const float*, float*, const TrunkInput*, const int* n_live = nullptr);
+                 const void*, const float*, const float*, float*, const TrunkInput*, const int* n_live = nullptr, int single_product = 0);
 hipError_t head_fc(const float*, long long, const float*, const float*, const float*, const float*, const float*, const float*, float*, float*, hipStream_t,
                    const int* n_live = nullptr);
 hipError_t rollout_begin(const uint64_t*, const uint64_t*, const uint64_t*, int, uint8_t*, uint8_t*, int8_t*, int*, hipStream_t);
@@ -830,6 +830,7 @@ int qz_nn_trunk_heads(const float* x, int64_t n, int n_blocks, const void* const
 static int nn_weights_check(const qz_nn_weights* w) {
     if (!w) return fail(QZ_E_INVALID, "null weights");
     if (w->n_blocks <= 0 || w->n_blocks > 8) return fail(QZ_E_INVALID, "n_blocks outside 1..8");
+    if (w->precision != 0 && w->precision != 1) return fail(QZ_E_INVALID, "precision must be 0 (split fp16 operands, fp32 accuracy) or 1 (fp16 operands)");
     if (!w->hot9 || !w->base0 || !w->wd || !w->gamma0 || !w->beta0 || !w->w16 || !w->gamma || !w->beta || !w->inv_scale || !w->w6_16 || !w->gamma6 ||
         !w->beta6 || !w->w1t || !w->b1 || !w->w2 || !w->b2 || !w->w3t || !w->b3)
         return fail(QZ_E_INVALID, "null argument");
@@ -843,7 +844,7 @@ static int nn_evaluate(const uint64_t* hb, const uint64_t* vb, const uint64_t* m
                        float* p_out, float* v_out, const int* n_live, hipStream_t s) {
     const qzl::TrunkInput in = {hb, vb, meta, terminal, w->hot9, w->base0, w->wd, w->gamma0, w->beta0};
     HIP_TRY(qzl::trunk(nullptr, nullptr, (long long)n, w->n_blocks, w->w16, w->gamma, w->beta, w->inv_scale, w->eps, 1, s, w->w6_16, w->gamma6, w->beta6, feat, &in,
-                       n_live));
+                       n_live, w->precision == 1));
     HIP_TRY(qzl::head_fc(feat, (long long)n, w->w1t, w->b1, w->w2, w->b2, w->w3t, w->b3, p_out, v_out, s, n_live));
     return 0;
 }
@@ -855,7 +856,7 @@ int qz_nn_evaluate(const qz_boards* boards, const uint8_t* terminal, int64_t n, 
     int r;
     if ((r = device_check())) return r;
     if (n < 0) return fail(QZ_E_INVALID, "n < 0");
-    const qz_nn_weights w = {hot9, base0, wd, gamma0, beta0, n_blocks, w16, gamma, beta, inv_scale, w6_16, gamma6, beta6, w1t, b1, w2, b2, w3t, b3, eps};
+    const qz_nn_weights w = {hot9, base0, wd, gamma0, beta0, n_blocks, w16, gamma, beta, inv_scale, w6_16, gamma6, beta6, w1t, b1, w2, b2, w3t, b3, eps, 0};
     if ((r = nn_weights_check(&w))) return r;
     if (n == 0) return 0;
     if (!boards || !boards->hbits || !boards->vbits || !boards->meta || !feat || !p_out || !v_out) return fail(QZ_E_INVALID, "null argument");
@@ -869,6 +870,18 @@ int qz_engine_leaf_boards(qz_engine* e, qz_boards* boards_out, const uint8_t** t
     boards_out->meta = e->dev.leaf_meta;
     if (terminal_out) *terminal_out = e->dev.leaf_term;
     return 0;
+}
+
+int qz_nn_evaluate_w(const qz_boards* boards, const uint8_t* terminal, int64_t n, const qz_nn_weights* w, float* feat, float* p_out, float* v_out,
+                     void* stream) {
+    int r;
+    if ((r = device_check())) return r;
+    if (n < 0) return fail(QZ_E_INVALID, "n < 0");
+    if ((r = nn_weights_check(w))) return r;
+    if (n == 0) return 0;
+    if (!boards || !boards->hbits || !boards->vbits || !boards->meta || !feat || !p_out || !v_out) return fail(QZ_E_INVALID, "null argument");
+    if (((uintptr_t)feat & 7) != 0) return fail(QZ_E_INVALID, "feat must be 8-byte aligned");
+    return nn_evaluate(boards->hbits, boards->vbits, boards->meta, terminal, n, w, feat, p_out, v_out, nullptr, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------ asynchronous self-play

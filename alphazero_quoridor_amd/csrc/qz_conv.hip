@@ -286,7 +286,11 @@ struct InputArgs {
     const float *hot9, *base0, *wd;  // [21][9][64], [81][64], [4][9][64] (qz_nn_input_layer)
     const float *gamma0, *beta0;     // bn1
 };
-template <bool FROM_BOARD>
+// SPLIT = true: every product as three MFMAs on split fp16 operands (fp32 accuracy, the parity mode, the default).
+// SPLIT = false: ONE MFMA per product on the hi halves only (fp16 operands, fp32 accumulation) -- the labelled
+// throughput mode (`nn_precision="fp16"`, bench.py --nn-dtype fp16): a third of the matrix work, p / v within ~1e-3
+// of the reference instead of 1e-5 (tests/test_gpu_conv.py states the bound); never the default.
+template <bool FROM_BOARD, bool SPLIT = true>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_trunk(const float* __restrict__ x, float* __restrict__ out, TrunkArgs A, int n_layers, float eps, HeadArgs H, InputArgs I,
                                                const int* __restrict__ n_live  // or nullptr: only the first *n_live leaves are evaluated (the engine's miss list)
 #ifdef QZ_TRUNK_STAMPS
@@ -490,8 +494,10 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur], b_hi, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur], b_lo, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur], b_hi, acc[t], 0, 0, 0);
+                if (SPLIT) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur], b_lo, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur], b_hi, acc[t], 0, 0, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -616,15 +622,19 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     const half8 a_hi = sm.a_hi[ro0 + 2 * kc];
                     const half8 a_lo = sm.a_lo[ro0 + 2 * kc];
                     ha0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, ha0, 0, 0, 0);
-                    ha0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, ha0, 0, 0, 0);
-                    ha0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, ha0, 0, 0, 0);
+                    if (SPLIT) {
+                        ha0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, ha0, 0, 0, 0);
+                        ha0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, ha0, 0, 0, 0);
+                    }
                 }
                 if (two) {
                     const half8 a_hi = sm.a_hi[ro1 + 2 * kc];
                     const half8 a_lo = sm.a_lo[ro1 + 2 * kc];
                     ha1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, ha1, 0, 0, 0);
-                    ha1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, ha1, 0, 0, 0);
-                    ha1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, ha1, 0, 0, 0);
+                    if (SPLIT) {
+                        ha1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, ha1, 0, 0, 0);
+                        ha1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, ha1, 0, 0, 0);
+                    }
                 }
             }
         }
@@ -705,7 +715,7 @@ struct TrunkInput {
 // from the packed boards in the same launch and x is not read (may be NULL)
 hipError_t trunk(float* x, float* tmp, long long n, int n_blocks, const void* const* w16, const float* const* gamma, const float* const* beta,
                  const float* inv_scale /*[dev]*/, float eps, int fused, hipStream_t s, const void* w6 = nullptr, const float* gamma6 = nullptr,
-                 const float* beta6 = nullptr, float* feat = nullptr, const TrunkInput* in = nullptr, const int* n_live = nullptr) {
+                 const float* beta6 = nullptr, float* feat = nullptr, const TrunkInput* in = nullptr, const int* n_live = nullptr, int single_product = 0) {
     if (n <= 0 || n_blocks <= 0) return hipSuccess;
     const int nl = 2 * n_blocks;
     if ((feat || in || n_live) && !(fused && nl <= MAX_TRUNK_LAYERS)) return hipErrorInvalidValue;
@@ -732,8 +742,10 @@ hipError_t trunk(float* x, float* tmp, long long n, int n_blocks, const void* co
         H.role_shift = 0;  // odd workgroups swap the roles: 787 -> 779 us for 4,096 leaves (shifts 1..8 and none measured: 783..791)
         InputArgs I = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         if (in) I = InputArgs{in->hb, in->vb, in->meta, in->terminal, in->hot9, in->base0, in->wd, in->gamma0, in->beta0};
-        if (in) hipLaunchKernelGGL(k_trunk<true>, dim3((unsigned)n), dim3(128), 0, s, x, feat ? nullptr : x, A, nl, eps, H, I, n_live);
-        else hipLaunchKernelGGL(k_trunk<false>, dim3((unsigned)n), dim3(128), 0, s, x, feat ? nullptr : x, A, nl, eps, H, I, n_live);
+        if (single_product && !in) return hipErrorInvalidValue;  // (the throughput mode exists on the route from the packed boards only)
+        if (in && single_product) hipLaunchKernelGGL((k_trunk<true, false>), dim3((unsigned)n), dim3(128), 0, s, x, feat ? nullptr : x, A, nl, eps, H, I, n_live);
+        else if (in) hipLaunchKernelGGL((k_trunk<true, true>), dim3((unsigned)n), dim3(128), 0, s, x, feat ? nullptr : x, A, nl, eps, H, I, n_live);
+        else hipLaunchKernelGGL((k_trunk<false, true>), dim3((unsigned)n), dim3(128), 0, s, x, feat ? nullptr : x, A, nl, eps, H, I, n_live);
         return hipGetLastError();
 #endif
     }

@@ -144,8 +144,14 @@ class LeafEvaluator:
     """
 
     def __init__(self, net: nn.Module, bn_mode="per_leaf", dtype=torch.float32, channels_last=False, fused_norm=True,
-                 board_input_layer=True, fused_head=True, mfma_trunk=True, fused_trunk=True, fused_heads_stage=True, fused_input_stage=True):
+                 board_input_layer=True, fused_head=True, mfma_trunk=True, fused_trunk=True, fused_heads_stage=True, fused_input_stage=True,
+                 nn_precision="fp32"):
         assert bn_mode in ("per_leaf", "batch", "eval")
+        # "fp32" (default, the parity mode): every product of the trunk as three MFMAs on split fp16 operands, 1e-5 against the
+        # reference.  "fp16": ONE MFMA per product on fp16 operands with fp32 accumulation -- the labelled THROUGHPUT mode of the
+        # HIP evaluation from packed boards (~1e-3 on p / v); results are no longer the reference's to 1e-5
+        assert nn_precision in ("fp32", "fp16")
+        self.nn_precision = nn_precision
         self.fused_norm = fused_norm  # per_leaf on the GPU: use the one-pass HIP normalisation kernel
         # first layer straight from the packed boards (qz_nn_input_layer) when the caller hands them
         # over: fp32, channels-last, per-leaf or folded BatchNorm
@@ -323,24 +329,17 @@ class LeafEvaluator:
         return p, v
 
     def _evaluate_boards_mfma(self, leaf):
-        """The whole evaluation from the packed leaf boards, two launches (qz_nn_evaluate): first layer from the
+        """The whole evaluation from the packed leaf boards, two launches (qz_nn_evaluate_w): first layer from the
         boards, trunk and head convolution in one persistent launch, then the fully connected layers."""
         from . import _cabi
         import ctypes as C
         st, term_ptr, n = leaf
-        w, g, b, sc = self._trunk_tables()
-        hd = self._head
-        _, _, gamma0, beta0 = self._layers[0]
-        hot9, base0, wd = self._in_tables
-        dev = gamma0.device
+        dev = self._layers[0][2].device
         p = torch.empty((n, N_ACTIONS), dtype=torch.float32, device=dev)
         v = torch.empty(n, dtype=torch.float32, device=dev)
         feat = torch.empty((n, 6 * 81), dtype=torch.float32, device=dev)
-        _cabi.check(_cabi.load().qz_nn_evaluate(
-            C.byref(st), term_ptr or 0, n, hot9.data_ptr(), base0.data_ptr(), wd.data_ptr(), gamma0.data_ptr(), beta0.data_ptr(), N_RES,
-            w, g, b, sc, self._w6_16[0].data_ptr(), hd[8].data_ptr(), hd[1].data_ptr(),
-            hd[2].data_ptr(), hd[3].data_ptr(), hd[4].data_ptr(), hd[5].data_ptr(), hd[6].data_ptr(), hd[7].data_ptr(),
-            feat.data_ptr(), p.data_ptr(), v.data_ptr(), BN_EPS, torch.cuda.current_stream(dev).cuda_stream))
+        _cabi.check(_cabi.load().qz_nn_evaluate_w(C.byref(st), term_ptr or 0, n, C.byref(self.nn_weights()), feat.data_ptr(), p.data_ptr(), v.data_ptr(),
+                                                  torch.cuda.current_stream(dev).cuda_stream))
         return p, v
 
     def _trunk_tables(self):
@@ -380,6 +379,7 @@ class LeafEvaluator:
             nw.gamma6, nw.beta6 = hd[8].data_ptr(), hd[1].data_ptr()
             nw.w1t, nw.b1, nw.w2, nw.b2, nw.w3t, nw.b3 = (hd[i].data_ptr() for i in (2, 3, 4, 5, 6, 7))
             nw.eps = BN_EPS
+            nw.precision = 1 if self.nn_precision == "fp16" else 0
             self._nn_weights = nw
         return self._nn_weights
 
@@ -549,16 +549,16 @@ class PolicyValueNet:
         self._evaluators = {}
 
     # engine-facing ---------------------------------------------------------------
-    def evaluator(self, bn_mode=None, dtype=torch.float32, channels_last=None) -> LeafEvaluator:
+    def evaluator(self, bn_mode=None, dtype=torch.float32, channels_last=None, nn_precision="fp32") -> LeafEvaluator:
         if channels_last is None:
             # MIOpen's NHWC fp32 convolutions are ~20 % faster on MI355X; "batch" mode stays NCHW
             # (MIOpen's NHWC BatchNorm-training path crashed on this stack)
             channels_last = self.device.type == "cuda" and (bn_mode or self.bn_mode) != "batch"
         # one evaluator per configuration, all kept: engines hold on to theirs (cloned, re-laid-out
         # weights), and weights_changed() must reach every one of them after a training step
-        key = (bn_mode or self.bn_mode, dtype, bool(channels_last))
+        key = (bn_mode or self.bn_mode, dtype, bool(channels_last), nn_precision)
         if key not in self._evaluators:
-            self._evaluators[key] = LeafEvaluator(self.policy_value_net, key[0], dtype, channels_last)
+            self._evaluators[key] = LeafEvaluator(self.policy_value_net, key[0], dtype, channels_last, nn_precision=nn_precision)
         return self._evaluators[key]
 
     def weights_changed(self):

@@ -551,7 +551,9 @@ def run_async(args, eng, net, rank, local, world, dev, qdist):
         "dtype": "u64 bitboards + f64 PUCT (rules/tree kernels); %s policy-value net" % args.nn_dtype,
         "data": "synthetic (random-init policy_value_net, seed %d; self-generated games)" % args.seed,
         "config": {
-            "workload": "%s: %d concurrent boards/GPU, n_playout=%d, 9x9, 10 walls/player, c_puct=5, temp=1.0, asynchronous self-play loop with "
+            "workload": ("NON-PARITY THROUGHPUT MODE (network products on fp16 operands, p / v ~1e-3 from the reference; %s) -- "
+                         % ("terminal sign fixed" if args.fix_terminal_sign else "reference-faithful terminal sign") if args.nn_dtype == "fp16" else "") +
+                        "%s: %d concurrent boards/GPU, n_playout=%d, 9x9, 10 walls/player, c_puct=5, temp=1.0, asynchronous self-play loop with "
                         "leaf-evaluation memo, finished tuples all-gathered every step"
                         % ("BASELINE configs[2] as an engine run" if B == 32768 else ("BASELINE configs[1]" if args.playouts == 100 else "BASELINE configs[3] per GPU"),
                            B, args.playouts),
@@ -652,7 +654,9 @@ def main():
                          "(mcts.py:55-62) overflows Python's recursion limit under `python train.py` and ends the run with a RecursionError")
     ap.add_argument("--no-memo", action="store_true", help="async A/B: no leaf-evaluation memo (every leaf goes to the network)")
     ap.add_argument("--bn", default="per_leaf", choices=["per_leaf", "eval", "batch"])
-    ap.add_argument("--nn-dtype", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--nn-dtype", default="fp32", choices=["fp32", "bf16", "fp16"],
+                    help="fp32 (default): the parity mode.  fp16: NON-PARITY throughput mode of the HIP evaluation (one MFMA per product on fp16 operands, "
+                         "p / v within ~1e-3 of the reference instead of 1e-5), async mode only; never the headline.  bf16: library ops, lock-step mode only")
     ap.add_argument("--channels-last", type=int, default=1)
     ap.add_argument("--desync-plies", type=int, default=700)
     ap.add_argument("--desync-playouts", type=int, default=4)
@@ -696,19 +700,20 @@ def main():
     torch.backends.cudnn.benchmark = True
     torch.manual_seed(args.seed)  # identical random-init weights on every rank
     net = PolicyValueNet(use_gpu=True, device=dev)
-    dt = torch.float32 if args.nn_dtype == "fp32" else torch.bfloat16
+    dt = torch.bfloat16 if args.nn_dtype == "bf16" else torch.float32
+    prec = "fp16" if args.nn_dtype == "fp16" else "fp32"
     if args.library_trunk:
         from alphazero_quoridor_amd.policy_value_net import LeafEvaluator
         lib_ev = LeafEvaluator(net.policy_value_net, args.bn, dt, bool(args.channels_last), mfma_trunk=False)
         make_ev = lambda: lib_ev  # noqa: E731
     else:
-        make_ev = lambda: net.evaluator(args.bn, dt, bool(args.channels_last))  # noqa: E731
+        make_ev = lambda: net.evaluator(args.bn, dt, bool(args.channels_last), nn_precision=prec)  # noqa: E731
     eng = BoardGroups(args.boards, args.groups, make_ev,
                       seed=qdist.shard_seed(args.seed, rank), device=dev,
                       n_playout=args.playouts, c_puct=5, temp=1.0, is_selfplay=1, fix_terminal_sign=args.fix_terminal_sign,
                       select_opts=args.select_opts, memo=not args.no_memo, max_depth=args.max_depth)
     if args.mode == "async":
-        assert args.nn_dtype == "fp32" and args.bn == "per_leaf" and not args.library_trunk, "the asynchronous loop runs the HIP evaluation (fp32, per-leaf BN)"
+        assert args.nn_dtype in ("fp32", "fp16") and args.bn == "per_leaf" and not args.library_trunk, "the asynchronous loop runs the HIP evaluation (per-leaf BN)"
         run_async(args, eng, net, rank, local, world, dev, qdist)
         eng.close()
         if world > 1:

@@ -382,10 +382,17 @@ typedef struct {
     const void* w6_16;
     const float *gamma6, *beta6, *w1t, *b1, *w2, *b2, *w3t, *b3;
     float eps;
+    int32_t precision;   /* 0 = every product as three MFMAs on split fp16 operands: fp32 accuracy, 1e-5 against the reference
+                            (the parity mode); 1 = one MFMA per product on fp16 operands with fp32 accumulation: the labelled
+                            THROUGHPUT mode (~1e-3 on p / v), a third of the matrix work.  qz_nn_evaluate always runs 0. */
 } qz_nn_weights;
 /* the engine's current leaf boards (what qz_mcts_select just produced) and their terminal flags,
  * as device pointers owned by the engine: input of qz_nn_input_layer */
 int qz_engine_leaf_boards(qz_engine* e, qz_boards* boards_out, const uint8_t** terminal_out);
+
+/* qz_nn_evaluate with the weights as one struct; honours qz_nn_weights.precision. */
+int qz_nn_evaluate_w(const qz_boards* boards /*[dev] arrays*/, const uint8_t* terminal /*[dev] or NULL*/, int64_t n, const qz_nn_weights* w,
+                     float* feat /*[dev] n*486 scratch*/, float* p_out /*[dev] n*140*/, float* v_out /*[dev] n*/, void* stream);
 
 /* ------------------------------------------------------------- asynchronous self-play
  * The loop of Quoridor.start_self_play / MCTSPlayer.choose_action / MCTS.get_move_probs (quoridor.py:582-593,

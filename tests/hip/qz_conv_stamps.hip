@@ -15,7 +15,7 @@ extern "C" int qzt_trunk_stamps(float* x, long long n, int n_layers, const void*
     A.inv_scale = inv_scale;
     // QZ_STAMPS_PAD_LDS=<bytes>: extra dynamic LDS per workgroup, to measure a wave that has its SIMD for itself (96 KB -> one workgroup per CU)
     const size_t pad = getenv("QZ_STAMPS_PAD_LDS") ? (size_t)atol(getenv("QZ_STAMPS_PAD_LDS")) : 0;
-    hipLaunchKernelGGL(k_trunk<false>, dim3((unsigned)n), dim3(128), pad, (hipStream_t)stream, x, x, A, n_layers, 1e-5f, HeadArgs{nullptr, nullptr, nullptr, nullptr, 31},
+    hipLaunchKernelGGL((k_trunk<false, true>), dim3((unsigned)n), dim3(128), pad, (hipStream_t)stream, x, x, A, n_layers, 1e-5f, HeadArgs{nullptr, nullptr, nullptr, nullptr, 31},
                        InputArgs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, nullptr, stamps);
     return (int)hipGetLastError();
 }

@@ -211,3 +211,50 @@ def test_input_stage_of_the_trunk_launch_equals_the_separate_input_kernel(gpu_de
             assert torch.isfinite(p1).all() and torch.isfinite(v1).all() and dp < 2e-6 and dv < 1e-5, (n, bool(tp), dp, dv)
         pa, va = staged(None, leaf=leaf)
         assert torch.equal(pa, p1) and torch.equal(va, v1)   # run to run: bit-identical
+
+
+def test_fp16_throughput_mode_stays_within_its_stated_bound(gpu_device, golden_dir):
+    """The labelled NON-PARITY mode (LeafEvaluator nn_precision="fp16", bench.py --nn-dtype fp16): one MFMA per product on
+    fp16 operands instead of three on split operands.  Against the reference's policy_value_fn on the 64 fixture states
+    it must stay within 5e-3 on p and 3e-2 on v (the parity mode: 1e-5), and a 64-playout search with it must mostly
+    visit what the parity evaluator's search visits (same boards, same seed): the printed figures are what the mode
+    costs; nothing in the product selects it by default."""
+    import sys, os
+    sys.path.insert(0, golden_dir)
+    from _stubs import det_fill_state_dict
+    from synth import synth_positions
+    from alphazero_quoridor_amd.boards import DeviceBoards
+    from alphazero_quoridor_amd.engine import SelfPlayEngine
+    from alphazero_quoridor_amd.policy_value_net import PolicyValueNet
+
+    d = np.load(golden_dir + "/net_fixture.npz")
+    pvn = PolicyValueNet(use_gpu=True, device=gpu_device)
+    pvn.policy_value_net.load_state_dict(det_fill_state_dict(pvn.policy_value_net.state_dict(), 2024))
+    ev32 = pvn.evaluator("per_leaf", torch.float32, True)
+    ev16 = pvn.evaluator("per_leaf", torch.float32, True, nn_precision="fp16")
+    assert ev16 is not ev32 and ev16.nn_precision == "fp16" and ev16.engine_route_ok() and ev16.nn_weights().precision == 1
+    db = DeviceBoards.from_packed(d["board"], gpu_device)
+    p, v = ev16(None, leaf=(db.struct(), 0, db.n))
+    p, v = p.cpu().numpy(), v.cpu().numpy()
+    worst_p = worst_v = 0.0
+    for i in range(64):
+        acts = d["leaf_acts"][i]
+        k = int((acts != 255).sum())
+        worst_p = max(worst_p, float(np.abs(p[i][acts[:k]] - d["leaf_p"][i][:k]).max()))
+        worst_v = max(worst_v, float(abs(v[i] - d["leaf_v"][i])))
+    boards = synth_positions(128, seed=3, max_walls=10)
+    engs = []
+    for ev in (ev32, ev16):
+        eng = SelfPlayEngine(128, n_playout=64, seed=1, device=gpu_device)
+        eng.set_boards(DeviceBoards.from_packed(boards, gpu_device), reset_trees=True)
+        eng.run_playouts_memo(ev)
+        engs.append(eng)
+    (pi_a, vis_a), (pi_b, vis_b) = engs[0].root_pi(), engs[1].root_pi()
+    same_best = float((pi_a.argmax(dim=1) == pi_b.argmax(dim=1)).float().mean())
+    l1 = float((pi_a - pi_b).abs().sum(dim=1).mean())
+    for eng in engs:
+        eng.close()
+    print("fp16 throughput mode vs reference policy_value_fn: max |dp| %.3g, max |dv| %.3g; 64-playout searches: same most-visited move on "
+          "%.0f %% of 128 boards, mean L1 distance of pi %.3f" % (worst_p, worst_v, 100 * same_best, l1))
+    assert worst_p < 5e-3 and worst_v < 3e-2, (worst_p, worst_v)
+    assert same_best > 0.6 and l1 < 0.8, (same_best, l1)
