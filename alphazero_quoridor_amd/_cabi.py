@@ -115,6 +115,7 @@ class qz_stats(C.Structure):
         ("waiting_boards", C.c_int64),
         ("aborted_depth", C.c_int64),
         ("runaway_descents", C.c_int64),
+        ("compact_slices", C.c_int64),
     ]
 
 

@@ -380,6 +380,7 @@ int qz_engine_create(const qz_config* cfg, qz_engine** out) {
     ALLOC(pl_done, B);
     ALLOC(pend_slot, B);
     ALLOC(reroot_pend, B);
+    ALLOC(compact_state, B * 8);
     ALLOC(compact_at, B);
     ALLOC(miss_count, (size_t)2);
     ALLOC(miss_hb, B);
@@ -446,6 +447,7 @@ int qz_engine_create(const qz_config* cfg, qz_engine** out) {
     if (he == hipSuccess) he = hipMemset(d.leaf_mask, 0, B * 5 * sizeof(uint32_t));
     if (he == hipSuccess) he = hipMemset(d.miss_count, 0, 2 * sizeof(int));
     if (he == hipSuccess) he = hipMemset(d.reroot_pend, 0, B * sizeof(uint32_t));
+    if (he == hipSuccess) he = hipMemset(d.compact_state, 0, B * 8 * sizeof(uint32_t));
     if (he == hipSuccess) he = hipMemset(d.bc_memo_hits, 0, B * sizeof(uint32_t));
     if (he == hipSuccess) he = hipMemset(d.bc_evals, 0, B * sizeof(uint32_t));
     if (he == hipSuccess) he = hipMemset(d.bc_open_rounds, 0, B * sizeof(uint32_t));
@@ -733,6 +735,7 @@ int qz_engine_stats(qz_engine* e, qz_stats* out, void* stream) {
     out->open_plies = (int64_t)sop;
     out->waiting_boards = (int64_t)sw;
     out->runaway_descents = (int64_t)h[QZ_C_RUNAWAY];
+    out->compact_slices = (int64_t)h[QZ_C_COMPACT_SLICES];
     return 0;
 }
 

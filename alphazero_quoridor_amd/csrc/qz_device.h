@@ -72,6 +72,7 @@ enum {
     QZ_C_MEMO_LOCKED,       // ... skipped because another wave held the bucket's lock
     QZ_C_ABORT_DEPTH,       // games dropped because a descent was deeper than qz_config.max_depth (the reference's RecursionError)
     QZ_C_RUNAWAY,           // descents cut off because they were deeper than a tree can be (corrupted storage; must stay 0)
+    QZ_C_COMPACT_SLICES,    // subtree copies that stopped at their launch's budget and went on in the next launch
     QZ_C_COUNT
 };
 // pool bookkeeping words (int): free-stack tops and low-water marks
@@ -175,6 +176,7 @@ struct EngineDev {
     uint32_t* pl_done;        // [B] playouts done on the current root
     uint32_t* pend_slot;      // [B] miss-list slot of the leaf this board waits for, QZ_NONE = none
     uint32_t* compact_at;     // [B] allocation cursor at which the board's next move compacts (compact_edges, or twice the tree's size after its last compaction)
+    uint32_t* compact_state;  // [B][8] a subtree copy that stopped at its launch's budget (wave_reroot): in progress, scan position, cursor, pages, nodes, cut, pool empty, root offset
     uint32_t* reroot_pend;    // [B] the subtree copy of the last move, left for the next k_advance launch: 0 none, 1 fresh root, e + 2 keep edge e
     int* miss_count;          // [1] slots used by this round's misses
     uint64_t *miss_hb, *miss_vb, *miss_meta;  // [B] the leaves awaiting evaluation, compacted

@@ -802,7 +802,13 @@ __device__ __forceinline__ void select_core(EngineDev& E, BoardRegs& S, const in
             bool left = false;
             QZ_SEL_MARK(t_walk)
             QZ_TS(1)
-            while (cur != QZ_NONE && walk_credit == 0u && plen + 8u <= cur_len && !left) {
+#ifndef QZ_REPLAY_MIN
+#define QZ_REPLAY_MIN 4   // recorded levels that must remain for a replay round to be tried
+#endif
+#ifndef QZ_WALK_CREDIT
+#define QZ_WALK_CREDIT 2  // levels walked after a round that confirmed fewer than QZ_REPLAY_MIN levels
+#endif
+            while (cur != QZ_NONE && walk_credit == 0u && plen + (uint32_t)QZ_REPLAY_MIN <= cur_len && !left) {
                 QZ_SEL_COUNT(n_rounds++;)
                 const uint32_t* const pe = pe0 + (size_t)cur * CAP;
                 const unsigned long long* const pb = pb0 + (size_t)cur * CAP;
@@ -930,7 +936,7 @@ __device__ __forceinline__ void select_core(EngineDev& E, BoardRegs& S, const in
                     ne = cne;
                 }
                 if (nconf < 64) left = true;
-                if (nconf < 8) walk_credit = 8u;
+                if (nconf < QZ_REPLAY_MIN) walk_credit = (uint32_t)QZ_WALK_CREDIT;
 #ifdef QZ_ADV_STAMPS
                 sel_rounds++;
                 if (nconf < 8) sel_failed++;
@@ -1468,7 +1474,13 @@ __device__ __forceinline__ void translate_records(EngineDev& E, int b, int lane,
 // without a subtree makes the whole tree garbage: the cursor goes back to 0 in the pages already mapped.  Same tree as
 // far as any descent, expansion or backup can tell; a move costs a few stores instead of a breadth-first copy whose
 // duration (up to tens of ms for the largest trees) every other board of the launch had to wait for.
-__device__ __forceinline__ void wave_reroot(EngineDev& E, int b, int lane, uint32_t edge, const bool in_place = false) {
+// Sliced (k_advance only: `deadline` in s_memrealtime ticks, `st` = the board's 8 words of E.compact_state): the queue of the
+// breadth-first copy is the new tree itself and the old tree is not modified, so the copy can stop between two windows and go on
+// in a later launch from (scan position, allocation cursor, pages mapped, node count).  A 1,000-level line copies at one level
+// per memory round trip -- ~2 M cycles, measured -- and a launch ends with its LAST wave: rather than hold up 4,095 boards, the
+// wave saves those words when the launch's budget is spent and returns false; the board sits out until its copy is done.
+__device__ __forceinline__ bool wave_reroot(EngineDev& E, int b, int lane, uint32_t edge, const bool in_place = false,
+                                            const unsigned long long deadline = 0ull, uint32_t* const st = nullptr) {
     const uint32_t half = rfl(E.tree_half[b]);
     const TreeView S = tree_view(E, b, half, lane);
     uint32_t s_off = 0u, childN = 0u;
@@ -1496,24 +1508,51 @@ __device__ __forceinline__ void wave_reroot(EngineDev& E, int b, int lane, uint3
                 if (E.compact_edges > 0) E.compact_at[b] = (uint32_t)E.compact_edges;
             }
         }
-        return;
+        return true;
     }
     uint32_t new_nodes = 0u, new_edges = 0u, dnp = 0u, root_off = 0u, truncated = 0u;
     int root_ne = 0;
     bool flipped = false;
     if (s_ne > 0) {
         TreeView D = tree_view(E, b, half ^ 1u, lane);
-        const uint32_t off = tree_alloc(E, D, new_edges, dnp, s_ne, lane, true);
+        const bool resumed = st != nullptr && rfl(st[0]) != 0u;
+        uint32_t off = 0u, q = 0u;
+        bool exhausted = false;
+        if (resumed) {
+            q = rfl(st[1]);
+            new_edges = rfl(st[2]);
+            dnp = rfl(st[3]);
+            new_nodes = rfl(st[4]);
+            truncated = rfl(st[5]);
+            exhausted = rfl(st[6]) != 0u;
+            off = rfl(st[7]);
+        } else {
+            off = tree_alloc(E, D, new_edges, dnp, s_ne, lane, true);
+            if (off != QZ_NONE) {
+                copy_block(S, s_off, D, off, s_ne, QZ_NONE, lane);
+                new_nodes = 1u;
+            }
+        }
         if (off != QZ_NONE) {
-            copy_block(S, s_off, D, off, s_ne, QZ_NONE, lane);
-            new_nodes = 1u;
             root_off = off;
             root_ne = s_ne;
             flipped = true;
-            bool exhausted = false;
-            uint32_t q = 0u;
             while (q < new_edges) {  // wave-uniform
                 wave_sync();
+                if (st != nullptr && __builtin_amdgcn_s_memrealtime() > deadline) {
+                    if (lane == 0) {
+                        st[0] = 1u;
+                        st[1] = q;
+                        st[2] = new_edges;
+                        st[3] = dnp;
+                        st[4] = new_nodes;
+                        st[5] = truncated;
+                        st[6] = exhausted ? 1u : 0u;
+                        st[7] = off;
+                        E.tree_npages[tree_slot(E, b, half ^ 1u)] = dnp;  // (what a reset of the engine hands back)
+                    }
+                    return false;
+                }
                 const uint32_t wbase = q & ~63u;
                 const uint32_t lim = new_edges < wbase + 64u ? new_edges : wbase + 64u;
                 const uint32_t idx = wbase + (uint32_t)lane;
@@ -1581,6 +1620,7 @@ __device__ __forceinline__ void wave_reroot(EngineDev& E, int b, int lane, uint3
     }
     translate_records(E, b, lane, flipped ? edge : QZ_NONE);
     if (lane == 0) {
+        if (st != nullptr) st[0] = 0u;
         // successful copy: the old tree (now the other half) goes back to the pool; otherwise the
         // board restarts from a fresh root and its current half is returned
         E.release[b] = flipped ? 1 : 2;
@@ -1606,6 +1646,7 @@ __device__ __forceinline__ void wave_reroot(EngineDev& E, int b, int lane, uint3
         E.root_ne[b] = (uint32_t)root_ne;
         if (truncated) E.bc_overflow[b] += truncated;
     }
+    return true;
 }
 
 // lane 0 only; pages are given back by the caller (push-only kernels)
@@ -1628,6 +1669,7 @@ __device__ __forceinline__ void reset_board_state(EngineDev& E, int b) {
     E.pl_done[b] = 0u;
     E.pend_slot[b] = QZ_NONE;
     E.reroot_pend[b] = 0u;
+    E.compact_state[(size_t)b * 8] = 0u;
     E.compact_at[b] = E.compact_edges > 0 ? (uint32_t)E.compact_edges : 0u;
     E.game_serial[b] = E.game_serial[b] + 1u;
 }
@@ -1655,6 +1697,7 @@ __global__ __launch_bounds__(TPB) void k_reset(EngineDev E, int reset_boards) {
         E.pl_done[b] = 0u;
         E.pend_slot[b] = QZ_NONE;
         E.reroot_pend[b] = 0u;
+        E.compact_state[(size_t)b * 8] = 0u;
         E.compact_at[b] = E.compact_edges > 0 ? (uint32_t)E.compact_edges : 0u;
     }
 }
@@ -2083,7 +2126,7 @@ __device__ __forceinline__ void memo_insert(const EngineDev& E, const uint64_t h
 __device__ unsigned long long g_adv_stamps[4096][16];  // per board, accumulated over launches: cycles per phase + counts
 __device__ unsigned long long g_adv_stamps3[4096][4];  // cycles inside the descents: replay rounds, walked levels (+ set-up), record commit
 __device__ unsigned long long g_adv_stamps2[4096][4];  // levels confirmed by replay, replay rounds, rounds that confirmed < 8 levels
-#define QZ_AS_MARK(k) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); as_acc[k] += now_ - as_t; if ((k) == 3 && now_ - as_t > as_max[0]) as_max[0] = now_ - as_t; if ((k) == 4 && now_ - as_t > as_max[1]) as_max[1] = now_ - as_t; as_t = now_; }
+#define QZ_AS_MARK(k) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); as_acc[k] += now_ - as_t; if ((k) == 0 && now_ - as_t > as_max[0]) as_max[0] = now_ - as_t; if ((k) == 4 && now_ - as_t > as_max[1]) as_max[1] = now_ - as_t; as_t = now_; }
 #define QZ_AS_COUNT(k, v) { as_acc[k] += (unsigned long long)(v); }
 #else
 #define QZ_AS_MARK(k)
@@ -2103,6 +2146,10 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(QZ_ADV_WAVE
     if (b == 0 && lane == 0) atomicAdd(&E.counters[QZ_C_ROUNDS], 1ull);
     if (rfl(E.status[b]) != QZ_PLAYING) return;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long t_it = t0;
+#ifndef QZ_BUDGET_PREDICT
+#define QZ_BUDGET_PREDICT 1
+#endif
 #ifdef QZ_ADV_STAMPS
     unsigned long long as_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, as_max[2] = {0, 0}, as_t = __builtin_amdgcn_s_memtime();
     const unsigned long long as_t0 = as_t;
@@ -2112,7 +2159,10 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(QZ_ADV_WAVE
     {   // the compacting half of a move k_moves left for this launch (it runs beside the other boards' playouts)
         const uint32_t rp = rfl(E.reroot_pend[b]);
         if (rp != 0u) {
-            wave_reroot(E, b, lane, rp == 1u ? QZ_NONE : rp - 2u, false);
+            if (!wave_reroot(E, b, lane, rp == 1u ? QZ_NONE : rp - 2u, false, t0 + budget, E.compact_state + (size_t)b * 8)) {
+                if (lane == 0) atomicAdd(&E.counters[QZ_C_COMPACT_SLICES], 1ull);
+                return;  // the copy goes on in the board's next launch
+            }
             if (lane == 0) E.reroot_pend[b] = 0u;
             wave_sync();
             // (the copy found the pool empty: the board restarts from a fresh root in the SAME table half, whose pages
@@ -2174,7 +2224,14 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(QZ_ADV_WAVE
         }
         if (it >= max_iters) break;
         if (done >= (uint32_t)E.n_playout) break;  // the move is k_moves' job (the next round's first launch)
-        if (it > 0 && (unsigned int)(__builtin_amdgcn_s_memrealtime() - t0) > budget) break;
+        {   // no new playout once the budget is spent -- or would be overrun by a playout as long as this board's last one: boards
+            // digging a long line take 100+ us per descent, and the launch ends with its LAST wave (profiles/round3: the
+            // launches ran 0.29 ms over a 1 ms budget before this)
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            const unsigned int last = (unsigned int)(now - t_it);
+            t_it = now;
+            if (it > 0 && (unsigned int)(now - t0) + (QZ_BUDGET_PREDICT ? last : 0u) > budget) break;
+        }
         Board leaf;
         select_core(E, S, bb, ln, PM, leaf, pedge, plen, term);
         if (drop_if_too_deep(E, bb, ln, plen)) break;
@@ -2230,10 +2287,15 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(QZ_ADV_WAVE
         const unsigned long long whole = __builtin_amdgcn_s_memtime() - as_t0;
         g_adv_stamps[b][10] += whole;
         g_adv_stamps[b][11] += 1ull;
-        if (as_max[0] > g_adv_stamps[b][12]) g_adv_stamps[b][12] = as_max[0];  // longest single move
+        // launches that ran 15 % over their budget: how many, and what their prologue (a deferred compaction) and longest descent took
+        if ((unsigned int)(__builtin_amdgcn_s_memrealtime() - t0) > budget + budget / 7u) {
+            g_adv_stamps[b][12] += 1ull;
+            g_adv_stamps2[b][3] += as_max[0];
+            g_adv_stamps3[b][3] += as_max[1];
+            g_adv_stamps[b][15] += whole;
+        }
         if (as_max[1] > g_adv_stamps[b][13]) g_adv_stamps[b][13] = as_max[1];  // longest single descent
         if (whole > g_adv_stamps[b][14]) g_adv_stamps[b][14] = whole;          // longest launch of this board
-        g_adv_stamps[b][15] += as_max[0] > 0 ? 1ull : 0ull;                      // launches with a move
     }
 #endif
     if (lane == 0) {

@@ -606,7 +606,7 @@ def run_async(args, eng, net, rank, local, world, dev, qdist):
                                           "note": "the reference cannot finish these games either: a path longer than 992 levels overflows its recursive backup "
                                                   "(RecursionError, mcts.py:55-62), a root without a legal move crashes start_self_play (mcts.py:195-196)"},
         "engine_stats": {kk: st1[kk] for kk in ("node_overflow", "games_aborted", "aborted_no_move", "aborted_max_plies", "aborted_pool", "aborted_depth", "nonfinite_values",
-                                                "runaway_descents", "arena_bytes", "max_nodes", "max_edges", "max_depth", "tree_pages_total", "tree_pages_peak",
+                                                "runaway_descents", "compact_slices", "arena_bytes", "max_nodes", "max_edges", "max_depth", "tree_pages_total", "tree_pages_peak",
                                                 "traj_pages_total", "traj_pages_peak", "memo_inserts", "memo_locked")},
         "clocks": sampler.summary() if sampler else None,
     }

@@ -190,6 +190,8 @@ typedef struct {
     int64_t aborted_depth;     /* games dropped because a descent exceeded qz_config.max_depth (the reference's RecursionError) */
     int64_t runaway_descents;  /* descents cut off because they were deeper than a tree has edges (a cycle = corrupted tree
                                   storage): must be 0; the guard exists so that such a bug cannot hang the GPU   */
+    int64_t compact_slices;    /* subtree copies of the asynchronous loop that stopped at their launch's budget and went on
+                                  in the board's next launch (a 1,000-level line copies one level per memory round trip)  */
 } qz_stats;
 
 /* MCTSPlayer.__init__ / MCTS.__init__ (mcts.py:89-100, 159-161) for n_boards trees +

@@ -76,3 +76,4 @@ extern "C" int qzt_victim(float* out, int blocks, int iters, int kind, void* str
     hipLaunchKernelGGL(k_victim, dim3(blocks), dim3(192), 0, (hipStream_t)stream, out, iters, kind);
     return (int)hipGetLastError();
 }
+

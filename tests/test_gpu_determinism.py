@@ -151,3 +151,52 @@ def test_engine_runs_are_reproducible(gpu_device):
         eng.close()
     for ply, ((m0, p0), (m1, p1)) in enumerate(zip(*logs)):
         assert torch.equal(m0, m1) and torch.equal(p0, p1), ply
+
+
+def test_packed_fp32_fma_fed_from_lds_next_to_mfma_neighbours(gpu_device):
+    """the packed-fp32 hazard as a minimal kernel pair (tests/hip/qz_pk_hazard.hip): per iteration a
+    ds_read_b64 of a weight pair, then the FMA on it as ONE v_pk_fma_f32 or as two v_fma_f32, both in inline assembly.
+    Each variant runs alone (its reference) and then 40 times next to an MFMA-dense neighbour on a second stream
+    (tests/hip/qz_stress_kernels.hip, the neighbour that broke k_head in round 2).
+      * the two-v_fma_f32 form -- what the product is built to contain exclusively (csrc/Makefile: NO_PACKED_FP32) --
+        must never differ: HARD assertion;
+      * alone, the two forms agree bit for bit (same arithmetic): HARD assertion;
+      * the packed form next to the neighbour: the number of differing runs is REPORTED.  Non-zero = the hazard
+        reproduces in this minimal form on this box; zero = this form is not enough (round 2's finding for a
+        register-only victim) and the product-level guards stay the regression: the disassembly check of the CPU tier
+        and the determinism tests above."""
+    import ctypes as C
+    import os
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    H = C.CDLL(os.path.join(here, "hip", "libqz_pk_hazard.so"))
+    T = C.CDLL(os.path.join(here, "hip", "libqz_testkernels.so"))
+    H.qzt_lds_fma_victim.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    T.qzt_stress.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    blocks, iters = 2048, 4000
+    main = torch.cuda.current_stream()
+    side = torch.cuda.Stream()
+    sink = torch.zeros(4096 * 256, dtype=torch.float32, device=gpu_device)
+    src = torch.zeros(4096 * 256 + 16 * 65536, dtype=torch.float32, device=gpu_device)
+
+    def victim(packed, stream):
+        out = torch.empty(blocks * 256, dtype=torch.float32, device=gpu_device)
+        assert H.qzt_lds_fma_victim(out.data_ptr(), blocks, iters, packed, stream.cuda_stream) == 0
+        return out
+
+    torch.cuda.synchronize()
+    ref = {pk: victim(pk, main) for pk in (0, 1)}
+    torch.cuda.synchronize()
+    assert torch.equal(ref[0], ref[1]), "v_pk_fma_f32 and 2 x v_fma_f32 disagree without any neighbour"
+    differing = {0: 0, 1: 0}
+    for pk in (0, 1):
+        for rep in range(40):
+            with torch.cuda.stream(side):
+                assert T.qzt_stress(sink.data_ptr(), src.data_ptr(), 4096, 3000, 1, 1, side.cuda_stream) == 0  # MFMA loop only, 1 KB LDS
+            out = victim(pk, main)
+            torch.cuda.synchronize()
+            differing[pk] += int(not torch.equal(out, ref[pk]))
+    print("LDS-fed FMA victim next to an MFMA-dense neighbour, runs that differ of 40: 2 x v_fma_f32 %d, v_pk_fma_f32 %d%s"
+          % (differing[0], differing[1], "  (the packed-fp32 hazard reproduces in this minimal form)" if differing[1] else
+             "  (this minimal form is not disturbed; the product-level guards remain the regression)"))
+    assert differing[0] == 0, "the scalar form -- the only one the product contains -- changed next to an MFMA neighbour"

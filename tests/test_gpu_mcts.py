@@ -457,6 +457,14 @@ def test_32768_boards_at_400_playouts_fit_one_gpu(gpu_device):
     omask, status = oracle.movegen_batch(live[::64])
     assert (status >= 0).all() and np.array_equal(mask.cpu().numpy().view(np.uint32)[::64], omask)
     assert np.array_equal(planes.cpu().numpy()[::64], oracle.encode_batch(live[::64]))
+    # ... and the asynchronous loop at this size (32,768 wavefronts per launch, the miss list's rules op on a device-side
+    # count, memo tables of 32,768 boards): moves are played, nothing overflows, the memo answers
+    eng.finish_move()
+    eng.harvest()
+    eng.run_rounds(ev, 24, max_playouts=32, budget_us=1000)
+    st = eng.stats()
+    assert st["node_overflow"] == 0 and st["runaway_descents"] == 0 and st["games_aborted"] == 0 and st["rounds"] == 24
+    assert st["nn_evals"] > 0 and st["memo_inserts"] > 0 and st["playouts"] > 32768 * 490
     eng.close()
 
 
