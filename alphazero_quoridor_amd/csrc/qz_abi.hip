@@ -17,6 +17,7 @@
 namespace qzl {
 hipError_t movegen_encode(const uint64_t*, const uint64_t*, const uint64_t*, int, uint32_t*, float*, const uint8_t*, void*, const RulesOpts&, hipStream_t, const int* n_dev = nullptr);
 hipError_t advance(const EngineDev&, int, unsigned int, int, int, hipStream_t);
+hipError_t moves(const EngineDev&, hipStream_t);
 hipError_t round_tail(const EngineDev&, int, hipStream_t);
 hipError_t memo_flush(const EngineDev&, hipStream_t);
 size_t movegen_scratch_bytes(int);
@@ -124,6 +125,10 @@ struct qz_engine {
     float* feat = nullptr;     // [B][486] head features of the miss list (qz_selfplay_evaluate)
     EngineDev* dev_mem = nullptr;  // `dev` once more in device memory (k_advance's rarely-run paths read it from there)
     int par = 0;               // which of the two miss counters the round in progress uses
+    bool async_moves = false;  // qz_selfplay_advance has run with auto_finish: boards may hold a move whose subtree copy is not done
+    // qz_selfplay_round: the rules op of the miss list and the finished boards' moves run beside the network's trunk
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     size_t memo_small_bytes = 0, memo_big_bytes = 0;
     unsigned flushes = 0;
     std::vector<void*> allocs;
@@ -248,6 +253,9 @@ int qz_engine_destroy(qz_engine* e) {
     if (!e) return 0;
     (void)hipSetDevice(e->cfg.device);
     (void)hipDeviceSynchronize();
+    if (e->side) (void)hipStreamDestroy(e->side);
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     for (void* p : e->allocs) (void)hipFree(p);
     delete e;
     return 0;
@@ -399,7 +407,10 @@ int qz_engine_create(const qz_config* cfg, qz_engine** out) {
     // memo tables: powers of two; auto = 4,096 small + 512 big entries per board
     if (c.memo_small_log2 >= 0 && c.memo_big_log2 >= 0) {
         auto log2_ceil = [](unsigned long long x) { int l = 0; while ((1ull << l) < x) l++; return l; };
-        if (c.memo_small_log2 == 0) c.memo_small_log2 = log2_ceil((unsigned long long)B * 4096ull / QZ_MEMO_S_WAYS);
+        if (c.memo_small_log2 == 0) {  // 16,384 entries per board (2 MB), at most 2^24 buckets (8 GB)
+            c.memo_small_log2 = log2_ceil((unsigned long long)B * 16384ull / QZ_MEMO_S_WAYS);
+            if (c.memo_small_log2 > 24) c.memo_small_log2 = 24;
+        }
         if (c.memo_big_log2 == 0) c.memo_big_log2 = log2_ceil((unsigned long long)B * 512ull / QZ_MEMO_B_WAYS);
         if (c.memo_small_log2 > 31 || c.memo_big_log2 > 31) rc = rc ? rc : fail(QZ_E_INVALID, "memo table too large");
         const size_t sb = ((size_t)1 << c.memo_small_log2), bb = ((size_t)1 << c.memo_big_log2);
@@ -474,10 +485,20 @@ int qz_engine_create(const qz_config* cfg, qz_engine** out) {
         if (!(e)) return fail(QZ_E_INVALID, "null engine");      \
         HIP_TRY(hipSetDevice((e)->cfg.device));                  \
     } while (0)
+// the lock-step tree entry points: not on an engine whose boards play on their own clocks (a board may be waiting for an
+// evaluation, or hold a move whose subtree copy is left for its next launch -- its root fields still describe the old tree)
+#define LOCKSTEP_CHECK(e)                                                                                                   \
+    do {                                                                                                                    \
+        ENGINE_CHECK(e);                                                                                                    \
+        if ((e)->async_moves)                                                                                               \
+            return fail(QZ_E_INVALID, "engine is in asynchronous self-play (qz_selfplay_advance with auto_finish): "       \
+                                      "reset it (qz_engine_reset / qz_engine_set_boards with reset_trees) before a lock-step call"); \
+    } while (0)
 
 int qz_engine_reset(qz_engine* e, void* stream) {
     ENGINE_CHECK(e);
     HIP_TRY(qzl::reset(e->dev, 1, (hipStream_t)stream));
+    e->async_moves = false;
     return 0;
 }
 
@@ -490,7 +511,10 @@ int qz_engine_set_boards(qz_engine* e, const qz_boards* src, int reset_trees, vo
     HIP_TRY(hipMemcpyAsync(e->dev.root_hb, src->hbits, nb, hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipMemcpyAsync(e->dev.root_vb, src->vbits, nb, hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipMemcpyAsync(e->dev.root_meta, src->meta, nb, hipMemcpyDeviceToDevice, s));
-    if (reset_trees) HIP_TRY(qzl::reset(e->dev, 0, s));
+    if (reset_trees) {
+        HIP_TRY(qzl::reset(e->dev, 0, s));
+        e->async_moves = false;
+    }
     return 0;
 }
 
@@ -542,7 +566,7 @@ int qz_engine_set_rules_opts(qz_engine* e, const qz_rules_opts* opts) {
 }
 
 int qz_mcts_descend(qz_engine* e, void* stream) {
-    ENGINE_CHECK(e);
+    LOCKSTEP_CHECK(e);
     HIP_TRY(qzl::select(e->dev, (hipStream_t)stream));
     return 0;
 }
@@ -565,7 +589,7 @@ int qz_mcts_select(qz_engine* e, float* leaf_planes, uint32_t* leaf_mask5, uint8
 }
 
 int qz_mcts_select_boards(qz_engine* e, const qz_boards* leaf_out, uint32_t* leaf_mask5, uint8_t* leaf_terminal, void* stream) {
-    ENGINE_CHECK(e);
+    LOCKSTEP_CHECK(e);
     int r;
     if ((r = check_boards(leaf_out, e->cfg.n_boards))) return r;
     hipStream_t s = (hipStream_t)stream;
@@ -583,14 +607,14 @@ int qz_mcts_select_boards(qz_engine* e, const qz_boards* leaf_out, uint32_t* lea
 }
 
 int qz_mcts_expand_backup(qz_engine* e, const float* p, const float* v, void* stream) {
-    ENGINE_CHECK(e);
+    LOCKSTEP_CHECK(e);
     if (!p || !v) return fail(QZ_E_INVALID, "p/v is null");
     HIP_TRY(qzl::expand_backup(e->dev, p, v, (hipStream_t)stream));
     return 0;
 }
 
 int qz_mcts_expand_backup_descend(qz_engine* e, const float* p, const float* v, void* stream) {
-    ENGINE_CHECK(e);
+    LOCKSTEP_CHECK(e);
     if (!p || !v) return fail(QZ_E_INVALID, "p/v is null");
     HIP_TRY(qzl::expand_backup_select(e->dev, p, v, (hipStream_t)stream));
     return 0;
@@ -610,14 +634,14 @@ int qz_mcts_root_children(qz_engine* e, int32_t* visits, double* q, float* prior
 }
 
 int qz_mcts_update_with_move(qz_engine* e, const uint8_t* moves, void* stream) {
-    ENGINE_CHECK(e);
+    LOCKSTEP_CHECK(e);
     if (!moves) return fail(QZ_E_INVALID, "moves is null");
     HIP_TRY(qzl::update_with_move(e->dev, moves, (hipStream_t)stream));
     return 0;
 }
 
 int qz_mcts_finish_move(qz_engine* e, const uint8_t* forced_move, float* pi_out, uint8_t* move_out, void* stream) {
-    ENGINE_CHECK(e);
+    LOCKSTEP_CHECK(e);
     HIP_TRY(qzl::finish_move(e->dev, forced_move, pi_out, move_out, (hipStream_t)stream));
     return 0;
 }
@@ -893,6 +917,7 @@ int qz_selfplay_advance(qz_engine* e, int max_playouts, int budget_us, int auto_
     if (max_playouts <= 0) return fail(QZ_E_INVALID, "max_playouts must be > 0");
     const unsigned int ticks = budget_us > 0 ? (unsigned int)budget_us * 100u : 0xFFFFFFFFu;  // s_memrealtime: 100 MHz
     HIP_TRY(qzl::advance(e->dev, max_playouts, ticks, auto_finish, e->par, (hipStream_t)stream));
+    if (auto_finish) e->async_moves = true;
     return 0;
 }
 int qz_selfplay_leaf_rules(qz_engine* e, void* stream) {
@@ -916,10 +941,34 @@ int qz_selfplay_round_tail(qz_engine* e, void* stream) {
     return 0;
 }
 int qz_selfplay_round(qz_engine* e, const qz_nn_weights* w, int max_playouts, int budget_us, int auto_finish, void* stream) {
+    // The four pieces, with what does not depend on the network beside it: after k_advance the legal sets of the miss list
+    // (read by the round's tail and the next launch, not by the network) and the moves of the boards that have done their
+    // playouts (k_moves: the boards' own trees, roots and trajectories; it only pops pages, the tail only pushes, and the
+    // tail waits for both) run on a second stream while the trunk has the matrix cores.  Per board the order of operations
+    // is the one of the separate calls: ... playouts, move, playouts ...
+    ENGINE_CHECK(e);
     int r;
-    if ((r = qz_selfplay_advance(e, max_playouts, budget_us, auto_finish, stream))) return r;
-    if ((r = qz_selfplay_leaf_rules(e, stream))) return r;
-    if ((r = qz_selfplay_evaluate(e, w, stream))) return r;
+    if (max_playouts <= 0) return fail(QZ_E_INVALID, "max_playouts must be > 0");
+    if ((r = nn_weights_check(w))) return r;
+    hipStream_t s = (hipStream_t)stream;
+    if (!e->side) {
+        HIP_TRY(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+    }
+    const EngineDev& d = e->dev;
+    const unsigned int ticks = budget_us > 0 ? (unsigned int)budget_us * 100u : 0xFFFFFFFFu;  // s_memrealtime: 100 MHz
+    HIP_TRY(qzl::advance(d, max_playouts, ticks, 0, e->par, s));
+    HIP_TRY(hipEventRecord(e->ev_fork, s));
+    HIP_TRY(hipStreamWaitEvent(e->side, e->ev_fork, 0));
+    HIP_TRY(qzl::movegen_encode(d.miss_hb, d.miss_vb, d.miss_meta, d.n_boards, d.miss_mask, nullptr, nullptr, e->scratch, e->rules, e->side, d.miss_count + e->par));
+    if (auto_finish) {
+        HIP_TRY(qzl::moves(d, e->side));
+        e->async_moves = true;
+    }
+    HIP_TRY(hipEventRecord(e->ev_join, e->side));
+    if ((r = nn_evaluate(d.miss_hb, d.miss_vb, d.miss_meta, nullptr, d.n_boards, w, e->feat, d.miss_p, d.miss_v, d.miss_count + e->par, s))) return r;
+    HIP_TRY(hipStreamWaitEvent(s, e->ev_join, 0));
     return qz_selfplay_round_tail(e, stream);
 }
 int qz_selfplay_misses(qz_engine* e, qz_boards* boards_out, const int32_t** n_dev_out, uint32_t** mask5_out, float** p_out, float** v_out) {

@@ -1009,7 +1009,9 @@ __device__ __forceinline__ void select_core(EngineDev& E, BoardRegs& S, const in
             }
             if (use && rfl(recorded) != e && !(cur != QZ_NONE && plen >= cur_len)) {  // (beyond the end of the record it follows, a descent extends it)
                 // the path leaves the record it was following (or follows none): go on in the record that took this
-                // edge last, if that record still holds the edge at this level
+                // edge last, if that record still holds the edge at this level.  (Asking memory costs this level a second
+                // dependent round trip; following the named record on trial instead -- the next replay round or walked level
+                // shows whether it holds the path -- measured 2 % SLOWER, same-box A/B: the hint is wrong too often)
                 if (cur != QZ_NONE) {
                     left_rec = cur;
                     left_at = plen;
@@ -1537,9 +1539,10 @@ __device__ __forceinline__ bool wave_reroot(EngineDev& E, int b, int lane, uint3
             root_off = off;
             root_ne = s_ne;
             flipped = true;
+            const uint32_t q_first = q;
             while (q < new_edges) {  // wave-uniform
                 wave_sync();
-                if (st != nullptr && __builtin_amdgcn_s_memrealtime() > deadline) {
+                if (st != nullptr && q > q_first && __builtin_amdgcn_s_memrealtime() > deadline) {  // (every call gets somewhere)
                     if (lane == 0) {
                         st[0] = 1u;
                         st[1] = q;
@@ -2645,6 +2648,10 @@ hipError_t finish_move(const EngineDev& E, const uint8_t* forced, float* pi_out,
 hipError_t advance(const EngineDev& E, int max_iters, unsigned int budget_ticks, int auto_finish, int par, hipStream_t s) {
     if (auto_finish) hipLaunchKernelGGL(k_moves, wave_grid(E.n_boards), dim3(TPB), 0, s, E);
     hipLaunchKernelGGL(k_advance, wave_grid(E.n_boards), dim3(TPB), 0, s, E, max_iters, budget_ticks, par);
+    return hipGetLastError();
+}
+hipError_t moves(const EngineDev& E, hipStream_t s) {
+    hipLaunchKernelGGL(k_moves, wave_grid(E.n_boards), dim3(TPB), 0, s, E);
     return hipGetLastError();
 }
 hipError_t round_tail(const EngineDev& E, int par, hipStream_t s) {

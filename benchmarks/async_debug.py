@@ -13,7 +13,7 @@ EVERY = int(os.environ.get("EVERY", max(1, ITERS // 20))); GRAPH = int(os.enviro
 dev = torch.device("cuda:0"); torch.manual_seed(int(os.environ.get("SEED", 0)))
 ev = PolicyValueNet(use_gpu=True).evaluator("per_leaf")
 G = int(os.environ.get("NGROUPS", 1))  # independent engines of B / G boards, each on its own HIP stream (their launches overlap)
-engs = [SelfPlayEngine(B // G, n_playout=NP, seed=77 + 1000 * g, device=dev, fix_terminal_sign=bool(FIX), select_opts=SEL, max_depth=int(os.environ.get("MAXD", 0))) for g in range(G)]
+engs = [SelfPlayEngine(B // G, n_playout=NP, seed=77 + 1000 * g, device=dev, fix_terminal_sign=bool(FIX), select_opts=SEL, max_depth=int(os.environ.get("MAXD", 0)), memo_small_log2=int(os.environ.get("MSL", 0)), memo_big_log2=int(os.environ.get("MBL", 0))) for g in range(G)]
 streams = [torch.cuda.Stream(device=dev) for _ in range(G)]
 SKIP = int(os.environ.get("SKIP_ROUNDS", 0))  # rounds played before the statistics start (from the opening to the late-game regime)
 

@@ -134,8 +134,8 @@ typedef struct {
     int32_t select_opts;       /* A/B switches of the descent kernel (0 = defaults): bit 0 = walk every level (no replay of
                                   recorded descents; same results, the test partner of the records), bit 1 = no readlane
                                   scan for nodes with <= 8 children */
-    /* Leaf-evaluation memo (qz_selfplay_*): log2 of the number of buckets of its two tables; 0 = auto (4,096 small entries
-     * and 512 big entries per board, rounded up to a power of two), < 0 = no memo (every leaf goes to the network).
+    /* Leaf-evaluation memo (qz_selfplay_*): log2 of the number of buckets of its two tables; 0 = auto (16,384 small entries
+     * -- at most 8 GB -- and 512 big entries per board, rounded up to a power of two), < 0 = no memo (every leaf goes to the network).
      * small: leaves whose mover has no wall left, 4 entries of 128 B per bucket; big: all others, 2 x 640 B. */
     int32_t memo_small_log2, memo_big_log2;
     /* qz_selfplay_*: update_with_move (mcts.py:146-151) keeps the chosen child's subtree WHERE IT IS while the tree's
@@ -409,13 +409,19 @@ int qz_nn_evaluate_w(const qz_boards* boards /*[dev] arrays*/, const uint8_t* te
  *     qz_selfplay_leaf_rules  Quoridor.actions() of the miss list (the same kernel as qz_mcts_leaf_inputs)
  *     qz_selfplay_evaluate    the network on the miss list (qz_nn_evaluate on the first *n boards)
  *     qz_selfplay_round_tail  store the evaluations in the memo; hand replaced trees back to the pool
- * and qz_selfplay_round is the four in one call.  Nothing synchronises; the whole round can be captured in a HIP
- * graph (the miss count stays on the device).  Per board the operations and their order are those of the lock-step
+ * and qz_selfplay_round is the four in one call, with what does not depend on the network moved beside it: the rules
+ * op and the moves of the boards that have done their playouts run on a second stream of the engine while the trunk
+ * has the matrix cores (the round's tail waits for both).  Nothing synchronises with the host; the whole round can be
+ * captured in a HIP graph (the miss count stays on the device; the second stream joins the capture through events).  Per board the operations and their order are those of the lock-step
  * entry points above, so trees, pi, sampled moves and harvested tuples are bit-identical to a lock-step run of the
  * same seed; only the interleaving between boards differs.  Finished games wait for qz_harvest as before.
  *   max_playouts  playouts a board may START per round (1 = the lock-step cadence: n_playout + 1 rounds per move)
  *   budget_us     a board starts no new playout once this much wall time of the launch has passed (0 = no limit)
- *   auto_finish   0: boards stop at n_playout and the host calls qz_mcts_finish_move */
+ *   auto_finish   0: boards stop at n_playout and the host calls qz_mcts_finish_move (once no board is waiting:
+ *                 qz_stats.waiting_boards == 0).  Non-zero: from then on the engine's boards are on their own clocks -- one
+ *                 may be waiting for an evaluation or hold a move whose subtree copy is left for its next launch -- and
+ *                 the lock-step tree entry points (qz_mcts_descend / select* / expand_backup* / update_with_move /
+ *                 finish_move) return QZ_E_INVALID until qz_engine_reset or qz_engine_set_boards(reset_trees) */
 int qz_selfplay_advance(qz_engine* e, int max_playouts, int budget_us, int auto_finish, void* stream);
 int qz_selfplay_leaf_rules(qz_engine* e, void* stream);
 int qz_selfplay_evaluate(qz_engine* e, const qz_nn_weights* w, void* stream);

@@ -106,7 +106,7 @@ def _games_by_slot(batches):
     return out
 
 
-@pytest.mark.parametrize("compact_edges,budget_us,pool_pages", [(0, 0, 0), (-1, 0, 0), (0, 300, 192 * 60)])
+@pytest.mark.parametrize("compact_edges,budget_us,pool_pages", [(0, 0, 0), (-1, 0, 0), (0, 300, 192 * 60), (-1, 1, 0)])
 def test_asynchronous_games_equal_lockstep_games(gpu_device, compact_edges, budget_us, pool_pages):
     """Complete self-play games (Dirichlet noise, sampled moves, subtree reuse, continuous refill) from the
     asynchronous loop -- boards on their own clocks, several playouts and whole moves per launch, memo on --
@@ -115,7 +115,10 @@ def test_asynchronous_games_equal_lockstep_games(gpu_device, compact_edges, budg
     ways a move treats the kept subtree: the default threshold of this small engine (one page: compacting
     moves, deferred to the start of a launch, and in-place moves mixed), always copied (-1, what the lock-step
     engine does), and a large pool whose threshold (20 pages) these trees rarely reach: moves in place, under a
-    wall-clock budget per launch."""
+    wall-clock budget per launch.  Last: always copied under a budget of 1 us -- one playout per launch, and every subtree
+    copy stops after its first window of 64 edges and goes on, window by window, in the board's next launches
+    (qz_stats.compact_slices).  Afterwards the engine refuses lock-step calls until it is reset."""
+    from alphazero_quoridor_amd import _cabi
     from alphazero_quoridor_amd.engine import SelfPlayEngine
 
     B, NP = 192, 24
@@ -152,6 +155,15 @@ def test_asynchronous_games_equal_lockstep_games(gpu_device, compact_edges, budg
               % (compared, st["rounds"], st["playouts"], st["memo_hits"], st["nn_evals"]))
         assert compared >= n_lock // 2, (compared, n_lock)
         assert st["node_overflow"] == 0 and st["runaway_descents"] == 0
+        if budget_us == 1:
+            assert st["compact_slices"] > 0, st
+            print("subtree copies suspended and resumed: %d" % st["compact_slices"])
+        else:
+            assert st["compact_slices"] == 0 or budget_us > 0, st
+        with pytest.raises(_cabi.QzError, match="asynchronous self-play"):
+            asyn.select(want_planes=False)
+        asyn.reset()
+        asyn.select(want_planes=False)
     finally:
         lock.close()
         asyn.close()
