@@ -2159,8 +2159,10 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(QZ_ADV_WAVE
 #endif
     PathMirror PM{(lds_u32*)s_we[wave], (lds_u64*)s_wb[wave], ADV_LCAP, 0u};
     const PathMirror NOPM{(lds_u32*)nullptr, (lds_u64*)nullptr, 0u, 0u};
+    bool copied = false;  // this launch finished a subtree copy: that is its progress if the budget went into it
     {   // the compacting half of a move k_moves left for this launch (it runs beside the other boards' playouts)
         const uint32_t rp = rfl(E.reroot_pend[b]);
+        copied = rp != 0u;
         if (rp != 0u) {
             if (!wave_reroot(E, b, lane, rp == 1u ? QZ_NONE : rp - 2u, false, t0 + budget, E.compact_state + (size_t)b * 8)) {
                 if (lane == 0) atomicAdd(&E.counters[QZ_C_COMPACT_SLICES], 1ull);
@@ -2234,6 +2236,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(QZ_ADV_WAVE
             const unsigned int last = (unsigned int)(now - t_it);
             t_it = now;
             if (it > 0 && (unsigned int)(now - t0) + (QZ_BUDGET_PREDICT ? last : 0u) > budget) break;
+            if (copied && (unsigned int)(now - t0) > budget) break;
         }
         Board leaf;
         select_core(E, S, bb, ln, PM, leaf, pedge, plen, term);

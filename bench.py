@@ -17,9 +17,10 @@ Every board runs its 400 playouts per move on its own clock; a leaf whose evalua
 leaf-evaluation memo (policy_value_fn on a batch of one is a pure function of the 24-byte board)
 is expanded from the memo, every other leaf is evaluated by the network as before, bit for bit
 the same search as the lock-step engine (tests/test_gpu_async.py).  A STEP is --rounds-per-step
-(256) rounds, a round = one pass of the hot path over all boards: k_moves (moves of the boards
-that finished their playouts), k_advance (playouts until every board needs the network),
-Quoridor.actions() + the network on the leaves the memo does not know, memo insert.  Then the
+(256) rounds, a round = one pass of the hot path over all boards: k_advance (playouts until every
+board needs the network or its time budget is used), the network on the leaves the memo does not
+know -- with Quoridor.actions() of those leaves and k_moves (the moves of the boards that have
+done their playouts) on a second stream beside it -- and the memo insert.  Then the
 finished games are harvested (+ all-gathered).  Nothing is skipped: every one of the 400
 playouts of every move descends, expands and backs up exactly as the reference does, every leaf
 gets the reference's evaluation -- from the network the first time, from the memo afterwards.
@@ -559,8 +560,10 @@ def run_async(args, eng, net, rank, local, world, dev, qdist):
                            B, args.playouts),
             "mode": "async", "boards_per_gpu": B, "board_groups": G, "fix_terminal_sign": bool(args.fix_terminal_sign), "n_playout": args.playouts,
             "bn_mode": args.bn, "nn_dtype": args.nn_dtype,
-            "step": "%d rounds; a round = k_moves + k_advance (every board: playouts until it needs the network, %d us budget) + actions() and "
-                    "network on the leaves the memo does not know + memo insert" % (R, args.budget_us),
+            "step": "%d rounds; a round = k_advance (every board: playouts until it needs the network, %d us budget) + network on the leaves the memo "
+                    "does not know (actions() of those leaves and k_moves, the moves of the boards that finished their playouts, on a second stream "
+                    "beside the trunk) + memo insert; every %d-th round is issued piece by piece (k_moves + k_advance, actions(), network, tail) "
+                    "with HIP events around the pieces" % (R, args.budget_us, ev_every),
             "max_depth": args.max_depth, "rounds_per_step": R, "budget_us": args.budget_us, "max_playouts_per_round": args.max_playouts, "graph_rounds": args.graph_rounds,
             "desync": "%d untimed plies at %d playouts/move (%.0fs, %d games finished)" % (args.desync_plies, args.desync_playouts, desync_s, len(lengths["desync"])),
         },
@@ -648,7 +651,7 @@ def main():
     ap.add_argument("--budget-us", type=int, default=1000, help="async: wall-clock budget of a k_advance launch")
     ap.add_argument("--max-playouts", type=int, default=4096, help="async: playouts a board may start per round")
     ap.add_argument("--graph-rounds", type=int, default=0, help="async: capture this many (even) rounds per HIP graph (0 = eager launches, per-kernel events)")
-    ap.add_argument("--event-every", type=int, default=4, help="async: every n-th round of group 0 is issued in pieces with HIP events around them")
+    ap.add_argument("--event-every", type=int, default=8, help="async: every n-th round of group 0 is issued in pieces with HIP events around them")
     ap.add_argument("--max-depth", type=int, default=992,
                     help="drop a game whose playout descends more than this many levels (0 = never).  992 = where the reference's recursive backup "
                          "(mcts.py:55-62) overflows Python's recursion limit under `python train.py` and ends the run with a RecursionError")
