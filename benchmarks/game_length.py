@@ -136,7 +136,7 @@ def main():
         "hazard_by_bin": hazards,
         "stats": {k: st[k] for k in ("games_finished", "plies_played", "playouts", "leaf_terminal", "node_overflow", "games_aborted",
                                      "aborted_no_move", "aborted_max_plies", "aborted_pool", "aborted_depth", "max_depth", "tree_pages_peak", "tree_pages_total",
-                                     "traj_pages_peak", "traj_pages_total", "max_edges")},
+                                     "traj_pages_peak", "traj_pages_total", "max_edges", "runaway_descents", "compact_slices", "memo_inserts", "memo_hits", "nn_evals", "rounds")},
     }
     text = json.dumps(out)
     if args.out:
