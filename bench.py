@@ -590,9 +590,12 @@ def run_async(args, eng, net, rank, local, world, dev, qdist):
         "roofline": line("k_moves + k_advance (one wavefront per board: moves of the boards that finished their playouts, then descents (recorded descents "
                          "replayed 64 levels per round trip), memo probes, expansions and backups until the board needs the network or the budget is used)",
                          adv_us, adv_bytes,
-                         "dependent-load latency, not bandwidth: a playout is a chain of ~10 memory round trips (record -> edge blocks -> ... -> memo "
-                         "bucket -> backup) of a single wavefront, four wavefronts per SIMD; %.0f playouts per launch, mean depth %.1f.  The launch lasts "
-                         "its time budget + the slowest board (a subtree compaction); see DESIGN" % (per_launch["playouts"], d["descent_levels"] / max(d["playouts"], 1)),
+                         "dependent-load latency and instruction issue, not bandwidth: a playout is a chain of ~10 memory round trips (record -> edge "
+                         "blocks -> ... -> memo bucket -> backup) of a single wavefront with ~1,300 instructions between them (the PUCT expression in "
+                         "float64), four wavefronts per SIMD (SQ counters: a wavefront issues in 39 %% of its cycles, profiles/round3/"
+                         "pmc_sq_async_late_game.json); %.0f playouts per launch, mean depth %.1f.  The launch lasts its time budget + the last "
+                         "playouts (subtree copies stop at the budget and resume in the next launch); see DESIGN 3.0"
+                         % (per_launch["playouts"], d["descent_levels"] / max(d["playouts"], 1)),
                          traffic=(t_adv or {}).get("traffic_bytes_per_launch"), src=("profiles: " + os.path.relpath(_latest_profile("pmc_traffic_advance.json"), ROOT)) if t_adv else None),
         "roofline_rules": line("k_wave_rules on the miss list (Quoridor.actions() of the leaves the memo does not know; legal sets only)", rules_us, miss_per_round * 44,
                                "%.0f leaves per launch: a launch lasts as long as one board's dependent chain" % miss_per_round),
@@ -602,8 +605,9 @@ def run_async(args, eng, net, rank, local, world, dev, qdist):
             "bound": "mfma", "achieved": conv_flops * miss_per_round / (nn_us * 1e-6) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
             "frac": conv_flops * miss_per_round / (nn_us * 1e-6) / 1e12 / 2500.0, "traffic": None, "avg_launch_us": nn_us, "launches_timed": len(evs),
             "leaves_per_launch": miss_per_round,
-            "note": "one leaf per 2-wave workgroup: with %.0f leaves per launch the launch lasts as long as ONE leaf's eleven layers (latency), the "
-                    "chip is mostly idle; at 4,096 leaves per launch (lock-step mode, the opening phase) the same kernel reaches 0.135" % miss_per_round},
+            "note": "one leaf per 2-wave workgroup, 1,024 workgroups resident: with %.0f leaves per launch every SIMD issues about one leaf's 28.5 k "
+                    "MFMAs (three products per fp32-accurate product: 3.56x the useful flops counted here), a second pass above 1,024 leaves; at 4,096 "
+                    "leaves per launch (lock-step mode, the opening phase) the same kernel reaches 0.135" % miss_per_round},
         "round_tail_us": tail_us,
         "games_dropped_in_timed_region": {"total": d["games_aborted"], "depth_over_%d_levels" % args.max_depth: d["aborted_depth"], "no_legal_move": d["aborted_no_move"],
                                           "note": "the reference cannot finish these games either: a path longer than 992 levels overflows its recursive backup "
