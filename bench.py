@@ -592,8 +592,8 @@ def run_async(args, eng, net, rank, local, world, dev, qdist):
                          adv_us, adv_bytes,
                          "dependent-load latency and instruction issue, not bandwidth: a playout is a chain of ~10 memory round trips (record -> edge "
                          "blocks -> ... -> memo bucket -> backup) of a single wavefront with ~1,300 instructions between them (the PUCT expression in "
-                         "float64), four wavefronts per SIMD (SQ counters: a wavefront issues in 39 %% of its cycles, profiles/round3/"
-                         "pmc_sq_async_late_game.json); %.0f playouts per launch, mean depth %.1f.  The launch lasts its time budget + the last "
+                         "float64), four wavefronts per SIMD which slow each other by 15 %% (SQ counters: a wavefront issues in 39 %% of its cycles, waits for "
+                         "memory in 44 %%: profiles/round3/pmc_sq_async_late_game.json); %.0f playouts per launch, mean depth %.1f.  The launch lasts its time budget + the last "
                          "playouts (subtree copies stop at the budget and resume in the next launch); see DESIGN 3.0"
                          % (per_launch["playouts"], d["descent_levels"] / max(d["playouts"], 1)),
                          traffic=(t_adv or {}).get("traffic_bytes_per_launch"), src=("profiles: " + os.path.relpath(_latest_profile("pmc_traffic_advance.json"), ROOT)) if t_adv else None),
