@@ -822,9 +822,6 @@ __device__ __forceinline__ void select_core(EngineDev& E, BoardRegs& S, const in
 #ifndef QZ_REPLAY_MIRROR
 #define QZ_REPLAY_MIRROR 1
 #endif
-#ifndef QZ_REPLAY_SPEC
-#define QZ_REPLAY_SPEC 0  // (the edge records requested before the parent-link check: measured no faster, same-box A/B)
-#endif
                 const bool mir = QZ_REPLAY_MIRROR && cur == src && cur_len <= PM.valid;  // wave-uniform (PM.valid = 0 without a mirror)
                 if (ok) {
                     if (mir) {
@@ -844,32 +841,29 @@ __device__ __forceinline__ void select_core(EngineDev& E, BoardRegs& S, const in
                 // BELIEVED after the check below (a stale entry points at memory of the pool that now means something else: the
                 // loads are harmless -- lne <= 8 records inside the pool -- and their values are thrown away)
                 ok = ok && lne >= 1 && lne <= 8;
-                // (only the fields the replay needs: Q, N, P, coff, act | cne | rid -- 6 registers per edge record, not 8:
-                // this array is the register peak of the descent)
-                struct EdgeLite {
-                    double Q;
-                    uint32_t N;
-                    float P;
-                    uint32_t coff;
-                    uint8_t act, cne;
-                    uint16_t rid;
+                // All of the round's loads are ISSUED TOGETHER, as raw dwords, before anything looks at them: the parent edge
+                // (its visit count and child block) and the node's <= 8 edge records -- Q, N, P, coff, act | cne | rid: 6
+                // registers per record, this array is the register peak of the descent.  (Written field by field the loads came
+                // out one record at a time, each behind an s_waitcnt for the previous one -- unpacking act / cne is a use --: eight
+                // dependent trips to the cache per round instead of one.)  A lane without a believable entry reads record 0 of the
+                // pool as its parent and throws it away.
+                struct EdgeRaw {
+                    uint32_t q_lo, q_hi, N, P, coff, misc;
                 };
-                EdgeLite ed[8];
-                if (ok) {
-                    if (lane > 0) {
-                        const Edge* pv = &pool[prev];
-                        pN = pv->N;
-                        pcoff = pv->coff;
-                    }
-#if QZ_REPLAY_SPEC
+                EdgeRaw er[8];
+                {
+                    const uint4* pq = reinterpret_cast<const uint4*>(&pool[(ok && lane > 0) ? prev : 0u]);
+                    const uint4 pa = pq[0], pc = pq[1];
 #pragma unroll
-                    for (int j = 0; j < 8; j++)
-                        if (j < lne) {
-                            const Edge* src_e = &pool[lbase + (uint32_t)j];
-                            ed[j].Q = src_e->Q; ed[j].N = src_e->N; ed[j].P = src_e->P; ed[j].coff = src_e->coff;
-                            ed[j].act = src_e->act; ed[j].cne = src_e->cne; ed[j].rid = src_e->rid;
+                    for (int j = 0; j < 8; j++) {
+                        if (ok && j < lne) {  // (a node has 2.2 children on average: no requests for the slots it does not have)
+                            const uint4* q = reinterpret_cast<const uint4*>(&pool[lbase + (uint32_t)j]);
+                            const uint4 a = q[0], c = q[1];
+                            er[j].q_lo = a.x; er[j].q_hi = a.y; er[j].N = a.z; er[j].P = a.w; er[j].coff = c.y; er[j].misc = c.z;
                         }
-#endif
+                    }
+                    pN = pa.z;
+                    pcoff = pc.y;
                 }
                 // an entry counts only if its block IS the child block of the entry above (lane 0: the current node)
                 const uint32_t linked = tree_phys_lanes(T, pcoff);
@@ -877,33 +871,26 @@ __device__ __forceinline__ void select_core(EngineDev& E, BoardRegs& S, const in
                 uint32_t lact = 0u, lcne = 0u, lN = 0u, lcoff = 0u;
                 if (ok) {
                     const double lsq = lane > 0 ? sqrt((double)pN) : sq;
-#if !QZ_REPLAY_SPEC
-#pragma unroll
-                    for (int j = 0; j < 8; j++)
-                        if (j < lne) {
-                            const Edge* src_e = &pool[lbase + (uint32_t)j];
-                            ed[j].Q = src_e->Q; ed[j].N = src_e->N; ed[j].P = src_e->P; ed[j].coff = src_e->coff;
-                            ed[j].act = src_e->act; ed[j].cne = src_e->cne; ed[j].rid = src_e->rid;
-                        }
-#endif
                     double lbest = 0.0;
                     int arg = 0;
+                    uint32_t lmisc = 0u;
 #pragma unroll
                     for (int j = 0; j < 8; j++) {
                         if (j < lne) {
-                            const float cp = E.c_puct * ed[j].P;
-                            const double u = (double)cp * lsq / (double)(1u + ed[j].N);
-                            const double val = ed[j].Q + u;
+                            const float cp = E.c_puct * __uint_as_float(er[j].P);
+                            const double u = (double)cp * lsq / (double)(1u + er[j].N);
+                            const double val = __hiloint2double((int)er[j].q_hi, (int)er[j].q_lo) + u;
                             if (j == 0 || val > lbest) {  // first maximum, like max() over the children dict
                                 lbest = val;
                                 arg = j;
-                                lact = ed[j].act;
-                                lcne = ed[j].cne;
-                                lN = ed[j].N;
-                                lcoff = ed[j].coff;
+                                lmisc = er[j].misc;
+                                lN = er[j].N;
+                                lcoff = er[j].coff;
                             }
                         }
                     }
+                    lact = lmisc & 0xFFu;
+                    lcne = (lmisc >> 8) & 0xFFu;
                     ok = (lbase + (uint32_t)arg == chosen) && (lbest == lbest);
                 }
                 const uint64_t bad = ~__ballot(ok);
@@ -959,20 +946,24 @@ __device__ __forceinline__ void select_core(EngineDev& E, BoardRegs& S, const in
             uint32_t mCOff = 0u, mMisc = 0u;
             double mSq = 0.0;
             for (int j = lane; j < ne; j += 64) {
-                const Edge ed = pool[base + (uint32_t)j];          // one 32-byte record per lane
-                uint32_t N = ed.N;
-                float cp = E.c_puct * ed.P;                         // c_puct * self._P in float32
+                // one 32-byte record per lane.  (The compiler fetches the second half -- coff, act | cne | rid -- inside the branch
+                // below, for the lanes whose candidate leads: a second trip to the cache.  Forcing both halves up front measured
+                // SLOWER, 4.1 k against 3.7 k cycles per walked level.)
+                const uint4* q = reinterpret_cast<const uint4*>(&pool[base + (uint32_t)j]);
+                const uint4 qa = q[0], qc = q[1];
+                uint32_t N = qa.z;
+                float cp = E.c_puct * __uint_as_float(qa.w);        // c_puct * self._P in float32
                 double u = (double)cp * sq / (double)(1u + N);      // mcts.py:69
-                double val = ed.Q + u;                              // mcts.py:70
+                double val = __hiloint2double((int)qa.y, (int)qa.x) + u;  // mcts.py:70
                 double sqN = sqrt((double)N);                       // the next level's sqrt(N_parent) if this edge wins
-                uint32_t misc = (uint32_t)ed.act | ((uint32_t)ed.cne << 8) | ((uint32_t)ed.rid << 16);
+                uint32_t misc = qc.z;                               // act | cne << 8 | rid << 16
                 // a lane's first candidate is always taken: with non-finite values (a diverged
                 // network) every comparison is false and Python's max() keeps the first child
                 if (val > best || bestk == 0x7fffffff) {
                     best = val;
                     bestk = j;
                     mSq = sqN;
-                    mCOff = ed.coff;
+                    mCOff = qc.y;
                     mMisc = misc;
                 }
             }
