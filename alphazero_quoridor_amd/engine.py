@@ -331,7 +331,10 @@ class SelfPlayEngine:
         """One ROUND of the asynchronous loop (include/qz_abi.h): every board runs playouts on its own -- leaves whose
         evaluation is in the memo and terminal leaves are resolved in place, a board that has done n_playout playouts
         plays its move and goes on -- until it meets a leaf that needs the network; those leaves are evaluated as one
-        compacted batch and stored in the memo.  Nothing synchronises with the host."""
+        compacted batch and stored in the memo (the legal sets of those leaves and the finished boards' moves are computed on
+        the engine's second stream beside the network).  Nothing synchronises with the host.  With auto_finish the boards
+        are on their own clocks from then on: select() / expand_backup() / finish_move() / update_with_move() raise
+        QzError until reset() or set_boards(reset_trees=True)."""
         self._memo_guard(evaluator)
         self._descended = False
         _cabi.check(self.L.qz_selfplay_round(self.h, C.byref(evaluator.nn_weights()), int(max_playouts), int(budget_us), int(bool(auto_finish)),
