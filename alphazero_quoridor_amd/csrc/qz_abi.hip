@@ -295,7 +295,7 @@ int qz_engine_create(const qz_config* cfg, qz_engine** out) {
     }
     if (c.tree_pool_pages > (1 << 21) - 1) return (delete e, fail(QZ_E_INVALID, "tree_pool_pages > 2^21 - 1 (32-bit edge indices)"));
     if (c.traj_pool_pages <= 0) {
-        // a page holds ~1,000 late-game plies; reference-faithful games average ~20,000 plies with a tail beyond 100,000
+        // a page holds ~1,000 late-game plies; reference-faithful games have a median of ~5,000 plies and a tail beyond 250,000
         // (profiles/round3/game_length_400playouts.json): 64 pages per board (4 MB) up to 8,192 boards, 16 beyond
         long long tot = (c.n_boards <= 8192 ? 64LL : 16LL) * c.n_boards;
         if (tot > 0x7fffffffLL) tot = 0x7fffffffLL;

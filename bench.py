@@ -26,8 +26,8 @@ playouts of every move descends, expands and backs up exactly as the reference d
 gets the reference's evaluation -- from the network the first time, from the memo afterwards.
 --mode lockstep is round 2's route (every leaf through the network), kept for A/B.
 
-games/sec needs finished games, and a reference-faithful 400-playout game lasts ~20,000 plies
-(the reference backs a won position up with the wrong sign, mcts.py:119-125), so the boards are
+games/sec needs finished games, and a reference-faithful 400-playout game lasts tens of thousands of plies
+(median 5,000, mean ~80,000: the reference backs a won position up with the wrong sign, mcts.py:119-125), so the boards are
 first DESYNCHRONISED (untimed): `--desync-plies` plies at `--desync-playouts` playouts per move
 spread the population over all game phases (continuous refill).
   value                     = games_per_s_steady_state.value when a length sample of this playout
