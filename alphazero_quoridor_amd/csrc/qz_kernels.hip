@@ -1051,7 +1051,10 @@ __device__ __forceinline__ void select_core(EngineDev& E, BoardRegs& S, const in
                 // the descent left its last record at left_at and walked the rest.  In place if the new levels are at least as
                 // many as the recorded ones they replace, else over the least valuable record (oldest last use, short before long)
                 const uint32_t l_left = left_rec != QZ_NONE ? rdl(rlen, (int)left_rec) : 0u;
-                if (left_rec != QZ_NONE && n - left_at >= l_left - left_at) {
+#ifndef QZ_INPLACE_SLACK
+#define QZ_INPLACE_SLACK 4u  // (a new tail up to four levels shorter than the recorded one still replaces it: 0 / 1 / 4 / 16 / 64 / always measured 495 / 500 / 503 / 495 / 478 / 427 k plies/s)
+#endif
+                if (left_rec != QZ_NONE && n - left_at + QZ_INPLACE_SLACK >= l_left - left_at) {
                     dest = left_rec;
                     from = left_at;
                 } else {
