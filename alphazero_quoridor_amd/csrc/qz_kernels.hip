@@ -1062,7 +1062,10 @@ __device__ __forceinline__ void select_core(EngineDev& E, BoardRegs& S, const in
                     dest = 0u;
                     for (uint32_t r = 0; r < R; r++) {
                         // (a long record is worth more than its age says: losing it costs a walk of its length)
-                        const uint32_t l = rdl(rlen, (int)r), v = l == 0u ? 0u : rdl(rstamp, (int)r) + 4u * l;
+#ifndef QZ_VICTIM_LEN_WEIGHT
+#define QZ_VICTIM_LEN_WEIGHT 64u  // (0 / 1 / 4 / 16 / 64 / 256 / 4096 measured 490 / 491 / 504 / 516 / 517 / 516 / 515 k plies/s, and the launches' tails shorter)
+#endif
+                        const uint32_t l = rdl(rlen, (int)r), v = l == 0u ? 0u : rdl(rstamp, (int)r) + QZ_VICTIM_LEN_WEIGHT * l;
                         if (v < bestv && r != left_rec && !((used >> r) & 1u)) {
                             bestv = v;
                             dest = r;
