@@ -31,7 +31,9 @@ assert L.qzt_advance_stamps_read(buf.ctypes.data_as(C.c_void_p), 0) == 0
 assert L.qzt_advance_stamps2_read(buf2.ctypes.data_as(C.c_void_p), 0) == 0
 assert L.qzt_advance_stamps3_read(buf3.ctypes.data_as(C.c_void_p), 0) == 0
 st1 = eng.stats()
-a = buf[:min(B, 4096)].astype(np.float64)
+# (the accumulators are unsigned 64-bit sums of stamp differences: read as two's complement, so that a board whose few
+# differences came out slightly negative counts as ~0 and not as 1.8e19)
+a = buf[:min(B, 4096)].view(np.int64).astype(np.float64)
 tot = a[:, 10].sum()
 names = ["prologue", "expand", "backup", "move", "descent", "probe_hit", "probe_miss", "epilogue"]
 po = a[:, 8].sum()
@@ -40,10 +42,10 @@ out = {"boards": B, "rounds": MEAS, "wall_s": dt, "playouts": int(st1["playouts"
        "cycles_per_launch_per_wave": tot / a[:, 11].sum(), "cycles_per_playout": tot / max(po, 1),
        "share": {n: a[:, k].sum() / tot for k, n in enumerate(names)},
        "cycles_per_playout_by_phase": {n: a[:, k].sum() / max(po, 1) for k, n in enumerate(names)}}
-lv = float(a[:, 9].sum()); r2 = buf2[:min(B, 4096)].astype(np.float64).sum(axis=0)
+lv = float(a[:, 9].sum()); r2 = buf2[:min(B, 4096)].view(np.int64).astype(np.float64).sum(axis=0)
 out["levels_replayed_frac"] = r2[0] / max(lv, 1); out["replay_rounds_per_playout"] = r2[1] / max(po, 1); out["replay_rounds_failed_frac"] = r2[2] / max(r2[1], 1)
 out["levels_per_replay_round"] = r2[0] / max(r2[1], 1)
-r3 = buf3[:min(B, 4096)].astype(np.float64).sum(axis=0)
+r3 = buf3[:min(B, 4096)].view(np.int64).astype(np.float64).sum(axis=0)
 out["descent_cycles_per_playout"] = {"replay_rounds": r3[0] / max(po, 1), "walk_and_setup": r3[1] / max(po, 1), "record_commit": r3[2] / max(po, 1)}
 out["cycles_per_replay_round"] = r3[0] / max(r2[1], 1); out["cycles_per_walked_level"] = r3[1] / max(lv - r2[0], 1)
 q = [0.5, 0.9, 0.99, 1.0]
