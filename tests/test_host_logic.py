@@ -41,11 +41,16 @@ def test_library_exports_every_declared_symbol(lib):
 
     with tempfile.TemporaryDirectory() as td:
         src = os.path.join(td, "sz.c")
-        open(src, "w").write('#include <stdio.h>\n#include "qz_abi.h"\nint main(void){printf("%zu %zu %zu %zu\\n", sizeof(qz_config), '
-                             'sizeof(qz_stats), sizeof(qz_boards), sizeof(qz_rules_opts));return 0;}\n')
+        open(src, "w").write('#include <stdio.h>\n#include "qz_abi.h"\nint main(void){printf("%zu %zu %zu %zu %zu\\n", sizeof(qz_config), '
+                             'sizeof(qz_stats), sizeof(qz_boards), sizeof(qz_rules_opts), sizeof(qz_nn_weights));return 0;}\n')
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", os.path.join(td, "sz"), src])
         sizes = [int(x) for x in subprocess.check_output([os.path.join(td, "sz")]).split()]
-    assert sizes == [C.sizeof(_cabi.qz_config), C.sizeof(_cabi.qz_stats), C.sizeof(_cabi.qz_boards), C.sizeof(_cabi.qz_rules_opts)]
+    assert sizes == [C.sizeof(_cabi.qz_config), C.sizeof(_cabi.qz_stats), C.sizeof(_cabi.qz_boards), C.sizeof(_cabi.qz_rules_opts),
+                     C.sizeof(_cabi.qz_nn_weights)]
+    # ... and the fields of the telemetry struct come in the header's order under the header's names
+    body = re.search(r"typedef struct qz_stats \{(.*?)\} qz_stats;", header, flags=re.S) or re.search(r"typedef struct \{([^{}]*?)\} qz_stats;", header, flags=re.S)
+    names = [n for decl in re.findall(r"\bu?int(?:32|64)_t\s+([^;]+);", body.group(1)) for n in re.split(r"\s*,\s*", decl.strip())]
+    assert names == [f[0] for f in _cabi.qz_stats._fields_], (names, [f[0] for f in _cabi.qz_stats._fields_])
 
 
 def test_no_cpu_fallback(lib):
