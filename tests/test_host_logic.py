@@ -457,3 +457,30 @@ def test_no_packed_fp32_instruction_in_the_device_code():
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count(": 0 packed-fp32 instructions") == 3, r.stdout
+
+
+def test_steady_state_estimator_of_the_bench_line(tmp_path):
+    """bench.py's `value`: boards / E[wall time of a game] from a committed length sample and the per-ply costs of the
+    two phases measured in the timed region.  Pure host arithmetic: checked on a hand-made sample, and against the
+    committed length file the default bench line reads."""
+    import json
+
+    import bench
+
+    f = tmp_path / "len.json"
+    f.write_text(json.dumps({"mean_plies_per_game": 1000.0, "mean_open_plies_per_game": 100.0, "mean_ci95": [800.0, 1300.0], "restricted_mean": 600.0,
+                             "games_finished": 10, "games_censored": 2, "T": 5000.0, "survival_at_T": 0.1, "estimator": "test"}))
+    # 50 open plies cost 5 board-seconds (0.1 each), 450 late plies 4.5 (0.01 each): a game = 100 x 0.1 + 900 x 0.01 = 19 board-seconds
+    ss = bench.steady_state_two_phase(4096, 50.0, 450.0, 5.0, 4.5, str(f))
+    assert abs(ss["seconds_per_game_per_board"] - 19.0) < 1e-9 and abs(ss["value"] - 4096 / 19.0) < 1e-9
+    assert abs(ss["open_phase_share_of_a_game"] - 10.0 / 19.0) < 1e-12
+    lo, hi = ss["ci95"]  # a longer game is a lower rate: the interval is ordered as rates
+    assert lo < ss["value"] < hi and abs(hi - 4096 / (10.0 + 700 * 0.01)) < 1e-9 and abs(lo - 4096 / (10.0 + 1200 * 0.01)) < 1e-9
+    assert abs(ss["upper_bound"] - 4096 / (10.0 + 500 * 0.01)) < 1e-9  # the restricted mean is a lower bound of the length
+    assert bench.steady_state_two_phase(4096, 0.0, 450.0, 0.0, 4.5, str(f)) is None  # no open plies seen: no estimate
+    assert bench.steady_state_two_phase(4096, 50.0, 450.0, 5.0, 4.5, str(tmp_path / "missing.json")) is None
+    # the committed sample of the default config carries everything the estimator needs
+    committed = bench._latest_profile("game_length_400playouts.json")
+    d = json.load(open(committed))
+    assert d["n_playout"] == 400 and d["mean_open_plies_per_game"] > 0 and d["restricted_mean"] < d["mean_plies_per_game"]
+    assert d["mean_ci95"][0] < d["mean_plies_per_game"] < d["mean_ci95"][1] and d["games_censored"] == d["boards"]
