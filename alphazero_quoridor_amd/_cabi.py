@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "libqzero_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "qz_abi.h")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 N_ACTIONS = 140
 PLANES = 26 * 81
 MASK_WORDS = 5
@@ -73,6 +73,14 @@ class qz_config(C.Structure):
     ]
 
 
+class qz_dropped_game(C.Structure):
+    _fields_ = [("hbits", C.c_uint64), ("vbits", C.c_uint64), ("meta", C.c_uint64), ("cause", C.c_int32), ("ply", C.c_int32),
+                ("board", C.c_int32), ("reserved", C.c_int32)]
+
+
+DROP_CAUSES = {1: "no_legal_move", 2: "depth", 3: "max_plies", 4: "trajectory_pool"}
+
+
 class qz_stats(C.Structure):
     _fields_ = [
         ("games_finished", C.c_int64),
@@ -116,6 +124,7 @@ class qz_stats(C.Structure):
         ("aborted_depth", C.c_int64),
         ("runaway_descents", C.c_int64),
         ("compact_slices", C.c_int64),
+        ("miss_overflow", C.c_int64),
     ]
 
 
@@ -161,6 +170,7 @@ _SIGNATURES = {
     "qz_engine_get_boards": (C.c_int, [_P, C.POINTER(qz_boards), _P]),
     "qz_engine_set_temp": (C.c_int, [_P, C.c_float]),
     "qz_engine_get_plies": (C.c_int, [_P, _P, _P]),
+    "qz_engine_dropped_games": (C.c_int, [_P, C.POINTER(qz_dropped_game), C.c_int, C.POINTER(C.c_int64), _P]),
     "qz_engine_set_rules_opts": (C.c_int, [_P, C.POINTER(qz_rules_opts)]),
     "qz_engine_set_playouts": (C.c_int, [_P, C.c_int]),
     "qz_mcts_select": (C.c_int, [_P, _P, _P, _P, _P]),
@@ -191,6 +201,7 @@ _SIGNATURES = {
     "qz_selfplay_evaluate": (C.c_int, [_P, C.POINTER(qz_nn_weights), _P]),
     "qz_selfplay_round_tail": (C.c_int, [_P, _P]),
     "qz_selfplay_round": (C.c_int, [_P, C.POINTER(qz_nn_weights), C.c_int, C.c_int, C.c_int, _P]),
+    "qz_selfplay_parity": (C.c_int, [_P]),
     "qz_selfplay_misses": (C.c_int, [_P, C.POINTER(qz_boards), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
     "qz_memo_flush": (C.c_int, [_P, _P]),
     "qz_nn_head": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, _P]),

@@ -377,6 +377,7 @@ int qz_engine_create(const qz_config* cfg, qz_engine** out) {
     ALLOC(status, B);
     ALLOC(winner, B);
     ALLOC(counters, (size_t)QZ_C_COUNT);
+    ALLOC(drop_log, (size_t)QZ_DROP_LOG * 4);
     ALLOC(bc_playouts, B);
     ALLOC(bc_terminal, B);
     ALLOC(bc_overflow, B);
@@ -495,10 +496,19 @@ int qz_engine_create(const qz_config* cfg, qz_engine** out) {
                                       "reset it (qz_engine_reset / qz_engine_set_boards with reset_trees) before a lock-step call"); \
     } while (0)
 
+// the round state of the asynchronous loop that lives outside k_reset's per-board words: both miss counters (a reset
+// between qz_selfplay_advance and qz_selfplay_round_tail would leave one non-zero with every pend_slot cleared) and the
+// host-side parity
+static hipError_t reset_round_state(qz_engine* e, hipStream_t s) {
+    e->async_moves = false;
+    e->par = 0;
+    return hipMemsetAsync(e->dev.miss_count, 0, 2 * sizeof(int), s);
+}
+
 int qz_engine_reset(qz_engine* e, void* stream) {
     ENGINE_CHECK(e);
     HIP_TRY(qzl::reset(e->dev, 1, (hipStream_t)stream));
-    e->async_moves = false;
+    HIP_TRY(reset_round_state(e, (hipStream_t)stream));
     return 0;
 }
 
@@ -513,7 +523,7 @@ int qz_engine_set_boards(qz_engine* e, const qz_boards* src, int reset_trees, vo
     HIP_TRY(hipMemcpyAsync(e->dev.root_meta, src->meta, nb, hipMemcpyDeviceToDevice, s));
     if (reset_trees) {
         HIP_TRY(qzl::reset(e->dev, 0, s));
-        e->async_moves = false;
+        HIP_TRY(reset_round_state(e, s));
     }
     return 0;
 }
@@ -535,6 +545,34 @@ int qz_engine_get_plies(qz_engine* e, int32_t* plies, void* stream) {
     if (!plies) return fail(QZ_E_INVALID, "plies is null");
     HIP_TRY(hipMemcpyAsync(plies, e->dev.ply, (size_t)e->cfg.n_boards * sizeof(uint32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return 0;
+}
+
+int qz_engine_dropped_games(qz_engine* e, qz_dropped_game* out, int cap, int64_t* total, void* stream) {
+    ENGINE_CHECK(e);
+    if (cap < 0 || (cap > 0 && !out)) return fail(QZ_E_INVALID, "bad out / cap");
+    hipStream_t s = (hipStream_t)stream;
+    unsigned long long n = 0;
+    HIP_TRY(hipMemcpyAsync(&n, e->dev.counters + QZ_C_DROPS_LOGGED, sizeof(n), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (total) *total = (int64_t)n;
+    const unsigned long long have = n < QZ_DROP_LOG ? n : QZ_DROP_LOG;
+    const int k = (int)(have < (unsigned long long)cap ? have : (unsigned long long)cap);
+    if (k == 0) return 0;
+    std::vector<unsigned long long> h((size_t)QZ_DROP_LOG * 4);
+    HIP_TRY(hipMemcpyAsync(h.data(), e->dev.drop_log, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (int i = 0; i < k; i++) {  // the newest k, oldest of them first
+        const unsigned long long* r = h.data() + ((n - (unsigned long long)k + (unsigned long long)i) % QZ_DROP_LOG) * 4ull;
+        out[i].hbits = r[0];
+        out[i].vbits = r[1];
+        out[i].meta = r[2];
+        const int c = (int)(r[3] & 0xFFull);
+        out[i].cause = c == QZ_C_ABORT_NO_MOVE ? QZ_DROP_NO_MOVE : c == QZ_C_ABORT_DEPTH ? QZ_DROP_DEPTH : c == QZ_C_ABORT_MAX_PLIES ? QZ_DROP_MAX_PLIES : QZ_DROP_POOL;
+        out[i].ply = (int32_t)((r[3] >> 8) & 0xFFFFFFFFull);
+        out[i].board = (int32_t)(r[3] >> 40);
+        out[i].reserved = 0;
+    }
+    return k;
 }
 
 int qz_engine_set_temp(qz_engine* e, float temp) {
@@ -760,6 +798,7 @@ int qz_engine_stats(qz_engine* e, qz_stats* out, void* stream) {
     out->waiting_boards = (int64_t)sw;
     out->runaway_descents = (int64_t)h[QZ_C_RUNAWAY];
     out->compact_slices = (int64_t)h[QZ_C_COMPACT_SLICES];
+    out->miss_overflow = (int64_t)h[QZ_C_MISS_OVERFLOW];
     return 0;
 }
 
@@ -972,6 +1011,7 @@ int qz_selfplay_round(qz_engine* e, const qz_nn_weights* w, int max_playouts, in
     HIP_TRY(hipStreamWaitEvent(s, e->ev_join, 0));
     return qz_selfplay_round_tail(e, stream);
 }
+int qz_selfplay_parity(qz_engine* e) { return e ? e->par : fail(QZ_E_INVALID, "null engine"); }
 int qz_selfplay_misses(qz_engine* e, qz_boards* boards_out, const int32_t** n_dev_out, uint32_t** mask5_out, float** p_out, float** v_out) {
     if (!e) return fail(QZ_E_INVALID, "null engine");
     if (boards_out) {

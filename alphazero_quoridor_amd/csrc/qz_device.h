@@ -52,6 +52,7 @@
 #define QZ_TRAJ_PT 256                       // page-table entries per game: >= 24k plies, ~140k typical
 #define QZ_TRAJ_HDR 8u
 #define QZ_TRAJ_SKIP 0xFFFFFFFFu
+#define QZ_DROP_LOG 4096u                    // dropped games remembered (root board, cause, ply, board slot): a ring
 
 enum { QZ_PLAYING = 0, QZ_FINISHED = 1, QZ_ABORTED = 2 };
 enum {
@@ -73,6 +74,8 @@ enum {
     QZ_C_ABORT_DEPTH,       // games dropped because a descent was deeper than qz_config.max_depth (the reference's RecursionError)
     QZ_C_RUNAWAY,           // descents cut off because they were deeper than a tree can be (corrupted storage; must stay 0)
     QZ_C_COMPACT_SLICES,    // subtree copies that stopped at their launch's budget and went on in the next launch
+    QZ_C_DROPS_LOGGED,      // dropped games written to drop_log so far (the log keeps the last QZ_DROP_LOG of them)
+    QZ_C_MISS_OVERFLOW,     // leaves that found the miss list full (a stale counter: must stay 0); their boards redo the descent next launch
     QZ_C_COUNT
 };
 // pool bookkeeping words (int): free-stack tops and low-water marks
@@ -165,6 +168,7 @@ struct EngineDev {
     uint32_t *ply, *game_serial, *harvest_off, *harvest_gid;
     uint8_t *status, *winner;
     unsigned long long* counters;  // QZ_C_COUNT (touched once per ply / harvest)
+    unsigned long long* drop_log;  // [QZ_DROP_LOG][4] root hbits, vbits, meta, (cause | ply << 8 | board slot << 40) of the games dropped last
     // per-board counters for the per-playout statistics: a shared atomic would serialise all
     // boards of a step on one address (~88 atomics/us on MI355X); summed by qz_engine_stats
     uint32_t *bc_playouts, *bc_terminal, *bc_overflow, *bc_nonfinite, *bc_maxdepth;

@@ -1145,11 +1145,22 @@ __device__ __forceinline__ void select_core(EngineDev& E, BoardRegs& S, const in
 // longer than ~992 levels ends the reference's whole self-play run with a RecursionError.  A board that gets there is
 // dropped (status ABORTED, counted in aborted_depth; restarted by k_release / k_round_tail) -- the one thing a batched
 // engine can do that mirrors "the reference cannot play this game on".  Returns true if the board was dropped.
+// a dropped game's root position, cause (the QZ_C_ABORT_* counter it is counted under), ply and board slot go into the
+// engine's drop log (qz_engine_dropped_games): what the reference could not play on from.  Lane 0 only.
+__device__ __forceinline__ void log_dropped_game(const EngineDev& E, const int b, const int cause) {
+    const unsigned long long k = atomicAdd(&E.counters[QZ_C_DROPS_LOGGED], 1ull) % QZ_DROP_LOG;
+    unsigned long long* o = E.drop_log + k * 4ull;
+    o[0] = E.root_hb[b];
+    o[1] = E.root_vb[b];
+    o[2] = E.root_meta[b];
+    o[3] = (unsigned long long)(uint32_t)cause | ((unsigned long long)E.ply[b] << 8) | ((unsigned long long)(uint32_t)b << 40);
+}
 __device__ __forceinline__ bool drop_if_too_deep(EngineDev& E, const int b, const int lane, const uint32_t plen) {
     if (E.max_depth <= 0 || plen <= (uint32_t)E.max_depth) return false;
     if (lane == 0) {
         E.status[b] = QZ_ABORTED;
         atomicAdd(&E.counters[QZ_C_ABORT_DEPTH], 1ull);
+        log_dropped_game(E, b, QZ_C_ABORT_DEPTH);
     }
     return true;
 }
@@ -1862,6 +1873,7 @@ __device__ __forceinline__ void finish_move_board(EngineDev& E, const int b, con
         if (lane == 0) {
             atomicAdd((unsigned long long*)&E.counters[abort_cause], 1ull);
             E.status[b] = QZ_ABORTED;
+            log_dropped_game(E, b, abort_cause);
         }
         return;
     }
@@ -2268,15 +2280,23 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(QZ_ADV_WAVE
         uint32_t s = 0u;
         if (lane == 0) s = (uint32_t)atomicAdd(E.miss_count + par, 1);
         s = rfl(s);
-        if (lane == 0) {
-            E.miss_hb[s] = miss_leaf.hb;
-            E.miss_vb[s] = miss_leaf.vb;
-            E.miss_meta[s] = pack_meta(miss_leaf);
-            E.pend_slot[b] = s;
-            E.leaf_pedge[b] = pedge;
-            E.path_len[b] = plen;
+        // (a board has at most one leaf in the list, so a slot beyond n_boards means the counter was not cleared -- a host
+        // that mixed up the two counters; the list must not be written past its end: the board forgets this descent and
+        // repeats it in its next launch, the rules op and the network clamp the count they read)
+        if (s >= (uint32_t)E.n_boards) {
+            if (lane == 0) atomicAdd(&E.counters[QZ_C_MISS_OVERFLOW], 1ull);
+            waiting = false;
+        } else {
+            if (lane == 0) {
+                E.miss_hb[s] = miss_leaf.hb;
+                E.miss_vb[s] = miss_leaf.vb;
+                E.miss_meta[s] = pack_meta(miss_leaf);
+                E.pend_slot[b] = s;
+                E.leaf_pedge[b] = pedge;
+                E.path_len[b] = plen;
+            }
+            lc_add(S, LC_EVALS, 1u, lane);
         }
-        lc_add(S, LC_EVALS, 1u, lane);
     }
     regs_store(E, b, lane, S);
 #ifdef QZ_ADV_STAMPS

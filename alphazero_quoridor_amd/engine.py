@@ -179,6 +179,21 @@ class SelfPlayEngine:
         _cabi.check(self.L.qz_engine_get_plies(self.h, out.data_ptr(), self._s()))
         return out
 
+    def dropped_games(self, cap=4096):
+        """The games dropped last (qz_engine_dropped_games) -> (packed root boards [k], causes list[str], plies int32 [k],
+        board slots int32 [k], total drops so far).  Synchronises."""
+        buf = (_cabi.qz_dropped_game * int(cap))()
+        total = C.c_int64()
+        k = self.L.qz_engine_dropped_games(self.h, buf, int(cap), C.byref(total), self._s())
+        if k < 0:
+            _cabi.check(k)
+        hb = np.array([buf[i].hbits for i in range(k)], dtype=np.uint64)
+        vb = np.array([buf[i].vbits for i in range(k)], dtype=np.uint64)
+        meta = np.array([buf[i].meta for i in range(k)], dtype=np.uint64)
+        packed = _cabi.soa_to_packed(hb.view(np.int64), vb.view(np.int64), meta.view(np.int64))
+        return (packed, [_cabi.DROP_CAUSES[buf[i].cause] for i in range(k)], np.array([buf[i].ply for i in range(k)], dtype=np.int32),
+                np.array([buf[i].board for i in range(k)], dtype=np.int32), int(total.value))
+
     def set_temp(self, temp: float):
         _cabi.check(self.L.qz_engine_set_temp(self.h, float(temp)))
 
@@ -355,20 +370,31 @@ class SelfPlayEngine:
         with torch.cuda.graph(g):
             for _ in range(rounds):
                 self.selfplay_round(evaluator, max_playouts, budget_us, auto_finish)
-        self._round_graph = (g, int(rounds), (id(evaluator), int(max_playouts), int(budget_us), bool(auto_finish)))
+        # (the graph bakes in the miss counter of its first round: `rounds` is even, so every replay starts and ends on it)
+        self._round_graph = (g, int(rounds), (id(evaluator), int(max_playouts), int(budget_us), bool(auto_finish)), self.round_parity())
 
     def run_rounds(self, evaluator, n, max_playouts=64, budget_us=0, auto_finish=True):
         """n rounds; whole multiples of a captured graph (capture_rounds, same arguments) are replayed."""
         n = int(n)
         done = 0
         g = self._round_graph
-        if g is not None and g[2] == (id(evaluator), int(max_playouts), int(budget_us), bool(auto_finish)):
+        if g is not None and g[2] == (id(evaluator), int(max_playouts), int(budget_us), bool(auto_finish)) and n >= g[1]:
             self._memo_guard(evaluator)
+            # an odd number of eager rounds since the capture (a leftover of the last call, run_playouts_memo, the split
+            # entry points) leaves the engine on the OTHER miss counter: one eager round first, or the replay would append
+            # to a counter the previous tail did not clear
+            if self.round_parity() != g[3]:
+                self.selfplay_round(evaluator, max_playouts, budget_us, auto_finish)
+                done += 1
             while n - done >= g[1]:
                 g[0].replay()
                 done += g[1]
         for _ in range(n - done):
             self.selfplay_round(evaluator, max_playouts, budget_us, auto_finish)
+
+    def round_parity(self) -> int:
+        """which of the two miss counters the next round uses (qz_selfplay_parity)"""
+        return int(self.L.qz_selfplay_parity(self.h))
 
     def run_playouts_memo(self, evaluator, n=None):
         """MCTS.get_move_probs's loop for every board in the LOCK-STEP cadence of run_playouts (every board starts one
@@ -400,6 +426,26 @@ class SelfPlayEngine:
         torch.cuda.synchronize(self.device)
         return (_cabi.soa_to_packed(hb.cpu().numpy(), vb.cpu().numpy(), meta.cpu().numpy()), mask.cpu().numpy().view(np.uint32),
                 p.cpu().numpy(), v.cpu().numpy())
+
+    def set_miss_outputs(self, p: torch.Tensor, v: torch.Tensor):
+        """Evaluations of the miss list's first len(v) leaves from ANOTHER evaluator (qz_selfplay_misses: "for callers
+        that evaluate the list themselves"): p float32 [n,140] (the policy at every action id; only legal entries are
+        read), v float32 [n], written where qz_selfplay_evaluate would put them.  Between qz_selfplay_leaf_rules and
+        qz_selfplay_round_tail, on the current stream."""
+        n = int(v.numel())
+        assert p.dtype == torch.float32 and v.dtype == torch.float32 and p.shape == (n, 140) and n <= self.n_boards
+        if n == 0:
+            return
+        pp, vv = C.c_void_p(), C.c_void_p()
+        _cabi.check(self.L.qz_selfplay_misses(self.h, None, None, None, C.byref(pp), C.byref(vv)))
+        self._miss_src = (p.to(self.device).contiguous(), v.to(self.device).contiguous())  # (alive until the copies have run)
+        global _hip
+        if _hip is None:
+            _hip = C.CDLL("libamdhip64.so")
+        for src, dst in zip(self._miss_src, (pp.value, vv.value)):
+            rc = _hip.hipMemcpyAsync(C.c_void_p(dst), C.c_void_p(src.data_ptr()), C.c_size_t(src.numel() * 4), 3, C.c_void_p(self._s()))
+            if rc != 0:
+                raise _cabi.QzError(_cabi.E_HIP, "hipMemcpyAsync failed: %d" % rc)
 
     # ------------------------------------------------------------------ end of a ply
     def finish_move(self, forced=None):

@@ -215,17 +215,42 @@ class ReplayBuffer:
         w = self.words[slots]
         return qdist.pack_tuples(w[:, 0].contiguous(), w[:, 1].contiguous(), w[:, 2].contiguous(), self.pi[slots], self.z[slots])
 
-    def to_reference_tuples(self):
-        """list[(float64 [26,9,9], float64 [140], float64)] like the reference's data_buffer."""
+    def reference_tuples(self, logical_indices):
+        """list[(float64 [26,9,9], float64 [140], float64)] -- the reference's data_buffer entries (quoridor.py:610,
+        train.py:23) -- at deque positions `logical_indices`; states re-encoded on the device (qz_encode)."""
         from . import rules
 
-        if self._size == 0:
+        logical_indices = list(logical_indices)
+        if not logical_indices:
             return []
-        boards, pi, z = self.gather(list(range(self._size)))
+        boards, pi, z = self.gather(logical_indices)
         st = rules.encode(boards).cpu().numpy().astype(np.float64)
         pi = pi.cpu().numpy().astype(np.float64)
         z = z.cpu().numpy().astype(np.float64)
-        return [(st[i], pi[i], z[i]) for i in range(self._size)]
+        return [(st[i], pi[i], z[i]) for i in range(len(logical_indices))]
+
+    def to_reference_tuples(self):
+        """the whole buffer, oldest first, like list(the reference's data_buffer)"""
+        return self.reference_tuples(range(self._size))
+
+    # ---- the deque's sequence protocol, so that code written against the reference's buffer -- `random.sample(
+    # self.data_buffer, self.batch_size)` (train.py:67), indexing, iteration -- runs unchanged.  Every entry comes back in
+    # the reference's shape; TrainPipeline.policy_update itself uses sample() (same positions, no host round trip).
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return self.reference_tuples(range(*i.indices(self._size)))
+        i = int(i)
+        if i < 0:
+            i += self._size
+        if not 0 <= i < self._size:
+            raise IndexError("ReplayBuffer index out of range")
+        return self.reference_tuples([i])[0]
+
+    def __iter__(self):
+        n = self._size  # (like a deque, the buffer must not be mutated during iteration)
+        for lo in range(0, n, 256):
+            for t in self.reference_tuples(range(lo, min(lo + 256, n))):
+                yield t
 
     # ---- shards
     def save_shard(self, path, n_games=0, n_playout=0):
@@ -235,6 +260,11 @@ class ReplayBuffer:
         packed, meta = read_shard(path)
         self.extend(packed)
         return meta
+
+
+import collections.abc as _abc
+
+_abc.Sequence.register(ReplayBuffer)  # random.sample() insists on a Sequence
 
 
 class ShardWriter:

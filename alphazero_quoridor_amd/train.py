@@ -33,7 +33,7 @@ from .replay import ReplayBuffer, ShardWriter
 
 class TrainPipeline(object):
     def __init__(self, init_model=None, n_boards=1024, device=None, seed=0, bn_mode="per_leaf",
-                 nn_dtype=torch.float32, use_graph=False, n_groups=1, shard_dir=None):
+                 nn_dtype=torch.float32, use_graph=False, n_groups=1, shard_dir=None, max_depth=REFERENCE_MAX_DEPTH):
         self.game = Quoridor()
         # the reference's hyper-parameters, same names and values (train.py:17-31)
         self.learn_rate = 2e-3
@@ -64,9 +64,13 @@ class TrainPipeline(object):
         self.async_loop = True        # self-play through the asynchronous loop (False: the lock-step engine, one ply of every board per harvest)
         self.rounds_per_harvest = 64  # rounds of the loop between two harvests (+ all-gathers)
         self.budget_us = 1000         # wall-clock budget of a k_advance launch
-        # a game whose search descends deeper than this is dropped (counted in engine stats): the reference's recursive
-        # backup raises RecursionError there (mcts.py:55-62, Python's recursion limit); 0 = play on
-        self.max_depth = REFERENCE_MAX_DEPTH
+        # a game whose search descends deeper than this is DROPPED (not in the replay data; counted and logged by
+        # collect_selfplay_data: `games_dropped`): the reference's recursive backup raises RecursionError there
+        # (mcts.py:55-62, Python's recursion limit) and its whole run ends.  An explicit choice, because it shapes the data:
+        # the dropped games are the long ones (1.5 % of reference-faithful random-net games).  max_depth=0 plays every game on,
+        # at the price of launches that last as long as one board's 10,000-level descent.
+        self.max_depth = int(max_depth)
+        self.games_dropped = {"depth": 0, "no_legal_move": 0, "other": 0}   # since the engine was created
         self.episode_len = 0
         self._engine = None
         self.shards = ShardWriter(shard_dir, rank=self._rank(), n_playout=self.n_playout) if shard_dir else None
@@ -100,7 +104,14 @@ class TrainPipeline(object):
                                        n_playout=self.n_playout, c_puct=self.c_puct, temp=self.temp, is_selfplay=1, max_depth=self.max_depth)
             if self.use_graph and self.n_groups == 1:
                 with torch.cuda.stream(self._engine.streams[0]):
-                    self._engine.engines[0].capture_steps(self._engine.evaluators[0], 1, warmup=2)
+                    e0, ev0 = self._engine.engines[0], self._engine.evaluators[0]
+                    if self._use_async(self._engine):
+                        # the asynchronous loop replays whole rounds; its warm-up rounds are ordinary playouts of the first
+                        # move (nothing extra is spent on a root: the loop counts playouts per board)
+                        e0.capture_rounds(ev0, rounds=16, max_playouts=4096, budget_us=self.budget_us)
+                    else:
+                        e0.capture_steps(ev0, 1, warmup=2)
+                        e0.reset()  # the warm-up's two playouts must not count towards the first move's n_playout
         return self._engine
 
     # ------------------------------------------------------------------ self-play -> replay buffer
@@ -132,7 +143,7 @@ class TrainPipeline(object):
         got = 0
         # the asynchronous loop (boards on their own clocks, leaf-evaluation memo: engine.SelfPlayEngine.selfplay_round)
         # whenever the evaluator is the HIP evaluation it can run on its miss list; the same games either way
-        use_async = self.async_loop and all(getattr(ev, "engine_route_ok", lambda: False)() for ev in eng.evaluators)
+        use_async = self._use_async(eng)
         while got < n_games:
             if use_async:
                 eng.run_rounds(self.rounds_per_harvest, max_playouts=4096, budget_us=self.budget_us)
@@ -144,6 +155,23 @@ class TrainPipeline(object):
                 self.episode_len = int((tb.game == last).sum().item())
             eng.synchronize()
             got += self._extend_buffer(tbs)
+        self._log_dropped(eng)
+
+    def _use_async(self, eng):
+        return self.async_loop and all(getattr(ev, "engine_route_ok", lambda: False)() for ev in eng.evaluators)
+
+    def _log_dropped(self, eng):
+        """Games the engine dropped since the last call, by cause (the reference would have crashed on them): they are
+        missing from the replay data, so say so."""
+        st = eng.stats()
+        now = {"depth": st["aborted_depth"], "no_legal_move": st["aborted_no_move"],
+               "other": st["games_aborted"] - st["aborted_depth"] - st["aborted_no_move"]}
+        new = {k: now[k] - self.games_dropped[k] for k in now}
+        self.games_dropped = now
+        if any(new.values()) and self._rank() == 0:
+            print("self-play dropped {} game(s): {} deeper than max_depth={} (the reference's RecursionError), {} without a legal "
+                  "move (the reference's 'the board is full' crash), {} other".format(sum(new.values()), new["depth"], self.max_depth,
+                                                                                     new["no_legal_move"], new["other"]))
 
     # ------------------------------------------------------------------ training
     def _mean_over_ranks(self, x: torch.Tensor) -> torch.Tensor:

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define QZ_ABI_VERSION 3
+#define QZ_ABI_VERSION 4
 #define QZ_N_ACTIONS 140            /* quoridor.py:12  action_space = 140            */
 #define QZ_PLANES (26 * 81)         /* quoridor.py:58-131  26x9x9 state tensor       */
 #define QZ_MASK_WORDS 5             /* 140-bit legal mask, bit a of word a/32        */
@@ -192,6 +192,8 @@ typedef struct {
                                   storage): must be 0; the guard exists so that such a bug cannot hang the GPU   */
     int64_t compact_slices;    /* subtree copies of the asynchronous loop that stopped at their launch's budget and went on
                                   in the board's next launch (a 1,000-level line copies one level per memory round trip)  */
+    int64_t miss_overflow;     /* leaves that found the miss list full (only a stale miss counter can do that): must be 0; the
+                                  guard exists so that such a bug cannot write past the list                    */
 } qz_stats;
 
 /* MCTSPlayer.__init__ / MCTS.__init__ (mcts.py:89-100, 159-161) for n_boards trees +
@@ -207,6 +209,22 @@ int qz_engine_get_boards(qz_engine* e, const qz_boards* dst, void* stream);
 /* plies[n_boards] int32 <- moves played so far in every board's current game (inspection: length statistics of games
  * that are still running) */
 int qz_engine_get_plies(qz_engine* e, int32_t* plies /*[dev]*/, void* stream);
+/* The games the engine dropped last (qz_stats.games_aborted counts them, by cause): the root position at which the game
+ * could not go on, why, after how many plies, on which board slot.  The reference cannot play these games on either:
+ * QZ_DROP_NO_MOVE = Quoridor.actions() of the root is empty -- MCTSPlayer.choose_action prints "WARNING: the board is full"
+ * and returns None (mcts.py:195-196), start_self_play's unpack of it raises TypeError (quoridor.py:587);
+ * QZ_DROP_DEPTH = a playout descended more than qz_config.max_depth levels (TreeNode.update_recursive's RecursionError,
+ * mcts.py:55-62).  out[0..return value) <- the newest min(cap, 4096, *total) drops, oldest first; *total = drops so far.
+ * Synchronises the stream (inspection / logging, not the hot path). */
+enum { QZ_DROP_NO_MOVE = 1, QZ_DROP_DEPTH = 2, QZ_DROP_MAX_PLIES = 3, QZ_DROP_POOL = 4 };
+typedef struct {
+    uint64_t hbits, vbits, meta; /* the root board, one record of qz_boards */
+    int32_t cause;               /* QZ_DROP_* */
+    int32_t ply;                 /* moves played in the game before it was dropped */
+    int32_t board;               /* engine board slot */
+    int32_t reserved;
+} qz_dropped_game;
+int qz_engine_dropped_games(qz_engine* e, qz_dropped_game* out /*[host] cap*/, int cap, int64_t* total /*[host] or NULL*/, void* stream);
 /* the `temp` argument of get_move_probs / choose_action (mcts.py:129,172) for later calls */
 int qz_engine_set_temp(qz_engine* e, float temp);
 /* the n_playout argument of MCTSPlayer (mcts.py:159) for later moves of the asynchronous loop (qz_selfplay_*): a board
@@ -430,6 +448,10 @@ int qz_selfplay_round(qz_engine* e, const qz_nn_weights* w, int max_playouts, in
 /* the miss list of the round in progress (between qz_selfplay_advance and qz_selfplay_round_tail), engine-owned
  * device memory: boards, *n_dev = how many, their legal sets / network outputs once the two calls above have run.
  * For callers that evaluate the list themselves (another network) and for the tests. */
+/* which of the engine's two miss counters the NEXT qz_selfplay_advance uses (0 | 1; qz_selfplay_round_tail flips it,
+ * qz_engine_reset / qz_engine_set_boards(reset_trees) set it to 0).  A HIP graph captured over whole rounds bakes the
+ * counter's address in: replay it only while this value is what it was at capture time (run one eager round otherwise). */
+int qz_selfplay_parity(qz_engine* e);
 int qz_selfplay_misses(qz_engine* e, qz_boards* boards_out, const int32_t** n_dev_out, uint32_t** mask5_out /*[n][5]*/,
                        float** p_out /*[n][140]*/, float** v_out /*[n]*/);
 /* the weights changed (training step, checkpoint load): every stored evaluation is dead.  O(1): bumps the epoch the

@@ -6,7 +6,7 @@ GPU box).  It imports the reference's quoridor.py / mcts.py / policy_value_net.p
 drives them on seeded inputs and stores inputs + expected outputs as small .npz
 files.  No reference source is copied: fixtures are data.
 
-    python tests/golden/gen_golden.py [--only rules,pawn,positions,steps,mcts,episodes,net,train,rollouts]
+    python tests/golden/gen_golden.py [--only rules,pawn,positions,steps,mcts,episodes,net,train,rollouts,no_move]
 
 The oracle (oracle/) and the HIP path are both checked against these files.
 """
@@ -744,9 +744,54 @@ def gen_rollouts(out_dir, procs, per_position=320):
     print("rollouts: 10 positions x %d reference rollouts in %.0fs:" % (per_position, time.time() - t0), counts.tolist())
 
 
+# --------------------------------------------------------------------------- F11
+def gen_no_move(out_dir):
+    """Roots WITHOUT a legal move.  no_move_roots_input.npy holds root positions at which the engine dropped a game under
+    qz_stats.aborted_no_move (harvested from a 4-playout self-play run on the GPU by benchmarks/capture_no_move_roots.py).
+    The REFERENCE is asked about each of them: Quoridor.actions() must be [] (quoridor.py:138-157), and
+    MCTSPlayer.choose_action (mcts.py:172-196) must take its `else` branch -- print "WARNING: the board is full" and return
+    None, which start_self_play's `move, move_probs = ...` (quoridor.py:587) cannot unpack: a TypeError ends the
+    reference's self-play there.  Stored with them: what the reference's own helper reports for the pawn
+    (_valid_pawn_actions on the root) and whether the game is over (it is not)."""
+    import mcts as ref_mcts
+
+    q = _ref()
+    boards = np.load(os.path.join(out_dir, "no_move_roots_input.npy"))
+    n = len(boards)
+    n_act = np.zeros(n, dtype=np.int32)
+    n_pawn = np.zeros(n, dtype=np.int32)
+    warned = np.zeros(n, dtype=bool)
+    returned_none = np.zeros(n, dtype=bool)
+    unpack_raises = np.zeros(n, dtype=bool)
+    over = np.zeros(n, dtype=bool)
+    for i, rec in enumerate(boards):
+        g = game_from_packed(rec)
+        over[i] = bool(g.has_a_winner()[0])
+        acts = g.actions()
+        n_act[i] = len(acts)
+        cur = g.current_player
+        n_pawn[i] = len(g._valid_pawn_actions(g._intersections, g._positions[cur], g._positions[3 - cur], cur))
+        player = ref_mcts.MCTSPlayer(uniform_policy_py, c_puct=5, n_playout=4, is_selfplay=1)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            r = player.choose_action(g, temp=1.0, return_prob=1)
+        warned[i] = "the board is full" in buf.getvalue()
+        returned_none[i] = r is None
+        try:
+            move, move_probs = r  # quoridor.py:587
+        except TypeError:
+            unpack_raises[i] = True
+    np.savez_compressed(os.path.join(out_dir, "no_move_roots.npz"), board=boards, n_actions=n_act, n_pawn_actions=n_pawn,
+                        game_over=over, prints_board_is_full=warned, returns_none=returned_none, unpack_raises_typeerror=unpack_raises)
+    print("no_move: %d roots: reference actions() empty on %d, 'the board is full' on %d, None returned on %d, unpack TypeError on %d, "
+          "game over on %d; movers with walls left: %d" % (n, int((n_act == 0).sum()), int(warned.sum()), int(returned_none.sum()),
+                                                          int(unpack_raises.sum()), int(over.sum()),
+                                                          int(sum(int(b["w1"] if b["cur"] == 1 else b["w2"]) > 0 for b in boards))))
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="rules,positions,steps,mcts,episodes,net,train,net_more,rollouts")
+    ap.add_argument("--only", default="rules,positions,steps,mcts,episodes,net,train,net_more,rollouts,no_move")
     ap.add_argument("--procs", type=int, default=8)
     ap.add_argument("--games", type=int, default=160)
     ap.add_argument("--synthetic", type=int, default=120)
@@ -770,6 +815,8 @@ def main():
         gen_net_more(HERE)
     if "rollouts" in only:
         gen_rollouts(HERE, args.procs)
+    if "no_move" in only:
+        gen_no_move(HERE)
 
 
 if __name__ == "__main__":

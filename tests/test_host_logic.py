@@ -332,6 +332,59 @@ def test_replay_buffer_is_a_deque_of_packed_tuples(tmp_path):
     assert torch.equal(third.pi, torch.from_numpy(pi[:300]))
 
 
+def test_replay_buffer_answers_like_the_reference_deque(monkeypatch):
+    """train.py:23,67: the reference's data_buffer is a deque of (float64 [26,9,9], float64 [140], float64) tuples and
+    policy_update does `random.sample(self.data_buffer, self.batch_size)`.  The device ring answers len / indexing (also
+    negative, slices) / iteration / random.sample with tuples of exactly that shape, at the positions the deque would
+    give.  (No GPU in this tier: the device encoder the ring calls is replaced by the oracle's state() -- the checker.)"""
+    import random
+    from collections import deque
+
+    import oracle
+    from alphazero_quoridor_amd import _cabi, replay, rules
+    from alphazero_quoridor_amd import dist as qdist
+
+    def encode_on_host(boards, out=None):
+        return torch.from_numpy(oracle.encode_batch(boards.to_packed()))
+
+    monkeypatch.setattr(rules, "encode", encode_on_host)
+    d = np.load(os.path.join(ROOT, "tests", "golden", "rules_positions.npz"))
+    b = d["board"]
+    b = b[(b["p1"] >= 0) & (b["p1"] <= 71) & (b["p2"] >= 9) & (b["p2"] <= 80)][:700]
+    rs = np.random.RandomState(3)
+    pi = rs.dirichlet(np.ones(140), size=len(b)).astype(np.float32)
+    z = rs.choice([-1.0, 1.0], size=len(b)).astype(np.float32)
+    words = b.view(np.uint64).reshape(-1, 3).view(np.int64)
+    packed = qdist.pack_tuples(*(torch.from_numpy(np.ascontiguousarray(words[:, i])) for i in range(3)), torch.from_numpy(pi), torch.from_numpy(z))
+    planes = oracle.encode_batch(b).astype(np.float64)
+    buf = replay.ReplayBuffer(capacity=300, device="cpu")
+    ref = deque(maxlen=300)
+    for lo, hi in ((0, 250), (250, 700)):  # fills, then wraps
+        buf.extend(packed[lo:hi])
+        ref.extend((planes[i], pi[i].astype(np.float64), np.float64(z[i])) for i in range(lo, hi))
+
+    def same(a, e):
+        return (a[0].dtype == np.float64 and a[0].shape == (26, 9, 9) and np.array_equal(a[0], e[0]) and a[1].dtype == np.float64
+                and np.array_equal(a[1], e[1]) and isinstance(a[2], np.float64) and a[2] == e[2])
+
+    assert len(buf) == len(ref) == 300
+    for i in (0, 1, 150, 299, -1, -300):
+        assert same(buf[i], ref[i])
+    with pytest.raises(IndexError):
+        buf[300]
+    assert all(same(a, e) for a, e in zip(buf[10:20], list(ref)[10:20]))
+    got = list(buf)  # iteration, chunked gathers underneath
+    assert len(got) == 300 and all(same(a, e) for a, e in zip(got, ref))
+    random.seed(11)
+    want = random.sample(ref, 128)  # train.py:67 on the reference's deque
+    random.seed(11)
+    mini = random.sample(buf, 128)  # ... and unchanged on the device ring
+    assert all(same(a, e) for a, e in zip(mini, want))
+    # the reference's next three lines (train.py:68-70) work on what comes back
+    state_batch = [data[0] for data in mini]
+    assert np.asarray(state_batch).shape == (128, 26, 9, 9) and np.asarray([data[1] for data in mini]).shape == (128, 140)
+
+
 def test_train_step_matches_reference_fixture_cpu():
     """policy_value_net.py:166-192 on the mirror module, CPU: three optimiser steps on the
     reference's own minibatch reproduce its loss, entropy and post-step weights (same torch, same

@@ -283,6 +283,28 @@ def test_episode_traces():
         assert np.array_equal(np.where(players == winner, 1.0, -1.0), z)  # quoridor.py:599-602
 
 
+def test_roots_without_a_legal_move():
+    """no_move_roots.npz: root positions at which a GPU self-play run dropped the game under aborted_no_move; the REAL
+    reference was asked about each (gen_golden.py:gen_no_move): actions() == [], MCTSPlayer.choose_action prints "the board
+    is full" and returns None (mcts.py:195-196), start_self_play's unpack raises (quoridor.py:587).  The oracle agrees:
+    no action, no pawn move, game not over; MCTS on such a root never expands it (root stays a leaf with n_playout visits)."""
+    d = load("no_move_roots.npz")
+    assert len(d["board"]) >= 20
+    assert (d["n_actions"] == 0).all() and d["prints_board_is_full"].all() and d["returns_none"].all() and d["unpack_raises_typeerror"].all()
+    assert not d["game_over"].any() and (d["n_pawn_actions"] == 0).all()
+    mask, status = oracle.movegen_batch(d["board"])
+    assert (status >= 0).all() and not mask.any()
+    for rec in d["board"]:
+        g = oracle.OracleGame.from_packed(rec)
+        assert g.actions() == [] and not g.has_a_winner()[0]
+        cur = g.get_current_player()
+        p = g.positions
+        assert oracle.valid_pawn_actions(g.inter, p[cur], p[3 - cur], cur) == []
+        t = oracle.OracleMCTS("uniform", c_puct=5, n_playout=4)
+        acts, visits, probs = t.get_move_probs(g, 1.0)
+        assert acts == [] and t.root_visits() == 4 and t.node_count() == 0
+
+
 def test_oracle_under_address_and_ub_sanitizers():
     """`make -C oracle libqz_oracle_asan.so` (gcc -fsanitize=address,undefined) really runs: the
     rules fixtures, a slice of the position fixtures, MCTS searches with subtree reuse and the
