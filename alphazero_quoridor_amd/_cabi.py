@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "libqzero_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "qz_abi.h")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 N_ACTIONS = 140
 PLANES = 26 * 81
 MASK_WORDS = 5

@@ -17,7 +17,7 @@
 namespace qzl {
 hipError_t movegen_encode(const uint64_t*, const uint64_t*, const uint64_t*, int, uint32_t*, float*, const uint8_t*, void*, const RulesOpts&, hipStream_t, const int* n_dev = nullptr);
 hipError_t advance(const EngineDev&, int, unsigned int, int, int, hipStream_t);
-hipError_t moves(const EngineDev&, hipStream_t);
+hipError_t moves(const EngineDev&, unsigned int, hipStream_t);
 hipError_t round_tail(const EngineDev&, int, hipStream_t);
 hipError_t memo_flush(const EngineDev&, hipStream_t);
 size_t movegen_scratch_bytes(int);
@@ -1004,7 +1004,7 @@ int qz_selfplay_round(qz_engine* e, const qz_nn_weights* w, int max_playouts, in
     HIP_TRY(hipStreamWaitEvent(e->side, e->ev_fork, 0));
     HIP_TRY(qzl::movegen_encode(d.miss_hb, d.miss_vb, d.miss_meta, d.n_boards, d.miss_mask, nullptr, nullptr, e->scratch, e->rules, e->side, d.miss_count + e->par));
     if (auto_finish) {
-        HIP_TRY(qzl::moves(d, e->side));
+        HIP_TRY(qzl::moves(d, ticks, e->side));
         e->async_moves = true;
     }
     HIP_TRY(hipEventRecord(e->ev_join, e->side));

@@ -182,7 +182,7 @@ struct EngineDev {
     uint32_t* compact_at;     // [B] allocation cursor at which the board's next move compacts (compact_edges, or twice the tree's size after its last compaction)
     uint32_t* compact_state;  // [B][8] a subtree copy that stopped at its launch's budget (wave_reroot): in progress, scan position, cursor, pages, nodes, cut, pool empty, root offset
     uint32_t* reroot_pend;    // [B] the subtree copy of the last move, left for the next k_advance launch: 0 none, 1 fresh root, e + 2 keep edge e
-    int* miss_count;          // [1] slots used by this round's misses
+    int* miss_count;          // [2] slots used by the misses of even / odd rounds
     uint64_t *miss_hb, *miss_vb, *miss_meta;  // [B] the leaves awaiting evaluation, compacted
     uint32_t* miss_mask;      // [B][5] their legal sets (rules op on the miss list)
     float *miss_p, *miss_v;   // [B][140], [B] the network's output per slot
@@ -191,11 +191,14 @@ struct EngineDev {
 };
 
 #if defined(__HIPCC__)
-// A tree's page table, held by the wave: lane l keeps entries l and l + 64.
+// A tree's page table, held by the wave: lane l keeps entry l in a register (pt0); entries 64..127 -- a tree of more than
+// 131,072 edge records, which a search of a few hundred playouts per move reaches only past its compaction threshold --
+// are read from the table in memory where they are needed (round 3 kept them in a second register per lane: one of the
+// registers k_advance does not have at eight wavefronts per SIMD).
 struct TreeView {
     Edge* pool;
     uint32_t* ptab;   // this tree's table in HBM (QZ_TREE_PT entries)
-    uint32_t pt0, pt1;
+    uint32_t pt0;
 };
 __device__ __forceinline__ size_t tree_slot(const EngineDev& E, int b, uint32_t half) {
     return (size_t)half * (size_t)E.n_boards + (size_t)b;
@@ -205,20 +208,28 @@ __device__ __forceinline__ TreeView tree_view(const EngineDev& E, int b, uint32_
     t.pool = E.edge_pool;
     t.ptab = E.tree_ptab + tree_slot(E, b, half) * QZ_TREE_PT;
     t.pt0 = t.ptab[lane];
-    t.pt1 = t.ptab[64 + lane];
     return t;
+}
+// an entry beyond the register copy, from memory (written by this wave's lane 0 in tree_alloc: device-scope load, past the L1)
+__device__ __forceinline__ uint32_t tree_ptab_high(const TreeView& t, uint32_t pg) {
+    return __hip_atomic_load(t.ptab + pg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // physical index of logical edge e; e must be wave-uniform
 __device__ __forceinline__ uint32_t tree_phys(const TreeView& t, uint32_t e) {
-    const uint32_t pg = e >> QZ_PAGE_SHIFT;
-    const int l = __builtin_amdgcn_readfirstlane((int)(pg & 63u));
-    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)t.pt0, l), c = (uint32_t)__builtin_amdgcn_readlane((int)t.pt1, l);
-    return ((pg < 64u ? a : c) << QZ_PAGE_SHIFT) | (e & (QZ_PAGE_EDGES - 1u));
+    const uint32_t pg = (uint32_t)__builtin_amdgcn_readfirstlane((int)(e >> QZ_PAGE_SHIFT));
+    uint32_t page;
+    if (pg < 64u) page = (uint32_t)__builtin_amdgcn_readlane((int)t.pt0, (int)pg);
+    else page = (uint32_t)__builtin_amdgcn_readfirstlane((int)tree_ptab_high(t, pg));
+    return (page << QZ_PAGE_SHIFT) | (e & (QZ_PAGE_EDGES - 1u));
 }
 // the same for a per-lane e (ALL lanes must call it: the page table is read from other lanes' registers)
 __device__ __forceinline__ uint32_t tree_phys_lanes(const TreeView& t, uint32_t e) {
     const uint32_t pg = e >> QZ_PAGE_SHIFT;
-    const uint32_t a = (uint32_t)__shfl((int)t.pt0, (int)(pg & 63u), 64), c = (uint32_t)__shfl((int)t.pt1, (int)(pg & 63u), 64);
-    return ((pg < 64u ? a : c) << QZ_PAGE_SHIFT) | (e & (QZ_PAGE_EDGES - 1u));
+    // (ds_bpermute directly: __shfl derives the lane's own index first and keeps it in a register of its own)
+    uint32_t page = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((pg & 63u) << 2), (int)t.pt0);
+    if (__ballot(pg >= 64u)) {  // wave-uniform, rare
+        if (pg >= 64u) page = tree_ptab_high(t, pg < (uint32_t)QZ_TREE_PT ? pg : 0u);
+    }
+    return (page << QZ_PAGE_SHIFT) | (e & (QZ_PAGE_EDGES - 1u));
 }
 #endif

@@ -115,19 +115,20 @@ __device__ __forceinline__ void encoder_group(EncShared<NBE>& sm, const uint64_t
 template <int NBE>
 __global__ __launch_bounds__(256) void k_pool_paths_enc(const uint64_t* __restrict__ hb, const uint64_t* __restrict__ vb,
                                                         const uint64_t* __restrict__ meta, int n, const uint8_t* __restrict__ terminal,
-                                                        PoolBoard* __restrict__ recs, PathTab* __restrict__ tabs, int n_path_groups,
+                                                        PoolHand* __restrict__ hands, int n_path_groups,
                                                         float* __restrict__ planes, int detour_mode) {
     __shared__ EncShared<NBE> sm;
     const int tid = (int)threadIdx.x;
     if ((int)blockIdx.x < n_path_groups) {
-        // lane = (board, player): board context + one shortest base path per player -> scratch.
+        // lane = (board, player): board context + one shortest base path per player -> the board's 184-byte hand-off record
+        // (qz_movegen_pool.h: path as a tile sequence, need masks, jump plan, pawn moves).
         // Long dependent chains, no LDS: latency-bound, ~1 wave per SIMD chip-wide.
         const int task = (int)blockIdx.x * 256 + tid;
         const int b = task >> 1, p = (task & 1) + 1;
         if (b >= n) return;
         Board bd = unpack(hb[b], vb[b], meta[b]);
         bool term = terminal ? (terminal[b] != 0) : false;
-        pool_k1(bd, term, true, p, recs[b], tabs[(size_t)b * 2 + (p - 1)], detour_mode);
+        pool_k1_hand(bd, term, p, hands[b], detour_mode);
         return;
     }
     encoder_group<NBE>(sm, hb, vb, meta, n, terminal, planes, ((int)blockIdx.x - n_path_groups) * NBE, tid);
@@ -355,8 +356,9 @@ __global__ __launch_bounds__(256) void k_wave_rules(const uint64_t* __restrict__
 
 template <int NB>
 struct MasksShared {
-    PoolBoard ctx[NB];
-    uint32_t srcpos[NB * 2][21];  // PathTab.srcpos of both players (84 B each), staged from scratch
+    PoolBoard ctx[NB];            // rebuilt from the hand-off records + the boards
+    PoolHand hand[NB];            // the tile's hand-off records (path tile sequences: what the floods take suffix sets from)
+    uint32_t srcpos[NB * 2][21];  // PathTab.srcpos of both players (84 B each), rebuilt from the sequences
     uint16_t items[NB * 256];     // every (slot, orientation, player) of every board at worst
     uint32_t n_items;
 };
@@ -370,7 +372,7 @@ union MasksEncShared {
 // encoder groups (HBM-bound) are independent of each other, so they share one grid and
 // overlap on the CUs.
 template <int NB, int NBE>
-__global__ __launch_bounds__(256) void k_pool_masks_enc(const PoolBoard* __restrict__ recs, const PathTab* __restrict__ tabs, int n,
+__global__ __launch_bounds__(256) void k_pool_masks_enc(const PoolHand* __restrict__ hands, int n,
                                                         uint32_t* __restrict__ mask5, int n_mask_groups, int enc_tile0,
                                                         const uint64_t* __restrict__ hb, const uint64_t* __restrict__ vb,
                                                         const uint64_t* __restrict__ meta, const uint8_t* __restrict__ terminal,
@@ -385,16 +387,19 @@ __global__ __launch_bounds__(256) void k_pool_masks_enc(const PoolBoard* __restr
     const int b0 = (int)blockIdx.x * NB;
     const int nb = (n - b0) < NB ? (n - b0) : NB;
     if (tid == 0) sm.n_items = 0u;
-    {  // stage the tile's board records in LDS (coalesced dword copy)
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(recs + b0);
-        uint32_t* dst = reinterpret_cast<uint32_t*>(sm.ctx);
-        const int nw = nb * (int)(sizeof(PoolBoard) / 4);
+    {  // the tile's hand-off records into LDS (coalesced dword copy); srcpos tables cleared
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(hands + b0);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(sm.hand);
+        const int nw = nb * (int)(sizeof(PoolHand) / 4);
         for (int i = tid; i < nw; i += 256) dst[i] = src[i];
-        for (int i = tid; i < nb * 2 * 21; i += 256) {
-            int t = i / 21, k = i - t * 21;
-            sm.srcpos[t][k] = reinterpret_cast<const uint32_t*>(tabs[(size_t)b0 * 2 + t].srcpos)[k];
-        }
+        for (int i = tid; i < nb * 2 * 21; i += 256) (&sm.srcpos[0][0])[i] = 0xFFFFFFFFu;
     }
+    __syncthreads();
+    // lane = board: blocked sets, static slot tests from the 24-byte board; need masks, jump plans, pawn moves from the record
+    if (tid < nb) pool_hand_rebuild_board(sm.ctx[tid], sm.hand[tid], unpack(hb[b0 + tid], vb[b0 + tid], meta[b0 + tid]));
+    __syncthreads();
+    // lane = (board, player): path edge sets, path tiles, jump positions, srcpos table from the tile sequence
+    if (tid < 2 * nb) pool_hand_rebuild_path(sm.ctx[tid >> 1], (tid & 1) + 1, sm.hand[tid >> 1].seq[tid & 1], reinterpret_cast<uint8_t*>(sm.srcpos[tid]));
     __syncthreads();
     // P2: lane = (board, slot); the 64 lanes of a wave share a board
     for (int base = 0; base < nb * 64; base += 256) {
@@ -420,8 +425,7 @@ __global__ __launch_bounds__(256) void k_pool_masks_enc(const PoolBoard* __restr
         uint32_t item = sm.items[it];
         int bd = (int)(item >> 8), ix = (int)(item & 63u);
         const int side = (item & 0x80u) ? 1 : 0;
-        bool ok = pool_p3(sm.ctx[bd], item, reinterpret_cast<const uint8_t*>(sm.srcpos[bd * 2 + side]),
-                          tabs[(size_t)(b0 + bd) * 2 + side].suffix);
+        bool ok = pool_p3_seq(sm.ctx[bd], item, reinterpret_cast<const uint8_t*>(sm.srcpos[bd * 2 + side]), sm.hand[bd].seq[side]);
         if (!ok) atomicOr(&sm.ctx[bd].blocked[((item & 0x40u) ? 0 : 2) + (ix >> 5)], 1u << (ix & 31));
     }
     __syncthreads();
@@ -544,10 +548,8 @@ __device__ __forceinline__ uint32_t tree_alloc(const EngineDev& E, TreeView& T, 
         const uint32_t page = wave_pop(E.free_tree, E.pool_words + QZ_P_TREE_TOP, E.pool_words + QZ_P_TREE_LOW, lane);
         if (page == QZ_NONE) return QZ_NONE;
         if (lane == 0) T.ptab[pg] = page;
-        if (lane == (int)(pg & 63u)) {
-            if (pg < 64u) T.pt0 = page;
-            else T.pt1 = page;
-        }
+        if (pg < 64u && lane == (int)pg) T.pt0 = page;
+        if (pg >= 64u) __threadfence();  // (read back from memory by tree_phys: the store first)
         np = pg + 1u;
     }
     neu = off + (uint32_t)k;
@@ -584,23 +586,60 @@ __device__ __forceinline__ uint32_t tree_alloc(const EngineDev& E, TreeView& T, 
 //    is in flight: the winner's is the next level's sqrt(N_parent), off the critical path;
 //  * nodes with <= 8 children (most of a long game: a mover without walls has 2-5 moves) pick
 //    their maximum by a uniform scan over readlanes instead of six rounds of LDS-crossbar shuffles.
+// np.sqrt of a visit count in float64 (mcts.py:69), correctly rounded: the library's sqrt(double) without the part that
+// rescales subnormal arguments -- a count is 0 or >= 1 -- whose three constants the compiler kept in vector registers
+// across the whole loop of k_advance.  v_rsq_f64 seeds two coupled Newton steps for sqrt(x) and 1 / (2 sqrt(x)); two
+// residual corrections make the result exact to the last place (qz_selftest_sqrt checks every n < 2^20 against the host's).
+__device__ __forceinline__ double sqrt_count(uint32_t n) {
+    const double x = (double)n;
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    return n == 0u ? 0.0 : g;
+}
 __device__ __forceinline__ double rdl_f64(double v, int l) {
     const uint64_t u = (uint64_t)__double_as_longlong(v);
     return __longlong_as_double((long long)((uint64_t)rdl((uint32_t)u, l) | ((uint64_t)rdl((uint32_t)(u >> 32), l) << 32)));
 }
-// the moves of lanes 0 .. n-1 (lane j = j-th move from `bd`, movers alternate) applied at once; returns done
+// sum of v over the wavefront by DPP row shifts / row broadcasts (no LDS crossbar trip, no scalar popcount chain): the
+// total arrives in lane 63 and is returned wave-uniform
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);  // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);  // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);  // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);  // row_shr:8: lane 15 of every row holds the row's sum
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+    return (uint32_t)__builtin_amdgcn_readlane(x, 63);
+}
+// the moves of lanes 0 .. n-1 (lane j = j-th move from `bd`, movers alternate) applied at once; returns done.
+// Pawn displacements and wall counts of the two movers are summed in ONE wave reduction: a lane contributes its biased
+// displacement (delta + 18, 0..36) to the 12-bit field of its parity (even lanes = the current player) or 1 to its
+// parity's 4-bit wall count (a player has at most 10 walls).
 __device__ __forceinline__ bool apply_actions_wave(Board& bd, uint32_t act, int n, int lane) {
     const uint64_t in = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
-    const uint64_t even = 0x5555555555555555ull & in, odd = 0xAAAAAAAAAAAAAAAAull & in;  // lane parity = mover: even lanes the current player
-    int d_even = 0, d_odd = 0;
-#pragma unroll
-    for (int a = 0; a < 12; a++) {
-        const uint64_t m = __ballot(act == (uint32_t)a);
-        d_even += action_delta(a) * __popcll(m & even);
-        d_odd += action_delta(a) * __popcll(m & odd);
-    }
-    uint64_t walls = __ballot(act >= 12u) & in;
-    const int w_even = __popcll(walls & even), w_odd = __popcll(walls & odd);
+    const bool mine = lane < n;
+    // action_delta(a) + 18 for a = 0..11, six bits each: N S E W NN | SS EE WW NE NW | SE SW
+    const uint32_t K0 = 27u | (9u << 6) | (19u << 12) | (17u << 18) | (36u << 24), K1 = 0u | (20u << 6) | (16u << 12) | (28u << 18) | (26u << 24),
+                   K2 = 10u | (8u << 6);
+    const uint32_t a = act < 12u ? act : 0u;
+    const uint32_t tb = a < 5u ? K0 : (a < 10u ? K1 : K2), sh = 6u * (a < 5u ? a : (a < 10u ? a - 5u : a - 10u));
+    const uint32_t dl = (tb >> sh) & 63u;
+    const uint32_t odd = (uint32_t)lane & 1u;
+    uint32_t contrib = 0u;
+    if (mine) contrib = act < 12u ? (dl << (12u * odd)) : (1u << (24u + 4u * odd));
+    const uint32_t tot = wave_sum_u32(contrib);
+    uint64_t walls = __ballot(mine && act >= 12u);
+    const int w_even = (int)((tot >> 24) & 15u), w_odd = (int)(tot >> 28);
+    const int n_even = __popcll(in & 0x5555555555555555ull), n_odd = __popcll(in & 0xAAAAAAAAAAAAAAAAull);
+    const int d_even = (int)(tot & 0xFFFu) - 18 * (n_even - w_even), d_odd = (int)((tot >> 12) & 0xFFFu) - 18 * (n_odd - w_odd);
     while (walls) {
         const int j = __ffsll((unsigned long long)walls) - 1;
         walls &= walls - 1ull;
@@ -676,13 +715,6 @@ struct PathMirror {
 };
 // the wave-uniform fields, forced into scalar registers (k_advance's loop: see there)
 __device__ __forceinline__ void regs_uniform(BoardRegs& R) {
-    R.root.hb = rfl64(R.root.hb);
-    R.root.vb = rfl64(R.root.vb);
-    R.root.p1 = (int)rfl((uint32_t)R.root.p1);
-    R.root.p2 = (int)rfl((uint32_t)R.root.p2);
-    R.root.w1 = (int)rfl((uint32_t)R.root.w1);
-    R.root.w2 = (int)rfl((uint32_t)R.root.w2);
-    R.root.cur = (int)rfl((uint32_t)R.root.cur);
     R.rootN = rfl(R.rootN);
     R.root_ne = rfl(R.root_ne);
     R.root_eoff = rfl(R.root_eoff);
@@ -753,8 +785,14 @@ __device__ __forceinline__ void regs_store(const EngineDev& E, const int b, cons
 // the descent of board b (MCTS._playout, mcts.py:107-113) on the register state R: no per-board scalar is read from or
 // written to memory here; the leaf comes back in registers.  term: 0 live leaf; 1 terminal & winner == current_player;
 // 2 terminal & winner != current_player; 3 board not playing (finished, waiting for harvest)
+// at_leaf(board, finished): called once, as soon as the leaf is known -- BEFORE the descent goes on record -- so that the caller
+// can put loads that only depend on the leaf (k_advance: the memo bucket) in flight under the record commit.
+struct NoLeafHook {
+    __device__ __forceinline__ void operator()(const Board&, bool) const {}
+};
+template <typename LeafHook = NoLeafHook>
 __device__ __forceinline__ void select_core(EngineDev& E, BoardRegs& S, const int b, const int lane, const PathMirror PM, Board& leaf_out,
-                                            uint32_t& pedge_out, uint32_t& plen_out, uint32_t& term_out) {
+                                            uint32_t& pedge_out, uint32_t& plen_out, uint32_t& term_out, LeafHook at_leaf_hook = LeafHook()) {
 #ifdef QZ_SELECT_STAMPS
     unsigned long long t_mark = __builtin_amdgcn_s_memtime();
     const unsigned long long t_begin = t_mark;
@@ -779,15 +817,16 @@ __device__ __forceinline__ void select_core(EngineDev& E, BoardRegs& S, const in
         const TreeView T = S.T;
         Edge* const pool = T.pool;
         uint32_t base = tree_phys(T, S.root_eoff);
-        double sq = sqrt((double)rootN);  // np.sqrt(self._parent._n_visits), float64
+        double sq = sqrt_count(rootN);  // np.sqrt(self._parent._n_visits), float64
         uint32_t* const pe0 = E.path_edges + (size_t)b * (R + 1u) * CAP;
         unsigned long long* const pb0 = E.path_blocks + (size_t)b * (R + 1u) * CAP;
         uint32_t* const we = pe0 + (size_t)R * CAP;  // this descent (what the backup reads)
         unsigned long long* const wb = pb0 + (size_t)R * CAP;
         const bool use = (E.select_opts & 1) == 0;
         // lane r < R keeps record r's length and the time it was last useful
-        uint32_t rlen = use ? S.rlen : 0u;
-        uint32_t rstamp = S.rstamp;
+        if (!use) S.rlen = 0u;
+        uint32_t& rlen = S.rlen;      // (ONE copy: a second one lived in a register of its own across the whole descent)
+        uint32_t& rstamp = S.rstamp;
         const uint32_t src = S.rec_last & (R - 1u);  // the record of the previous descent
         const uint32_t src_len = rdl(rlen, (int)src);
         // the record being followed: its levels below plen are this descent's (records are whole root-to-leaf paths and
@@ -800,6 +839,9 @@ __device__ __forceinline__ void select_core(EngineDev& E, BoardRegs& S, const in
         while (!at_leaf) {
             // ---- replay of record cur from level plen, 64 levels per round
             bool left = false;
+            bool sel_valid = false, sel_nan = false;  // a replay round's lane has already made this level's selection
+            int sel_kk = 0;
+            uint32_t sel_N = 0u, sel_rec = QZ_NONE;
             QZ_SEL_MARK(t_walk)
             QZ_TS(1)
 #ifndef QZ_REPLAY_MIN
@@ -813,9 +855,12 @@ __device__ __forceinline__ void select_core(EngineDev& E, BoardRegs& S, const in
                 const uint32_t* const pe = pe0 + (size_t)cur * CAP;
                 const unsigned long long* const pb = pb0 + (size_t)cur * CAP;
                 const uint32_t i = plen + (uint32_t)lane;
-                bool ok = i < cur_len;
-                uint32_t lbase = 0u, chosen = 0u, prev = 0u, pN = 0u, pcoff = 0u;
-                unsigned long long w = 0ull;
+                // lane = level.  Levels below cur_len have a recorded choice to confirm; level cur_len -- one past the record's end --
+                // may still have a BLOCK entry: the node the recorded descent ended on, written there when it was expanded
+                // (note_expansion).  Such an "open" level has nothing to confirm, but its lane can do the selection.
+                const bool rec = i < cur_len;
+                bool ok = i <= cur_len && i < CAP;
+                uint32_t lbase = 0u, chosen = QZ_NONE, prev = 0u;
                 int lne = 0;
                 // the record of the PREVIOUS descent of this launch is still in the LDS mirror (levels below PM.valid, not
                 // yet overwritten above the current level): no memory round trip for its entries
@@ -824,91 +869,118 @@ __device__ __forceinline__ void select_core(EngineDev& E, BoardRegs& S, const in
 #endif
                 const bool mir = QZ_REPLAY_MIRROR && cur == src && cur_len <= PM.valid;  // wave-uniform (PM.valid = 0 without a mirror)
                 if (ok) {
+                    unsigned long long w;
                     if (mir) {
-                        w = PM.wb[i];
-                        chosen = PM.we[i];
+                        w = i < PM.cap ? PM.wb[i] : 0ull;
+                        if (rec) chosen = PM.we[i];
                         if (lane > 0) prev = PM.we[i - 1u];
                     } else {
                         w = pb[i];
-                        chosen = pe[i];
+                        if (rec) chosen = pe[i];
                         if (lane > 0) prev = pe[i - 1u];
                     }
                     lbase = (uint32_t)(w >> 8);
                     lne = (int)(w & 0xFFull);
                 }
-                // ONE round trip for the parent edge (its visit count and child block) AND the node's edge records: the block
-                // address comes from the record, so the loads need not wait for the parent edge; what the record says is only
-                // BELIEVED after the check below (a stale entry points at memory of the pool that now means something else: the
-                // loads are harmless -- lne <= 8 records inside the pool -- and their values are thrown away)
-                ok = ok && lne >= 1 && lne <= 8;
-                // All of the round's loads are ISSUED TOGETHER, as raw dwords, before anything looks at them: the parent edge
-                // (its visit count and child block) and the node's <= 8 edge records -- Q, N, P, coff, act | cne | rid: 6
-                // registers per record, this array is the register peak of the descent.  (Written field by field the loads came
-                // out one record at a time, each behind an s_waitcnt for the previous one -- unpacking act / cne is a use --: eight
-                // dependent trips to the cache per round instead of one.)  A lane without a believable entry reads record 0 of the
-                // pool as its parent and throws it away.
-                struct EdgeRaw {
-                    uint32_t q_lo, q_hi, N, P, coff, misc;
-                };
-                EdgeRaw er[8];
-                {
-                    const uint4* pq = reinterpret_cast<const uint4*>(&pool[(ok && lane > 0) ? prev : 0u]);
-                    const uint4 pa = pq[0], pc = pq[1];
-#pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        if (ok && j < lne) {  // (a node has 2.2 children on average: no requests for the slots it does not have)
-                            const uint4* q = reinterpret_cast<const uint4*>(&pool[lbase + (uint32_t)j]);
-                            const uint4 a = q[0], c = q[1];
-                            er[j].q_lo = a.x; er[j].q_hi = a.y; er[j].N = a.z; er[j].P = a.w; er[j].coff = c.y; er[j].misc = c.z;
-                        }
-                    }
-                    pN = pa.z;
-                    pcoff = pc.y;
+                // ONE round trip for the parent edge (its visit count and child block), the node's edge records and the RECORDED
+                // edge's child block: the block address comes from the record, so the loads need not wait for the parent edge;
+                // what the record says is only BELIEVED after the check below (a stale entry points at memory of the pool that
+                // now means something else: the loads are harmless -- <= 8 records inside the pool -- and their values are thrown
+                // away).  A lane without a believable entry reads record 0 of the pool and throws it away.
+                // (the open level's entry may never have been written -- fresh memory, whatever it holds: its block must lie inside
+                // the pool before anything is loaded from it; every other entry was written by a record commit)
+                ok = ok && lne >= 1 && lne <= 8 && lbase <= (uint32_t)E.tree_pool_pages * QZ_PAGE_EDGES - 8u;
+                if (!ok) {
+                    lbase = 0u;
+                    lne = 1;
                 }
-                // an entry counts only if its block IS the child block of the entry above (lane 0: the current node)
+                // All of the round's loads are ISSUED TOGETHER, as raw dwords, before anything looks at them.  Of a child only
+                // (Q, N, P) -- its first 16 bytes -- take part in the comparison; coff / act / cne are needed of ONE edge per
+                // level, the recorded one (the level only counts if the argmax comes out as recorded), whose address the record
+                // gives: 4 x 4 + 2 registers per lane instead of round 3's 8 x 6 (what set the kernel's register count).  The
+                // children come four at a time: slot j is requested if ANY lane's node has more than j children (a wave-uniform
+                // branch; a lane with fewer asks for its last child again: same cache line, and an equal value never replaces
+                // the maximum); nodes with five to eight children take a second pass through the same registers.
+                const uint32_t* const pp = reinterpret_cast<const uint32_t*>(&pool[lane > 0 ? prev : 0u]);
+                const uint32_t* const cq = reinterpret_cast<const uint32_t*>(&pool[(ok && rec) ? chosen : 0u]);
+                const uint32_t last_child = (uint32_t)lne - 1u;
+                const bool any2 = __ballot(lne >= 2) != 0ull, any3 = __ballot(lne >= 3) != 0ull, any4 = __ballot(lne >= 4) != 0ull,
+                           any5 = __ballot(lne >= 5) != 0ull;
+                // (the parent edge first: what it says is needed first -- the link test, the square root -- while the children are
+                // still on their way; all seven requests back to back, no branch between them: behind a branch the compiler's
+                // wait for ONE of them becomes a wait for all, and a slot initialised with a copy of slot 0 waits for slot 0 --
+                // measured: two dependent trips per round instead of one)
+                const uint32_t pN = pp[2], pcoff = pp[5], pmisc = pp[6];
+                const uint32_t ccoff = cq[5], cmisc = cq[6];
+                uint4 c0 = *reinterpret_cast<const uint4*>(&pool[lbase]);
+                uint4 c1 = *reinterpret_cast<const uint4*>(&pool[lbase + (1u < last_child ? 1u : last_child)]);
+                uint4 c2 = *reinterpret_cast<const uint4*>(&pool[lbase + (2u < last_child ? 2u : last_child)]);
+                uint4 c3 = *reinterpret_cast<const uint4*>(&pool[lbase + (3u < last_child ? 3u : last_child)]);
+                // an entry counts only if its block IS the child block of the entry above (lane 0: the current node), with that
+                // node's number of children (an entry past a record's end may be left over from another tree in the same pages)
                 const uint32_t linked = tree_phys_lanes(T, pcoff);
-                ok = ok && lbase == (lane > 0 ? linked : base);
-                uint32_t lact = 0u, lcne = 0u, lN = 0u, lcoff = 0u;
-                if (ok) {
-                    const double lsq = lane > 0 ? sqrt((double)pN) : sq;
-                    double lbest = 0.0;
-                    int arg = 0;
-                    uint32_t lmisc = 0u;
-#pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        if (j < lne) {
-                            const float cp = E.c_puct * __uint_as_float(er[j].P);
-                            const double u = (double)cp * lsq / (double)(1u + er[j].N);
-                            const double val = __hiloint2double((int)er[j].q_hi, (int)er[j].q_lo) + u;
-                            if (j == 0 || val > lbest) {  // first maximum, like max() over the children dict
-                                lbest = val;
-                                arg = j;
-                                lmisc = er[j].misc;
-                                lN = er[j].N;
-                                lcoff = er[j].coff;
-                            }
-                        }
-                    }
-                    lact = lmisc & 0xFFu;
-                    lcne = (lmisc >> 8) & 0xFFu;
-                    ok = (lbase + (uint32_t)arg == chosen) && (lbest == lbest);
+                ok = ok && lbase == (lane > 0 ? linked : base) && lne == (lane > 0 ? (int)((pmisc >> 8) & 0xFFu) : ne);
+                const double lsq = lane > 0 ? sqrt_count(pN) : sq;
+                double lbest;
+                uint32_t arg = 0u, lN;
+#define QZ_PUCT_OF(c) (__hiloint2double((int)(c).y, (int)(c).x) + (double)(E.c_puct * __uint_as_float((c).w)) * lsq / (double)(1u + (c).z))
+#define QZ_PUCT_NEXT(c, j)                                         \
+    {                                                              \
+        const double val_ = QZ_PUCT_OF(c);                         \
+        if (val_ > lbest) { /* first maximum, like max() over the children dict */ \
+            lbest = val_;                                          \
+            arg = (j);                                             \
+            lN = (c).z;                                            \
+        }                                                          \
+    }
+                lbest = QZ_PUCT_OF(c0);
+                lN = c0.z;
+                if (any2) QZ_PUCT_NEXT(c1, 1u)
+                if (any3) QZ_PUCT_NEXT(c2, 2u)
+                if (any4) QZ_PUCT_NEXT(c3, 3u)
+                if (any5) {  // (wave-uniform, rare in the late game: a mover without walls has two to five moves)
+                    const bool any6 = __ballot(lne >= 6) != 0ull, any7 = __ballot(lne >= 7) != 0ull, any8 = __ballot(lne >= 8) != 0ull;
+                    c0 = *reinterpret_cast<const uint4*>(&pool[lbase + (4u < last_child ? 4u : last_child)]);
+                    if (any6) c1 = *reinterpret_cast<const uint4*>(&pool[lbase + (5u < last_child ? 5u : last_child)]);
+                    if (any7) c2 = *reinterpret_cast<const uint4*>(&pool[lbase + (6u < last_child ? 6u : last_child)]);
+                    if (any8) c3 = *reinterpret_cast<const uint4*>(&pool[lbase + (7u < last_child ? 7u : last_child)]);
+                    // (a lane whose node has <= 4 children sees one of its first four again: equal, never greater)
+                    QZ_PUCT_NEXT(c0, 4u)
+                    if (any6) QZ_PUCT_NEXT(c1, 5u)
+                    if (any7) QZ_PUCT_NEXT(c2, 6u)
+                    if (any8) QZ_PUCT_NEXT(c3, 7u)
                 }
-                const uint64_t bad = ~__ballot(ok);
+#undef QZ_PUCT_NEXT
+#undef QZ_PUCT_OF
+                // ok: the lane's node IS the node of its level (given that the levels above came out as recorded), and arg is what
+                // TreeNode.select picks there.  The level is CONFIRMED if that is the recorded edge.
+                const bool match = ok && rec && (lbase + arg == chosen) && (lbest == lbest);
+                const uint32_t lact = cmisc & 0xFFu, lcne = (cmisc >> 8) & 0xFFu;
+                const uint64_t okm = __ballot(ok);
+                const uint64_t bad = ~__ballot(match);
                 const int nconf = bad ? (__ffsll((unsigned long long)bad) - 1) : 64;  // leading levels of this round that came out as recorded
                 if (nconf > 0) {
+                    // the confirmed levels into the descent buffer: its first PM.cap levels live in the LDS mirror only (a leaf
+                    // that has to wait for the network writes them out: k_advance), deeper ones in memory
                     if (lane < nconf && i < CAP) {
-                        we[i] = chosen;
-                        wb[i] = w;
                         if (i < PM.cap) {
-                            PM.we[i] = chosen;
-                            PM.wb[i] = w;
+                            if (!mir) {  // (replayed FROM the mirror: the entries are there)
+                                PM.we[i] = chosen;
+                                PM.wb[i] = ((unsigned long long)lbase << 8) | (unsigned long long)lne;  // (= the record's entry: this lane is ok)
+                            }
+                        } else {
+                            we[i] = chosen;
+                            wb[i] = ((unsigned long long)lbase << 8) | (unsigned long long)lne;
                         }
                     }
                     used |= 1u << cur;
                     done = apply_actions_wave(bd, lact, nconf, lane);
-                    uint32_t sc = (lane < nconf) ? (uint32_t)lne : 0u;
-                    for (int o = 32; o > 0; o >>= 1) sc += __shfl_xor(sc, o);
-                    scanned += rfl(sc);
+                    {   // edge records scanned by the confirmed levels (statistics): lne is 1..8, four ballots
+                        const uint64_t inm = nconf >= 64 ? ~0ull : ((1ull << nconf) - 1ull);
+                        const uint32_t l1 = (uint32_t)lne - 1u;  // 0..7
+                        scanned += (uint32_t)nconf + (uint32_t)__popcll(__ballot((l1 & 1u) != 0u) & inm) + 2u * (uint32_t)__popcll(__ballot((l1 & 2u) != 0u) & inm) +
+                                   4u * (uint32_t)__popcll(__ballot((l1 & 4u) != 0u) & inm);
+                    }
                     plen += (uint32_t)nconf;
                     replayed += (uint32_t)nconf;
                     const int last = nconf - 1;
@@ -918,9 +990,21 @@ __device__ __forceinline__ void select_core(EngineDev& E, BoardRegs& S, const in
                         at_leaf = true;
                         break;
                     }
-                    sq = sqrt((double)rdl(lN, last));
-                    base = tree_phys(T, rdl(lcoff, last));
+                    sq = sqrt_count(rdl(lN, last));
+                    base = tree_phys(T, rdl(ccoff, last));
                     ne = cne;
+                }
+                // The first level that did NOT come out as recorded (or the open level past the record's end): if its lane's
+                // node is right (ok), the lane has just done what the walk would do there -- the same loads, the same float64
+                // expressions, first maximum wins -- so its pick IS the level's selection: the walk below only completes it
+                // (the move, the record, the hint).  One level per round for free: round 3 walked it, a full dependent trip.
+                if (nconf < 64 && ((okm >> nconf) & 1ull)) {
+                    sel_valid = true;
+                    sel_kk = (int)rdl(arg, nconf);
+                    sel_N = rdl(lN, nconf);
+                    sel_nan = rdl((uint32_t)!(lbest == lbest), nconf) != 0u;
+                    sel_rec = rdl(chosen, nconf);  // the recorded edge of that level (QZ_NONE: the open level)
+                    // (base / ne of that level: what the confirmed prefix left in base / ne -- the lane's block passed the same test)
                 }
                 if (nconf < 64) left = true;
                 if (nconf < QZ_REPLAY_MIN) walk_credit = (uint32_t)QZ_WALK_CREDIT;
@@ -937,65 +1021,100 @@ __device__ __forceinline__ void select_core(EngineDev& E, BoardRegs& S, const in
             QZ_SEL_COUNT(if (ne <= 8) n_narrow++; else n_wide++;)
             // ---- one level of the walk (all lanes scan this node's children)
             uint32_t recorded = QZ_NONE;
-            if (cur != QZ_NONE && plen < cur_len) recorded = pe0[(size_t)cur * CAP + plen];  // uniform load, in flight during the scan
+            if (sel_valid) recorded = sel_rec;
+            else if (cur != QZ_NONE && plen < cur_len) recorded = pe0[(size_t)cur * CAP + plen];  // uniform load, in flight during the scan
             scanned += (uint32_t)ne;
-            double best = -__builtin_inf();
-            int bestk = 0x7fffffff;
-            // everything the descent needs about the winning edge rides along with the
-            // candidates, so the next level costs one dependent round trip, not three
-            uint32_t mCOff = 0u, mMisc = 0u;
-            double mSq = 0.0;
-            for (int j = lane; j < ne; j += 64) {
-                // one 32-byte record per lane.  (The compiler fetches the second half -- coff, act | cne | rid -- inside the branch
-                // below, for the lanes whose candidate leads: a second trip to the cache.  Forcing both halves up front measured
-                // SLOWER, 4.1 k against 3.7 k cycles per walked level.)
-                const uint4* q = reinterpret_cast<const uint4*>(&pool[base + (uint32_t)j]);
-                const uint4 qa = q[0], qc = q[1];
-                uint32_t N = qa.z;
-                float cp = E.c_puct * __uint_as_float(qa.w);        // c_puct * self._P in float32
-                double u = (double)cp * sq / (double)(1u + N);      // mcts.py:69
-                double val = __hiloint2double((int)qa.y, (int)qa.x) + u;  // mcts.py:70
-                double sqN = sqrt((double)N);                       // the next level's sqrt(N_parent) if this edge wins
-                uint32_t misc = qc.z;                               // act | cne << 8 | rid << 16
-                // a lane's first candidate is always taken: with non-finite values (a diverged
-                // network) every comparison is false and Python's max() keeps the first child
-                if (val > best || bestk == 0x7fffffff) {
-                    best = val;
-                    bestk = j;
-                    mSq = sqN;
-                    mCOff = qc.y;
-                    mMisc = misc;
-                }
-            }
             int kk;
-            if (ne <= 8 && !(E.select_opts & 2)) {  // wave-uniform: lane j < ne holds (val_j, j); first maximum wins like max()
-                double bv = rdl_f64(best, 0);
+            uint32_t misc, w_coff;
+            double w_sq;  // of the winning edge: act | cne << 8 | rid << 16, its child block, sqrt(its visit count) = the next level's sqrt(N_parent)
+            if (sel_valid) {
+#ifdef QZ_ADV_STAMPS
+                S.t_sel[3] += 1ull;  // levels whose selection came from a replay round's lane
+#endif
+                // selected by the last replay round's lane (same arithmetic as below); what is left to fetch is the winner's
+                // act | cne | rid and child block: 8 bytes of a record the round has just read
+                kk = sel_kk;
+                const uint32_t* const q = reinterpret_cast<const uint32_t*>(&pool[base + (uint32_t)kk]);
+                w_coff = rfl(q[5]);
+                misc = rfl(q[6]);
+                w_sq = sqrt_count(sel_N);
+                nonfinite = nonfinite || sel_nan;
+            } else if (ne <= 8 && !(E.select_opts & 2)) {
+                // a narrow node (most of a long game: a mover without walls has two to five moves): lane j < ne takes edge j -- both
+                // halves of the record requested together, the square root of its own visit count beside the division (two
+                // independent chains the scheduler interleaves) -- and the maximum is picked by a wave-uniform scan over
+                // readlanes: first maximum wins like max() over the children dict (mcts.py:42)
+                uint4 qa = make_uint4(0u, 0u, 0u, 0u);
+                uint32_t qcoff = 0u, qmisc = 0u;
+                if (lane < ne) {
+                    const uint32_t* const q = reinterpret_cast<const uint32_t*>(&pool[base + (uint32_t)lane]);
+                    qa = *reinterpret_cast<const uint4*>(q);
+                    qcoff = q[5];
+                    qmisc = q[6];
+                }
+                const float cp = E.c_puct * __uint_as_float(qa.w);                       // c_puct * self._P in float32
+                const double u = (double)cp * sq / (double)(1u + qa.z);                  // mcts.py:69
+                const double val = __hiloint2double((int)qa.y, (int)qa.x) + u;           // mcts.py:70
+                const double sqN = sqrt_count(qa.z);
+                double bv = rdl_f64(val, 0);
                 kk = 0;
                 for (int j = 1; j < ne; j++) {
-                    const double vj = rdl_f64(best, j);
+                    const double vj = rdl_f64(val, j);
                     if (vj > bv) {
                         bv = vj;
                         kk = j;
                     }
                 }
                 nonfinite = nonfinite || !(bv == bv);
+                misc = rdl(qmisc, kk);
+                w_coff = rdl(qcoff, kk);
+                w_sq = rdl_f64(sqN, kk);
             } else {
+                double best = -__builtin_inf();
+                int bestk = 0x7fffffff;
+                // everything the descent needs about the winning edge rides along with the
+                // candidates, so the next level costs one dependent round trip, not three
+                uint32_t mCOff = 0u, mMisc = 0u;
+                double mSq = 0.0;
+                for (int j = lane; j < ne; j += 64) {
+                    // one 32-byte record per lane.  (The compiler fetches the second half -- coff, act | cne | rid -- inside the branch
+                    // below, for the lanes whose candidate leads: a second trip to the cache.)
+                    const uint4* q = reinterpret_cast<const uint4*>(&pool[base + (uint32_t)j]);
+                    const uint4 qa = q[0], qc = q[1];
+                    uint32_t N = qa.z;
+                    float cp = E.c_puct * __uint_as_float(qa.w);        // c_puct * self._P in float32
+                    double u = (double)cp * sq / (double)(1u + N);      // mcts.py:69
+                    double val = __hiloint2double((int)qa.y, (int)qa.x) + u;  // mcts.py:70
+                    double sqN = sqrt_count(N);                         // the next level's sqrt(N_parent) if this edge wins
+                    // a lane's first candidate is always taken: with non-finite values (a diverged
+                    // network) every comparison is false and Python's max() keeps the first child
+                    if (val > best || bestk == 0x7fffffff) {
+                        best = val;
+                        bestk = j;
+                        mSq = sqN;
+                        mCOff = qc.y;
+                        mMisc = qc.z;                                   // act | cne << 8 | rid << 16
+                    }
+                }
                 wave_argmax(best, bestk);
                 kk = (int)rfl((uint32_t)bestk);  // lane 0 always holds a valid pair (k = 0 is its own)
                 nonfinite = nonfinite || !(best == best);
+                const int wl = kk & 63;  // the winning edge is the winning lane's own best candidate
+                misc = rdl(mMisc, wl);
+                w_coff = rdl(mCOff, wl);
+                w_sq = rdl_f64(mSq, wl);
             }
-            const int wl = kk & 63;  // the winning edge is the winning lane's own best candidate
             const uint32_t e = base + (uint32_t)kk;
-            const uint32_t misc = rdl(mMisc, wl);
             const int a = (int)(misc & 0xFFu);
             done = apply_action(bd, a);  // game.step(action), mcts.py:113
             if (lane == 0 && plen < CAP) {
                 const unsigned long long blk = ((unsigned long long)base << 8) | (unsigned long long)(ne > 255 ? 255 : ne);
-                we[plen] = e;
-                wb[plen] = blk;
-                if (plen < PM.cap) {
+                if (plen < PM.cap) {  // (the mirror's levels reach memory only if the leaf has to wait for the network: k_advance)
                     PM.we[plen] = e;
                     PM.wb[plen] = blk;
+                } else {
+                    we[plen] = e;
+                    wb[plen] = blk;
                 }
             }
             if (use && rfl(recorded) != e && !(cur != QZ_NONE && plen >= cur_len)) {  // (beyond the end of the record it follows, a descent extends it)
@@ -1026,11 +1145,12 @@ __device__ __forceinline__ void select_core(EngineDev& E, BoardRegs& S, const in
                 if (lane == 0) atomicAdd(&E.counters[QZ_C_RUNAWAY], 1ull);
                 break;
             }
-            sq = rdl_f64(mSq, wl);
-            base = tree_phys(T, rdl(mCOff, wl));
+            sq = w_sq;
+            base = tree_phys(T, w_coff);
             ne = cne;
         }
         QZ_TS(1)
+        at_leaf_hook(bd, done);
         // (all wave-uniform by construction; said so explicitly, or the compiler carries them -- and the record bookkeeping
         // derived from them -- in vector registers it does not have: their scratch reloads each drain the store queue)
         cur = rfl(cur);
@@ -1082,18 +1202,19 @@ __device__ __forceinline__ void select_core(EngineDev& E, BoardRegs& S, const in
                 wave_sync();  // lane 0 stored walked levels into the descent buffer, all lanes read it below
                 uint32_t* const qe = pe0 + (size_t)dest * CAP;
                 unsigned long long* const qb = pb0 + (size_t)dest * CAP;
-                for (uint32_t i = from + (uint32_t)lane; i < n; i += 64u) {
-                    uint32_t ed;
-                    unsigned long long bk;
-                    if (i < PM.cap) {
-                        ed = PM.we[i];
-                        bk = PM.wb[i];
-                    } else {
-                        ed = we[i];
-                        bk = wb[i];
-                    }
+                // (two loops with wave-uniform bounds, not one with a per-lane choice of the source: there the LDS reads had to
+                // wait for every global load in flight -- the same destination registers -- among them the caller's memo probe)
+                const uint32_t n_lds = n < PM.cap ? n : PM.cap;
+                for (uint32_t i = from + (uint32_t)lane; i < n_lds; i += 64u) {
+                    const uint32_t ed = PM.we[i];
                     qe[i] = ed;
-                    qb[i] = bk;
+                    qb[i] = PM.wb[i];
+                    if (i >= first) pool[ed].rid = (uint16_t)(dest + 1u);
+                }
+                for (uint32_t i = (from > PM.cap ? from : PM.cap) + (uint32_t)lane; i < n; i += 64u) {
+                    const uint32_t ed = we[i];
+                    qe[i] = ed;
+                    qb[i] = wb[i];
                     if (i >= first) pool[ed].rid = (uint16_t)(dest + 1u);
                 }
             }
@@ -1102,8 +1223,6 @@ __device__ __forceinline__ void select_core(EngineDev& E, BoardRegs& S, const in
                     if (from < n) rlen = n;
                     rstamp = clock;
                 } else if ((used >> lane) & 1u) rstamp = clock;
-                S.rlen = rlen;
-                S.rstamp = rstamp;
             }
             S.rec_last = dest;
             S.rec_clock = clock;
@@ -1193,9 +1312,11 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
 // TreeNode.expand (mcts.py:27-35): a block of k edges in actions() order under physical edge `pedge` (QZ_NONE: the
 // root), priors from prior(a) -- called by the lane that owns action a (a = lane, lane + 64, lane + 128).
+// -> (first physical edge << 8 | edge count) of the new node's block, 0 if nothing was built (no legal move, arena full)
 template <typename PriorFn>
-__device__ __forceinline__ void expand_node(EngineDev& E, BoardRegs& S, const int lane, const uint32_t pedge, const uint32_t m0,
-                                            const uint32_t m1, const uint32_t m2, const uint32_t m3, const uint32_t m4, PriorFn prior) {
+__device__ __forceinline__ unsigned long long expand_node(EngineDev& E, BoardRegs& S, const int lane, const uint32_t pedge, const uint32_t m0,
+                                                          const uint32_t m1, const uint32_t m2, const uint32_t m3, const uint32_t m4, PriorFn prior) {
+    unsigned long long built = 0ull;
     uint32_t pawn = m0 & 0xFFFu;
     uint64_t lh = ((uint64_t)m0 >> 12) | ((uint64_t)m1 << 20) | ((uint64_t)(m2 & 0xFFFu) << 52);
     uint64_t lv = ((uint64_t)m2 >> 12) | ((uint64_t)m3 << 20) | ((uint64_t)(m4 & 0xFFFu) << 52);
@@ -1206,21 +1327,17 @@ __device__ __forceinline__ void expand_node(EngineDev& E, BoardRegs& S, const in
         if (E.node_cap <= 0 || S.nn < (uint32_t)E.node_cap) off = tree_alloc(E, S.T, neu, np, k, lane, false);
         if (off != QZ_NONE) {
             const uint32_t base = tree_phys(S.T, off);
+            // (the record's constant fields from a zero the optimiser cannot see through: as literals they were hoisted out of
+            // k_advance's loop into vector registers of their own -- 0.0, QZ_NONE -- and those registers spilled)
+            uint32_t zero = 0u;
+            asm volatile("" : "+v"(zero));
             for (int a = lane; a < QZ_N_ACT; a += 64) {
                 uint32_t w = a < 32 ? m0 : (a < 64 ? m1 : (a < 96 ? m2 : (a < 128 ? m3 : m4)));
                 if ((w >> (a & 31)) & 1u) {
                     uint32_t e = base + (uint32_t)order_index(pawn, lh, lv, a);
-                    Edge ed;
-                    ed.Q = 0.0;
-                    ed.N = 0u;
-                    ed.P = prior(a);
-                    ed.pedge = pedge;
-                    ed.coff = 0u;
-                    ed.act = (uint8_t)a;
-                    ed.cne = 0;
-                    ed.rid = 0;
-                    ed.spare = QZ_NONE;
-                    S.T.pool[e] = ed;
+                    uint4* const q = reinterpret_cast<uint4*>(&S.T.pool[e]);
+                    q[0] = make_uint4(zero, zero, zero, __float_as_uint(prior(a)));   // Q = 0.0 | N = 0 | P
+                    q[1] = make_uint4(pedge, zero, (uint32_t)a | zero, ~zero);       // pedge | coff = 0 | act, cne = 0, rid = 0 | spare = QZ_NONE
                 }
             }
             if (pedge != QZ_NONE) {
@@ -1236,10 +1353,23 @@ __device__ __forceinline__ void expand_node(EngineDev& E, BoardRegs& S, const in
             S.neu = neu;
             S.np = np;
             lc_add64(S, LC_EXPANDED, (unsigned long long)k, lane);
+            built = ((unsigned long long)base << 8) | (unsigned long long)(k > 255 ? 255 : k);
         } else {
             lc_add(S, LC_OVERFLOW, 1u, lane);
             S.np = np;
         }
+    }
+    return built;
+}
+// The node a descent ended on has just been expanded: its block goes into the descent's record ONE PAST the record's end
+// (level plen: the record holds levels 0 .. plen-1), where the next descent's replay round finds it -- a level with nothing to
+// confirm but everything its lane needs to make the selection there (select_core).  blk = expand_node's result.
+__device__ __forceinline__ void note_expansion(EngineDev& E, const BoardRegs& S, const int b, const int lane, const PathMirror PM, const uint32_t plen,
+                                               const unsigned long long blk) {
+    if (blk == 0ull || plen >= (uint32_t)QZ_PATH_CAP || (E.select_opts & 1)) return;
+    if (lane == 0) {
+        E.path_blocks[((size_t)b * (QZ_PATH_RECS + 1u) + (S.rec_last & (QZ_PATH_RECS - 1u))) * QZ_PATH_CAP + plen] = blk;
+        if (plen < PM.cap) PM.wb[plen] = blk;
     }
 }
 // node.update_recursive(-leaf_value) (mcts.py:44-62, 127): the leaf edge gets -leaf_value, its
@@ -1298,7 +1428,8 @@ __device__ __forceinline__ void expand_backup_board(EngineDev& E, BoardRegs& S, 
         leaf_value = (double)v[b];
         const uint32_t* mask = E.leaf_mask + (size_t)b * 5;
         const float* prow = p + (size_t)b * QZ_N_ACT;
-        expand_node(E, S, lane, pedge, rfl(mask[0]), rfl(mask[1]), rfl(mask[2]), rfl(mask[3]), rfl(mask[4]), [&](int a) { return prow[a]; });
+        const unsigned long long blk = expand_node(E, S, lane, pedge, rfl(mask[0]), rfl(mask[1]), rfl(mask[2]), rfl(mask[3]), rfl(mask[4]), [&](int a) { return prow[a]; });
+        note_expansion(E, S, b, lane, PathMirror{(lds_u32*)nullptr, (lds_u64*)nullptr, 0u, 0u}, plen, blk);
     } else {
         leaf_value = terminal_value(E, term);
     }
@@ -1441,19 +1572,24 @@ __device__ __forceinline__ void translate_records(EngineDev& E, int b, int lane,
         uint32_t newlen = 0u;
         if (edge != QZ_NONE && len > 1u && rfl(re[0]) == edge) {
             newlen = len - 1u;
-            for (uint32_t c = 1u; c < len; c += 64u) {
+            // (level len, one past the end, may hold the block of the node the recorded descent ended on -- note_expansion --:
+            // it moves up with the rest.  Nothing says it is there: whatever arrives at the new index is only believed after
+            // the replay round's link test, like every entry.)
+            for (uint32_t c = 1u; c <= len; c += 64u) {
                 const uint32_t i = c + (uint32_t)lane;
-                const bool in = i < len;
+                const bool open = i == len && i < CAP;
+                const bool in = i < len || open;
                 uint32_t fe = QZ_NONE, fb = QZ_NONE;
                 unsigned long long bo = 0ull;
                 if (in) {
                     bo = rb[i];
+                    const uint32_t be = (uint32_t)(bo >> 8) < (uint32_t)E.tree_pool_pages * QZ_PAGE_EDGES ? (uint32_t)(bo >> 8) : 0u;
                     if (in_place) {  // the subtree stays where it is: the entries only move up one level
-                        fe = re[i];
-                        fb = (uint32_t)(bo >> 8);
+                        fe = open ? 0u : re[i];
+                        fb = be;
                     } else {
-                        fe = pool[re[i]].spare;
-                        fb = pool[(uint32_t)(bo >> 8)].spare;
+                        fe = open ? 0u : pool[re[i]].spare;
+                        fb = pool[be].spare;
                     }
                 }
                 const uint64_t bad = __ballot(in && (fe == QZ_NONE || fb == QZ_NONE));
@@ -2006,39 +2142,58 @@ struct MemoHit {
     float p_lane;        // small table: the prior of pawn code `lane` (lane < 12)
     const float* p_row;  // big table: p[140]; nullptr for a small-table hit
 };
-// one coalesced load of the bucket, key compare by ballot.  All lanes must call.
-__device__ __forceinline__ bool memo_probe(const EngineDev& E, const uint32_t epoch, const Board& bd, const int lane, MemoHit& H) {
+// The probe in two halves, so that its one trip to memory (an 8-GB table: HBM, often a TLB miss) runs under other work:
+// memo_probe_issue requests the bucket (small table: 512 B = 2 dwords per lane; big table: the two entries' first 16 dwords,
+// one per lane) and memo_probe_finish compares the 24-byte keys by ballot.  All lanes must call both.
+struct MemoProbe {
+    uint32_t d0, d1;            // the lane's dwords of the bucket
+    const uint32_t* bucket;     // big table: the bucket (p rows behind the headers); small table: unused
+    bool small;
+};
+__device__ __forceinline__ MemoProbe memo_probe_issue(const EngineDev& E, const Board& bd, const int lane) {
+    // (no branch around the loads: a conditionally loaded value meets its default in a phi, and the copy the phi needs waits
+    // for the load on the spot -- the requests would not be in flight under anything.  Without a memo the lanes read the
+    // descent records instead, an array that always exists, and memo_probe_finish ignores what comes back.)
+    MemoProbe P;
+    P.small = memo_is_small(bd);
+    const uint64_t h = memo_hash(bd.hb, bd.vb, pack_meta(bd));
+    const uint32_t* const Bs = E.memo.small + (size_t)((uint32_t)h & E.memo.small_mask) * (QZ_MEMO_S_WAYS * QZ_MEMO_S_DW);
+    const uint32_t* const Bb = E.memo.big + (size_t)((uint32_t)h & E.memo.big_mask) * (QZ_MEMO_B_WAYS * QZ_MEMO_B_DW);
+    const uint32_t* const B = E.memo.small ? (P.small ? Bs : Bb) : E.path_edges;
+    const uint32_t pos = (uint32_t)lane & 31u;
+    const uint32_t ib = ((uint32_t)lane >> 5) * QZ_MEMO_B_DW + (pos < 16u ? pos : 15u);
+    const uint32_t i0 = P.small ? (uint32_t)lane : ib, i1 = P.small ? (uint32_t)lane + 64u : ib;
+    P.bucket = B;
+    P.d0 = B[E.memo.small ? i0 : 0u];
+    P.d1 = B[E.memo.small ? i1 : 0u];
+    return P;
+}
+__device__ __forceinline__ bool memo_probe_finish(const EngineDev& E, const uint32_t epoch, const Board& bd, const int lane, const MemoProbe& P, MemoHit& H) {
     if (!E.memo.small) return false;
-    const uint64_t hb = bd.hb, vb = bd.vb, mk = pack_meta(bd) | ((uint64_t)epoch << 48);
-    const uint64_t h = memo_hash(hb, vb, pack_meta(bd));
+    const uint64_t mk = pack_meta(bd) | ((uint64_t)epoch << 48);
     const int pos = lane & 31;
-    const uint32_t kd = memo_key_dword(pos, hb, vb, mk);
-    if (memo_is_small(bd)) {
-        const uint32_t* B = E.memo.small + (size_t)((uint32_t)h & E.memo.small_mask) * (QZ_MEMO_S_WAYS * QZ_MEMO_S_DW);
-        const uint32_t d0 = B[lane], d1 = B[lane + 64];
+    const uint32_t kd = memo_key_dword(pos, bd.hb, bd.vb, mk);
+    if (P.small) {
+        const uint32_t d0 = P.d0, d1 = P.d1;
         const uint64_t e0 = __ballot(pos >= 6 || d0 == kd), e1 = __ballot(pos >= 6 || d1 == kd);
-        int e = -1;
-        if ((uint32_t)e0 == 0xFFFFFFFFu) e = 0;
-        else if ((uint32_t)(e0 >> 32) == 0xFFFFFFFFu) e = 1;
-        else if ((uint32_t)e1 == 0xFFFFFFFFu) e = 2;
-        else if ((uint32_t)(e1 >> 32) == 0xFFFFFFFFu) e = 3;
+        // (the four halves as scalar words, compared with -1 by the scalar unit: written on the 64-bit ballots the compiler
+        // made 64-bit VECTOR compares against constants it kept -- and spilled -- in vector register pairs)
+        const uint32_t a0 = rfl((uint32_t)e0), a1 = rfl((uint32_t)(e0 >> 32)), a2 = rfl((uint32_t)e1), a3 = rfl((uint32_t)(e1 >> 32));
+        const int e = a0 == 0xFFFFFFFFu ? 0 : (a1 == 0xFFFFFFFFu ? 1 : (a2 == 0xFFFFFFFFu ? 2 : (a3 == 0xFFFFFFFFu ? 3 : -1)));
         if (e < 0) return false;
         const uint32_t d = (e & 2) ? d1 : d0;
         const int base = (e & 1) * 32;
         H.v = __uint_as_float(rdl(d, base + 6));
         H.m0 = rdl(d, base + 7);
         H.m1 = H.m2 = H.m3 = H.m4 = 0u;
-        H.p_lane = __uint_as_float((uint32_t)__shfl((int)d, base + 8 + (lane < 12 ? lane : 0), 64));
+        H.p_lane = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute((base + 8 + (lane < 12 ? lane : 0)) << 2, (int)d));
         H.p_row = nullptr;
         return true;
     }
-    const uint32_t* B = E.memo.big + (size_t)((uint32_t)h & E.memo.big_mask) * (QZ_MEMO_B_WAYS * QZ_MEMO_B_DW);
-    const bool in = pos < 16;
-    const uint32_t d = in ? B[(lane >> 5) * QZ_MEMO_B_DW + pos] : 0u;
+    const uint32_t d = P.d0;  // (lanes 16..31 of a half hold dword 15 again: not part of the key)
     const uint64_t e0 = __ballot(pos >= 6 || d == kd);
-    int e = -1;
-    if ((uint32_t)e0 == 0xFFFFFFFFu) e = 0;
-    else if ((uint32_t)(e0 >> 32) == 0xFFFFFFFFu) e = 1;
+    const uint32_t a0 = rfl((uint32_t)e0), a1 = rfl((uint32_t)(e0 >> 32));
+    const int e = a0 == 0xFFFFFFFFu ? 0 : (a1 == 0xFFFFFFFFu ? 1 : -1);
     if (e < 0) return false;
     const int base = e * 32;
     H.v = __uint_as_float(rdl(d, base + 6));
@@ -2048,7 +2203,7 @@ __device__ __forceinline__ bool memo_probe(const EngineDev& E, const uint32_t ep
     H.m3 = rdl(d, base + 11);
     H.m4 = rdl(d, base + 12);
     H.p_lane = 0.f;
-    H.p_row = reinterpret_cast<const float*>(B + e * QZ_MEMO_B_DW + 16);
+    H.p_row = reinterpret_cast<const float*>(P.bucket + e * QZ_MEMO_B_DW + 16);
     return true;
 }
 // store one evaluation (wave-cooperative; k_round_tail only: no probe runs at the same time)
@@ -2144,17 +2299,30 @@ __device__ unsigned long long g_adv_stamps2[4096][4];  // levels confirmed by re
 #define QZ_AS_MARK(k)
 #define QZ_AS_COUNT(k, v)
 #endif
-constexpr uint32_t ADV_LCAP = 512;  // levels of a descent mirrored in LDS (6 KB per wavefront); deeper levels are read back from memory
-#ifndef QZ_ADV_WAVES
-#define QZ_ADV_WAVES 4  // wavefronts per SIMD the register allocation of k_advance aims at (A/B builds: tests/hip/Makefile)
+constexpr uint32_t ADV_LCAP = 320;  // levels of a descent mirrored in LDS (3.75 KB per wavefront: 32 wavefronts per CU fit in the 160 KB); deeper levels are read back from memory
+#ifndef QZ_ADV_WAVES_SMALL
+#define QZ_ADV_WAVES_SMALL 4  // wavefronts per SIMD the build of k_advance for engines of <= 4,096 boards aims at (A/B: 8 = one build for all sizes)
 #endif
-__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(QZ_ADV_WAVES, QZ_ADV_WAVES))) void k_advance(EngineDev E, int max_iters, unsigned int budget, int par) {
+__device__ __forceinline__ void advance_board(EngineDev& E, const int max_iters, const unsigned int budget, const int par) {
     __shared__ uint32_t s_we[WPB][ADV_LCAP];
     __shared__ unsigned long long s_wb[WPB][ADV_LCAP];
     __shared__ uint32_t s_lc[WPB][LC_WORDS];
     const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
     const int b = __builtin_amdgcn_readfirstlane((int)blockIdx.x * WPB + wave);  // in an SGPR: every per-board address below is scalar arithmetic
     if (b >= E.n_boards) return;
+    // The engine descriptor arrives in the kernel-argument segment and is fetched in 16-dword pieces; left alone, a piece is ONE
+    // value to the register allocator -- kept or spilled whole, and reloaded whole (sixteen v_readlane) wherever one field of
+    // it is used.  The fields the loop uses are made values of their own here.
+    // (A pointer goes through the asm as an integer and comes back as a pointer to GLOBAL memory -- address space 1 --
+    // explicitly: left generic, every access through it becomes a FLAT instruction, whose wait is vmcnt(0) lgkmcnt(0).)
+#define QZ_OWN_S(x) asm volatile("" : "+s"(x))
+#define QZ_OWN_P(T, x) { unsigned long long a_ = (unsigned long long)(x); QZ_OWN_S(a_); (x) = (T*)(__attribute__((address_space(1))) T*)a_; }
+    QZ_OWN_P(Edge, E.edge_pool); QZ_OWN_P(uint32_t, E.path_edges); QZ_OWN_P(unsigned long long, E.path_blocks); QZ_OWN_P(uint32_t, E.memo.small);
+    QZ_OWN_P(uint32_t, E.memo.big); QZ_OWN_P(uint32_t, E.free_tree); QZ_OWN_P(int, E.pool_words); QZ_OWN_P(unsigned long long, E.counters);
+    QZ_OWN_S(E.memo.small_mask); QZ_OWN_S(E.memo.big_mask); QZ_OWN_S(E.c_puct); QZ_OWN_S(E.n_playout); QZ_OWN_S(E.max_depth);
+    QZ_OWN_S(E.select_opts); QZ_OWN_S(E.node_cap); QZ_OWN_S(E.edge_cap); QZ_OWN_S(E.fix_terminal_sign); QZ_OWN_S(E.tree_pool_pages);
+#undef QZ_OWN_P
+#undef QZ_OWN_S
     if (b == 0 && lane == 0) atomicAdd(&E.counters[QZ_C_ROUNDS], 1ull);
     if (rfl(E.status[b]) != QZ_PLAYING) return;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -2168,46 +2336,37 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(QZ_ADV_WAVE
 #endif
     PathMirror PM{(lds_u32*)s_we[wave], (lds_u64*)s_wb[wave], ADV_LCAP, 0u};
     const PathMirror NOPM{(lds_u32*)nullptr, (lds_u64*)nullptr, 0u, 0u};
-    bool copied = false;  // this launch finished a subtree copy: that is its progress if the budget went into it
-    {   // the compacting half of a move k_moves left for this launch (it runs beside the other boards' playouts)
-        const uint32_t rp = rfl(E.reroot_pend[b]);
-        copied = rp != 0u;
-        if (rp != 0u) {
-            if (!wave_reroot(E, b, lane, rp == 1u ? QZ_NONE : rp - 2u, false, t0 + budget, E.compact_state + (size_t)b * 8)) {
-                if (lane == 0) atomicAdd(&E.counters[QZ_C_COMPACT_SLICES], 1ull);
-                return;  // the copy goes on in the board's next launch
-            }
-            if (lane == 0) E.reroot_pend[b] = 0u;
-            wave_sync();
-            // (the copy found the pool empty: the board restarts from a fresh root in the SAME table half, whose pages
-            // k_round_tail is about to hand back -- nothing may be built there before)
-            if (rfl((uint32_t)E.release[b]) & 2u) return;
-        }
-    }
+    // a move whose subtree copy is not done yet (k_compact, sliced at ITS budget): the board sits out.  A copy that found the
+    // pool empty restarts the board from a fresh root in the SAME table half, whose pages k_round_tail is about to hand
+    // back: nothing may be built there before
+    if (rfl(E.reroot_pend[b]) != 0u || (rfl((uint32_t)E.release[b]) & 2u)) return;
     BoardRegs S = regs_load(E, b, lane, (lds_u32*)s_lc[wave]);
     const uint32_t epoch = rfl(*E.memo.epoch);
     uint32_t done = rfl(E.pl_done[b]), open_rounds = 0u;
     if ((S.root.cur == 1 ? S.root.w1 : S.root.w2) > 0) open_rounds = 1u;
-    // One resolved leaf at a time: (legal set, priors, value) of the leaf the last descent found -- from the network
-    // (the evaluation this board was waiting for), from the memo, or a terminal leaf's +-1 -- is applied at the top of
-    // the loop by the one copy of TreeNode.expand + update_recursive.
+    // The evaluation this board was waiting for (the leaf of the previous launch: its descent's path is in memory only) is
+    // applied first -- TreeNode.expand + update_recursive with the network's answer -- then the loop: descend, resolve the
+    // leaf (a terminal leaf's +-1, or its evaluation from the memo), apply at once.  (Round 3 carried the resolved leaf --
+    // legal set, priors, value, path -- over the loop's back edge into ONE copy of the apply code: sixteen loop-carried
+    // scalars more than the kernel has scalar registers for.)
     const uint32_t slot = rfl(E.pend_slot[b]);
-    bool have = slot != QZ_NONE, waiting = false, from_memory = have;
+    bool waiting = false;
     Board miss_leaf = S.root;
-    uint32_t m0 = 0u, m1 = 0u, m2 = 0u, m3 = 0u, m4 = 0u, term = 0u, pedge = QZ_NONE, plen = 0u;
-    const float* prow = nullptr;  // priors as a row of 140 floats, or (nullptr) this lane's prior in pl (small-table hit)
-    float pl = 0.f;
-    double value = 0.0;
-    if (have) {  // the leaf of the previous launch: its descent buffer is in memory only
+    uint32_t pedge = QZ_NONE, plen = 0u;
+    if (slot != QZ_NONE) {
         const uint32_t* mk = E.miss_mask + (size_t)slot * 5;
-        m0 = rfl(mk[0]); m1 = rfl(mk[1]); m2 = rfl(mk[2]); m3 = rfl(mk[3]); m4 = rfl(mk[4]);
-        prow = E.miss_p + (size_t)slot * QZ_N_ACT;
-        value = (double)E.miss_v[slot];
+        const float* const prow = E.miss_p + (size_t)slot * QZ_N_ACT;
+        const double value = (double)E.miss_v[slot];
         pedge = rfl(E.leaf_pedge[b]);
         plen = rfl(E.path_len[b]);
+        const unsigned long long blk = expand_node(E, S, lane, pedge, rfl(mk[0]), rfl(mk[1]), rfl(mk[2]), rfl(mk[3]), rfl(mk[4]), [&](int a) { return prow[a]; });
+        note_expansion(E, S, b, lane, NOPM, plen, blk);
+        backup_leaf(E, S, b, lane, NOPM, value, pedge, plen, 0u);
+        done++;
+        wave_sync();
     }
-    QZ_AS_MARK(0)  // 0: launch prologue (state load, pending evaluation's scalars)
-    for (int it = 0;; it++) {
+    QZ_AS_MARK(0)  // 0: launch prologue (state load, the pending evaluation)
+    for (int it = 0; it < max_iters; it++) {
         // the lane / board indices of THIS iteration, opaque to the optimiser: without this every per-lane and per-board
         // address of the loop body is hoisted out of the loop as a 64-bit value -- dozens of them, more than there are
         // registers, so they went to scratch and came back through memory in the dependent chain of every playout
@@ -2217,26 +2376,12 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(QZ_ADV_WAVE
         // every loop-carried scalar is wave-uniform; said so explicitly at the top of each iteration, or the compiler keeps
         // them (and everything computed from them) in vector registers it does not have: the copies went to scratch, and a
         // scratch reload waits for s_waitcnt vmcnt(0), i.e. for every global store issued before it
+        // the root position is read again for every descent (three scalar loads, issued here, used after the budget check): it
+        // does not change during the launch -- moves are k_moves' -- and held in registers it was nine loop-carried scalars
+        S.root = load_board(E.root_hb, E.root_vb, E.root_meta, bb);
         regs_uniform(S);
-        m0 = rfl(m0); m1 = rfl(m1); m2 = rfl(m2); m3 = rfl(m3); m4 = rfl(m4);
-        term = rfl(term); pedge = rfl(pedge); plen = rfl(plen); done = rfl(done);
-        have = rfl((uint32_t)have) != 0u;
-        from_memory = rfl((uint32_t)from_memory) != 0u;
-        value = __longlong_as_double((long long)rfl64((uint64_t)__double_as_longlong(value)));
-        prow = reinterpret_cast<const float*>(rfl64(reinterpret_cast<uint64_t>(prow)));
+        done = rfl(done);
         PM.valid = rfl(PM.valid);
-        if (have) {
-            if (term == 0u) expand_node(E, S, ln, pedge, m0, m1, m2, m3, m4, [&](int a) { return prow ? prow[a] : pl; });
-            QZ_AS_MARK(1)  // 1: expansion
-            backup_leaf(E, S, bb, ln, from_memory ? NOPM : PM, value, pedge, plen, term);
-            done++;
-            have = false;
-            from_memory = false;
-            wave_sync();
-            QZ_AS_MARK(2)  // 2: backup
-            QZ_AS_COUNT(8, 1)
-        }
-        if (it >= max_iters) break;
         if (done >= (uint32_t)E.n_playout) break;  // the move is k_moves' job (the next round's first launch)
         {   // no new playout once the budget is spent -- or would be overrun by a playout as long as this board's last one: boards
             // digging a long line take 100+ us per descent, and the launch ends with its LAST wave (profiles/round3: the
@@ -2245,29 +2390,38 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(QZ_ADV_WAVE
             const unsigned int last = (unsigned int)(now - t_it);
             t_it = now;
             if (it > 0 && (unsigned int)(now - t0) + (QZ_BUDGET_PREDICT ? last : 0u) > budget) break;
-            if (copied && (unsigned int)(now - t0) > budget) break;
         }
         Board leaf;
-        select_core(E, S, bb, ln, PM, leaf, pedge, plen, term);
+        uint32_t term;
+        MemoProbe MP;  // the memo bucket of the leaf, requested the moment the leaf is known: in flight under the record commit
+        select_core(E, S, bb, ln, PM, leaf, pedge, plen, term, [&](const Board& lf, bool) { MP = memo_probe_issue(E, lf, ln); });
         if (drop_if_too_deep(E, bb, ln, plen)) break;
         PM.valid = plen < ADV_LCAP ? plen : ADV_LCAP;
         wave_sync();  // the descent buffer (lane 0 / other lanes) before the backup reads it
         QZ_AS_MARK(4)  // 4: descent
         QZ_AS_COUNT(9, plen)
         if (term != 0u) {
-            value = terminal_value(E, term);
-            have = true;
+            backup_leaf(E, S, bb, ln, PM, terminal_value(E, term), pedge, plen, term);
+            done++;
+            wave_sync();
+            QZ_AS_MARK(2)  // 2: backup
+            QZ_AS_COUNT(8, 1)
             continue;
         }
         MemoHit H;
-        if (memo_probe(E, epoch, leaf, ln, H)) {
-            m0 = H.m0; m1 = H.m1; m2 = H.m2; m3 = H.m3; m4 = H.m4;
-            prow = H.p_row;
-            pl = H.p_lane;
-            value = (double)H.v;
-            have = true;
+        if (memo_probe_finish(E, epoch, leaf, ln, MP, H)) {
             lc_add(S, LC_HITS, 1u, ln);
             QZ_AS_MARK(5)  // 5: memo probe (hit)
+            const float* const prow = H.p_row;  // priors as a row of 140 floats, or (nullptr) this lane's prior in p_lane (small-table hit)
+            const float pl = H.p_lane;
+            const unsigned long long blk = expand_node(E, S, ln, pedge, H.m0, H.m1, H.m2, H.m3, H.m4, [&](int a) { return prow ? prow[a] : pl; });
+            note_expansion(E, S, bb, ln, PM, plen, blk);
+            QZ_AS_MARK(1)  // 1: expansion
+            backup_leaf(E, S, bb, ln, PM, (double)H.v, pedge, plen, 0u);
+            done++;
+            wave_sync();
+            QZ_AS_MARK(2)  // 2: backup
+            QZ_AS_COUNT(8, 1)
             continue;
         }
         QZ_AS_MARK(6)  // 6: memo probe (miss)
@@ -2295,6 +2449,11 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(QZ_ADV_WAVE
                 E.leaf_pedge[b] = pedge;
                 E.path_len[b] = plen;
             }
+            {   // the path of this descent for the backup of the NEXT launch: the levels the LDS mirror holds, out to memory
+                uint32_t* const path = E.path_edges + ((size_t)b * (QZ_PATH_RECS + 1) + QZ_PATH_RECS) * QZ_PATH_CAP;
+                const uint32_t nm = plen < ADV_LCAP ? plen : ADV_LCAP;
+                for (uint32_t i = (uint32_t)lane; i < nm; i += 64u) path[i] = PM.we[i];
+            }
             lc_add(S, LC_EVALS, 1u, lane);
         }
     }
@@ -2303,7 +2462,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(QZ_ADV_WAVE
     QZ_AS_MARK(7)  // 7: epilogue (miss record, state store)
     if (lane == 0 && b < 4096) {
         for (int k = 0; k < 10; k++) g_adv_stamps[b][k] += as_acc[k];
-        for (int k = 0; k < 3; k++) g_adv_stamps3[b][k] += S.t_sel[k];
+        for (int k = 0; k < 4; k++) g_adv_stamps3[b][k] += S.t_sel[k];
         g_adv_stamps2[b][0] += S.lc[LC_SPARE];
         g_adv_stamps2[b][1] += S.lc[14];
         g_adv_stamps2[b][2] += S.lc[15];
@@ -2314,7 +2473,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(QZ_ADV_WAVE
         if ((unsigned int)(__builtin_amdgcn_s_memrealtime() - t0) > budget + budget / 7u) {
             g_adv_stamps[b][12] += 1ull;
             g_adv_stamps2[b][3] += as_max[0];
-            g_adv_stamps3[b][3] += as_max[1];
+
             g_adv_stamps[b][15] += whole;
         }
         if (as_max[1] > g_adv_stamps[b][13]) g_adv_stamps[b][13] = as_max[1];  // longest single descent
@@ -2328,21 +2487,47 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(QZ_ADV_WAVE
     }
 }
 
+// Two builds of the loop.  k_advance<8>: at most 64 vector registers, EIGHT wavefronts per SIMD -- 8,192 boards at a time on the
+// 1,024 SIMDs: the throughput of the loop is the number of dependent chains the chip holds times the speed of one chain, and a
+// chain is bound by its own latencies (round 3: one / two / four wavefronts per SIMD ran 78.8 / 74.0 / 66.6 playouts per board and
+// round).  k_advance<4>: 73 registers, no spill at all, for engines of up to 4,096 boards, where the extra residency buys nothing
+// and the eight-wave build's few spills cost 9 %.
+template <int W>
+__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(W, W))) void k_advance(EngineDev E, int max_iters, unsigned int budget, int par) {
+    advance_board(E, max_iters, budget, par);
+}
+
 // k_moves: MCTSPlayer.choose_action's tail + one iteration of start_self_play's loop (finish_move_board) for every
 // board that has done its n_playout playouts.  The move keeps the subtree in place while the tree is small; once the
-// allocation cursor has passed compact_edges it compacts (breadth-first copy into fresh pages; the old half goes back
-// to the pool in k_round_tail).  POP-ONLY.
-__global__ __launch_bounds__(TPB) void k_moves(EngineDev E) {
+// allocation cursor has passed compact_edges it compacts: the breadth-first copy of the kept subtree into fresh pages (the
+// old half goes back to the pool in k_round_tail), by the same wavefront right after its move and in SLICES -- a copy that
+// has not finished when `budget` (s_memrealtime ticks since the launch began) is spent saves its position in
+// compact_state[b] and goes on in the next round's launch; the board sits out of k_advance meanwhile (reroot_pend).  Round 3
+// ran the copies in k_advance's prologue: their registers and scratch were k_advance's.  POP-ONLY.
+__global__ __launch_bounds__(TPB) void k_moves(EngineDev E, unsigned int budget) {
     const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
     const int b = __builtin_amdgcn_readfirstlane((int)blockIdx.x * WPB + wave);
     if (b >= E.n_boards) return;
-    if (rfl(E.status[b]) != QZ_PLAYING || rfl(E.pl_done[b]) < (uint32_t)E.n_playout || rfl((uint32_t)E.release[b]) != 0u ||
-        rfl(E.reroot_pend[b]) != 0u)
-        return;
-    const bool compact = E.compact_edges <= 0 || rfl(E.n_edges[b]) >= rfl(E.compact_at[b]);
-    const Board rb = unpack(0ull, 0ull, rfl64(E.root_meta[b]));
-    if ((rb.cur == 1 ? rb.w1 : rb.w2) > 0 && lane == 0) E.bc_open_plies[b] += 1u;
-    finish_move_board(E, b, lane, nullptr, nullptr, nullptr, compact ? 2 : 1);
+    if (rfl(E.status[b]) != QZ_PLAYING || rfl((uint32_t)E.release[b]) != 0u) return;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    uint32_t rp = rfl(E.reroot_pend[b]);
+    if (rp == 0u) {
+        if (rfl(E.pl_done[b]) < (uint32_t)E.n_playout) return;
+        const bool compact = E.compact_edges <= 0 || rfl(E.n_edges[b]) >= rfl(E.compact_at[b]);
+        const Board rb = unpack(0ull, 0ull, rfl64(E.root_meta[b]));
+        if ((rb.cur == 1 ? rb.w1 : rb.w2) > 0 && lane == 0) E.bc_open_plies[b] += 1u;
+        finish_move_board(E, b, lane, nullptr, nullptr, nullptr, compact ? 2 : 1);
+        if (!compact) return;
+        __threadfence();
+        wave_sync();
+        rp = rfl(__hip_atomic_load(E.reroot_pend + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));  // (lane 0 of this wave stored it)
+        if (rp == 0u || rfl((uint32_t)__hip_atomic_load(E.status + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != QZ_PLAYING) return;
+    }
+    if (!wave_reroot(E, b, lane, rp == 1u ? QZ_NONE : rp - 2u, false, t0 + budget, E.compact_state + (size_t)b * 8)) {
+        if (lane == 0) atomicAdd(&E.counters[QZ_C_COMPACT_SLICES], 1ull);
+        return;  // the copy goes on in the next round
+    }
+    if (lane == 0) E.reroot_pend[b] = 0u;
 }
 
 // After the network: (a) every evaluated leaf goes into the memo, (b) the OTHER miss counter is cleared for the next
@@ -2554,7 +2739,7 @@ __global__ void k_pool_init(EngineDev E) {
 
 __global__ void k_sqrt_table(double* out, int n) {  // self-test helper: device sqrt(double(i))
     int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (i < n) out[i] = sqrt((double)i);
+    if (i < n) out[i] = sqrt_count((uint32_t)i);  // (what the descents use)
 }
 
 }  // namespace
@@ -2570,16 +2755,16 @@ static inline dim3 wave_grid(int n) { return dim3((unsigned)((n + WPB - 1) / WPB
 constexpr int NBE = QZ_NBE;  // boards per encoder group (8 and 32 measured at 32,768 boards: see DESIGN 9.2)
 
 template <int NB>
-static void launch_masks_enc(const PoolBoard* recs, const PathTab* tabs, int n, uint32_t* mask5, const uint64_t* hb,
+static void launch_masks_enc(const PoolHand* hands, int n, uint32_t* mask5, const uint64_t* hb,
                              const uint64_t* vb, const uint64_t* meta, const uint8_t* terminal, float* planes, int enc_tile0,
                              int n_enc_groups, hipStream_t s) {
     const int n_mask_groups = mask5 ? (n + NB - 1) / NB : 0;
     if (n_mask_groups + n_enc_groups == 0) return;
-    hipLaunchKernelGGL((k_pool_masks_enc<NB, NBE>), dim3((unsigned)(n_mask_groups + n_enc_groups)), dim3(256), 0, s, recs, tabs, n,
+    hipLaunchKernelGGL((k_pool_masks_enc<NB, NBE>), dim3((unsigned)(n_mask_groups + n_enc_groups)), dim3(256), 0, s, hands, n,
                        mask5, n_mask_groups, enc_tile0, hb, vb, meta, terminal, planes);
 }
 
-size_t movegen_scratch_bytes(int n) { return (size_t)n * (sizeof(PoolBoard) + 2 * sizeof(PathTab)); }
+size_t movegen_scratch_bytes(int n) { return (size_t)n * sizeof(PoolHand); }  // 184 B per board (round 3: 1,522)
 
 hipError_t movegen_encode(const uint64_t* hb, const uint64_t* vb, const uint64_t* meta, int n, uint32_t* mask5,
                           float* planes, const uint8_t* terminal, void* scratch, const RulesOpts& ro, hipStream_t s, const int* n_dev) {
@@ -2606,8 +2791,7 @@ hipError_t movegen_encode(const uint64_t* hb, const uint64_t* vb, const uint64_t
         else hipLaunchKernelGGL((k_wave_rules<NBE, 2, false>), grid, dim3(256), 0, s, hb, vb, meta, n, terminal, mask5, planes, n_mg_groups, ro.detour_wave, n_dev);
         return hipGetLastError();
     }
-    PoolBoard* recs = reinterpret_cast<PoolBoard*>(scratch);
-    PathTab* tabs = reinterpret_cast<PathTab*>(recs + n);
+    PoolHand* hands = reinterpret_cast<PoolHand*>(scratch);
     // encoder tiles are split over the two launches: half of them ride beside the path search (a
     // latency-bound dependent chain of ~27 us that leaves issue slots and the memory pipe idle),
     // the rest beside the mask groups (~22 us alone).  Sweep at 32,768 boards on the final kernels
@@ -2618,15 +2802,15 @@ hipError_t movegen_encode(const uint64_t* hb, const uint64_t* vb, const uint64_t
     if (mask5) {
         const int n_path_groups = (2 * n + 255) / 256;
         hipLaunchKernelGGL((k_pool_paths_enc<NBE>), dim3((unsigned)(n_path_groups + enc_a)), dim3(256), 0, s, hb, vb, meta, n,
-                           terminal, recs, tabs, n_path_groups, planes, ro.detour_pooled);
+                           terminal, hands, n_path_groups, planes, ro.detour_pooled);
     }
     int nbt = ro.variant >= 8 ? ro.variant : (n >= 16384 ? 24 : (n >= 8192 ? 16 : 8));
     const int enc_b = enc_total - enc_a;
-    if (nbt >= 32) launch_masks_enc<32>(recs, tabs, n, mask5, hb, vb, meta, terminal, planes, enc_a, enc_b, s);
-    else if (nbt >= 24) launch_masks_enc<24>(recs, tabs, n, mask5, hb, vb, meta, terminal, planes, enc_a, enc_b, s);
-    else if (nbt >= 16) launch_masks_enc<16>(recs, tabs, n, mask5, hb, vb, meta, terminal, planes, enc_a, enc_b, s);
-    else if (nbt >= 12) launch_masks_enc<12>(recs, tabs, n, mask5, hb, vb, meta, terminal, planes, enc_a, enc_b, s);
-    else launch_masks_enc<8>(recs, tabs, n, mask5, hb, vb, meta, terminal, planes, enc_a, enc_b, s);
+    if (nbt >= 32) launch_masks_enc<32>(hands, n, mask5, hb, vb, meta, terminal, planes, enc_a, enc_b, s);
+    else if (nbt >= 24) launch_masks_enc<24>(hands, n, mask5, hb, vb, meta, terminal, planes, enc_a, enc_b, s);
+    else if (nbt >= 16) launch_masks_enc<16>(hands, n, mask5, hb, vb, meta, terminal, planes, enc_a, enc_b, s);
+    else if (nbt >= 12) launch_masks_enc<12>(hands, n, mask5, hb, vb, meta, terminal, planes, enc_a, enc_b, s);
+    else launch_masks_enc<8>(hands, n, mask5, hb, vb, meta, terminal, planes, enc_a, enc_b, s);
     return hipGetLastError();
 }
 hipError_t step(uint64_t* hb, uint64_t* vb, uint64_t* meta, const uint8_t* action, int n, uint8_t* done, uint8_t* winner,
@@ -2665,13 +2849,22 @@ hipError_t finish_move(const EngineDev& E, const uint8_t* forced, float* pi_out,
     hipLaunchKernelGGL(k_release, wave_grid(E.n_boards), dim3(TPB), 0, s, E);
     return hipGetLastError();
 }
+// subtree copies get an eighth of the round's budget per round: the moves' launch runs beside / right after the network
+// (qz_selfplay_round) and the round's tail waits for it -- a 1,000-level line, which copies at one level per memory round
+// trip (~1 ms), must not hold every round up (measured: with a quarter, 250 us, the launch ALWAYS ran to its budget -- there
+// is always such a board somewhere -- and the round grew by as much); the board concerned sits out a few rounds instead
+static unsigned int compact_budget(unsigned int budget_ticks) {
+    return budget_ticks == 0xFFFFFFFFu ? budget_ticks : (budget_ticks / 8u > 0u ? budget_ticks / 8u : 1u);
+}
 hipError_t advance(const EngineDev& E, int max_iters, unsigned int budget_ticks, int auto_finish, int par, hipStream_t s) {
-    if (auto_finish) hipLaunchKernelGGL(k_moves, wave_grid(E.n_boards), dim3(TPB), 0, s, E);
-    hipLaunchKernelGGL(k_advance, wave_grid(E.n_boards), dim3(TPB), 0, s, E, max_iters, budget_ticks, par);
+    if (auto_finish) hipLaunchKernelGGL(k_moves, wave_grid(E.n_boards), dim3(TPB), 0, s, E, compact_budget(budget_ticks));
+    if (E.n_boards > 4096 * QZ_ADV_WAVES_SMALL / 4) hipLaunchKernelGGL(k_advance<8>, wave_grid(E.n_boards), dim3(TPB), 0, s, E, max_iters, budget_ticks, par);
+    else hipLaunchKernelGGL(k_advance<QZ_ADV_WAVES_SMALL>, wave_grid(E.n_boards), dim3(TPB), 0, s, E, max_iters, budget_ticks, par);
     return hipGetLastError();
 }
-hipError_t moves(const EngineDev& E, hipStream_t s) {
-    hipLaunchKernelGGL(k_moves, wave_grid(E.n_boards), dim3(TPB), 0, s, E);
+// the moves of the boards that have done their playouts + the subtree copies they leave (and the slices earlier moves left)
+hipError_t moves(const EngineDev& E, unsigned int budget_ticks, hipStream_t s) {
+    hipLaunchKernelGGL(k_moves, wave_grid(E.n_boards), dim3(TPB), 0, s, E, compact_budget(budget_ticks));
     return hipGetLastError();
 }
 hipError_t round_tail(const EngineDev& E, int par, hipStream_t s) {

@@ -133,6 +133,8 @@ QZ_HD K1Pre pool_k1_pre(const Board& b, bool terminal, bool want_moves, int p, P
     }
     return k;
 }
+QZ_HD void pool_need_masks(const Board& b, int p, const K1Pre& k, const PathEdges& pe, int detour_mode, const CutMasks* cuts, uint64_t& nh_out,
+                           uint64_t& nv_out);
 // `op`: the base path of player p (found == false, len == 0 where there was nothing to search)
 // `cuts`: path_cut_masks(op.e) if the caller has it already (k_wave_rules gets it from the search), else nullptr
 QZ_HD void pool_k1_post(const Board& b, int p, PoolBoard& out, const K1Pre& k, const OrderedPath& op, int lj, int fj, int detour_mode,
@@ -144,8 +146,15 @@ QZ_HD void pool_k1_post(const Board& b, int p, PoolBoard& out, const K1Pre& k, c
     out.lastjump[p - 1] = lj;
     out.farjump[p - 1] = fj;
     out.tiles[p - 1] = len > 0 ? bb_or(op.last, bb_bit(side_start(b, p))) : bb_zero();
-    // candidates that remove an edge of this path (or, if the path jumps, that sit next to the
-    // opponent): only those need a flood for player p
+    uint64_t nh, nv;
+    pool_need_masks(b, p, k, pe, detour_mode, cuts, nh, nv);
+    out.need[p - 1] = nh;
+    out.need[2 + p - 1] = nv;
+}
+// which wall slots need a flood for player p: the candidates that remove an edge of p's base path (or, if the path jumps,
+// that sit next to the opponent), minus those a group detour clears
+QZ_HD void pool_need_masks(const Board& b, int p, const K1Pre& k, const PathEdges& pe, int detour_mode, const CutMasks* cuts, uint64_t& nh_out,
+                           uint64_t& nv_out) {
     uint64_t nh = 0, nv = 0;
     if (pe.found) {
         const CutMasks cm = cuts ? *cuts : path_cut_masks(pe);
@@ -172,8 +181,8 @@ QZ_HD void pool_k1_post(const Board& b, int p, PoolBoard& out, const K1Pre& k, c
             }
         }
     }
-    out.need[p - 1] = nh;
-    out.need[2 + p - 1] = nv;
+    nh_out = nh;
+    nv_out = nv;
 }
 // FINDER 0: one search per lane on three-word sets (find_path_tables); 1: the nine-rows formulation in
 // its array form (find_path_rows; what the host check runs in place of the SIMT form of k_wave_rules)
@@ -193,6 +202,123 @@ QZ_HD void pool_k1(const Board& b, bool terminal, bool want_moves, int p, PoolBo
         else op = find_path_rows(g, side_start(b, p), side_goal(p), POOL_MAX_LAYERS + 1, tab, lj, fj);
     }
     pool_k1_post(b, p, out, k, op, lj, fj, detour_mode);
+}
+
+// ---- the hand-off between the two launches of the pooled pipeline ---------------------------------------------------
+// Round 3 wrote a PoolBoard and two PathTab records per board into the scratch area (~1.4 KB written, ~0.6 KB read back:
+// 1.30 x the op's algorithmic traffic).  What the second launch cannot cheaply recompute from the 24-byte board is only:
+// the two base paths -- as the bare tile sequence, goal end first -- the need masks (group detours already applied), the
+// jump plans and the pawn moves: 184 bytes.  Blocked sets and static slot tests are recomputed from the board; path edge
+// sets, path tiles, jump positions and the srcpos table are rebuilt from the sequences (pool_hand_rebuild_path); a suffix set
+// is the OR of a prefix of the sequence, taken when a flood needs it (pool_p3_seq).
+struct PathSeq {
+    uint8_t len;                        // edges; 0: no path (or nothing to search); 255: found but longer than the tables
+    uint8_t goal;                       // the goal-row tile the path ends on
+    uint8_t src[POOL_MAX_LAYERS + 2];   // src[k]: the tile edge k leaves, k counting from the GOAL end (src[len - 1] = the pawn's tile)
+};
+struct PoolHand {
+    uint32_t pawn;
+    uint32_t flags;        // PoolBoard::flags
+    uint64_t need[4];
+    JumpPlan plan[2];
+    PathSeq seq[2];
+};
+static_assert(sizeof(PathSeq) == 44 && sizeof(PoolHand) == 184, "hand-off record layout");
+
+// launch 1, lane = (board, player): pool_k1 with the hand-off record as its only output
+QZ_HD void pool_k1_hand(const Board& b, bool terminal, int p, PoolHand& out, int detour_mode) {
+    // (pool_k1_pre / pool_k1_post without a PoolBoard in between: a record indexed by the player would live in scratch memory)
+    const bool live = !terminal;
+    K1Pre k;
+    k.walls = live && ((b.cur == 1 ? b.w1 : b.w2) > 0);
+    k.base.n = k.base.s = k.base.e = k.base.w = bb_zero();
+    if (k.walls) k.base = blk_or(blocked_from(spread8(b.hb), spread8(b.vb)), blocked_borders());
+    if (p == 1) {
+        const int loc = b.cur == 1 ? b.p1 : b.p2, opp = b.cur == 1 ? b.p2 : b.p1;
+        out.pawn = live ? pawn_actions_tab(b.hb, b.vb, loc, opp, b.cur) : 0u;
+        out.flags = (terminal ? 2u : 0u) | (k.walls ? 1u : 0u);
+    }
+    PathSeq& sq = out.seq[p - 1];
+    OrderedPath op;
+    op.e.pn = op.e.ps = op.e.pe = op.e.pw = bb_zero();
+    op.e.jump = false;
+    op.e.found = false;
+    op.len = 0;
+    op.last = bb_zero();
+    int lj = -1, fj = -1;
+    if (k.walls) {
+        const JumpPlan plan = make_jump_plan(b.hb, b.vb, side_opp(b, p));
+        out.plan[p - 1] = plan;
+        const Graph g = make_graph_plan(k.base, plan, -1, false);
+        op = find_path_walk(
+            g, side_start(b, p), side_goal(p), POOL_MAX_LAYERS + 1, lj, fj, []() {},
+            [&](int kk, int s, int t, const BB&) {
+                if (kk == 0) sq.goal = (uint8_t)t;
+                sq.src[kk] = (uint8_t)s;
+            });
+    }
+    sq.len = !op.e.found ? 0 : (op.len < 0 ? 255 : (uint8_t)op.len);
+    uint64_t nh, nv;
+    pool_need_masks(b, p, k, op.e, detour_mode, nullptr, nh, nv);
+    out.need[p - 1] = nh;
+    out.need[2 + p - 1] = nv;
+}
+// launch 2, lane = board: the board's context from the board itself + the record
+QZ_HD void pool_hand_rebuild_board(PoolBoard& c, const PoolHand& h, const Board& b) {
+    c.b = b;
+    c.flags = h.flags;
+    c.pawn = h.pawn;
+    for (int i = 0; i < 4; i++) c.blocked[i] = 0u;
+    for (int i = 0; i < 4; i++) c.need[i] = h.need[i];
+    const bool walls = (h.flags & 3u) == 1u;
+    c.base.n = c.base.s = c.base.e = c.base.w = bb_zero();
+    if (walls) c.base = blk_or(blocked_from(spread8(b.hb), spread8(b.vb)), blocked_borders());
+    c.sh = walls ? static_ok_h(b.hb, b.vb) : 0ull;
+    c.sv = walls ? static_ok_v(b.hb, b.vb) : 0ull;
+    c.plan[0] = h.plan[0];
+    c.plan[1] = h.plan[1];
+}
+// launch 2, lane = (board, player): edge sets, path tiles, jump positions and the srcpos table (84 bytes, pre-filled with 255
+// by the caller) from the tile sequence
+QZ_HD void pool_hand_rebuild_path(PoolBoard& c, int p, const PathSeq& sq, uint8_t* srcpos) {
+    PathEdges e;
+    e.pn = e.ps = e.pe = e.pw = bb_zero();
+    e.jump = false;
+    e.found = sq.len != 0;
+    int len = sq.len == 255 ? -1 : (int)sq.len, lj = -1, fj = -1;
+    BB tiles = bb_zero();
+    if (len < 0) {  // found but longer than the tables: every candidate gets a full re-check (find_path_walk's conservative answer)
+        e.pn = e.ps = e.pe = e.pw = bb_not(bb_zero());
+        e.jump = true;
+    }
+    int t = sq.goal;
+    for (int k = 0; k < len; k++) {
+        const int s = sq.src[k], d = t - s;
+        if (d == 9) e.pn = bb_or(e.pn, bb_bit(s));
+        else if (d == -9) e.ps = bb_or(e.ps, bb_bit(s));
+        else if (d == 1) e.pe = bb_or(e.pe, bb_bit(s));
+        else if (d == -1) e.pw = bb_or(e.pw, bb_bit(s));
+        else {
+            e.jump = true;
+            if (lj < 0) lj = k;
+            fj = k;
+        }
+        tiles = bb_or(tiles, bb_bit(t));
+        srcpos[s] = (uint8_t)k;
+        t = s;
+    }
+    if (len > 0) tiles = bb_or(tiles, bb_bit(side_start(c.b, p)));
+    c.pe[p - 1] = e;
+    c.len[p - 1] = len;
+    c.lastjump[p - 1] = lj;
+    c.farjump[p - 1] = fj;
+    c.tiles[p - 1] = tiles;
+}
+// PathTab::suffix[k] from the sequence: the goal tile and the sources of the edges closer to the goal than edge k
+QZ_HD BB pool_seq_suffix(const PathSeq& sq, int k) {
+    BB acc = bb_bit(sq.goal);
+    for (int j = 0; j < k; j++) acc = bb_or(acc, bb_bit(sq.src[j]));
+    return acc;
 }
 
 // ---- P2 ---------------------------------------------------------------------------------
@@ -228,7 +354,8 @@ QZ_HD uint32_t pool_item(int board, int ix, bool horizontal, int p) {
 
 // ---- P3 ---------------------------------------------------------------------------------
 // true if player p can still reach its goal with the candidate wall added
-QZ_HD bool pool_p3(const PoolBoard& c, uint32_t item, const uint8_t* srcpos, const BB* suffix) {
+template <typename SuffixFn>
+QZ_HD bool pool_p3_with(const PoolBoard& c, uint32_t item, const uint8_t* srcpos, SuffixFn suffix) {
     int ix = (int)(item & 63u);
     bool hz = (item & 0x40u) != 0u;
     int p = (item & 0x80u) ? 2 : 1;
@@ -255,18 +382,25 @@ QZ_HD bool pool_p3(const PoolBoard& c, uint32_t item, const uint8_t* srcpos, con
             worst = pos > worst ? pos : worst;
         }
         if (best == 255) return true;  // nothing on the path is touched
-        const BB behind_best = suffix[best];
+        const BB behind_best = suffix(best);
         target = bb_or(target, behind_best);
         // tiles of the path in front of edge `worst` = all path tiles minus (its destination and
         // everything behind it); one removed edge is the common case: no second table read
-        const BB behind_worst = worst == best ? behind_best : suffix[worst];
+        const BB behind_worst = worst == best ? behind_best : suffix(worst);
         from = bb_andn(c.tiles[p - 1], behind_worst);
     }
     Graph g = make_graph_plan(blk_or(c.base, d), c.plan[p - 1], ix, hz);
     return flood_to(g, from, target);
 }
 
+QZ_HD bool pool_p3(const PoolBoard& c, uint32_t item, const uint8_t* srcpos, const BB* suffix) {
+    return pool_p3_with(c, item, srcpos, [&](int k) { return suffix[k]; });
+}
 QZ_HD bool pool_p3(const PoolBoard& c, uint32_t item, const PathTab& tab) { return pool_p3(c, item, tab.srcpos, tab.suffix); }
+// the pooled pipeline's form: srcpos rebuilt by pool_hand_rebuild_path, suffix sets from the tile sequence
+QZ_HD bool pool_p3_seq(const PoolBoard& c, uint32_t item, const uint8_t* srcpos, const PathSeq& sq) {
+    return pool_p3_with(c, item, srcpos, [&](int k) { return pool_seq_suffix(sq, k); });
+}
 
 // ---- P4 ---------------------------------------------------------------------------------
 QZ_HD void pool_p4(const PoolBoard& c, uint32_t mask5[5]) {

@@ -991,9 +991,12 @@ QZ_HD OrderedPath find_path_ordered(const Graph& g, int start, BB goal, BB* laye
 // first_jump_r = reverse position of the jump edge closest to the goal (-1: none).
 // len = number of edges (0 if !found).  tab.suffix must hold max_edges entries; a longer path
 // is reported with len = -1 and all-ones path sets (every candidate then gets re-checked).
-template <typename Tab>
-QZ_HD OrderedPath find_path_tables(const Graph& g, int start, BB goal, int max_edges, Tab& tab, int& first_jump_r,
-                                   int& far_jump_r) {
+// find_path_walk: the search + the walk back; `on_found()` is called once a path exists (before the walk), `on_edge(k, s, t,
+// acc)` for every edge, k counting from the GOAL end: the edge leaves tile s for tile t, acc = t and every tile behind it.
+// find_path_tables writes them into lookup tables; the pooled pipeline's hand-off keeps the bare tile sequence (PathSeq).
+template <typename OnFound, typename OnEdge>
+QZ_HD OrderedPath find_path_walk(const Graph& g, int start, BB goal, int max_edges, int& first_jump_r, int& far_jump_r, OnFound on_found,
+                                 OnEdge on_edge) {
     OrderedPath p;
     p.e.pn = p.e.ps = p.e.pe = p.e.pw = bb_zero();
     p.e.jump = false;
@@ -1042,7 +1045,7 @@ QZ_HD OrderedPath find_path_tables(const Graph& g, int start, BB goal, int max_e
         R = R2;
     }
     if (!p.e.found) return p;
-    for (int i = 0; i < 21; i++) reinterpret_cast<uint32_t*>(tab.srcpos)[i] = 0xFFFFFFFFu;
+    on_found();
     int t = bb_lowest(hit);
     BB acc = bb_zero();
     int k = 0;
@@ -1075,8 +1078,7 @@ QZ_HD OrderedPath find_path_tables(const Graph& g, int start, BB goal, int max_e
             return p;
         }
         acc = bb_or(acc, bb_bit(t));  // t and everything behind it
-        tab.suffix[k] = acc;
-        tab.srcpos[s] = (uint8_t)k;
+        on_edge(k, s, t, acc);
         if (jump && first_jump_r < 0) first_jump_r = k;
         if (jump) far_jump_r = k;
         k++;
@@ -1085,6 +1087,19 @@ QZ_HD OrderedPath find_path_tables(const Graph& g, int start, BB goal, int max_e
     p.len = k;
     p.last = acc;
     return p;
+}
+template <typename Tab>
+QZ_HD OrderedPath find_path_tables(const Graph& g, int start, BB goal, int max_edges, Tab& tab, int& first_jump_r,
+                                   int& far_jump_r) {
+    return find_path_walk(
+        g, start, goal, max_edges, first_jump_r, far_jump_r,
+        [&]() {
+            for (int i = 0; i < 21; i++) reinterpret_cast<uint32_t*>(tab.srcpos)[i] = 0xFFFFFFFFu;
+        },
+        [&](int k, int s, int, const BB& acc) {
+            tab.suffix[k] = acc;
+            tab.srcpos[s] = (uint8_t)k;
+        });
 }
 
 // Tiles of the base path from which the goal stays reachable whatever candidate (ix, horizontal)

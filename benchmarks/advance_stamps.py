@@ -48,12 +48,13 @@ out["levels_per_replay_round"] = r2[0] / max(r2[1], 1)
 r3 = buf3[:min(B, 4096)].view(np.int64).astype(np.float64).sum(axis=0)
 out["descent_cycles_per_playout"] = {"replay_rounds": r3[0] / max(po, 1), "walk_and_setup": r3[1] / max(po, 1), "record_commit": r3[2] / max(po, 1)}
 out["cycles_per_replay_round"] = r3[0] / max(r2[1], 1); out["cycles_per_walked_level"] = r3[1] / max(lv - r2[0], 1)
+out["levels_selected_by_a_replay_lane_per_playout"] = r3[3] / max(po, 1); out["levels_not_confirmed_per_playout"] = (lv - r2[0]) / max(po, 1)
 q = [0.5, 0.9, 0.99, 1.0]
 out["longest_single_descent_cycles_quantiles_over_boards_50_90_99_100"] = np.quantile(a[:, 13], q).tolist()
 out["longest_launch_cycles_quantiles"] = np.quantile(a[:, 14], q).tolist()
 # launches (board x round) that ran 15 % over their budget: the launch ends with its last wave
 n_over = a[:, 12].sum()
 out["overrunning_launches"] = {"per_round": n_over / MEAS, "frac_of_board_launches": n_over / a[:, 11].sum(), "mean_cycles": a[:, 15].sum() / max(n_over, 1),
-                               "mean_prologue_cycles": r2[3] / max(n_over, 1), "mean_longest_descent_cycles": r3[3] / max(n_over, 1),
+                               "mean_prologue_cycles": r2[3] / max(n_over, 1),
                                "boards_with_any": int((a[:, 12] > 0).sum())}
 print(json.dumps(out, indent=1))

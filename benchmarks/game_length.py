@@ -52,6 +52,21 @@ def km_mean(times, events):
     return mean, rmst, ST, lam, float(T)
 
 
+def window_doubling(times, events):
+    """E[length] estimated from the first HALF of the observation window (every observation truncated at T/2) against the whole
+    window: how much the estimate still moves when the window doubles."""
+    times = np.asarray(times, dtype=np.float64)
+    events = np.asarray(events, dtype=bool)
+    T = float(times.max())
+    half_t = np.minimum(times, T / 2.0)
+    half_e = events & (times <= T / 2.0)
+    if half_e.sum() < 2:
+        return None
+    m_half = km_mean(half_t, half_e)[0]
+    m_full = km_mean(times, events)[0]
+    return {"mean_at_half_window": m_half, "mean_at_full_window": m_full, "delta": m_full / m_half - 1.0, "half_window_plies": T / 2.0}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--boards", type=int, default=512)
@@ -77,6 +92,7 @@ def main():
     # restart at once when their game is harvested.  Per finished game: its length and the plies of its OPEN phase (the
     # mover still has walls: the part of a game whose leaves are almost all new to the memo)
     finished, finished_open = [], []
+    dropped, dropped_seen = [], 0   # (ply at which a game was dropped, cause): right-censored observations
     t0 = time.time()
     rounds = 0
     stream = torch.cuda.Stream(device=dev)
@@ -93,6 +109,12 @@ def main():
                 walls = torch.where(cur == 1, (meta >> 16) & 0xFF, (meta >> 24) & 0xFF)
                 finished.extend(torch.bincount(gid, minlength=tb.n_games).tolist())
                 finished_open.extend(torch.bincount(gid, weights=(walls > 0).double(), minlength=tb.n_games).tolist())
+            if rounds % 1024 == 0:  # games the engine dropped (depth limit, root without a move): censored at their ply, not ignored
+                packed, causes, plies, slots, total = eng.dropped_games()
+                new = min(total - dropped_seen, len(plies))
+                if new > 0:
+                    dropped.extend(zip(plies[-new:].tolist(), causes[-new:]))
+                dropped_seen = total
             if time.time() - t_print > 60:
                 st = eng.stats()
                 sys.stderr.write("t %.0fs rounds %d plies/s %.0f games %d mean depth %.1f max depth %d deep descents %d (levels %d) max edges %d pages in use %d\n"
@@ -104,8 +126,15 @@ def main():
         ply = int(st["plies_played"] // B)
         age = eng.get_plies().long()
         censored = age[age > 0].cpu().tolist()
-    times = np.array(finished + censored, dtype=np.float64)
-    events = np.array([True] * len(finished) + [False] * len(censored))
+        packed, causes, plies, slots, total = eng.dropped_games()
+        new = min(total - dropped_seen, len(plies))
+        if new > 0:
+            dropped.extend(zip(plies[-new:].tolist(), causes[-new:]))
+    # a dropped game is an observation "longer than the ply it was dropped at" (depth drops come with long forced lines:
+    # informative censoring, so the estimate still leans low -- said in the output)
+    censored_dropped = [max(int(p), 1) for p, _ in dropped]
+    times = np.array(finished + censored + censored_dropped, dtype=np.float64)
+    events = np.array([True] * len(finished) + [False] * (len(censored) + len(censored_dropped)))
     mean, rmst, ST, lam, T = km_mean(times, events)
     rng = np.random.RandomState(0)
     boots = []
@@ -124,7 +153,12 @@ def main():
     out = {
         "boards": B, "n_playout": args.playouts, "max_depth": args.max_depth, "fix_terminal_sign": bool(args.fix_sign), "plies_run": ply, "seconds": seconds,
         "plies_per_s": st["plies_played"] / seconds,
-        "games_finished": len(finished), "games_censored": len(censored),
+        "games_finished": len(finished), "games_censored": len(censored), "games_dropped_as_censored": len(censored_dropped),
+        "dropped_by_cause": {c: sum(1 for _, cc in dropped if cc == c) for c in sorted(set(c for _, c in dropped))},
+        "dropped_ply_percentiles_10_50_90": [float(x) for x in np.percentile(censored_dropped, [10, 50, 90])] if censored_dropped else None,
+        "dropped_mean_ply": float(np.mean(censored_dropped)) if censored_dropped else None,
+        "finished_fraction_of_started": len(finished) / max(len(finished) + len(censored_dropped), 1),
+        "window_doubling": window_doubling(times, events),
         "finished_length_percentiles_10_50_90": [float(x) for x in np.percentile(finished, [10, 50, 90])] if finished else None,
         "finished_mean": float(np.mean(finished)) if finished else None,
         "mean_open_plies_per_game": float(np.mean(finished_open)) if finished_open else None,

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define QZ_ABI_VERSION 4
+#define QZ_ABI_VERSION 5
 #define QZ_N_ACTIONS 140            /* quoridor.py:12  action_space = 140            */
 #define QZ_PLANES (26 * 81)         /* quoridor.py:58-131  26x9x9 state tensor       */
 #define QZ_MASK_WORDS 5             /* 140-bit legal mask, bit a of word a/32        */

@@ -182,14 +182,68 @@ static int g_try_detour = 0;
 extern "C" void hc_set_detour(int on) { g_try_detour = on; }
 static int g_finder = 0;  // 0: find_path_tables, 1: find_path_rows (the nine-rows formulation of k_wave_rules)
 extern "C" void hc_set_finder(int f) { g_finder = f; }
+static int g_handoff = 0;  // 1: launch 1 -> launch 2 through the 184-byte PoolHand record (what the device's pooled pipeline does)
+extern "C" void hc_set_handoff(int on) { g_handoff = on; }
+static long g_handoff_mismatch = 0;  // fields of the rebuilt PoolBoard / srcpos / suffix sets that differ from pool_k1's own
+extern "C" long hc_handoff_mismatches() { return g_handoff_mismatch; }
+static bool bb_same(const BB& a, const BB& b) { return a.w0 == b.w0 && a.w1 == b.w1 && a.w2 == b.w2; }
 static void pool_tile(const Board* boards, int nb, uint32_t* mask5, float* planes, int64_t* floods, int64_t* flood_iters) {
     std::vector<PoolBoard> ctx(nb);
     std::vector<PathTab> tabs((size_t)nb * 2);
+    std::vector<PoolHand> hand(nb);
     for (int i = 0; i < nb; i++)  // launch 1: lane = (board, player)
         for (int p = 2; p >= 1; p--) {
             if (g_finder == 0) pool_k1<0>(boards[i], false, true, p, ctx[i], tabs[(size_t)i * 2 + p - 1], g_try_detour);
             else pool_k1<1>(boards[i], false, true, p, ctx[i], tabs[(size_t)i * 2 + p - 1], g_try_detour);
         }
+    if (g_handoff) {
+        // the same boards through the hand-off record; what launch 2 rebuilds from it must be what pool_k1 left in its
+        // PoolBoard / PathTab (compared field by field), and the rest of the tile then runs on the REBUILT records
+        std::vector<PoolBoard> rb(nb);
+        std::vector<uint8_t> sp((size_t)nb * 2 * 84, 255);
+        for (int i = 0; i < nb; i++) {
+            memset(&hand[i], 0xCD, sizeof(PoolHand));
+            for (int p = 2; p >= 1; p--) pool_k1_hand(boards[i], false, p, hand[i], g_try_detour);
+            pool_hand_rebuild_board(rb[i], hand[i], boards[i]);
+            for (int p = 1; p <= 2; p++) pool_hand_rebuild_path(rb[i], p, hand[i].seq[p - 1], &sp[((size_t)i * 2 + p - 1) * 84]);
+            const PoolBoard &a = ctx[i], &r = rb[i];
+            long bad = 0;
+            bad += a.flags != r.flags || a.pawn != r.pawn || a.sh != r.sh || a.sv != r.sv;
+            for (int q = 0; q < 4; q++) bad += a.need[q] != r.need[q];
+            bad += !bb_same(a.base.n, r.base.n) || !bb_same(a.base.s, r.base.s) || !bb_same(a.base.e, r.base.e) || !bb_same(a.base.w, r.base.w);
+            if ((a.flags & 3u) == 1u)
+                for (int p = 0; p < 2; p++) {
+                    bad += a.len[p] != r.len[p] || a.pe[p].found != r.pe[p].found || a.pe[p].jump != r.pe[p].jump;
+                    bad += !bb_same(a.pe[p].pn, r.pe[p].pn) || !bb_same(a.pe[p].ps, r.pe[p].ps) || !bb_same(a.pe[p].pe, r.pe[p].pe) || !bb_same(a.pe[p].pw, r.pe[p].pw);
+                    bad += memcmp(&a.plan[p], &r.plan[p], sizeof(JumpPlan)) != 0;
+                    if (a.len[p] > 0) {
+                        bad += a.lastjump[p] != r.lastjump[p] || a.farjump[p] != r.farjump[p] || !bb_same(a.tiles[p], r.tiles[p]);
+                        bad += memcmp(tabs[(size_t)i * 2 + p].srcpos, &sp[((size_t)i * 2 + p) * 84], 81) != 0;
+                        for (int k = 0; k < a.len[p]; k++) bad += !bb_same(tabs[(size_t)i * 2 + p].suffix[k], pool_seq_suffix(hand[i].seq[p], k));
+                    }
+                }
+            g_handoff_mismatch += bad;
+        }
+        std::vector<uint32_t> items;
+        for (int i = 0; i < nb; i++)
+            for (int ix = 0; ix < 64; ix++) {
+                uint32_t m = pool_p2(rb[i], ix);
+                if (m & 1u) items.push_back(pool_item(i, ix, true, 1));
+                if (m & 2u) items.push_back(pool_item(i, ix, true, 2));
+                if (m & 4u) items.push_back(pool_item(i, ix, false, 1));
+                if (m & 8u) items.push_back(pool_item(i, ix, false, 2));
+            }
+        for (uint32_t it : items) {
+            int bd = (int)(it >> 8), ix = (int)(it & 63u), p = (it & 0x80u) ? 2 : 1;
+            bool hz = (it & 0x40u) != 0u;
+            bool ok = pool_p3_seq(rb[bd], it, &sp[((size_t)bd * 2 + p - 1) * 84], hand[bd].seq[p - 1]);
+            if (floods) (*floods)++;
+            if (!ok) rb[bd].blocked[(hz ? 0 : 2) + (ix >> 5)] |= 1u << (ix & 31);
+        }
+        for (int i = 0; i < nb; i++) pool_p4(rb[i], mask5 + 5 * (long)i);
+        (void)planes;
+        return;
+    }
     std::vector<uint32_t> items;
     for (int i = 0; i < nb; i++)
         for (int ix = 0; ix < 64; ix++) {

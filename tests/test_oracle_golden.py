@@ -180,6 +180,21 @@ def test_bitboard_movegen_equals_oracle(hostcheck, positions):
         hostcheck.hc_set_finder(0)
         hostcheck.hc_set_detour(0)
         assert np.array_equal(m, omask), "rows finder, detour mode %d" % mode
+    # the hand-off of the device's pooled pipeline (launch 1 -> 184-byte PoolHand record -> launch 2): what the second launch
+    # rebuilds from the record -- blocked sets, slot tests, path edge sets, path tiles, jump positions, the srcpos table, every
+    # suffix set -- equals what pool_k1 computes directly, field by field, and the tile run on the rebuilt records (suffix
+    # sets taken from the tile sequence: pool_p3_seq) gives the oracle's masks, with and without group detours
+    hostcheck.hc_handoff_mismatches.restype = C.c_long
+    for mode in (0, 1, 2):
+        hostcheck.hc_set_handoff(1)
+        hostcheck.hc_set_detour(mode)
+        m = np.zeros((n, 5), dtype=np.uint32)
+        hostcheck.hc_movegen_pool(hb.ctypes.data_as(C.c_void_p), vb.ctypes.data_as(C.c_void_p), meta.ctypes.data_as(C.c_void_p),
+                                  n, 24, m.ctypes.data_as(C.c_void_p), None, None)
+        hostcheck.hc_set_handoff(0)
+        hostcheck.hc_set_detour(0)
+        assert np.array_equal(m, omask), "hand-off record, detour mode %d" % mode
+        assert hostcheck.hc_handoff_mismatches() == 0
     hostcheck.hc_cut_row_mismatches.restype = C.c_long
     assert hostcheck.hc_cut_row_mismatches() == 0  # cut masks in rows == path_cut_masks() on every path the rows finder found
     hostcheck.hc_plan_rows_mismatches.restype = C.c_long
