@@ -845,10 +845,10 @@ __device__ __forceinline__ void select_core(EngineDev& E, BoardRegs& S, const in
             QZ_SEL_MARK(t_walk)
             QZ_TS(1)
 #ifndef QZ_REPLAY_MIN
-#define QZ_REPLAY_MIN 4   // recorded levels that must remain for a replay round to be tried
+#define QZ_REPLAY_MIN 2   // recorded levels that must remain for a replay round to be tried (a round also selects the level after them)
 #endif
 #ifndef QZ_WALK_CREDIT
-#define QZ_WALK_CREDIT 2  // levels walked after a round that confirmed fewer than QZ_REPLAY_MIN levels
+#define QZ_WALK_CREDIT 1  // levels walked after a round that confirmed fewer than QZ_REPLAY_MIN levels (4 / 2, 2 / 1, 1 / 1 measured 236.2 / 238.1 / 238.1 M playouts/s)
 #endif
             while (cur != QZ_NONE && walk_credit == 0u && plen + (uint32_t)QZ_REPLAY_MIN <= cur_len && !left) {
                 QZ_SEL_COUNT(n_rounds++;)
@@ -1178,19 +1178,27 @@ __device__ __forceinline__ void select_core(EngineDev& E, BoardRegs& S, const in
                     dest = left_rec;
                     from = left_at;
                 } else {
-                    uint32_t bestv = 0xFFFFFFFFu;
-                    dest = 0u;
-                    for (uint32_t r = 0; r < R; r++) {
-                        // (a long record is worth more than its age says: losing it costs a walk of its length)
+                    // lane r < R weighs record r (a long record is worth more than its age says: losing it costs a walk of its
+                    // length); the minimum over the sixteen lanes by DPP row shifts, the FIRST record that has it wins (round 3: a
+                    // scalar loop of sixteen readlane pairs, ~200 instructions of every descent that left its record)
 #ifndef QZ_VICTIM_LEN_WEIGHT
 #define QZ_VICTIM_LEN_WEIGHT 64u  // (0 / 1 / 4 / 16 / 64 / 256 / 4096 measured 490 / 491 / 504 / 516 / 517 / 516 / 515 k plies/s, and the launches' tails shorter)
 #endif
-                        const uint32_t l = rdl(rlen, (int)r), v = l == 0u ? 0u : rdl(rstamp, (int)r) + QZ_VICTIM_LEN_WEIGHT * l;
-                        if (v < bestv && r != left_rec && !((used >> r) & 1u)) {
-                            bestv = v;
-                            dest = r;
-                        }
+                    static_assert(QZ_PATH_RECS <= 16, "the victim search reduces over one DPP row");
+                    uint32_t v = 0xFFFFFFFFu;
+                    if (lane < (int)R && (uint32_t)lane != left_rec && !((used >> lane) & 1u)) v = rlen == 0u ? 0u : rstamp + QZ_VICTIM_LEN_WEIGHT * rlen;
+                    int m = (int)v;  // (unsigned minimum through a signed DPP chain: flip the sign bit)
+                    m ^= (int)0x80000000;
+                    {
+                        int t;
+                        t = __builtin_amdgcn_update_dpp(0x7fffffff, m, 0x111, 0xf, 0xf, false); m = t < m ? t : m;
+                        t = __builtin_amdgcn_update_dpp(0x7fffffff, m, 0x112, 0xf, 0xf, false); m = t < m ? t : m;
+                        t = __builtin_amdgcn_update_dpp(0x7fffffff, m, 0x114, 0xf, 0xf, false); m = t < m ? t : m;
+                        t = __builtin_amdgcn_update_dpp(0x7fffffff, m, 0x118, 0xf, 0xf, false); m = t < m ? t : m;
                     }
+                    const uint32_t bestv = (uint32_t)__builtin_amdgcn_readlane(m, 15) ^ 0x80000000u;
+                    const uint64_t who = __ballot(lane < (int)R && v == bestv);
+                    dest = who ? (uint32_t)(__ffsll((unsigned long long)who) - 1) : 0u;
                     if (bestv == 0xFFFFFFFFu) dest = left_rec != QZ_NONE ? left_rec : 0u;  // every record was useful just now
                     from = 0u;
                 }
@@ -1331,7 +1339,9 @@ __device__ __forceinline__ unsigned long long expand_node(EngineDev& E, BoardReg
             // k_advance's loop into vector registers of their own -- 0.0, QZ_NONE -- and those registers spilled)
             uint32_t zero = 0u;
             asm volatile("" : "+v"(zero));
-            for (int a = lane; a < QZ_N_ACT; a += 64) {
+            // (a mover without walls -- most leaves of a long game -- has pawn moves only: one pass over action ids 0..11)
+            const int a_end = (lh | lv) == 0ull ? 12 : QZ_N_ACT;
+            for (int a = lane; a < a_end; a += 64) {
                 uint32_t w = a < 32 ? m0 : (a < 64 ? m1 : (a < 96 ? m2 : (a < 128 ? m3 : m4)));
                 if ((w >> (a & 31)) & 1u) {
                     uint32_t e = base + (uint32_t)order_index(pawn, lh, lv, a);
@@ -2849,12 +2859,15 @@ hipError_t finish_move(const EngineDev& E, const uint8_t* forced, float* pi_out,
     hipLaunchKernelGGL(k_release, wave_grid(E.n_boards), dim3(TPB), 0, s, E);
     return hipGetLastError();
 }
-// subtree copies get an eighth of the round's budget per round: the moves' launch runs beside / right after the network
-// (qz_selfplay_round) and the round's tail waits for it -- a 1,000-level line, which copies at one level per memory round
-// trip (~1 ms), must not hold every round up (measured: with a quarter, 250 us, the launch ALWAYS ran to its budget -- there
-// is always such a board somewhere -- and the round grew by as much); the board concerned sits out a few rounds instead
+// Subtree copies get 1/32 of the round's budget per round (31 us of a millisecond): the moves' launch runs beside / right
+// after the network (qz_selfplay_round) and the round's tail waits for it, and the launch lasts at least as long as its
+// copies are allowed to -- there is always a board somewhere whose copy is a 1,000-level line (one level per memory round
+// trip, ~1 ms in all).  Measured at 8,192 boards: with a quarter the launch ALWAYS ran to its budget (262 us; the trunk
+// beside it 191), with an eighth it lasted 200 us of which ~100 stuck out behind the network.  The board concerned sits out
+// some thirty rounds instead (a dozen boards of 8,192 at any time); an ordinary compaction (a few thousand edges) still
+// fits one slice.
 static unsigned int compact_budget(unsigned int budget_ticks) {
-    return budget_ticks == 0xFFFFFFFFu ? budget_ticks : (budget_ticks / 8u > 0u ? budget_ticks / 8u : 1u);
+    return budget_ticks == 0xFFFFFFFFu ? budget_ticks : (budget_ticks / 32u > 0u ? budget_ticks / 32u : 1u);
 }
 hipError_t advance(const EngineDev& E, int max_iters, unsigned int budget_ticks, int auto_finish, int par, hipStream_t s) {
     if (auto_finish) hipLaunchKernelGGL(k_moves, wave_grid(E.n_boards), dim3(TPB), 0, s, E, compact_budget(budget_ticks));
