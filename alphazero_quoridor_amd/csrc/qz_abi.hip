@@ -999,7 +999,8 @@ int qz_selfplay_round(qz_engine* e, const qz_nn_weights* w, int max_playouts, in
     const unsigned int ticks = budget_us > 0 ? (unsigned int)budget_us * 100u : 0xFFFFFFFFu;  // s_memrealtime: 100 MHz
     HIP_TRY(qzl::advance(d, max_playouts, ticks, 0, e->par, s));
     HIP_TRY(hipEventRecord(e->ev_fork, s));
-    // (the network is queued first: its workgroups -- 4 per CU, most of the LDS -- should be placed before the side kernels')
+    // (the network is queued first: its workgroups -- 4 per CU, most of the LDS -- should be placed before the side kernels'; queuing
+    // the side kernels first and / or a high-priority side stream measured the same: profiles/round4/SUMMARY.md)
     if ((r = nn_evaluate(d.miss_hb, d.miss_vb, d.miss_meta, nullptr, d.n_boards, w, e->feat, d.miss_p, d.miss_v, d.miss_count + e->par, s))) return r;
     HIP_TRY(hipStreamWaitEvent(e->side, e->ev_fork, 0));
     HIP_TRY(qzl::movegen_encode(d.miss_hb, d.miss_vb, d.miss_meta, d.n_boards, d.miss_mask, nullptr, nullptr, e->scratch, e->rules, e->side, d.miss_count + e->par));

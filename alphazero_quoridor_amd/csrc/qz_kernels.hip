@@ -1575,13 +1575,21 @@ __device__ __forceinline__ void translate_records(EngineDev& E, int b, int lane,
     constexpr uint32_t R = QZ_PATH_RECS, CAP = QZ_PATH_CAP;
     const Edge* pool = E.edge_pool;
     wave_sync();  // the forwarding addresses were stored by other lanes
-    for (uint32_t r = 0; r < R; r++) {
-        const uint32_t len = rfl(E.rec_len[(size_t)b * R + r]);
+    // lane r < R looks at record r: its length and its first edge in ONE trip for all sixteen (round 3 asked record after
+    // record: two dependent trips each, a third of the latency of a move); only the records that went through the move are
+    // then shifted, the others are simply emptied
+    const uint32_t len_l = lane < (int)R ? E.rec_len[(size_t)b * R + lane] : 0u;
+    const uint32_t first_l = lane < (int)R ? E.path_edges[((size_t)b * (R + 1u) + (uint32_t)lane) * CAP] : QZ_NONE;
+    uint64_t keep = __ballot(lane < (int)R && edge != QZ_NONE && len_l > 1u && first_l == edge);
+    if (lane < (int)R && !((keep >> lane) & 1ull)) E.rec_len[(size_t)b * R + lane] = 0u;
+    while (keep) {
+        const uint32_t r = (uint32_t)(__ffsll((unsigned long long)keep) - 1);
+        keep &= keep - 1ull;
+        const uint32_t len = rdl(len_l, (int)r);
         uint32_t* const re = E.path_edges + ((size_t)b * (R + 1u) + r) * CAP;
         unsigned long long* const rb = E.path_blocks + ((size_t)b * (R + 1u) + r) * CAP;
-        uint32_t newlen = 0u;
-        if (edge != QZ_NONE && len > 1u && rfl(re[0]) == edge) {
-            newlen = len - 1u;
+        uint32_t newlen = len - 1u;
+        {
             // (level len, one past the end, may hold the block of the node the recorded descent ended on -- note_expansion --:
             // it moves up with the rest.  Nothing says it is there: whatever arrives at the new index is only believed after
             // the replay round's link test, like every entry.)
