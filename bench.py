@@ -185,13 +185,16 @@ class Run:
         def len_stats(v):
             return {"n": len(v), "mean": float(np.mean(v)) if v else None, "median": float(np.median(v)) if v else None}
 
-        name = "BASELINE configs[2] as an engine run" if B == 32768 else ("BASELINE configs[1]" if a.playouts == 100 else "BASELINE configs[3] per GPU")
+        name = "BASELINE configs[2] as an engine run" if B == 32768 else ("BASELINE configs[1]" if a.playouts == 100 else (
+            "BASELINE configs[3] per GPU" if B == 4096 else "BASELINE configs[3]'s per-GPU workload with %d instead of 4,096 boards per GPU (the engine keeps eight "
+            "k_advance wavefronts per SIMD busy; same_loop_at_4096_boards is the literal board count)" % B))
         label = ("NON-PARITY THROUGHPUT MODE (network products on fp16 operands, p / v ~1e-3 from the reference) -- " if a.nn_dtype == "fp16" else "") + \
                 ("TERMINAL SIGN FIXED (not the reference's mcts.py:125) -- " if a.fix_terminal_sign else "")
         cfg = {"workload": label + "%s: %d concurrent boards/GPU, n_playout=%d, 9x9, 10 walls/player, c_puct=5, temp=1.0, %s" % (name, B, a.playouts, workload_tail),
                "boards_per_gpu": B, "board_groups": a.groups, "fix_terminal_sign": bool(a.fix_terminal_sign), "n_playout": a.playouts, "bn_mode": a.bn,
                "nn_dtype": a.nn_dtype, "max_depth": a.max_depth,
-               "desync": "%d untimed plies at %d playouts/move (%.0fs, %d games finished)" % (a.desync_plies, a.desync_playouts, desync_s, len(self.lengths["desync"]))}
+               "desync": "%d untimed plies at %d playouts/move, then %d untimed rounds at %d playouts/move (%.0fs, %d games finished)"
+                         % (a.desync_plies, a.desync_playouts, a.settle_rounds if a.mode == "async" else 0, a.playouts, desync_s, len(self.lengths["desync"]))}
         cfg.update(mode_cfg)
         out = {"metric": "self-play games/sec (9x9, n_playout=%d)" % a.playouts, "value": value, "unit": "games/s", "n_gpus": self.world, "steps": a.steps,
                "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -224,6 +227,10 @@ class Run:
         if self.world == 1 and not a.no_c3:
             out["roofline_c3"] = c3_microbench(self.dev)
         if self.world == 1 and a.mode == "async" and not a.fix_terminal_sign and a.second_line_seconds > 0:
+            self.eng.close()
+            torch.cuda.empty_cache()
+            if a.boards != 4096 and a.playouts == 400:
+                out["same_loop_at_4096_boards"] = line_at_4096_boards(a, self.dev, self.qdist)
             out["second_line_fix_terminal_sign"] = second_line(a, self.dev, self.qdist)
         if not a.no_cpu_baseline and self.world == 1:
             self.eng.close()
@@ -262,6 +269,40 @@ def make_engine(args, net, dev, seed, fix_sign, boards=None):
                        fix_terminal_sign=fix_sign, select_opts=args.select_opts, memo=not args.no_memo, max_depth=args.max_depth)
 
 
+def line_at_4096_boards(args, dev, qdist):
+    """BASELINE configs[3] names 4,096 boards per GPU; the headline runs 8,192 (eight wavefronts of k_advance per SIMD).  The same
+    loop at exactly 4,096 boards (k_advance<4>), same phases, a short timed region: so that both are in the driver's line."""
+    from alphazero_quoridor_amd.policy_value_net import PolicyValueNet
+
+    torch.manual_seed(args.seed)
+    net = PolicyValueNet(use_gpu=True, device=dev)
+    eng = make_engine(args, net, dev, qdist.shard_seed(args.seed, 0), False, boards=4096)
+    kw = dict(max_playouts=args.max_playouts, budget_us=args.budget_us)
+    eng.set_playouts(args.desync_playouts)
+    for _ in range(0, args.desync_plies * (args.desync_playouts + 1), 64):
+        eng.run_rounds(64, **kw)
+        eng.harvest()
+    eng.set_playouts(args.playouts)
+    for _ in range(0, args.settle_rounds + 1280, 64):
+        eng.run_rounds(64, **kw)
+        eng.harvest()
+    st0 = eng.stats()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(0, 2560, 64):
+        eng.run_rounds(64, **kw)
+        eng.harvest()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    st1 = eng.stats()
+    d = {k: st1[k] - st0[k] for k in st1}
+    eng.close()
+    return {"boards": 4096, "kernel": "k_advance<4> (73 registers, four wavefronts per SIMD)", "rounds": 2560, "seconds": dt, "ms_per_round": dt / 2560 * 1e3,
+            "plies_per_s": d["plies_played"] / dt, "playouts_per_s": d["playouts"] / dt, "nn_evaluations_per_s": d["nn_evals"] / dt,
+            "memo_hit_rate": d["memo_hits"] / max(d["playouts"], 1),
+            "note": "same desync / settle phases as the headline + 1,280 warm-up rounds, then 2,560 rounds timed by this process"}
+
+
 def second_line(args, dev, qdist):
     """The target-reaching mode, timed by the same process: a winning move backed up as +1 (NOT the reference's mcts.py:125, which
     backs it up as -1 and makes searches avoid winning).  Games then last ~300 plies, so REAL finished games / wall time is a
@@ -272,7 +313,7 @@ def second_line(args, dev, qdist):
     torch.manual_seed(args.seed)
     net = PolicyValueNet(use_gpu=True, device=dev)
     eng = make_engine(args, net, dev, qdist.shard_seed(args.seed + 1, 0), True)
-    kw = dict(max_playouts=args.max_playouts, budget_us=args.budget_us)
+    kw = dict(max_playouts=args.max_playouts, budget_us=args.second_line_budget_us)
     lens = []
 
     def harvest():
@@ -283,7 +324,7 @@ def second_line(args, dev, qdist):
         return n
 
     eng.set_playouts(args.desync_playouts)
-    for _ in range(0, 300 * (args.desync_playouts + 1), 64):
+    for _ in range(0, args.desync_plies * (args.desync_playouts + 1), 64):
         eng.run_rounds(64, **kw)
         harvest()
     eng.set_playouts(args.playouts)
@@ -310,8 +351,12 @@ def second_line(args, dev, qdist):
             "mean_plies_per_game": float(np.mean(lens)) if lens else None, "plies_per_s": d["plies_played"] / dt, "playouts_per_s": d["playouts"] / dt,
             "nn_evaluations_per_s": d["nn_evals"] / dt, "memo_hit_rate": d["memo_hits"] / max(d["playouts"], 1),
             "board_seconds_per_open_ply": open_s / max(d["open_plies"], 1), "nn_precision": "fp32 (parity: three fp16 MFMAs per product)",
+            "budget_us": args.second_line_budget_us, "nn_evaluations_per_game": d["nn_evals"] / max(games, 1),
+            "note": "network-bound: with the sign fixed a game is ~150 plies of the open phase (the mover has walls: nearly every leaf is new) at 400 evaluations "
+                    "each; evaluations per game x games/s = the network's throughput.  Round 3's 409 games/s counted the games the 4-playout desync phase had left "
+                    "close to their end (a transient); this line is taken after the population has played at 400 playouts for --second-line-warm-seconds",
             "measured": "real finished games / wall time after %d desync plies at %d playouts and %.0f s of warm-up at %d playouts"
-                        % (300, args.desync_playouts, args.second_line_warm_seconds, args.playouts)}
+                        % (args.desync_plies, args.desync_playouts, args.second_line_warm_seconds, args.playouts)}
 
 
 # ------------------------------------------------------------------------------ the asynchronous loop (default)
@@ -330,6 +375,11 @@ def run_async(R):
             eng.run_rounds(64, **kw)
             R.harvest()
         eng.set_playouts(args.playouts)
+        # ... then settle at the full playout count (untimed): the boards the short searches left in mid-game grow their trees and
+        # the memo learns their neighbourhoods, as in any run longer than a few seconds (a 300-s soak: profiles/round3)
+        for _ in range(0, args.settle_rounds, 64):
+            eng.run_rounds(64, **kw)
+            R.harvest()
     desync_s = time.time() - t0
     if args.graph_rounds:
         eng.capture_rounds(rounds=args.graph_rounds, **kw)
@@ -573,12 +623,14 @@ def main():
     ap.add_argument("--channels-last", type=int, default=1)
     ap.add_argument("--desync-plies", type=int, default=700)
     ap.add_argument("--desync-playouts", type=int, default=4)
+    ap.add_argument("--settle-rounds", type=int, default=2560, help="async: untimed rounds at the full playout count between the desync phase and the warm-up steps")
     ap.add_argument("--seed", type=int, default=2026)
     ap.add_argument("--cpu-seconds", type=float, default=16.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fix-terminal-sign", action="store_true", help="NOT the headline: back a winning move up as +1 (the reference backs it up as -1, mcts.py:125)")
-    ap.add_argument("--second-line-seconds", type=float, default=4.0, help="async, 1 GPU: length of the labelled second run with the terminal sign fixed (0 = skip it)")
+    ap.add_argument("--second-line-seconds", type=float, default=5.0, help="async, 1 GPU: length of the labelled second run with the terminal sign fixed (0 = skip it)")
     ap.add_argument("--second-line-warm-seconds", type=float, default=12.0)
+    ap.add_argument("--second-line-budget-us", type=int, default=500, help="budget of a k_advance launch in the second line (its boards wait for the network nearly every playout)")
     ap.add_argument("--no-c3", action="store_true", help="skip the 32,768-board microbenchmark line (roofline_c3)")
     ap.add_argument("--no-planes", action="store_true", help="lockstep: the rules op only produces the legal sets (the evaluator reads the leaf boards)")
     ap.add_argument("--library-trunk", action="store_true", help="lockstep A/B: trunk convolutions through MIOpen instead of the split-fp16 MFMA kernel")
