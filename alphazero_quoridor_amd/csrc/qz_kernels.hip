@@ -2879,7 +2879,7 @@ static unsigned int compact_budget(unsigned int budget_ticks) {
 }
 hipError_t advance(const EngineDev& E, int max_iters, unsigned int budget_ticks, int auto_finish, int par, hipStream_t s) {
     if (auto_finish) hipLaunchKernelGGL(k_moves, wave_grid(E.n_boards), dim3(TPB), 0, s, E, compact_budget(budget_ticks));
-    if (E.n_boards > 4096 * QZ_ADV_WAVES_SMALL / 4) hipLaunchKernelGGL(k_advance<8>, wave_grid(E.n_boards), dim3(TPB), 0, s, E, max_iters, budget_ticks, par);
+    if (E.n_boards > 4096 * QZ_ADV_WAVES_SMALL / 4 || (E.select_opts & 4)) hipLaunchKernelGGL(k_advance<8>, wave_grid(E.n_boards), dim3(TPB), 0, s, E, max_iters, budget_ticks, par);
     else hipLaunchKernelGGL(k_advance<QZ_ADV_WAVES_SMALL>, wave_grid(E.n_boards), dim3(TPB), 0, s, E, max_iters, budget_ticks, par);
     return hipGetLastError();
 }

@@ -133,7 +133,8 @@ typedef struct {
     qz_rules_opts rules;       /* formulation of the leaf rules op (all zero = defaults)        */
     int32_t select_opts;       /* A/B switches of the descent kernel (0 = defaults): bit 0 = walk every level (no replay of
                                   recorded descents; same results, the test partner of the records), bit 1 = no readlane
-                                  scan for nodes with <= 8 children */
+                                  scan for nodes with <= 8 children, bit 2 = the 64-register build of the asynchronous loop's
+                                  kernel (eight wavefronts per SIMD: what engines above 4,096 boards run) whatever the engine's size */
     /* Leaf-evaluation memo (qz_selfplay_*): log2 of the number of buckets of its two tables; 0 = auto (16,384 small entries
      * -- at most 8 GB -- and 512 big entries per board, rounded up to a power of two), < 0 = no memo (every leaf goes to the network).
      * small: leaves whose mover has no wall left, 4 entries of 128 B per bucket; big: all others, 2 x 640 B. */

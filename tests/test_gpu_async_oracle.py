@@ -89,12 +89,13 @@ def search_to_completion(eng, name, n, max_playouts, budget_us, limit=100000):
     return rounds, evals
 
 
-# the loop's regimes: (memo, playouts a board may start per launch, wall-clock budget of a launch in us)
-REGIMES = [(True, 1, 0), (True, 4096, 0), (False, 4096, 0), (True, 4096, 1)]
+# the loop's regimes: (memo, playouts a board may start per launch, wall-clock budget of a launch in us, select_opts)
+# select_opts 4 = the 64-register build of k_advance (eight wavefronts per SIMD: what engines above 4,096 boards, i.e. the bench, run)
+REGIMES = [(True, 1, 0, 0), (True, 4096, 0, 0), (False, 4096, 0, 0), (True, 4096, 1, 0), (True, 4096, 0, 4), (True, 4096, 1, 4)]
 
 
-@pytest.mark.parametrize("memo,max_playouts,budget_us", REGIMES)
-def test_async_route_reproduces_the_reference_search_fixture(gpu_device, golden_dir, memo, max_playouts, budget_us):
+@pytest.mark.parametrize("memo,max_playouts,budget_us,select_opts", REGIMES)
+def test_async_route_reproduces_the_reference_search_fixture(gpu_device, golden_dir, memo, max_playouts, budget_us, select_opts):
     """mcts_stub.npz (360 searches recorded from the reference's MCTS.get_move_probs with stub policies, 8..400 playouts,
     c_puct 2.5 / 5, temperatures 1 / 0.5 / 1e-3, terminal leaves inside the trees) through k_advance: lock-step cadence,
     free-running (a board does all its playouts in as few launches as its misses allow), without the memo, and with a
@@ -106,7 +107,7 @@ def test_async_route_reproduces_the_reference_search_fixture(gpu_device, golden_
         groups.setdefault(key, []).append(i)
     checked = hits = 0
     for (pol, n, c_puct, temp), idx in groups.items():
-        eng = make_engine(d["board"][idx], n, c_puct=c_puct, temp=temp, memo=memo)
+        eng = make_engine(d["board"][idx], n, c_puct=c_puct, temp=temp, memo=memo, select_opts=select_opts)
         try:
             search_to_completion(eng, pol, n, max_playouts, budget_us)
             visits, q, prior, root_n = (t.cpu().numpy() for t in eng.root_children())
@@ -193,13 +194,15 @@ def _move_between(og, cur_rec, nxt_rec):
     return None
 
 
-@pytest.mark.parametrize("name,compact_edges,budget_us,pool_pages,memo", [
-    ("hash", 0, 0, 0, True),          # this small engine's default threshold (one page): compacting and in-place moves mixed
-    ("hash", 0, 300, 64 * 60, True),  # a large pool: moves in place, under a wall-clock budget
-    ("hash", -1, 1, 0, True),         # every move copies its subtree; 1-us budget: the copies proceed in 64-edge slices
-    ("uniform", 0, 0, 0, False),      # no memo: every leaf through the caller
+@pytest.mark.parametrize("name,compact_edges,budget_us,pool_pages,memo,select_opts", [
+    ("hash", 0, 0, 0, True, 0),          # this small engine's default threshold (one page): compacting and in-place moves mixed
+    ("hash", 0, 300, 64 * 60, True, 0),  # a large pool: moves in place, under a wall-clock budget
+    ("hash", -1, 1, 0, True, 0),         # every move copies its subtree; 1-us budget: the copies proceed in 64-edge slices
+    ("uniform", 0, 0, 0, False, 0),      # no memo: every leaf through the caller
+    ("hash", 0, 0, 0, True, 4),          # the 64-register build of k_advance (what the bench's 8,192-board engine runs)
+    ("hash", -1, 1, 0, True, 4),
 ])
-def test_games_the_loop_plays_on_its_own_replay_in_the_oracle(gpu_device, name, compact_edges, budget_us, pool_pages, memo):
+def test_games_the_loop_plays_on_its_own_replay_in_the_oracle(gpu_device, name, compact_edges, budget_us, pool_pages, memo, select_opts):
     """The free-running loop (auto_finish: k_moves samples, records, steps and re-roots on the device; k_advance resumes
     sliced subtree copies; the memo answers repeated leaves) with the caller as the evaluator, short games (terminal sign
     fixed, 24 playouts).  Every harvested game is then replayed ply by ply in oracle.OracleMCTS (mcts.py:103-151 restated
@@ -211,7 +214,7 @@ def test_games_the_loop_plays_on_its_own_replay_in_the_oracle(gpu_device, name, 
     from alphazero_quoridor_amd.boards import opening_packed
 
     B, NP = 64, 24
-    eng = make_engine(opening_packed(B), NP, seed=5, fix_terminal_sign=True, compact_edges=compact_edges, tree_pool_pages=pool_pages, memo=memo)
+    eng = make_engine(opening_packed(B), NP, seed=5, fix_terminal_sign=True, compact_edges=compact_edges, tree_pool_pages=pool_pages, memo=memo, select_opts=select_opts)
     batches = []
     try:
         rounds = 0
@@ -269,7 +272,8 @@ def _wins(og, a):
     return bool(g.step(a))
 
 
-def test_real_network_search_equals_the_oracle_fed_with_the_miss_list_evaluations(gpu_device):
+@pytest.mark.parametrize("select_opts", [0, 4])
+def test_real_network_search_equals_the_oracle_fed_with_the_miss_list_evaluations(gpu_device, select_opts):
     """The kernel the bench times, with the real network and the reference's terminal sign: 64 late-game boards (movers
     without walls: the memo's regime), 400 playouts per move, three plies.  Every (board -> p, v) the network produced is
     collected from the miss lists; oracle.OracleMCTS with THAT table as its policy must arrive at bit-equal root visits and
@@ -293,7 +297,7 @@ def test_real_network_search_equals_the_oracle_fed_with_the_miss_list_evaluation
     boards["w2"] = 0
     boards = boards[[not oracle.OracleGame.from_packed(b).has_a_winner()[0] for b in boards]]
     B = len(boards)
-    eng = make_engine(boards, NP, seed=3)
+    eng = make_engine(boards, NP, seed=3, select_opts=select_opts)  # (4: the 64-register build of k_advance, the bench's)
     L = eng.L
     table = {}
 
