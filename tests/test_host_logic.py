@@ -530,10 +530,39 @@ def test_steady_state_estimator_of_the_bench_line(tmp_path):
     lo, hi = ss["ci95"]  # a longer game is a lower rate: the interval is ordered as rates
     assert lo < ss["value"] < hi and abs(hi - 4096 / (10.0 + 700 * 0.01)) < 1e-9 and abs(lo - 4096 / (10.0 + 1200 * 0.01)) < 1e-9
     assert abs(ss["upper_bound"] - 4096 / (10.0 + 500 * 0.01)) < 1e-9  # the restricted mean is a lower bound of the length
+    # the bracket of the headline: the restricted mean is a lower bound of the length -> value_high; the tail
+    # with half the hazard -> value_low (length 600 + 2 x 0.1 / 1e-4 = 2600); no window-doubling figure in this file -> not converged
+    assert ss["value_high"] == ss["upper_bound"] and ss["value_low"] is None and ss["length_estimate_converged"] is None
+    g = tmp_path / "len2.json"
+    g.write_text(json.dumps({"mean_plies_per_game": 1000.0, "mean_open_plies_per_game": 100.0, "mean_ci95": [800.0, 1300.0], "restricted_mean": 600.0,
+                             "games_finished": 10, "games_censored": 2, "T": 5000.0, "survival_at_T": 0.1, "tail_hazard_per_ply": 1e-4, "estimator": "test",
+                             "window_doubling": {"delta": 0.25}, "finished_fraction_of_started": 0.9, "dropped_mean_ply": 500.0, "games_dropped_as_censored": 1}))
+    s2 = bench.steady_state_two_phase(4096, 50.0, 450.0, 5.0, 4.5, str(g))
+    dur, drop = 19.0, 100 * 0.1 + 400 * 0.01  # a finished game; a dropped one (its open phase + 400 late plies)
+    assert abs(s2["value"] - 0.9 * 4096 / (0.9 * dur + 0.1 * drop)) < 1e-9  # dropped games cost board time and yield no game
+    assert abs(s2["value_low"] - 0.9 * 4096 / (0.9 * (10.0 + 2500 * 0.01) + 0.1 * drop)) < 1e-9 and s2["value_low"] < s2["value"] < s2["value_high"]
+    assert s2["length_window_doubling_delta"] == 0.25 and s2["length_estimate_converged"] is False and s2["n_games_dropped_as_censored"] == 1
     assert bench.steady_state_two_phase(4096, 0.0, 450.0, 0.0, 4.5, str(f)) is None  # no open plies seen: no estimate
     assert bench.steady_state_two_phase(4096, 50.0, 450.0, 5.0, 4.5, str(tmp_path / "missing.json")) is None
     # the committed sample of the default config carries everything the estimator needs
     committed = bench._latest_profile("game_length_400playouts.json")
     d = json.load(open(committed))
     assert d["n_playout"] == 400 and d["mean_open_plies_per_game"] > 0 and d["restricted_mean"] < d["mean_plies_per_game"]
-    assert d["mean_ci95"][0] < d["mean_plies_per_game"] < d["mean_ci95"][1] and d["games_censored"] == d["boards"]
+    assert d["mean_ci95"][0] < d["mean_plies_per_game"] < d["mean_ci95"][1] and d["games_censored"] <= d["boards"]
+    # benchmarks/game_length.py's estimators on a hand-made sample: Kaplan-Meier with right-censored observations, and the
+    # window-doubling comparison the bench line quotes
+    sys.path.insert(0, os.path.join(ROOT, "benchmarks"))
+    try:
+        import importlib
+
+        gl = importlib.import_module("game_length")
+    except Exception:  # (imports torch / the package; fine on this tier, but keep the estimator test independent of it)
+        gl = None
+    if gl is not None:
+        times = np.array([10.0, 20.0, 30.0, 40.0, 40.0])
+        events = np.array([True, True, False, True, False])
+        mean, rmst, ST, lam, T = gl.km_mean(times, events)
+        # S: 1 -> 0.8 (t=10) -> 0.6 (t=20) -> 0.6 (censored at 30) -> 0.3 (t=40; 2 at risk) ; integral = 10 + 0.8*10 + 0.6*20 = 30
+        assert abs(rmst - 30.0) < 1e-9 and abs(ST - 0.3) < 1e-9 and T == 40.0 and mean > rmst
+        wd = gl.window_doubling(times, events)
+        assert wd["half_window_plies"] == 20.0 and wd["mean_at_full_window"] == mean and abs(wd["delta"] - (mean / wd["mean_at_half_window"] - 1.0)) < 1e-12
