@@ -81,17 +81,22 @@ enum {
 // pool bookkeeping words (int): free-stack tops and low-water marks
 enum { QZ_P_TREE_TOP = 0, QZ_P_TREE_LOW, QZ_P_TRAJ_TOP, QZ_P_TRAJ_LOW, QZ_P_COUNT };
 
+// (dword 0-1 Q, 2 N, 3 P, 4 coff, 5 act | cne << 8 | rid << 16, 6 pedge, 7 spare: what a descent needs of a PARENT -- N, child block,
+// child count -- is one 16-byte load at dword 2, of a chosen child -- child block, action, child count -- one 8-byte load at dword 4)
 struct Edge {
     double Q;
     uint32_t N;
     float P;
-    uint32_t pedge;
     uint32_t coff;
     uint8_t act, cne;
     uint16_t rid;    // 1 + the descent record (k_select) that went through this edge last; 0 = none.  A hint: re-verified
+    uint32_t pedge;
     uint32_t spare;
 };
 static_assert(sizeof(Edge) == 32, "edge record must be 32 bytes");
+typedef uint32_t qz_u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));  // 16 bytes at an 8-byte boundary: one global_load_dwordx4
+typedef uint32_t qz_u32x2_a8 __attribute__((ext_vector_type(2), aligned(8)));
+typedef uint32_t qz_u32x3_a16 __attribute__((ext_vector_type(3), aligned(16)));  // 12 bytes: one global_store_dwordx3
 
 // Which formulation of the rules op (actions() + state()) a call uses: per engine / per call,
 // never process-global.  variant: 0 = by batch size (k_wave_rules below 8,192 boards, pooled

@@ -685,7 +685,9 @@ struct BoardRegs {
     bool live;
     TreeView T;                       // page table of the current half (two registers per lane)
     uint32_t nn, neu, np;             // nodes, edge cursor, pages mapped
-    uint32_t rlen, rstamp;            // lane r < QZ_PATH_RECS: descent record r's length / last-use stamp
+    uint32_t rlen;                    // lane r < QZ_PATH_RECS: descent record r's length.  (Its
+                                      // last-use stamp lives in LDS, lc[LC_RSTAMP + r]: looked at once per descent, and a vector register the
+                                      // 64-register build does not have -- it went to scratch, whose reload waits for every store in flight)
     uint32_t rec_last, rec_clock;
     // The per-board counters' deltas of this launch live in LDS (16 dwords per wavefront, bumped by fire-and-forget
     // ds_add / ds_max): as loop-carried scalars they cost k_advance two dozen SGPRs it does not have -- the compiler
@@ -696,7 +698,8 @@ struct BoardRegs {
 #endif
 };
 enum { LC_PLAYOUTS = 0, LC_TERMINAL, LC_OVERFLOW, LC_NONFINITE, LC_MAXDEPTH, LC_HITS, LC_EVALS, LC_SPARE, LC_LEVELS /*u64*/ = 8, LC_SCANNED /*u64*/ = 10,
-       LC_EXPANDED /*u64*/ = 12, LC_WORDS = 16 };
+       LC_EXPANDED /*u64*/ = 12, LC_RSTAMP = 16 /* .. 31: the descent records' last-use stamps */, LC_WORDS = 32 };
+static_assert(QZ_PATH_RECS <= 16, "LC_RSTAMP holds sixteen stamps");
 __device__ __forceinline__ void lc_add(const BoardRegs& S, int i, uint32_t v, int lane) {
     if (lane == 0) __hip_atomic_fetch_add(S.lc + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
@@ -727,11 +730,11 @@ __device__ __forceinline__ void regs_uniform(BoardRegs& R) {
 }
 __device__ __forceinline__ BoardRegs regs_load(const EngineDev& E, const int b, const int lane, lds_u32* lc) {
     BoardRegs R;
-    R.lc = lc;
+    R.lc = (lds_u32*)(uintptr_t)rfl((uint32_t)(uintptr_t)lc);  // (one per wavefront: a scalar, not a vector register per lane)
 #ifdef QZ_ADV_STAMPS
     R.t_sel[0] = R.t_sel[1] = R.t_sel[2] = R.t_sel[3] = 0ull;
 #endif
-    if (lane < LC_WORDS) lc[lane] = 0u;
+    if (lane < LC_RSTAMP) lc[lane] = 0u;
     R.root = load_board(E.root_hb, E.root_vb, E.root_meta, b);
     R.rootN = rfl(E.root_N[b]);
     R.root_ne = rfl(E.root_ne[b]);
@@ -743,7 +746,7 @@ __device__ __forceinline__ BoardRegs regs_load(const EngineDev& E, const int b, 
     R.neu = rfl(E.n_edges[b]);
     R.np = rfl(E.tree_npages[tree_slot(E, b, R.half)]);
     R.rlen = lane < QZ_PATH_RECS ? E.rec_len[(size_t)b * QZ_PATH_RECS + lane] : 0u;
-    R.rstamp = lane < QZ_PATH_RECS ? E.rec_stamp[(size_t)b * QZ_PATH_RECS + lane] : 0u;
+    if (lane < QZ_PATH_RECS) lc[LC_RSTAMP + lane] = E.rec_stamp[(size_t)b * QZ_PATH_RECS + lane];
     R.rec_last = rfl(E.rec_last[b]);
     R.rec_clock = rfl(E.rec_clock[b]);
     wave_sync();
@@ -752,7 +755,7 @@ __device__ __forceinline__ BoardRegs regs_load(const EngineDev& E, const int b, 
 __device__ __forceinline__ void regs_store(const EngineDev& E, const int b, const int lane, const BoardRegs& R) {
     if (lane < QZ_PATH_RECS) {
         E.rec_len[(size_t)b * QZ_PATH_RECS + lane] = R.rlen;
-        E.rec_stamp[(size_t)b * QZ_PATH_RECS + lane] = R.rstamp;
+        E.rec_stamp[(size_t)b * QZ_PATH_RECS + lane] = R.lc[LC_RSTAMP + lane];
     }
     wave_sync();
     if (lane == 0) {
@@ -826,7 +829,6 @@ __device__ __forceinline__ void select_core(EngineDev& E, BoardRegs& S, const in
         // lane r < R keeps record r's length and the time it was last useful
         if (!use) S.rlen = 0u;
         uint32_t& rlen = S.rlen;      // (ONE copy: a second one lived in a register of its own across the whole descent)
-        uint32_t& rstamp = S.rstamp;
         const uint32_t src = S.rec_last & (R - 1u);  // the record of the previous descent
         const uint32_t src_len = rdl(rlen, (int)src);
         // the record being followed: its levels below plen are this descent's (records are whole root-to-leaf paths and
@@ -910,12 +912,31 @@ __device__ __forceinline__ void select_core(EngineDev& E, BoardRegs& S, const in
                 // still on their way; all seven requests back to back, no branch between them: behind a branch the compiler's
                 // wait for ONE of them becomes a wait for all, and a slot initialised with a copy of slot 0 waits for slot 0 --
                 // measured: two dependent trips per round instead of one)
-                const uint32_t pN = pp[2], pcoff = pp[5], pmisc = pp[6];
-                const uint32_t ccoff = cq[5], cmisc = cq[6];
+#ifndef QZ_EDGE_WIDE_LOADS
+#define QZ_EDGE_WIDE_LOADS 0  // (1: the parent's three words as one 16-byte load, the backup's Q and N as 12-byte load / store: measured 2 % slower, 269.7 against 275.8 M playouts/s -- the compiler already pairs adjacent dwords and the wide forms cost four more scratch slots)
+#endif
+                // (every vector load instruction costs the CU's texture path one pass over the lanes' cache lines -- a gather: one
+                // line per lane -- and at eight wavefronts per SIMD that path is what the kernel queues for: the parent's three
+                // words come as ONE 16-byte load, the recorded edge's two as one 8-byte load)
+#if QZ_EDGE_WIDE_LOADS
+                const qz_u32x4_a8 pv = *reinterpret_cast<const qz_u32x4_a8*>(pp + 2);
+                const qz_u32x2_a8 cv = *reinterpret_cast<const qz_u32x2_a8*>(cq + 4);
+                const uint32_t pN = pv.x, pcoff = pv.z, pmisc = pv.w;
+                const uint32_t ccoff = cv.x, cmisc = cv.y;
+#else
+                const uint32_t pN = pp[2], pcoff = pp[4], pmisc = pp[5];
+                const uint32_t ccoff = cq[4], cmisc = cq[5];
+#endif
                 uint4 c0 = *reinterpret_cast<const uint4*>(&pool[lbase]);
                 uint4 c1 = *reinterpret_cast<const uint4*>(&pool[lbase + (1u < last_child ? 1u : last_child)]);
                 uint4 c2 = *reinterpret_cast<const uint4*>(&pool[lbase + (2u < last_child ? 2u : last_child)]);
                 uint4 c3 = *reinterpret_cast<const uint4*>(&pool[lbase + (3u < last_child ? 3u : last_child)]);
+#if QZ_EDGE_WIDE_LOADS
+                // (the parent's P arrives with its load and is never looked at: left dead, its register is handed out as a temporary
+                // while the load is still in flight, and the address arithmetic of the children waits for the parent -- vmcnt --
+                // before it may write there: a second dependent trip.  It stays "in use" until every request is out.)
+                asm volatile("" : : "v"(pv.y));
+#endif
                 // an entry counts only if its block IS the child block of the entry above (lane 0: the current node), with that
                 // node's number of children (an entry past a record's end may be left over from another tree in the same pages)
                 const uint32_t linked = tree_phys_lanes(T, pcoff);
@@ -1035,8 +1056,14 @@ __device__ __forceinline__ void select_core(EngineDev& E, BoardRegs& S, const in
                 // act | cne | rid and child block: 8 bytes of a record the round has just read
                 kk = sel_kk;
                 const uint32_t* const q = reinterpret_cast<const uint32_t*>(&pool[base + (uint32_t)kk]);
-                w_coff = rfl(q[5]);
-                misc = rfl(q[6]);
+#if QZ_EDGE_WIDE_LOADS
+                const qz_u32x2_a8 qv = *reinterpret_cast<const qz_u32x2_a8*>(q + 4);
+                w_coff = rfl(qv.x);
+                misc = rfl(qv.y);
+#else
+                w_coff = rfl(q[4]);
+                misc = rfl(q[5]);
+#endif
                 w_sq = sqrt_count(sel_N);
                 nonfinite = nonfinite || sel_nan;
             } else if (ne <= 8 && !(E.select_opts & 2)) {
@@ -1049,8 +1076,14 @@ __device__ __forceinline__ void select_core(EngineDev& E, BoardRegs& S, const in
                 if (lane < ne) {
                     const uint32_t* const q = reinterpret_cast<const uint32_t*>(&pool[base + (uint32_t)lane]);
                     qa = *reinterpret_cast<const uint4*>(q);
-                    qcoff = q[5];
-                    qmisc = q[6];
+#if QZ_EDGE_WIDE_LOADS
+                    const qz_u32x2_a8 qv = *reinterpret_cast<const qz_u32x2_a8*>(q + 4);
+                    qcoff = qv.x;
+                    qmisc = qv.y;
+#else
+                    qcoff = q[4];
+                    qmisc = q[5];
+#endif
                 }
                 const float cp = E.c_puct * __uint_as_float(qa.w);                       // c_puct * self._P in float32
                 const double u = (double)cp * sq / (double)(1u + qa.z);                  // mcts.py:69
@@ -1092,8 +1125,8 @@ __device__ __forceinline__ void select_core(EngineDev& E, BoardRegs& S, const in
                         best = val;
                         bestk = j;
                         mSq = sqN;
-                        mCOff = qc.y;
-                        mMisc = qc.z;                                   // act | cne << 8 | rid << 16
+                        mCOff = qc.x;
+                        mMisc = qc.y;                                   // act | cne << 8 | rid << 16
                     }
                 }
                 wave_argmax(best, bestk);
@@ -1126,6 +1159,10 @@ __device__ __forceinline__ void select_core(EngineDev& E, BoardRegs& S, const in
                     left_rec = cur;
                     left_at = plen;
                 }
+                // (A record NAMED by the edge and followed on trial -- the next replay round or walked level showing whether it
+                // holds the path -- was measured 2 % slower in round 3; a generation number per record stamped into the edges, so
+                // that the hint needs no question asked of memory, 3 % slower in round 4 -- 266.7 against 274.8 M playouts/s:
+                // tails replaced in place keep their record's generation, and the launches' longest descents got longer.)
                 const uint32_t rid = misc >> 16;
                 cur = QZ_NONE;
                 if (rid >= 1u && rid <= R && plen < CAP) {
@@ -1186,7 +1223,7 @@ __device__ __forceinline__ void select_core(EngineDev& E, BoardRegs& S, const in
 #endif
                     static_assert(QZ_PATH_RECS <= 16, "the victim search reduces over one DPP row");
                     uint32_t v = 0xFFFFFFFFu;
-                    if (lane < (int)R && (uint32_t)lane != left_rec && !((used >> lane) & 1u)) v = rlen == 0u ? 0u : rstamp + QZ_VICTIM_LEN_WEIGHT * rlen;
+                    if (lane < (int)R && (uint32_t)lane != left_rec && !((used >> lane) & 1u)) v = rlen == 0u ? 0u : S.lc[LC_RSTAMP + lane] + QZ_VICTIM_LEN_WEIGHT * rlen;
                     int m = (int)v;  // (unsigned minimum through a signed DPP chain: flip the sign bit)
                     m ^= (int)0x80000000;
                     {
@@ -1205,6 +1242,7 @@ __device__ __forceinline__ void select_core(EngineDev& E, BoardRegs& S, const in
             }
             dest = rfl(dest);
             from = rfl(from);
+            const uint16_t stamp = (uint16_t)(dest + 1u);
             const uint32_t first = from > 0u ? from : (left_rec != QZ_NONE ? left_at : 0u);
             if (from < n) {
                 wave_sync();  // lane 0 stored walked levels into the descent buffer, all lanes read it below
@@ -1213,24 +1251,40 @@ __device__ __forceinline__ void select_core(EngineDev& E, BoardRegs& S, const in
                 // (two loops with wave-uniform bounds, not one with a per-lane choice of the source: there the LDS reads had to
                 // wait for every global load in flight -- the same destination registers -- among them the caller's memo probe)
                 const uint32_t n_lds = n < PM.cap ? n : PM.cap;
-                for (uint32_t i = from + (uint32_t)lane; i < n_lds; i += 64u) {
-                    const uint32_t ed = PM.we[i];
-                    qe[i] = ed;
-                    qb[i] = PM.wb[i];
-                    if (i >= first) pool[ed].rid = (uint16_t)(dest + 1u);
+                // The first 64 levels -- nearly always all there are: the tail below the point where the path left its record --
+                // WITHOUT a loop: in front of a loop that stores, the compiler waits for every load in flight (s_waitcnt vmcnt(0)
+                // in the preheader), i.e. for the caller's memo probe, issued a moment ago precisely to be in flight under these
+                // stores; and the probe's own wait then counted the stores' acknowledgements as well: two dependent trips
+                // where one was meant (stamps: commit 2.2 k + probe 1.6 k cycles per playout).
+                {
+                    const uint32_t i = from + (uint32_t)lane;
+                    if (i < n_lds) {
+                        const uint32_t ed = PM.we[i];
+                        qe[i] = ed;
+                        qb[i] = PM.wb[i];
+                        if (i >= first) pool[ed].rid = stamp;
+                    }
                 }
-                for (uint32_t i = (from > PM.cap ? from : PM.cap) + (uint32_t)lane; i < n; i += 64u) {
-                    const uint32_t ed = we[i];
-                    qe[i] = ed;
-                    qb[i] = wb[i];
-                    if (i >= first) pool[ed].rid = (uint16_t)(dest + 1u);
+                if (n > from + 64u || n > PM.cap) {  // wave-uniform, rare: a longer tail, or levels beyond the mirror
+                    for (uint32_t i = from + 64u + (uint32_t)lane; i < n_lds; i += 64u) {
+                        const uint32_t ed = PM.we[i];
+                        qe[i] = ed;
+                        qb[i] = PM.wb[i];
+                        if (i >= first) pool[ed].rid = stamp;
+                    }
+                    for (uint32_t i = (from > PM.cap ? from : PM.cap) + (uint32_t)lane; i < n; i += 64u) {
+                        const uint32_t ed = we[i];
+                        qe[i] = ed;
+                        qb[i] = wb[i];
+                        if (i >= first) pool[ed].rid = stamp;
+                    }
                 }
             }
             if (lane < (int)R) {
                 if ((uint32_t)lane == dest) {
                     if (from < n) rlen = n;
-                    rstamp = clock;
-                } else if ((used >> lane) & 1u) rstamp = clock;
+                    S.lc[LC_RSTAMP + lane] = clock;
+                } else if ((used >> lane) & 1u) S.lc[LC_RSTAMP + lane] = clock;
             }
             S.rec_last = dest;
             S.rec_clock = clock;
@@ -1347,7 +1401,7 @@ __device__ __forceinline__ unsigned long long expand_node(EngineDev& E, BoardReg
                     uint32_t e = base + (uint32_t)order_index(pawn, lh, lv, a);
                     uint4* const q = reinterpret_cast<uint4*>(&S.T.pool[e]);
                     q[0] = make_uint4(zero, zero, zero, __float_as_uint(prior(a)));   // Q = 0.0 | N = 0 | P
-                    q[1] = make_uint4(pedge, zero, (uint32_t)a | zero, ~zero);       // pedge | coff = 0 | act, cne = 0, rid = 0 | spare = QZ_NONE
+                    q[1] = make_uint4(zero, (uint32_t)a | zero, pedge, ~zero);       // coff = 0 | act, cne = 0, rid = 0 | pedge | spare = QZ_NONE
                 }
             }
             if (pedge != QZ_NONE) {
@@ -1396,11 +1450,25 @@ __device__ __forceinline__ void backup_leaf(EngineDev& E, BoardRegs& S, const in
             if (i < PM.cap) pe = PM.we[i];
             else pe = path[i];
             double val = ((plen - 1u - i) & 1u) ? leaf_value : -leaf_value;
+#if QZ_EDGE_WIDE_LOADS
+            // (Q and N as one 12-byte load and one 12-byte store: two passes of the texture path per level, not four)
+            uint32_t* const rec = reinterpret_cast<uint32_t*>(&pool[pe]);
+            const qz_u32x3_a16 old = *reinterpret_cast<const qz_u32x3_a16*>(rec);
+            const uint32_t N = old.z + 1u;  // mcts.py:51
+            double Q = __hiloint2double((int)old.y, (int)old.x);
+            Q += 1.0 * (val - Q) / (double)N;  // mcts.py:53
+            qz_u32x3_a16 neu;
+            neu.x = (uint32_t)__double2loint(Q);
+            neu.y = (uint32_t)__double2hiint(Q);
+            neu.z = N;
+            *reinterpret_cast<qz_u32x3_a16*>(rec) = neu;
+#else
             uint32_t N = pool[pe].N + 1u;  // mcts.py:51
             double Q = pool[pe].Q;
             Q += 1.0 * (val - Q) / (double)N;  // mcts.py:53
             pool[pe].N = N;
             pool[pe].Q = Q;
+#endif
         }
     } else if (lane == 0) {
         double val = -leaf_value;
@@ -2346,13 +2414,14 @@ __device__ __forceinline__ void advance_board(EngineDev& E, const int max_iters,
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long t_it = t0;
 #ifndef QZ_BUDGET_PREDICT
-#define QZ_BUDGET_PREDICT 1
+#define QZ_BUDGET_PREDICT 2  // what a board expects its next playout to last: 0 = nothing, 1 = as long as its last one, 2 = the largest of its recent ones (a maximum that decays by a quarter per playout)
 #endif
+    unsigned int pred = 0u;
 #ifdef QZ_ADV_STAMPS
     unsigned long long as_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, as_max[2] = {0, 0}, as_t = __builtin_amdgcn_s_memtime();
     const unsigned long long as_t0 = as_t;
 #endif
-    PathMirror PM{(lds_u32*)s_we[wave], (lds_u64*)s_wb[wave], ADV_LCAP, 0u};
+    PathMirror PM{(lds_u32*)(uintptr_t)rfl((uint32_t)(uintptr_t)(lds_u32*)s_we[wave]), (lds_u64*)(uintptr_t)rfl((uint32_t)(uintptr_t)(lds_u64*)s_wb[wave]), ADV_LCAP, 0u};
     const PathMirror NOPM{(lds_u32*)nullptr, (lds_u64*)nullptr, 0u, 0u};
     // a move whose subtree copy is not done yet (k_compact, sliced at ITS budget): the board sits out.  A copy that found the
     // pool empty restarts the board from a fresh root in the SAME table half, whose pages k_round_tail is about to hand
@@ -2407,7 +2476,10 @@ __device__ __forceinline__ void advance_board(EngineDev& E, const int max_iters,
             const unsigned long long now = __builtin_amdgcn_s_memrealtime();
             const unsigned int last = (unsigned int)(now - t_it);
             t_it = now;
-            if (it > 0 && (unsigned int)(now - t0) + (QZ_BUDGET_PREDICT ? last : 0u) > budget) break;
+            pred = rfl(pred);
+            pred -= pred >> 2;
+            if (QZ_BUDGET_PREDICT != 2 || last > pred) pred = last;
+            if (it > 0 && (unsigned int)(now - t0) + (QZ_BUDGET_PREDICT ? pred : 0u) > budget) break;
         }
         Board leaf;
         uint32_t term;
