@@ -2414,7 +2414,7 @@ __device__ __forceinline__ void advance_board(EngineDev& E, const int max_iters,
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long t_it = t0;
 #ifndef QZ_BUDGET_PREDICT
-#define QZ_BUDGET_PREDICT 2  // what a board expects its next playout to last: 0 = nothing, 1 = as long as its last one, 2 = the largest of its recent ones (a maximum that decays by a quarter per playout)
+#define QZ_BUDGET_PREDICT 1  // what a board expects its next playout to last: 0 = nothing, 1 = as long as its last one, 2 = the largest of its recent ones (a maximum that decays by a quarter per playout: measured no different from 1, 289.1 against 290.6 M playouts/s)
 #endif
     unsigned int pred = 0u;
 #ifdef QZ_ADV_STAMPS

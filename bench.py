@@ -610,7 +610,7 @@ def main():
     ap.add_argument("--groups", type=int, default=1, help="split the boards of a GPU into this many independent groups on their own HIP streams")
     ap.add_argument("--mode", default="async", choices=["async", "lockstep"])
     ap.add_argument("--rounds-per-step", type=int, default=256, help="async: rounds of the loop per step")
-    ap.add_argument("--budget-us", type=int, default=1000, help="async: wall-clock budget of a k_advance launch")
+    ap.add_argument("--budget-us", type=int, default=1800, help="async: wall-clock budget of a k_advance launch (8,192 boards, same box: 1000 / 1400 / 1800 / 2400 us = 271 / 285 / 291 / 287 M playouts/s)")
     ap.add_argument("--max-playouts", type=int, default=4096, help="async: playouts a board may start per round")
     ap.add_argument("--graph-rounds", type=int, default=0, help="async: capture this many (even) rounds per HIP graph (0 = eager launches, per-kernel events)")
     ap.add_argument("--event-every", type=int, default=8, help="async: every n-th round of group 0 is issued in pieces with HIP events around them")

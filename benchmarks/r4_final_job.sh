@@ -20,7 +20,8 @@ line() { timeout 400 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no
 if has ab; then
   line --boards 4096 > $O/bench_boards4096.json 2> $O/bench_boards4096.err
   line --boards 16384 > $O/bench_boards16384.json 2> $O/bench_boards16384.err
-  line --budget-us 1400 > $O/bench_budget1400.json 2> $O/bench_budget1400.err
+  line --budget-us 1000 > $O/bench_budget1000.json 2> $O/bench_budget1000.err
+  line --budget-us 2400 > $O/bench_budget2400.json 2> $O/bench_budget2400.err
   line --no-memo > $O/bench_no_memo.json 2> $O/bench_no_memo.err
   line --playouts 800 > $O/bench_c5_playouts800_1gpu.json 2> $O/bench_c5.err
   line --playouts 100 > $O/bench_c2_playouts100.json 2> $O/bench_c2.err
@@ -51,7 +52,7 @@ if has pmc; then
   rm -rf $R/$O/pmc_FETCH_SIZE $R/$O/pmc_WRITE_SIZE
 fi
 if has sq; then
-  BOARDS=8192 PLAYOUTS=400 MAXP=4096 BUDGET=1000 FIX=0 MAXD=992 ITERS=150 ROUNDS=64 EVERY=50 timeout 800 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d $R/$O/pmc_sq -- /usr/bin/python3 $R/benchmarks/async_debug.py > $R/$O/pmc_sq.log 2>&1
+  BOARDS=8192 PLAYOUTS=400 MAXP=4096 BUDGET=1800 FIX=0 MAXD=992 ITERS=150 ROUNDS=64 EVERY=50 timeout 800 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d $R/$O/pmc_sq -- /usr/bin/python3 $R/benchmarks/async_debug.py > $R/$O/pmc_sq.log 2>&1
   c=$(find $R/$O/pmc_sq -name "*counter_collection.csv" | head -1)
   python3 $R/benchmarks/pmc_tail_stats.py "$c" 0.3 > $R/$O/pmc_sq_async_late_game_8192boards.json; head -c 1500 $R/$O/pmc_sq_async_late_game_8192boards.json
   rm -rf $R/$O/pmc_sq
