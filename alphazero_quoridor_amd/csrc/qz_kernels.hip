@@ -2386,15 +2386,22 @@ __device__ unsigned long long g_adv_stamps2[4096][4];  // levels confirmed by re
 #define QZ_AS_COUNT(k, v)
 #endif
 constexpr uint32_t ADV_LCAP = 320;  // levels of a descent mirrored in LDS (3.75 KB per wavefront: 32 wavefronts per CU fit in the 160 KB); deeper levels are read back from memory
+#ifndef QZ_ADV_WPB
+#define QZ_ADV_WPB 1  // wavefronts (= boards) per workgroup of k_advance (4: rounds 3-4; A/B)
+#endif
+// ONE wavefront per workgroup: the chip hands a workgroup's slot to the next workgroup when ALL its wavefronts have left, and a
+// board leaves the launch the moment it meets a leaf for the network -- a board whose mover still has walls after one playout.
+// With four boards per workgroup such a slot stayed empty until its three neighbours were done too.
+constexpr int ADV_WPB = QZ_ADV_WPB;
 #ifndef QZ_ADV_WAVES_SMALL
 #define QZ_ADV_WAVES_SMALL 4  // wavefronts per SIMD the build of k_advance for engines of <= 4,096 boards aims at (A/B: 8 = one build for all sizes)
 #endif
 __device__ __forceinline__ void advance_board(EngineDev& E, const int max_iters, const unsigned int budget, const int par) {
-    __shared__ uint32_t s_we[WPB][ADV_LCAP];
-    __shared__ unsigned long long s_wb[WPB][ADV_LCAP];
-    __shared__ uint32_t s_lc[WPB][LC_WORDS];
+    __shared__ uint32_t s_we[ADV_WPB][ADV_LCAP];
+    __shared__ unsigned long long s_wb[ADV_WPB][ADV_LCAP];
+    __shared__ uint32_t s_lc[ADV_WPB][LC_WORDS];
     const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
-    const int b = __builtin_amdgcn_readfirstlane((int)blockIdx.x * WPB + wave);  // in an SGPR: every per-board address below is scalar arithmetic
+    const int b = __builtin_amdgcn_readfirstlane((int)blockIdx.x * ADV_WPB + wave);  // in an SGPR: every per-board address below is scalar arithmetic
     if (b >= E.n_boards) return;
     // The engine descriptor arrives in the kernel-argument segment and is fetched in 16-dword pieces; left alone, a piece is ONE
     // value to the register allocator -- kept or spilled whole, and reloaded whole (sixteen v_readlane) wherever one field of
@@ -2583,7 +2590,7 @@ __device__ __forceinline__ void advance_board(EngineDev& E, const int max_iters,
 // round).  k_advance<4>: 73 registers, no spill at all, for engines of up to 4,096 boards, where the extra residency buys nothing
 // and the eight-wave build's few spills cost 9 %.
 template <int W>
-__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(W, W))) void k_advance(EngineDev E, int max_iters, unsigned int budget, int par) {
+__global__ __launch_bounds__(64 * ADV_WPB) __attribute__((amdgpu_waves_per_eu(W, W))) void k_advance(EngineDev E, int max_iters, unsigned int budget, int par) {
     advance_board(E, max_iters, budget, par);
 }
 
@@ -2951,8 +2958,9 @@ static unsigned int compact_budget(unsigned int budget_ticks) {
 }
 hipError_t advance(const EngineDev& E, int max_iters, unsigned int budget_ticks, int auto_finish, int par, hipStream_t s) {
     if (auto_finish) hipLaunchKernelGGL(k_moves, wave_grid(E.n_boards), dim3(TPB), 0, s, E, compact_budget(budget_ticks));
-    if (E.n_boards > 4096 * QZ_ADV_WAVES_SMALL / 4 || (E.select_opts & 4)) hipLaunchKernelGGL(k_advance<8>, wave_grid(E.n_boards), dim3(TPB), 0, s, E, max_iters, budget_ticks, par);
-    else hipLaunchKernelGGL(k_advance<QZ_ADV_WAVES_SMALL>, wave_grid(E.n_boards), dim3(TPB), 0, s, E, max_iters, budget_ticks, par);
+    const dim3 adv_grid((unsigned)((E.n_boards + ADV_WPB - 1) / ADV_WPB)), adv_block(64 * ADV_WPB);
+    if (E.n_boards > 4096 * QZ_ADV_WAVES_SMALL / 4 || (E.select_opts & 4)) hipLaunchKernelGGL(k_advance<8>, adv_grid, adv_block, 0, s, E, max_iters, budget_ticks, par);
+    else hipLaunchKernelGGL(k_advance<QZ_ADV_WAVES_SMALL>, adv_grid, adv_block, 0, s, E, max_iters, budget_ticks, par);
     return hipGetLastError();
 }
 // the moves of the boards that have done their playouts + the subtree copies they leave (and the slices earlier moves left)

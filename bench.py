@@ -7,8 +7,10 @@
 
 Workload (config.workload): BASELINE.json configs[3] per GPU -- n_playout=400, 9x9, reference defaults (10 walls, c_puct=5,
 temp=1, Dirichlet 0.3/0.25), random-init policy_value_net in fp32 with the reference's per-leaf BatchNorm statistics; weak
-scaling, finished tuples all-gathered every step.  --boards concurrent boards per GPU (default 8,192: eight wavefronts of
-k_advance per SIMD; configs[3] names 4,096 as the per-GPU minimum of concurrent boards and `--boards 4096` runs exactly that).
+scaling, finished tuples all-gathered every step.  --boards concurrent boards per GPU (default 9,728: the chip holds 8,192
+wavefronts of k_advance, eight per SIMD, and about a seventh of the boards -- those whose mover still has walls -- leave a launch
+after one playout: their slots go to the boards beyond the 8,192nd; configs[3] names 4,096 as the per-GPU minimum of concurrent
+boards and `--boards 4096` runs exactly that).
 
 DEFAULT ROUTE (--mode async): the asynchronous self-play loop (qz_selfplay_*, include/qz_abi.h): every board runs its 400
 playouts per move on its own clock; a leaf whose evaluation is in the leaf-evaluation memo is expanded from the memo, every
@@ -187,7 +189,7 @@ class Run:
 
         name = "BASELINE configs[2] as an engine run" if B == 32768 else ("BASELINE configs[1]" if a.playouts == 100 else (
             "BASELINE configs[3] per GPU" if B == 4096 else "BASELINE configs[3]'s per-GPU workload with %d instead of 4,096 boards per GPU (the engine keeps eight "
-            "k_advance wavefronts per SIMD busy; same_loop_at_4096_boards is the literal board count)" % B))
+            "k_advance wavefronts per SIMD busy, and the slots of boards that leave a launch early go to the boards beyond the 8,192nd; same_loop_at_4096_boards is the literal board count)" % B))
         label = ("NON-PARITY THROUGHPUT MODE (network products on fp16 operands, p / v ~1e-3 from the reference) -- " if a.nn_dtype == "fp16" else "") + \
                 ("TERMINAL SIGN FIXED (not the reference's mcts.py:125) -- " if a.fix_terminal_sign else "")
         cfg = {"workload": label + "%s: %d concurrent boards/GPU, n_playout=%d, 9x9, 10 walls/player, c_puct=5, temp=1.0, %s" % (name, B, a.playouts, workload_tail),
@@ -270,7 +272,7 @@ def make_engine(args, net, dev, seed, fix_sign, boards=None):
 
 
 def line_at_4096_boards(args, dev, qdist):
-    """BASELINE configs[3] names 4,096 boards per GPU; the headline runs 8,192 (eight wavefronts of k_advance per SIMD).  The same
+    """BASELINE configs[3] names 4,096 boards per GPU; the headline runs more (eight wavefronts of k_advance per SIMD + the slots of the boards that leave early).  The same
     loop at exactly 4,096 boards (k_advance<4>), same phases, a short timed region: so that both are in the driver's line."""
     from alphazero_quoridor_amd.policy_value_net import PolicyValueNet
 
@@ -605,7 +607,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--boards", type=int, default=8192, help="concurrent boards per GPU (8,192 = eight k_advance wavefronts per SIMD; 4,096 = BASELINE configs[3]'s number)")
+    ap.add_argument("--boards", type=int, default=9728, help="concurrent boards per GPU (8,192 = eight k_advance wavefronts per SIMD; same box: 8,192 / 9,216 / 9,728 / 10,240 / 11,264 boards = 294 / 306 / 312 / 313 / 284 M playouts/s; 4,096 = BASELINE configs[3]'s number)")
     ap.add_argument("--playouts", type=int, default=400)
     ap.add_argument("--groups", type=int, default=1, help="split the boards of a GPU into this many independent groups on their own HIP streams")
     ap.add_argument("--mode", default="async", choices=["async", "lockstep"])
