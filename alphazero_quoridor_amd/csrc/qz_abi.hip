@@ -391,7 +391,7 @@ int qz_engine_create(const qz_config* cfg, qz_engine** out) {
     ALLOC(reroot_pend, B);
     ALLOC(compact_state, B * 8);
     ALLOC(compact_at, B);
-    ALLOC(miss_count, (size_t)2);
+    ALLOC(miss_count, (size_t)8);
     ALLOC(miss_hb, B);
     ALLOC(miss_vb, B);
     ALLOC(miss_meta, B);
@@ -457,7 +457,7 @@ int qz_engine_create(const qz_config* cfg, qz_engine** out) {
     if (he == hipSuccess) he = hipMemset(d.bc_scanned, 0, B * sizeof(unsigned long long));
     if (he == hipSuccess) he = hipMemset(d.bc_expanded, 0, B * sizeof(unsigned long long));
     if (he == hipSuccess) he = hipMemset(d.leaf_mask, 0, B * 5 * sizeof(uint32_t));
-    if (he == hipSuccess) he = hipMemset(d.miss_count, 0, 2 * sizeof(int));
+    if (he == hipSuccess) he = hipMemset(d.miss_count, 0, 8 * sizeof(int));
     if (he == hipSuccess) he = hipMemset(d.reroot_pend, 0, B * sizeof(uint32_t));
     if (he == hipSuccess) he = hipMemset(d.compact_state, 0, B * 8 * sizeof(uint32_t));
     if (he == hipSuccess) he = hipMemset(d.bc_memo_hits, 0, B * sizeof(uint32_t));
@@ -502,7 +502,7 @@ int qz_engine_create(const qz_config* cfg, qz_engine** out) {
 static hipError_t reset_round_state(qz_engine* e, hipStream_t s) {
     e->async_moves = false;
     e->par = 0;
-    return hipMemsetAsync(e->dev.miss_count, 0, 2 * sizeof(int), s);
+    return hipMemsetAsync(e->dev.miss_count, 0, 8 * sizeof(int), s);
 }
 
 int qz_engine_reset(qz_engine* e, void* stream) {

@@ -187,7 +187,8 @@ struct EngineDev {
     uint32_t* compact_at;     // [B] allocation cursor at which the board's next move compacts (compact_edges, or twice the tree's size after its last compaction)
     uint32_t* compact_state;  // [B][8] a subtree copy that stopped at its launch's budget (wave_reroot): in progress, scan position, cursor, pages, nodes, cut, pool empty, root offset
     uint32_t* reroot_pend;    // [B] the subtree copy of the last move, left for the next k_advance launch: 0 none, 1 fresh root, e + 2 keep edge e
-    int* miss_count;          // [2] slots used by the misses of even / odd rounds
+    int* miss_count;          // [8]: [0], [1] slots used by the misses of even / odd rounds; [2] rounds finished (k_round_tail); [4..5] (64 bits) the
+                              // s_memrealtime stamp << 20 | round number of the running launch's first wavefront (select_opts bit 3)
     uint64_t *miss_hb, *miss_vb, *miss_meta;  // [B] the leaves awaiting evaluation, compacted
     uint32_t* miss_mask;      // [B][5] their legal sets (rules op on the miss list)
     float *miss_p, *miss_v;   // [B][140], [B] the network's output per slot

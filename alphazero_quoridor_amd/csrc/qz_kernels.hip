@@ -2386,6 +2386,7 @@ __device__ unsigned long long g_adv_stamps2[4096][4];  // levels confirmed by re
 #define QZ_AS_COUNT(k, v)
 #endif
 constexpr uint32_t ADV_LCAP = 320;  // levels of a descent mirrored in LDS (3.75 KB per wavefront: 32 wavefronts per CU fit in the 160 KB); deeper levels are read back from memory
+#define QZ_ADV_ROT 2048u  // boards the first slot moves on per round (select_opts bit 3)
 #ifndef QZ_ADV_WPB
 #define QZ_ADV_WPB 1  // wavefronts (= boards) per workgroup of k_advance (4: rounds 3-4; A/B)
 #endif
@@ -2401,8 +2402,22 @@ __device__ __forceinline__ void advance_board(EngineDev& E, const int max_iters,
     __shared__ unsigned long long s_wb[ADV_WPB][ADV_LCAP];
     __shared__ uint32_t s_lc[ADV_WPB][LC_WORDS];
     const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
-    const int b = __builtin_amdgcn_readfirstlane((int)blockIdx.x * ADV_WPB + wave);  // in an SGPR: every per-board address below is scalar arithmetic
-    if (b >= E.n_boards) return;
+    const int w_ = __builtin_amdgcn_readfirstlane((int)blockIdx.x * ADV_WPB + wave);
+    if (w_ >= E.n_boards) return;
+    // select_opts bit 3, for engines of more boards than the chip holds wavefronts: ONE deadline for the launch -- the budget counts
+    // from the start of the launch's first wavefront, not from each one's own -- so that a board that gets its slot in the middle
+    // of the launch (when a board that met a leaf for the network has left) works until the same moment as the others instead of
+    // stretching the launch by its own budget; and the boards take the first slots in turn (QZ_ADV_ROT further on every round:
+    // a multiple of 8, so a board stays on its XCD and its tree in that XCD's L2).
+    // (Only with a budget of 100 us or more: under a shorter one the boards behind the first slots would never start a playout.)
+    const bool shared = (E.select_opts & 8) != 0 && budget >= 10000u && budget != 0xFFFFFFFFu;
+    uint32_t seq = 0u;
+    int b_ = w_;
+    if (shared) {
+        seq = rfl((uint32_t)E.miss_count[2]);
+        b_ = (int)(((unsigned int)w_ + (seq % 4096u) * QZ_ADV_ROT) % (unsigned int)E.n_boards);
+    }
+    const int b = __builtin_amdgcn_readfirstlane(b_);  // in an SGPR: every per-board address below is scalar arithmetic
     // The engine descriptor arrives in the kernel-argument segment and is fetched in 16-dword pieces; left alone, a piece is ONE
     // value to the register allocator -- kept or spilled whole, and reloaded whole (sixteen v_readlane) wherever one field of
     // it is used.  The fields the loop uses are made values of their own here.
@@ -2418,8 +2433,29 @@ __device__ __forceinline__ void advance_board(EngineDev& E, const int max_iters,
 #undef QZ_OWN_S
     if (b == 0 && lane == 0) atomicAdd(&E.counters[QZ_C_ROUNDS], 1ull);
     if (rfl(E.status[b]) != QZ_PLAYING) return;
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long t_it = t0;
+    bool late = false;  // this wavefront's budget began before it did
+    if (shared) {
+        // the launch's first wavefront leaves (its start << 20 | round number) for the others; a wavefront that finds another
+        // round's number there started in the launch's first microsecond: its own start will do.  (Read past the CU's L1: a line
+        // fetched by an early wavefront of this CU would answer the late ones.)
+        unsigned long long* const st = reinterpret_cast<unsigned long long*>(E.miss_count + 4);
+        if (w_ == 0) {
+            if (lane == 0) __hip_atomic_store(st, (t0 << 20) | (unsigned long long)(seq & 0xFFFFFu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            const unsigned long long sv = rfl64(__hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if ((uint32_t)(sv & 0xFFFFFull) == (seq & 0xFFFFFu)) {
+                constexpr unsigned long long M44 = (1ull << 44) - 1ull;
+                unsigned long long first = (t0 & ~M44) | (sv >> 20);
+                if (first > t0) first -= 1ull << 44;
+                if (t0 - first < 0x40000000ull) {  // (a stamp of this round number from a million rounds ago is not this launch's)
+                    t0 = first;
+                    late = true;
+                }
+            }
+        }
+    }
 #ifndef QZ_BUDGET_PREDICT
 #define QZ_BUDGET_PREDICT 1  // what a board expects its next playout to last: 0 = nothing, 1 = as long as its last one, 2 = the largest of its recent ones (a maximum that decays by a quarter per playout: measured no different from 1, 289.1 against 290.6 M playouts/s)
 #endif
@@ -2486,7 +2522,7 @@ __device__ __forceinline__ void advance_board(EngineDev& E, const int max_iters,
             pred = rfl(pred);
             pred -= pred >> 2;
             if (QZ_BUDGET_PREDICT != 2 || last > pred) pred = last;
-            if (it > 0 && (unsigned int)(now - t0) + (QZ_BUDGET_PREDICT ? pred : 0u) > budget) break;
+            if ((it > 0 || late) && (unsigned int)(now - t0) + (QZ_BUDGET_PREDICT ? pred : 0u) > budget) break;
         }
         Board leaf;
         uint32_t term;
@@ -2637,7 +2673,10 @@ __global__ __launch_bounds__(TPB) void k_round_tail(EngineDev E, int par) {
         const int n = (int)rfl((uint32_t)E.miss_count[par]);
         if (w < n) memo_insert(E, rfl64(E.miss_hb[w]), rfl64(E.miss_vb[w]), rfl64(E.miss_meta[w]), E.miss_mask + (size_t)w * 5,
                                E.miss_p + (size_t)w * QZ_N_ACT, E.miss_v[w], lane);
-        if (w == 0 && lane == 0) E.miss_count[par ^ 1] = 0;
+        if (w == 0 && lane == 0) {
+            E.miss_count[par ^ 1] = 0;
+            E.miss_count[2] = (E.miss_count[2] + 1) & 0xFFFFF;  // rounds finished (k_advance's shared deadline, select_opts bit 3)
+        }
         return;
     }
     const int b = w - E.n_boards;

@@ -134,7 +134,10 @@ typedef struct {
     int32_t select_opts;       /* A/B switches of the descent kernel (0 = defaults): bit 0 = walk every level (no replay of
                                   recorded descents; same results, the test partner of the records), bit 1 = no readlane
                                   scan for nodes with <= 8 children, bit 2 = the 64-register build of the asynchronous loop's
-                                  kernel (eight wavefronts per SIMD: what engines above 4,096 boards run) whatever the engine's size */
+                                  kernel (eight wavefronts per SIMD: what engines above 4,096 boards run) whatever the engine's size,
+                                  bit 3 = qz_selfplay_advance's budget (if >= 100 us) counts from the launch's FIRST wavefront -- one
+                                  deadline for all boards -- and the boards take the first slots in turn: for engines of more boards
+                                  than the chip holds wavefronts (8,192), where a board may get its slot in the middle of a launch */
     /* Leaf-evaluation memo (qz_selfplay_*): log2 of the number of buckets of its two tables; 0 = auto (16,384 small entries
      * -- at most 8 GB -- and 512 big entries per board, rounded up to a power of two), < 0 = no memo (every leaf goes to the network).
      * small: leaves whose mover has no wall left, 4 entries of 128 B per bucket; big: all others, 2 x 640 B. */

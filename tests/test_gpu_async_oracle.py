@@ -91,7 +91,9 @@ def search_to_completion(eng, name, n, max_playouts, budget_us, limit=100000):
 
 # the loop's regimes: (memo, playouts a board may start per launch, wall-clock budget of a launch in us, select_opts)
 # select_opts 4 = the 64-register build of k_advance (eight wavefronts per SIMD: what engines above 4,096 boards, i.e. the bench, run)
-REGIMES = [(True, 1, 0, 0), (True, 4096, 0, 0), (False, 4096, 0, 0), (True, 4096, 1, 0), (True, 4096, 0, 4), (True, 4096, 1, 4)]
+# 8 = one deadline per launch (counted from its first wavefront; budgets of 100 us and more) and boards taking the first slots in turn
+REGIMES = [(True, 1, 0, 0), (True, 4096, 0, 0), (False, 4096, 0, 0), (True, 4096, 1, 0), (True, 4096, 0, 4), (True, 4096, 1, 4),
+           (True, 4096, 120, 12), (True, 4096, 100, 8)]
 
 
 @pytest.mark.parametrize("memo,max_playouts,budget_us,select_opts", REGIMES)
@@ -201,6 +203,7 @@ def _move_between(og, cur_rec, nxt_rec):
     ("uniform", 0, 0, 0, False, 0),      # no memo: every leaf through the caller
     ("hash", 0, 0, 0, True, 4),          # the 64-register build of k_advance (what the bench's 8,192-board engine runs)
     ("hash", -1, 1, 0, True, 4),
+    ("hash", -1, 150, 0, True, 12),      # one deadline per launch, boards rotate through the first slots
 ])
 def test_games_the_loop_plays_on_its_own_replay_in_the_oracle(gpu_device, name, compact_edges, budget_us, pool_pages, memo, select_opts):
     """The free-running loop (auto_finish: k_moves samples, records, steps and re-roots on the device; k_advance resumes
