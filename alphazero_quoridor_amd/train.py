@@ -63,7 +63,7 @@ class TrainPipeline(object):
         self.n_groups = n_groups  # board groups on separate HIP streams (engine.BoardGroups)
         self.async_loop = True        # self-play through the asynchronous loop (False: the lock-step engine, one ply of every board per harvest)
         self.rounds_per_harvest = 64  # rounds of the loop between two harvests (+ all-gathers)
-        self.budget_us = 1800         # wall-clock budget of a k_advance launch (profiles/round4/SUMMARY.md: the sweep)
+        self.budget_us = 2400         # wall-clock budget of a k_advance launch (profiles/round4/SUMMARY.md: the sweeps)
         # a game whose search descends deeper than this is DROPPED (not in the replay data; counted and logged by
         # collect_selfplay_data: `games_dropped`): the reference's recursive backup raises RecursionError there
         # (mcts.py:55-62, Python's recursion limit) and its whole run ends.  An explicit choice, because it shapes the data:

@@ -7,7 +7,7 @@
 
 Workload (config.workload): BASELINE.json configs[3] per GPU -- n_playout=400, 9x9, reference defaults (10 walls, c_puct=5,
 temp=1, Dirichlet 0.3/0.25), random-init policy_value_net in fp32 with the reference's per-leaf BatchNorm statistics; weak
-scaling, finished tuples all-gathered every step.  --boards concurrent boards per GPU (default 9,728: the chip holds 8,192
+scaling, finished tuples all-gathered every step.  --boards concurrent boards per GPU (default 10,240: the chip holds 8,192
 wavefronts of k_advance, eight per SIMD, and about a seventh of the boards -- those whose mover still has walls -- leave a launch
 after one playout: their slots go to the boards beyond the 8,192nd; configs[3] names 4,096 as the per-GPU minimum of concurrent
 boards and `--boards 4096` runs exactly that).
@@ -354,6 +354,7 @@ def second_line(args, dev, qdist):
             "nn_evaluations_per_s": d["nn_evals"] / dt, "memo_hit_rate": d["memo_hits"] / max(d["playouts"], 1),
             "board_seconds_per_open_ply": open_s / max(d["open_plies"], 1), "nn_precision": "fp32 (parity: three fp16 MFMAs per product)",
             "budget_us": args.second_line_budget_us, "nn_evaluations_per_game": d["nn_evals"] / max(games, 1),
+            "plies_per_s_over_mean_length_of_the_finished": (d["plies_played"] / dt / float(np.mean(lens))) if lens else None,  # an UPPER figure: the games that finish in a short window are the short ones
             "note": "network-bound: with the sign fixed a game is ~150 plies of the open phase (the mover has walls: nearly every leaf is new) at 400 evaluations "
                     "each; evaluations per game x games/s = the network's throughput.  Round 3's 409 games/s counted the games the 4-playout desync phase had left "
                     "close to their end (a transient); this line is taken after the population has played at 400 playouts for --second-line-warm-seconds",
@@ -607,12 +608,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--boards", type=int, default=9728, help="concurrent boards per GPU (8,192 = eight k_advance wavefronts per SIMD; same box: 8,192 / 9,216 / 9,728 / 10,240 / 11,264 boards = 294 / 306 / 312 / 313 / 284 M playouts/s; 4,096 = BASELINE configs[3]'s number)")
+    ap.add_argument("--boards", type=int, default=10240, help="concurrent boards per GPU (8,192 = eight k_advance wavefronts per SIMD; same box, 1.8-ms budget: 8,192 / 9,216 / 9,728 / 10,240 / 11,264 boards = 294 / 306 / 312 / 313 / 284 M playouts/s; 4,096 = BASELINE configs[3]'s number)")
     ap.add_argument("--playouts", type=int, default=400)
     ap.add_argument("--groups", type=int, default=1, help="split the boards of a GPU into this many independent groups on their own HIP streams")
     ap.add_argument("--mode", default="async", choices=["async", "lockstep"])
     ap.add_argument("--rounds-per-step", type=int, default=256, help="async: rounds of the loop per step")
-    ap.add_argument("--budget-us", type=int, default=1800, help="async: wall-clock budget of a k_advance launch (8,192 boards, same box: 1000 / 1400 / 1800 / 2400 us = 271 / 285 / 291 / 287 M playouts/s)")
+    ap.add_argument("--budget-us", type=int, default=2400, help="async: wall-clock budget of a k_advance launch (8,192 boards, same box: 1000 / 1400 / 1800 / 2400 us = 271 / 285 / 291 / 287 M playouts/s; 9,728 boards: 1800 / 2400 / 3000 / 3600 us = 301 / 305 / 292 / 282 M; 10,240 boards at 2400 us: 310 M)")
     ap.add_argument("--max-playouts", type=int, default=4096, help="async: playouts a board may start per round")
     ap.add_argument("--graph-rounds", type=int, default=0, help="async: capture this many (even) rounds per HIP graph (0 = eager launches, per-kernel events)")
     ap.add_argument("--event-every", type=int, default=8, help="async: every n-th round of group 0 is issued in pieces with HIP events around them")

@@ -22,7 +22,8 @@ if has ab; then
   line --boards 8192 > $O/bench_boards8192.json 2> $O/bench_boards8192.err
   line --boards 16384 > $O/bench_boards16384.json 2> $O/bench_boards16384.err
   line --budget-us 1000 > $O/bench_budget1000.json 2> $O/bench_budget1000.err
-  line --budget-us 2400 > $O/bench_budget2400.json 2> $O/bench_budget2400.err
+  line --budget-us 1800 > $O/bench_budget1800.json 2> $O/bench_budget1800.err
+  line --boards 9728 > $O/bench_boards9728.json 2> $O/bench_boards9728.err
   line --no-memo > $O/bench_no_memo.json 2> $O/bench_no_memo.err
   line --playouts 800 > $O/bench_c5_playouts800_1gpu.json 2> $O/bench_c5.err
   line --playouts 100 > $O/bench_c2_playouts100.json 2> $O/bench_c2.err
@@ -48,14 +49,14 @@ if has pmc; then
     timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/$O/pmc_$c -- /usr/bin/python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-c3 --second-line-seconds 0 > $R/$O/pmc_$c.json 2> $R/$O/pmc_$c.err
   done
   bpb=$(python3 -c "import json; d=json.load(open('$R/$O/pmc_FETCH_SIZE.json')); print(d['roofline']['algorithmic_bytes_per_launch'] / d['config']['boards_per_gpu'])")
-  python3 $R/benchmarks/pmc_traffic.py --fetch $R/$O/pmc_FETCH_SIZE --write $R/$O/pmc_WRITE_SIZE --kernels k_advance --boards 9728 --bytes-per-board $bpb --last 200 \
-     --label "k_advance<8> (9,728 boards, n_playout=400, last 200 launches of a bench run)" --out $R/$O/pmc_traffic_advance.json > /dev/null && cat $R/$O/pmc_traffic_advance.json | head -12
+  python3 $R/benchmarks/pmc_traffic.py --fetch $R/$O/pmc_FETCH_SIZE --write $R/$O/pmc_WRITE_SIZE --kernels k_advance --boards 10240 --bytes-per-board $bpb --last 200 \
+     --label "k_advance<8> (10,240 boards, n_playout=400, last 200 launches of a bench run)" --out $R/$O/pmc_traffic_advance.json > /dev/null && cat $R/$O/pmc_traffic_advance.json | head -12
   rm -rf $R/$O/pmc_FETCH_SIZE $R/$O/pmc_WRITE_SIZE
 fi
 if has sq; then
-  BOARDS=9728 PLAYOUTS=400 MAXP=4096 BUDGET=1800 FIX=0 MAXD=992 ITERS=150 ROUNDS=64 EVERY=50 timeout 800 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d $R/$O/pmc_sq -- /usr/bin/python3 $R/benchmarks/async_debug.py > $R/$O/pmc_sq.log 2>&1
+  BOARDS=10240 PLAYOUTS=400 MAXP=4096 BUDGET=2400 FIX=0 MAXD=992 ITERS=150 ROUNDS=64 EVERY=50 timeout 800 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d $R/$O/pmc_sq -- /usr/bin/python3 $R/benchmarks/async_debug.py > $R/$O/pmc_sq.log 2>&1
   c=$(find $R/$O/pmc_sq -name "*counter_collection.csv" | head -1)
-  python3 $R/benchmarks/pmc_tail_stats.py "$c" 0.3 > $R/$O/pmc_sq_async_late_game_9728boards.json; head -c 1500 $R/$O/pmc_sq_async_late_game_9728boards.json
+  python3 $R/benchmarks/pmc_tail_stats.py "$c" 0.3 > $R/$O/pmc_sq_async_late_game_10240boards.json; head -c 1500 $R/$O/pmc_sq_async_late_game_10240boards.json
   rm -rf $R/$O/pmc_sq
 fi
 cd $R
