@@ -279,7 +279,7 @@ def line_at_4096_boards(args, dev, qdist):
     torch.manual_seed(args.seed)
     net = PolicyValueNet(use_gpu=True, device=dev)
     eng = make_engine(args, net, dev, qdist.shard_seed(args.seed, 0), False, boards=4096)
-    kw = dict(max_playouts=args.max_playouts, budget_us=args.budget_us)
+    kw = dict(max_playouts=args.max_playouts, budget_us=1000)  # (4,096 boards, no board beyond the slots: 1,000 / 1,800 / 2,400 us = 214 / 205 / 181 M playouts/s)
     eng.set_playouts(args.desync_playouts)
     for _ in range(0, args.desync_plies * (args.desync_playouts + 1), 64):
         eng.run_rounds(64, **kw)
@@ -302,7 +302,8 @@ def line_at_4096_boards(args, dev, qdist):
     return {"boards": 4096, "kernel": "k_advance<4> (73 registers, four wavefronts per SIMD)", "rounds": 2560, "seconds": dt, "ms_per_round": dt / 2560 * 1e3,
             "plies_per_s": d["plies_played"] / dt, "playouts_per_s": d["playouts"] / dt, "nn_evaluations_per_s": d["nn_evals"] / dt,
             "memo_hit_rate": d["memo_hits"] / max(d["playouts"], 1),
-            "note": "same desync / settle phases as the headline + 1,280 warm-up rounds, then 2,560 rounds timed by this process"}
+            "budget_us": 1000,
+            "note": "same desync / settle phases as the headline + 1,280 warm-up rounds, then 2,560 rounds timed by this process; its own budget of 1,000 us"}
 
 
 def second_line(args, dev, qdist):
@@ -314,7 +315,8 @@ def second_line(args, dev, qdist):
 
     torch.manual_seed(args.seed)
     net = PolicyValueNet(use_gpu=True, device=dev)
-    eng = make_engine(args, net, dev, qdist.shard_seed(args.seed + 1, 0), True)
+    B2 = min(args.boards, 4096)  # (round 3's board count: with fewer boards a board gets more of the network and the population ages faster towards its steady state)
+    eng = make_engine(args, net, dev, qdist.shard_seed(args.seed + 1, 0), True, boards=B2)
     kw = dict(max_playouts=args.max_playouts, budget_us=args.second_line_budget_us)
     lens = []
 
@@ -349,7 +351,7 @@ def second_line(args, dev, qdist):
     eng.close()
     open_s = d["open_rounds"] * dt / max(d["rounds"], 1)
     return {"label": "NOT the headline and NOT the reference's arithmetic: terminal sign fixed (a won position backed up as +1; mcts.py:125 backs it up as -1)",
-            "value": games / dt, "unit": "games/s", "games_finished": games, "seconds": dt, "boards": args.boards, "n_playout": args.playouts,
+            "value": games / dt, "unit": "games/s", "games_finished": games, "seconds": dt, "boards": B2, "n_playout": args.playouts,
             "mean_plies_per_game": float(np.mean(lens)) if lens else None, "plies_per_s": d["plies_played"] / dt, "playouts_per_s": d["playouts"] / dt,
             "nn_evaluations_per_s": d["nn_evals"] / dt, "memo_hit_rate": d["memo_hits"] / max(d["playouts"], 1),
             "board_seconds_per_open_ply": open_s / max(d["open_plies"], 1), "nn_precision": "fp32 (parity: three fp16 MFMAs per product)",
