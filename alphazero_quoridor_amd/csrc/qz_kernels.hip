@@ -2522,6 +2522,8 @@ __device__ __forceinline__ void advance_board(EngineDev& E, const int max_iters,
             pred = rfl(pred);
             pred -= pred >> 2;
             if (QZ_BUDGET_PREDICT != 2 || last > pred) pred = last;
+            if (QZ_BUDGET_PREDICT == 3) pred = last + (last >> 2);  // (A/B: a margin of a quarter / a half of the last playout)
+            if (QZ_BUDGET_PREDICT == 4) pred = last + (last >> 1);
             if ((it > 0 || late) && (unsigned int)(now - t0) + (QZ_BUDGET_PREDICT ? pred : 0u) > budget) break;
         }
         Board leaf;

@@ -169,6 +169,53 @@ def test_asynchronous_games_equal_lockstep_games(gpu_device, compact_edges, budg
         asyn.close()
 
 
+@pytest.mark.parametrize("select_opts", [0, 8])
+def test_more_boards_than_wavefront_slots_play_the_lockstep_games(gpu_device, select_opts):
+    """The bench's shape: MORE boards (8,704) than the chip holds wavefronts of k_advance<8> (8,192), one wavefront per workgroup --
+    the boards behind the 8,192nd start when a board that needs the network has left -- against the lock-step engine with the
+    same seed and board count: every slot's games in the same order with identical (board, pi, z) tuples.  select_opts 8: one
+    deadline per launch, boards rotating through the first slots.  Short games (terminal sign fixed, 12 playouts)."""
+    from alphazero_quoridor_amd.engine import SelfPlayEngine
+
+    B, NP = 8704, 12
+    ev = _net(gpu_device, 7).evaluator("per_leaf")
+    lock = SelfPlayEngine(B, n_playout=NP, seed=41, device=gpu_device, fix_terminal_sign=True)
+    asyn = SelfPlayEngine(B, n_playout=NP, seed=41, device=gpu_device, fix_terminal_sign=True, select_opts=select_opts)
+    try:
+        lb, ab = [], []
+        for _ in range(150):
+            lock.play_ply(ev)
+            tb = lock.harvest()
+            if tb is not None:
+                lb.append(tb)
+        n_lock = sum(t.n_games for t in lb)
+        assert n_lock >= B // 8, n_lock
+        rounds = 0
+        while sum(t.n_games for t in ab) < n_lock and rounds < 20000:
+            asyn.run_rounds(ev, 16, max_playouts=NP + 8, budget_us=200)
+            rounds += 16
+            tb = asyn.harvest()
+            if tb is not None:
+                ab.append(tb)
+        gl, ga = _games_by_slot(lb), _games_by_slot(ab)
+        compared = late = 0
+        for slot, games in gl.items():
+            other = ga.get(slot, [])
+            k = min(len(games), len(other))
+            for i in range(k):
+                assert games[i] == other[i], (slot, i)
+            compared += k
+            late += k if slot >= 8192 else 0
+        st = asyn.stats()
+        print("%d games compared tuple by tuple (%d of them on boards behind the 8,192nd); asynchronous run: %d rounds, %d playouts, %d memo hits"
+              % (compared, late, st["rounds"], st["playouts"], st["memo_hits"]))
+        assert compared >= n_lock // 2 and late > 0, (compared, late, n_lock)
+        assert st["node_overflow"] == 0 and st["runaway_descents"] == 0 and st["miss_overflow"] == 0
+    finally:
+        lock.close()
+        asyn.close()
+
+
 def test_miss_list_in_situ_against_oracle_and_full_batch_evaluation(gpu_device):
     """The pieces of a round, one by one, on a mid-run engine: after qz_selfplay_advance the miss list holds
     exactly the boards that wait (one slot each, no duplicates of a board slot); qz_selfplay_leaf_rules gives
