@@ -2457,7 +2457,7 @@ __device__ __forceinline__ void advance_board(EngineDev& E, const int max_iters,
         }
     }
 #ifndef QZ_BUDGET_PREDICT
-#define QZ_BUDGET_PREDICT 1  // what a board expects its next playout to last: 0 = nothing, 1 = as long as its last one, 2 = the largest of its recent ones (a maximum that decays by a quarter per playout: measured no different from 1, 289.1 against 290.6 M playouts/s)
+#define QZ_BUDGET_PREDICT 1  // what a board expects its next playout to last: 0 = nothing, 1 = as long as its last one, 2 = the largest of its recent ones (a maximum that decays by a quarter per playout: measured no different from 1, 289.1 against 290.6 M playouts/s; nor is a margin of a quarter or a half of the last playout on top: 309.5 / 309.8 against 309.0 M, launches as long as before -- the launch's overrun of ~100 us is the extreme of ten thousand boards' playout times, not a misprediction of the typical one)
 #endif
     unsigned int pred = 0u;
 #ifdef QZ_ADV_STAMPS
@@ -2522,8 +2522,6 @@ __device__ __forceinline__ void advance_board(EngineDev& E, const int max_iters,
             pred = rfl(pred);
             pred -= pred >> 2;
             if (QZ_BUDGET_PREDICT != 2 || last > pred) pred = last;
-            if (QZ_BUDGET_PREDICT == 3) pred = last + (last >> 2);  // (A/B: a margin of a quarter / a half of the last playout)
-            if (QZ_BUDGET_PREDICT == 4) pred = last + (last >> 1);
             if ((it > 0 || late) && (unsigned int)(now - t0) + (QZ_BUDGET_PREDICT ? pred : 0u) > budget) break;
         }
         Board leaf;
