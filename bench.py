@@ -359,7 +359,9 @@ def second_line(args, dev, qdist):
             "plies_per_s_over_mean_length_of_the_finished": (d["plies_played"] / dt / float(np.mean(lens))) if lens else None,  # an UPPER figure: the games that finish in a short window are the short ones
             "note": "network-bound: with the sign fixed a game is ~150 plies of the open phase (the mover has walls: nearly every leaf is new) at 400 evaluations "
                     "each; evaluations per game x games/s = the network's throughput.  Round 3's 409 games/s counted the games the 4-playout desync phase had left "
-                    "close to their end (a transient); this line is taken after the population has played at 400 playouts for --second-line-warm-seconds",
+                    "close to their end (a transient); this line is taken after the population has played at 400 playouts for --second-line-warm-seconds -- "
+                    "and is STILL a transient: over seven minutes the same engine goes from 300 to 146 games/s while the finished games' mean length grows from 500 to "
+                    "1,450 plies and plies/s settles at 308 k (profiles/round4/second_line_time_course_4096boards.json)",
             "measured": "real finished games / wall time after %d desync plies at %d playouts and %.0f s of warm-up at %d playouts"
                         % (args.desync_plies, args.desync_playouts, args.second_line_warm_seconds, args.playouts)}
 
