@@ -620,7 +620,7 @@ def main():
     ap.add_argument("--budget-us", type=int, default=2400, help="async: wall-clock budget of a k_advance launch (8,192 boards, same box: 1000 / 1400 / 1800 / 2400 us = 271 / 285 / 291 / 287 M playouts/s; 9,728 boards: 1800 / 2400 / 3000 / 3600 us = 301 / 305 / 292 / 282 M; 10,240 boards at 2400 us: 310 M)")
     ap.add_argument("--max-playouts", type=int, default=4096, help="async: playouts a board may start per round")
     ap.add_argument("--graph-rounds", type=int, default=0, help="async: capture this many (even) rounds per HIP graph (0 = eager launches, per-kernel events)")
-    ap.add_argument("--event-every", type=int, default=8, help="async: every n-th round of group 0 is issued in pieces with HIP events around them")
+    ap.add_argument("--event-every", type=int, default=64, help="async: every n-th round of group 0 is issued in pieces with HIP events around them (those rounds run their pieces one after the other: every 8th / 32nd / 64th / 256th = 308.3 / 312.7 / 313.7 / 314.7 M playouts/s)")
     ap.add_argument("--max-depth", type=int, default=992, help="drop a game whose playout descends more than this many levels (0 = never): where the reference's "
                                                               "recursive backup (mcts.py:55-62) overflows Python's recursion limit and ends the run")
     ap.add_argument("--no-memo", action="store_true", help="async A/B: no leaf-evaluation memo (every leaf goes to the network)")
