@@ -63,7 +63,9 @@ class TrainPipeline(object):
         self.n_groups = n_groups  # board groups on separate HIP streams (engine.BoardGroups)
         self.async_loop = True        # self-play through the asynchronous loop (False: the lock-step engine, one ply of every board per harvest)
         self.rounds_per_harvest = 64  # rounds of the loop between two harvests (+ all-gathers)
-        self.budget_us = 2400         # wall-clock budget of a k_advance launch (profiles/round4/SUMMARY.md: the sweeps)
+        self.budget_us = 1000         # wall-clock budget of a k_advance launch.  (bench.py runs 2,400 us: the optimum for ten thousand boards deep
+                                      # in random-network games, where nearly every leaf is in the memo; a board whose mover still has walls makes
+                                      # ONE playout per round, so a population of short games is better served by short rounds)
         # a game whose search descends deeper than this is DROPPED (not in the replay data; counted and logged by
         # collect_selfplay_data: `games_dropped`): the reference's recursive backup raises RecursionError there
         # (mcts.py:55-62, Python's recursion limit) and its whole run ends.  An explicit choice, because it shapes the data:
