@@ -1290,6 +1290,11 @@ __device__ __forceinline__ void select_core(EngineDev& E, BoardRegs& S, const in
             S.rec_clock = clock;
         }
         QZ_TS(2)
+    } else {
+        // a root that is not expanded yet (the first playout of a new game or of a fresh-root restart) IS the leaf: the hook
+        // must see it too -- k_advance's memo probe is issued from the hook and finished by the caller whatever the path here
+        // (round 4 left the probe of such a root unissued: an indeterminate key compare)
+        at_leaf_hook(bd, done);
     }
 #ifdef QZ_SELECT_STAMPS
     QZ_SEL_MARK(t_walk)

@@ -69,13 +69,54 @@ def collectives_on(group=None) -> bool:
     return dist.get_world_size(group) > 1 or force_collectives()
 
 
+class ExchangeLog:
+    """What the path's only exchange costs ("games/s total and all-gather ms"): one entry per allgather_tuples
+    call that really ran its collectives -- wall milliseconds from the count all-gather to the arrival of the payload (the
+    device is synchronised at the end of a timed call: an exchange happens once per harvest, which synchronises anyway),
+    bytes this rank contributed and received."""
+
+    def __init__(self):
+        self.ms, self.bytes_in, self.bytes_out = [], [], []
+
+    def add(self, ms, n_in, n_out):
+        self.ms.append(float(ms))
+        self.bytes_in.append(int(n_in))
+        self.bytes_out.append(int(n_out))
+
+    def clear(self):
+        del self.ms[:], self.bytes_in[:], self.bytes_out[:]
+
+    def summary(self):
+        n = len(self.ms)
+        if n == 0:
+            return {"calls": 0, "mean_ms": None, "max_ms": None, "mean_bytes_contributed": None, "mean_bytes_received": None}
+        return {"calls": n, "mean_ms": sum(self.ms) / n, "max_ms": max(self.ms), "mean_bytes_contributed": sum(self.bytes_in) / n,
+                "mean_bytes_received": sum(self.bytes_out) / n}
+
+
+exchange_log = ExchangeLog()
+
+
 def allgather_tuples(buf: torch.Tensor, group=None, n_games=None):
     """Every rank contributes uint8 [n_r, 588]; every rank gets the concatenation in rank
     order, uint8 [sum n_r, 588].  With `n_games` (this rank's finished games) the call returns
     (tuples, games summed over ranks) -- the same number on every rank, so loops that run
-    "until N games" stay in lockstep and issue the same sequence of collectives."""
+    "until N games" stay in lockstep and issue the same sequence of collectives.  Every call that runs
+    its collectives is timed into `exchange_log`."""
     if not collectives_on(group):
         return buf if n_games is None else (buf, int(n_games))
+    import time
+
+    t0 = time.perf_counter()
+    out = _allgather_tuples(buf, group, n_games)
+    got = out[0] if n_games is not None else out
+    if got.is_cuda:
+        torch.cuda.synchronize(got.device)
+    exchange_log.add((time.perf_counter() - t0) * 1e3, buf.numel(), got.numel())
+    return out
+
+
+def _allgather_tuples(buf, group, n_games):
     world = dist.get_world_size(group)
     dev = buf.device
     count = torch.tensor([buf.shape[0], int(n_games or 0)], dtype=torch.int64, device=dev)

@@ -134,7 +134,9 @@ class SelfPlayEngine:
         self._leaf_ref = None
         self._descended = False  # the last expand / backup launch also ran the next playout's descent
         self._memo_version = None   # (evaluator id, evaluator.version) the memo's contents belong to
-        self._round_graph = None    # captured rounds of the asynchronous loop: (graph, rounds, key)
+        self._round_graph = None    # captured rounds of the asynchronous loop: ({parity: graph}, rounds, key)
+        self._graph_warned = False
+        self.graph_replays = 0      # replays of captured round graphs (a test asserts that a captured graph is actually used)
 
     @property
     def planes(self):
@@ -356,7 +358,11 @@ class SelfPlayEngine:
                                              self._s()))
 
     def capture_rounds(self, evaluator, rounds=16, max_playouts=64, budget_us=0, auto_finish=True, warmup=2):
-        """Capture `rounds` (even: the two miss counters alternate) rounds into one HIP graph for run_rounds."""
+        """Capture `rounds` (even: the two miss counters alternate) rounds into HIP graphs for run_rounds -- ONE GRAPH PER
+        MISS-COUNTER PARITY: a graph bakes in which of the two counters its first round appends to (a kernel argument), and a
+        caller may arrive on either (an odd leftover of the last call, run_playouts_memo, the split entry points).  Round 4
+        repaired the parity with one eager round, which left `n - 1 < rounds` for the graph whenever n == rounds --
+        TrainPipeline's exact shape -- so the graph was silently never replayed."""
         assert rounds % 2 == 0
         self._memo_guard(evaluator)
         s = torch.cuda.Stream(device=self.device)
@@ -365,30 +371,37 @@ class SelfPlayEngine:
             for _ in range(2 * ((warmup + 1) // 2)):
                 self.selfplay_round(evaluator, max_playouts, budget_us, auto_finish)
         torch.cuda.current_stream(self.device).wait_stream(s)
-        torch.cuda.synchronize(self.device)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            for _ in range(rounds):
+        graphs = {}
+        for k in range(2):
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for _ in range(rounds):
+                    self.selfplay_round(evaluator, max_playouts, budget_us, auto_finish)
+            graphs[self.round_parity()] = g  # (a capture executes nothing: the parity is the one the graph's first round will find)
+            if k == 0:  # one eager round puts the engine on the other counter for the second capture
                 self.selfplay_round(evaluator, max_playouts, budget_us, auto_finish)
-        # (the graph bakes in the miss counter of its first round: `rounds` is even, so every replay starts and ends on it)
-        self._round_graph = (g, int(rounds), (id(evaluator), int(max_playouts), int(budget_us), bool(auto_finish)), self.round_parity())
+        assert len(graphs) == 2, "qz_selfplay_parity did not alternate between two eager rounds"
+        self._round_graph = (graphs, int(rounds), (id(evaluator), int(max_playouts), int(budget_us), bool(auto_finish)))
+        return 2 * ((warmup + 1) // 2) + 1  # eager rounds this call has run
 
     def run_rounds(self, evaluator, n, max_playouts=64, budget_us=0, auto_finish=True):
-        """n rounds; whole multiples of a captured graph (capture_rounds, same arguments) are replayed."""
+        """n rounds; whole multiples of a captured graph (capture_rounds, same arguments) are replayed -- the graph of the
+        miss-counter parity the engine is on (an even number of rounds per replay keeps it there)."""
         n = int(n)
         done = 0
         g = self._round_graph
-        if g is not None and g[2] == (id(evaluator), int(max_playouts), int(budget_us), bool(auto_finish)) and n >= g[1]:
-            self._memo_guard(evaluator)
-            # an odd number of eager rounds since the capture (a leftover of the last call, run_playouts_memo, the split
-            # entry points) leaves the engine on the OTHER miss counter: one eager round first, or the replay would append
-            # to a counter the previous tail did not clear
-            if self.round_parity() != g[3]:
-                self.selfplay_round(evaluator, max_playouts, budget_us, auto_finish)
-                done += 1
-            while n - done >= g[1]:
-                g[0].replay()
-                done += g[1]
+        if g is not None and n >= g[1]:
+            if g[2] == (id(evaluator), int(max_playouts), int(budget_us), bool(auto_finish)):
+                self._memo_guard(evaluator)
+                while n - done >= g[1]:
+                    g[0][self.round_parity()].replay()
+                    self.graph_replays += 1
+                    done += g[1]
+            elif not self._graph_warned:
+                self._graph_warned = True
+                import warnings
+                warnings.warn("run_rounds: the captured graph was made with other arguments (evaluator / max_playouts / budget_us / auto_finish): running eager")
         for _ in range(n - done):
             self.selfplay_round(evaluator, max_playouts, budget_us, auto_finish)
 

@@ -151,6 +151,7 @@ class Run:
         self.args, self.eng, self.qdist, self.rank, self.local, self.world, self.dev = args, eng, qdist, rank, local, world, dev
         self.lengths = {"desync": [], "warmup": [], "timed": []}
         self.phase = "desync"
+        self.exch = None
 
     def barrier(self):
         if self.world > 1:
@@ -171,6 +172,19 @@ class Run:
             bufs.append(torch.zeros((0, self.qdist.TUPLE_BYTES), dtype=torch.uint8, device=self.dev))
             self.qdist.allgather_tuples(torch.cat(bufs))
         return n_games
+
+    def exchange_summary(self):
+        """`allgather_ms` of an N > 1 line: this run's exchanges (dist.exchange_log), the slowest rank's mean and maximum."""
+        if self.world == 1:
+            return None
+        d = self.qdist.exchange_log.summary()
+        assert d["calls"] >= self.args.steps, "every step of an N > 1 run ends with one exchange"
+        t = torch.tensor([d["mean_ms"] or 0.0, d["max_ms"] or 0.0, d["mean_bytes_received"] or 0.0], dtype=torch.float64, device=self.dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        self.exch = {"calls": d["calls"], "mean": float(t[0]), "max": float(t[1]), "unit": "ms", "bytes_received_per_call_mean": float(t[2]),
+                "what": "dist.allgather_tuples per harvest (count all-gather + one padded payload all-gather of 588-byte tuples, then a device sync); "
+                        "max over ranks of each rank's mean / maximum; inside the timed region and inside ms_per_step"}
+        return self.exch
 
     def reduce(self, elapsed, totals):
         el = torch.tensor([elapsed], dtype=torch.float64, device=self.dev)
@@ -223,6 +237,8 @@ class Run:
                              % (st1["games_aborted"], a.max_depth, st1["aborted_depth"], st1["aborted_no_move"], st1["aborted_max_plies"], st1["aborted_pool"]))
         assert st1["node_overflow"] == 0 and st1["runaway_descents"] == 0 and st1.get("miss_overflow", 0) == 0, "tree storage overflowed / corrupted during the run"
         out["clocks"] = sampler.summary() if sampler else None
+        if self.world > 1:
+            out["allgather_ms"] = self.exch
         if a.clock_log and sampler:
             with open(a.clock_log, "w") as f:
                 json.dump({"step_ms": step_ms, "samples": sampler.samples}, f)
@@ -248,9 +264,31 @@ class Run:
         print(json.dumps(out))
 
 
+def round_schedule(rounds_per_step, event_every, graph_rounds=0):
+    """The rounds of ONE step of the asynchronous loop as a list of ("timed", 1) / ("plain", n) items.  A "timed" round is
+    issued as its four pieces with HIP events around them (what roofline / roofline_rules / roofline_nn are computed from);
+    "plain" rounds go through run_rounds (graph replays when --graph-rounds).  Whatever the arguments, every step times at
+    least ONE round: a bench line without `roofline` is unmeasured (round 4's GPU tier went red on exactly that:
+    --event-every 64 with --rounds-per-step 48 timed nothing).  With a graph the first round of the step is the timed one
+    (eager, piece by piece; run_rounds picks the graph of the miss-counter parity it finds)."""
+    NR = int(rounds_per_step)
+    if NR < 1:
+        raise ValueError("--rounds-per-step must be >= 1")
+    every = NR if graph_rounds else max(1, min(int(event_every), NR))
+    out, done = [], 0
+    while done < NR:
+        out.append(("timed", 1))
+        done += 1
+        n = min(every - 1, NR - done)
+        if n > 0:
+            out.append(("plain", n))
+            done += n
+    return out
+
+
 def hbm_line(kernel, us, nbytes, note, launches, traffic=None, src=None):
-    if us is None:
-        return None
+    if us is None or not launches:
+        raise SystemExit("bench.py: no timed launch of '%s' -- a line without its roofline is unmeasured (round_schedule must time >= 1 round per step)" % kernel[:40])
     gbs = nbytes / (us * 1e-6) / 1e9
     return {"kernel": kernel, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
             "traffic_source": src, "avg_launch_us": us, "launches_timed": launches, "algorithmic_bytes_per_launch": nbytes, "note": note}
@@ -398,7 +436,8 @@ def run_async(R):
     R.phase = "timed"
     eng0, ev0, st0_stream = eng.engines[0], eng.evaluators[0], eng.streams[0]
     L = _cabi.load()
-    ev_every = max(1, args.event_every)
+    schedule = round_schedule(NR, args.event_every, args.graph_rounds)
+    ev_every = NR if args.graph_rounds else max(1, min(args.event_every, NR))
     evs = []
 
     def timed_round():
@@ -416,6 +455,7 @@ def run_async(R):
 
     sampler = ClockSampler(R.local) if rank == 0 else None
     st0 = eng.stats()
+    R.qdist.exchange_log.clear()
     R.barrier()
     if sampler:
         sampler.start()
@@ -423,18 +463,14 @@ def run_async(R):
     games, step_ms = 0, []
     for _ in range(args.steps):
         ts = time.perf_counter()
-        done = 0
-        while done < NR:
-            if args.graph_rounds == 0 and ev_every <= NR:
+        for kind, n in schedule:
+            if kind == "timed":
                 timed_round()
                 for g in range(1, G):
                     with torch.cuda.stream(eng.streams[g]):
                         eng.engines[g].run_rounds(eng.evaluators[g], 1, **kw)
-                done += 1
-            n = min(ev_every - 1 if args.graph_rounds == 0 else NR - done, NR - done)
-            if n > 0:
+            else:
                 eng.run_rounds(n, **kw)
-                done += n
         games += R.harvest()  # (synchronises with the device: the step's wall time)
         step_ms.append((time.perf_counter() - ts) * 1e3)
     R.barrier()
@@ -443,6 +479,7 @@ def run_async(R):
         sampler.stop()
     st1 = eng.stats()
     d = {k: st1[k] - st0[k] for k in st1}
+    exch = R.exchange_summary()
     elapsed, (games_all, plies_all, playouts_all, term_all, evals_all, hits_all, open_plies_all, open_rounds_all) = R.reduce(
         elapsed, [games, d["plies_played"], d["playouts"], d["leaf_terminal"], d["nn_evals"], d["memo_hits"], d["open_plies"], d["open_rounds"]])
     if rank != 0:
@@ -454,7 +491,9 @@ def run_async(R):
     length_file = args.length_file or (None if args.fix_terminal_sign else _latest_profile("game_length_%dplayouts.json" % args.playouts))
     ss = steady_state_two_phase(B * world, open_plies_all, plies_all - open_plies_all, open_board_s, end_board_s, length_file)
     ss_simple = steady_state(plies_all / elapsed, length_file)
-    adv_us, rules_us, nn_us, tail_us = (sum(p[i][0].elapsed_time(p[i][1]) for p in evs) / len(evs) * 1e3 for i in range(4)) if evs else (None,) * 4
+    if not evs:
+        raise SystemExit("bench.py: the timed region issued no timed round (rounds_per_step=%d, event_every=%d, graph_rounds=%d): no roofline, no line" % (NR, args.event_every, args.graph_rounds))
+    adv_us, rules_us, nn_us, tail_us = (sum(p[i][0].elapsed_time(p[i][1]) for p in evs) / len(evs) * 1e3 for i in range(4))
     per_launch = {k: d[k] / (rounds * G) for k in ("edges_scanned", "edges_expanded", "descent_levels", "playouts", "memo_hits", "nn_evals")}
     # k_advance's algorithmic bytes: every level of a descent reads the node's edge records (32 B each) and its 12-byte record entry,
     # the backup rewrites 24 B per level, a new leaf probes one 512-byte memo bucket and its expansion writes 32 B per legal move
@@ -544,6 +583,7 @@ def run_lockstep(R):
     nevs = [[pair() for _ in range(G)] for _ in range(n_launch)]
     sampler = ClockSampler(R.local) if rank == 0 else None
     st0 = eng.stats()
+    R.qdist.exchange_log.clear()
     R.barrier()
     if sampler:
         sampler.start()
@@ -563,6 +603,7 @@ def run_lockstep(R):
         sampler.stop()
     st1 = eng.stats()
     d = {kk: st1[kk] - st0[kk] for kk in st1}
+    exch = R.exchange_summary()
     elapsed, (games_all, plies_all, playouts_all, term_all) = R.reduce(elapsed, [games, d["plies_played"], d["playouts"], d["leaf_terminal"]])
     if rank != 0:
         return

@@ -293,6 +293,41 @@ def test_memo_is_flushed_when_the_weights_change(gpu_device):
         b.close()
 
 
+def test_unexpanded_root_probes_the_memo(gpu_device):
+    """a root that is not expanded yet -- the first playout of every new game / fresh-root restart -- is
+    itself the leaf of its descent, and k_advance's memo probe (issued from select_core's leaf hook) must be issued for it
+    too.  64 boards each on a mid-game position, the opening and a position without walls in hand: round 1 sends every root to the network (one evaluation
+    per board, nothing is in the memo), the tail stores them; after reset + the same boards, the first playout of every
+    board must be a memo HIT, no leaf goes to the network, and the expanded roots equal the first run's bit for bit."""
+    from synth import synth_positions
+
+    mid = synth_positions(1, seed=21, max_walls=10, mover_has_walls=True)
+    start = np.zeros(1, dtype=mid.dtype)
+    start["p1"], start["p2"], start["w1"], start["w2"], start["cur"] = 4, 76, 10, 10, 1
+    late = synth_positions(1, seed=22, max_walls=8)
+    late["w1"] = 0
+    late["w2"] = 0     # (the memo's small table: the mover has no wall left)
+    boards = np.concatenate([np.repeat(mid, 64), np.repeat(start, 64), np.repeat(late, 64)])
+    ev = _net(gpu_device, 4).evaluator("per_leaf")
+    e = _engine(boards, 8, seed=1)
+    try:
+        e.run_rounds(ev, 1, max_playouts=1, auto_finish=False)   # every root: probe (miss) -> network -> memo insert
+        e.run_rounds(ev, 1, max_playouts=1, auto_finish=False)   # ... consumed: the roots are expanded, one more playout each
+        st1 = e.stats()
+        assert st1["nn_evals"] >= 192 and st1["memo_inserts"] >= 3
+        first = [x.clone() for x in e.root_children()]
+        from alphazero_quoridor_amd.boards import DeviceBoards
+        e.set_boards(DeviceBoards.from_packed(boards, e.device), reset_trees=True)
+        e.run_rounds(ev, 1, max_playouts=1, auto_finish=False)
+        st2 = e.stats()
+        assert st2["memo_hits"] - st1["memo_hits"] == 192, "the probe of an unexpanded root must find what the first run stored"
+        assert st2["nn_evals"] == st1["nn_evals"]
+        _, _, prior, _ = e.root_children()
+        assert torch.equal(prior, first[2])  # the root's priors from the memo are the network's bits
+    finally:
+        e.close()
+
+
 def test_captured_rounds_follow_the_weights(gpu_device):
     """capture_rounds -> weight change -> replay: the replayed launches read the new weight images AND the new
     per-layer scales (device memory), so the graph run equals an eager run after the same change."""
@@ -303,8 +338,8 @@ def test_captured_rounds_follow_the_weights(gpu_device):
     g = _engine(boards, NP, seed=2)
     e = _engine(boards, NP, seed=2)
     try:
-        e.run_rounds(ev, 2, max_playouts=4)   # the same two eager rounds capture_rounds warms up with
-        g.capture_rounds(ev, rounds=4, max_playouts=4, warmup=2)
+        n0 = g.capture_rounds(ev, rounds=4, max_playouts=4, warmup=2)
+        e.run_rounds(ev, n0, max_playouts=4)   # the eager rounds capture_rounds has run (warm-up + one between its two captures)
         with torch.no_grad():
             for prm in net.policy_value_net.parameters():
                 prm.mul_(2.7)

@@ -372,13 +372,17 @@ def test_a_leftover_of_eager_rounds_does_not_break_a_captured_graph(gpu_device):
     g = make_engine(boards, 16, seed=2)
     e = make_engine(boards, 16, seed=2)
     try:
-        e.run_rounds(ev, 2, max_playouts=4)   # what capture_rounds warms up with
-        g.capture_rounds(ev, rounds=4, max_playouts=4, warmup=2)
+        n0 = g.capture_rounds(ev, rounds=4, max_playouts=4, warmup=2)
+        e.run_rounds(ev, n0, max_playouts=4)   # the eager rounds capture_rounds has run (warm-up + one between its two captures)
         for _ in range(2):
             g.run_rounds(ev, 5, max_playouts=4)   # 4 replayed + 1 eager: the engine is left on the other counter
             e.run_rounds(ev, 5, max_playouts=4)
-        g.run_rounds(ev, 9, max_playouts=4)       # 1 eager (parity), 2 x 4 replayed
+        assert g.graph_replays == 2               # ... and the second call replayed the OTHER parity's graph
+        g.run_rounds(ev, 9, max_playouts=4)       # 2 x 4 replayed + 1 eager
         e.run_rounds(ev, 9, max_playouts=4)
+        g.run_rounds(ev, 4, max_playouts=4)       # n == the graph's rounds on an odd leftover (TrainPipeline's shape): still a replay
+        e.run_rounds(ev, 4, max_playouts=4)
+        assert g.graph_replays == 5
         for x, y in zip(g.root_children(), e.root_children()):
             assert torch.equal(x, y)
         assert torch.equal(g.get_boards().meta, e.get_boards().meta)

@@ -1,0 +1,118 @@
+"""GPU tier, LAST file in collection order (the name sorts after every kernel-parity file): bench.py as a subprocess -- the N > 1
+path on one GPU, the self-launch, the contract keys of the N = 1 line.  These tests assert on the FORMAT of the bench line;
+round 4's driver run died on one of them (test 11 of 106 under `-x`) before a single kernel-parity file had been collected, so
+they live here: a formatting regression can no longer hide kernel parity."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_bench_multi_rank_path_on_one_gpu(gpu_device):
+    """bench.py's N>1 path (one engine per rank, per-ply all-gather of finished tuples, MAX /
+    SUM reductions, one JSON line from rank 0) with two ranks sharing this GPU over gloo
+    (RCCL refuses two ranks on one device; the driver's real runs use nccl)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, QZ_DIST_BACKEND="gloo", QZ_SHARE_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+         "--master-port", "29541", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+         "--boards", "256", "--playouts", "16", "--desync-plies", "200", "--rounds-per-step", "48", "--no-cpu-baseline"],
+        env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 2 and d["config"]["mode"] == "async"
+    assert d["playouts_per_s"] > 0 and d["roofline"]["achieved"] > 0 and d["rounds"] == 2 * 48
+    assert d["roofline"]["launches_timed"] == 2  # --rounds-per-step 48 below the default --event-every 64: one timed round per step (round 4: none, and no line)
+    ag = d["allgather_ms"]  # the exchange is timed
+    assert ag["calls"] >= 2 and 0 < ag["mean"] <= ag["max"] and ag["unit"] == "ms"
+    # both ranks' work is in the aggregate: every round advances every board of both ranks, a move needs 16 playouts
+    plies = d["plies_per_s"] * d["ms_per_step"] * 2 / 1e3
+    assert 2 * 256 * 2 <= plies and d["playouts_per_s"] / d["plies_per_s"] == pytest.approx(16, rel=0.2)
+    assert d["engine_stats"]["node_overflow"] == 0 and d["engine_stats"]["runaway_descents"] == 0
+
+
+def test_bench_launches_its_own_ranks(gpu_device):
+    """`python bench.py --gpus 2` with NO launcher around it (the driver's command shape): the
+    process spawns its two ranks itself and relays rank 0's single JSON line with n_gpus = 2.
+    Same gloo / shared-device hooks as above (one GPU on this box)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(QZ_DIST_BACKEND="gloo", QZ_SHARE_DEVICE="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--boards", "256",
+                        "--playouts", "16", "--desync-plies", "100", "--no-cpu-baseline", "--mode", "lockstep"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]   # stdout is the JSON line and nothing else
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 2 and d["value"] >= 0
+    assert abs(d["plies_per_s"] * d["ms_per_step"] * 2 / 1e3 - 2 * 256 * 2) < 2 * 256 * 2 * 0.05
+
+
+def test_bench_single_gpu_line_carries_the_contract(gpu_device):
+    """`python bench.py` (N=1, tiny workload): ONE JSON line with the driver's contract keys, the
+    roofline of the rules op in the timed region, the 32,768-board microbenchmark (roofline_c3) and
+    the CPU baseline; no expansion skipped."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    def run(*extra):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--boards", "256",
+                            "--playouts", "16", "--desync-plies", "100", "--cpu-seconds", "2"] + list(extra),
+                           capture_output=True, text=True, timeout=900, cwd=root)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1
+        return json.loads(lines[0])
+
+    # the default route: the asynchronous self-play loop
+    a = run("--rounds-per-step", "64")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in a, k
+    assert a["config"]["mode"] == "async" and a["n_gpus"] == 1 and a["steps"] == 2 and a["vs_baseline"] is None and a["unit"] == "games/s"
+    assert "workload" in a["config"] and "model" not in a["config"] and a["rounds"] == 2 * 64
+    for rf in (a["roofline"], a["roofline_rules"], a["roofline_c3"]):
+        assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+        assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0 < rf["frac"] < 1
+    assert a["roofline_nn"]["bound"] == "mfma" and a["roofline_nn"]["avg_launch_us"] > 0 and "k_advance" in a["roofline"]["kernel"]
+    assert 0 <= a["memo_hit_rate"] <= 1 and a["nn_evaluations_per_s"] > 0 and a["playouts_per_s"] > a["nn_evaluations_per_s"]
+    assert a["engine_stats"]["node_overflow"] == 0 and a["engine_stats"]["runaway_descents"] == 0
+    assert a["cpu_baseline"]["kind"] == "port" and a["cpu_baseline"]["value"] > 0
+    assert "games_per_s_steady_state" in a and "games_in_timed_region" in a and len(a["ms_per_step_series"]) == 2
+    # with the rounds captured in HIP graphs the step's first round is still issued piece by piece: the line keeps its roofline
+    g = run("--rounds-per-step", "32", "--graph-rounds", "8", "--no-c3", "--no-cpu-baseline", "--second-line-seconds", "0")
+    assert g["config"]["graph_rounds"] == 8 and g["roofline"]["launches_timed"] == 2 and 0 < g["roofline"]["frac"] < 1 and g["rounds"] == 2 * 32
+    # round 2's route, kept for A/B
+    d = run("--mode", "lockstep")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["unit"] == "games/s" and "workload" in d["config"] and "model" not in d["config"]
+    for rf in (d["roofline"], d["roofline_c3"]):
+        assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+        assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0 < rf["frac"] < 1
+    assert d["roofline_c3"]["algorithmic_bytes_per_launch"] == 32768 * 8468
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+    assert cb["playouts_per_s_allcores"] >= 0.5 * cb["playouts_per_s_1core"] > 0 and cb["compare_on"].startswith("playouts_per_s")
+    assert d["engine_stats"]["node_overflow"] == 0
+    assert [t["kernel"] for t in d["roofline_tree"]] == ["k_expand_backup_select"] and all(t["achieved"] > 0 for t in d["roofline_tree"])
+    assert "games_per_s_steady_state" in d and "game_lengths_seen" in d and len(d["ms_per_step_series"]) == 2
+    assert d["roofline"]["planes_written"] is True and d["roofline"]["planes_consumed_by_evaluator"] is False

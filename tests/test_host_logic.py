@@ -148,6 +148,12 @@ assert e2.shape[0] == 16 and games == 3
 e3, games = qd.allgather_tuples(qd.pack_tuples(hb[:0], vb[:0], meta[:0], pi[:0], z[:0]), n_games=0)
 assert e3.shape[0] == 0 and games == 0
 assert qd.shard_seed(7, 0) != qd.shard_seed(7, 1)
+# every exchange was timed (SURVEY C4: "all-gather ms"): 4 calls, positive durations, this rank's bytes in / everyone's out
+lg = qd.exchange_log.summary()
+assert lg["calls"] == 4 and lg["mean_ms"] > 0 and lg["max_ms"] >= lg["mean_ms"]
+assert qd.exchange_log.bytes_in[0] == n * 588 and qd.exchange_log.bytes_out[0] == 16 * 588 and qd.exchange_log.bytes_out[3] == 0
+qd.exchange_log.clear()
+assert qd.exchange_log.summary()["calls"] == 0
 dist.destroy_process_group()
 open(os.path.join(sys.argv[2], "ok_%d" % rank), "w").write("ok")
 '''
@@ -510,6 +516,36 @@ def test_no_packed_fp32_instruction_in_the_device_code():
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count(": 0 packed-fp32 instructions") == 3, r.stdout
+
+
+def test_bench_round_schedule_always_times_a_round():
+    """`--event-every 64` with `--rounds-per-step 48` timed no round, the line had `roofline: None` and the
+    GPU tier died on it at test 11 of 106.  The schedule of a step is a pure function now: for every argument combination the
+    GPU tests and the driver use (and a sweep around them) it covers exactly rounds_per_step rounds and times at least one;
+    with a graph the timed round is the step's first and the rest is ONE run_rounds call; hbm_line refuses to build a line
+    from zero launches instead of returning None."""
+    import bench
+
+    used = [(48, 64, 0), (64, 64, 0), (256, 64, 0), (32, 64, 8), (256, 64, 16), (1, 64, 0), (2, 1, 0), (7, 3, 0), (256, 8, 0)]
+    sweep = [(nr, ev, g) for nr in (1, 2, 3, 16, 47, 48, 64, 65, 255, 256) for ev in (0, 1, 2, 8, 63, 64, 65, 1000) for g in (0, 2, 16)]
+    for nr, ev, g in used + sweep:
+        sch = bench.round_schedule(nr, ev, g)
+        assert sum(n for _, n in sch) == nr, (nr, ev, g)
+        assert all(n >= 1 for _, n in sch) and all(n == 1 for k, n in sch if k == "timed")
+        timed = sum(1 for k, _ in sch if k == "timed")
+        assert timed >= 1, (nr, ev, g)
+        if g:
+            assert sch[0] == ("timed", 1) and timed == 1 and len(sch) <= 2
+        else:
+            assert timed == -(-nr // max(1, min(ev, nr)))
+    assert bench.round_schedule(256, 64, 0) == [("timed", 1), ("plain", 63)] * 4
+    with pytest.raises(ValueError):
+        bench.round_schedule(0, 64, 0)
+    with pytest.raises(SystemExit):
+        bench.hbm_line("k_advance", None, 1.0, "", 0)
+    with pytest.raises(SystemExit):
+        bench.hbm_line("k_advance", 10.0, 1.0, "", 0)
+    assert bench.hbm_line("k_advance", 10.0, 8e6, "", 3)["achieved"] == pytest.approx(800.0)
 
 
 def test_steady_state_estimator_of_the_bench_line(tmp_path):
