@@ -465,6 +465,35 @@ def test_32768_boards_at_400_playouts_fit_one_gpu(gpu_device):
     st = eng.stats()
     assert st["node_overflow"] == 0 and st["runaway_descents"] == 0 and st["games_aborted"] == 0 and st["rounds"] == 24
     assert st["nn_evals"] > 0 and st["memo_inserts"] > 0 and st["playouts"] > 32768 * 490
+    # ... and IN SITU (configs[2] on the asynchronous loop): four more rounds issued piece by piece; the miss
+    # list of each -- the leaves the memo did not know, whose legal sets the loop's own rules op has just produced from a
+    # device-side count -- against the oracle (every 8th leaf), and the evaluations the loop stored for them against the
+    # full-batch evaluation of the same boards (the purity the memo rests on)
+    import ctypes as C
+
+    from alphazero_quoridor_amd import _cabi
+
+    checked = 0
+    for it in range(4):
+        eng._memo_guard(ev)
+        _cabi.check(eng.L.qz_selfplay_advance(eng.h, 32, 1000, 1, eng._s()))
+        _cabi.check(eng.L.qz_selfplay_leaf_rules(eng.h, eng._s()))
+        _cabi.check(eng.L.qz_selfplay_evaluate(eng.h, C.byref(ev.nn_weights()), eng._s()))
+        packed, mmask, mp, mv = eng.misses()
+        assert eng.stats()["waiting_boards"] == len(packed)
+        if len(packed):
+            omask, status = oracle.movegen_batch(packed[::8])
+            assert (status >= 0).all() and np.array_equal(mmask[::8], omask), it
+            sub = packed[::32]
+            sdb = DeviceBoards.from_packed(sub, gpu_device)
+            pr, vr = ev(None, leaf=(sdb.struct(), 0, len(sub)))
+            assert np.array_equal(mp[::32], pr.cpu().numpy()) and np.array_equal(mv[::32], vr.cpu().numpy()), it
+            checked += len(packed[::8])
+        _cabi.check(eng.L.qz_selfplay_round_tail(eng.h, eng._s()))
+    st = eng.stats()
+    assert checked > 1000 and st["node_overflow"] == 0 and st["miss_overflow"] == 0 and st["runaway_descents"] == 0 and st["rounds"] == 28
+    print("32,768 boards x n_playout=400 on the asynchronous loop: %d miss-list leaves in situ against the oracle, %d playouts, %d evaluations, %d memo hits"
+          % (checked, st["playouts"], st["nn_evals"], st["memo_hits"]))
     eng.close()
 
 
