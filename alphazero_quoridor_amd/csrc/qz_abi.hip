@@ -954,6 +954,11 @@ int qz_nn_evaluate_w(const qz_boards* boards, const uint8_t* terminal, int64_t n
 int qz_selfplay_advance(qz_engine* e, int max_playouts, int budget_us, int auto_finish, void* stream) {
     ENGINE_CHECK(e);
     if (max_playouts <= 0) return fail(QZ_E_INVALID, "max_playouts must be > 0");
+    // (a board whose move's subtree copy is not done sits out of k_advance -- reroot_pend -- and only k_moves, the launch
+    // auto_finish adds, continues the copy: without it such a board would sit out for ever, silently: ADVICE r4)
+    if (e->async_moves && !auto_finish)
+        return fail(QZ_E_INVALID, "engine is in asynchronous self-play (boards may hold a move whose subtree copy only a launch with auto_finish continues): "
+                                  "keep auto_finish set, or reset the engine (qz_engine_reset / qz_engine_set_boards with reset_trees) first");
     const unsigned int ticks = budget_us > 0 ? (unsigned int)budget_us * 100u : 0xFFFFFFFFu;  // s_memrealtime: 100 MHz
     HIP_TRY(qzl::advance(e->dev, max_playouts, ticks, auto_finish, e->par, (hipStream_t)stream));
     if (auto_finish) e->async_moves = true;
@@ -988,6 +993,8 @@ int qz_selfplay_round(qz_engine* e, const qz_nn_weights* w, int max_playouts, in
     ENGINE_CHECK(e);
     int r;
     if (max_playouts <= 0) return fail(QZ_E_INVALID, "max_playouts must be > 0");
+    if (e->async_moves && !auto_finish)  // (see qz_selfplay_advance: a pending subtree copy is only continued by the moves' launch)
+        return fail(QZ_E_INVALID, "engine is in asynchronous self-play: keep auto_finish set, or reset the engine first");
     if ((r = nn_weights_check(w))) return r;
     hipStream_t s = (hipStream_t)stream;
     if (!e->side) {

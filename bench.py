@@ -216,6 +216,7 @@ class Run:
                "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "u64 bitboards + f64 PUCT (rules/tree kernels); %s policy-value net" % a.nn_dtype,
                "data": "synthetic (random-init policy_value_net, seed %d; self-generated games)" % a.seed, "config": cfg, "value_is": value_is,
+               "tracked_scalar": "plies_per_s",
                "games_in_timed_region": games_all, "games_in_timed_region_per_s": games_all / elapsed, "games_per_s_steady_state": ss,
                "plies_per_s": plies_all / elapsed, "playouts_per_s": playouts_all / elapsed, "terminal_leaf_frac": term_all / max(playouts_all, 1.0),
                "game_lengths_seen": {"timed_region_%d_playouts" % a.playouts: len_stats(self.lengths["timed"] + self.lengths["warmup"]),
@@ -250,6 +251,9 @@ class Run:
             if a.boards != 4096 and a.playouts == 400:
                 out["same_loop_at_4096_boards"] = line_at_4096_boards(a, self.dev, self.qdist)
             out["second_line_fix_terminal_sign"] = second_line(a, self.dev, self.qdist)
+            if not a.no_non_parity_line:  # SURVEY 7 hard part 1 "report both modes": the throughput-precision network, labelled, never the headline
+                torch.cuda.empty_cache()
+                out["second_line_NON_PARITY_fp16"] = second_line(a, self.dev, self.qdist, nn_precision="fp16")
         if not a.no_cpu_baseline and self.world == 1:
             self.eng.close()
             torch.cuda.empty_cache()
@@ -294,10 +298,10 @@ def hbm_line(kernel, us, nbytes, note, launches, traffic=None, src=None):
             "traffic_source": src, "avg_launch_us": us, "launches_timed": launches, "algorithmic_bytes_per_launch": nbytes, "note": note}
 
 
-def make_engine(args, net, dev, seed, fix_sign, boards=None):
+def make_engine(args, net, dev, seed, fix_sign, boards=None, nn_precision=None):
     from alphazero_quoridor_amd.engine import BoardGroups
 
-    prec = "fp16" if args.nn_dtype == "fp16" else "fp32"
+    prec = nn_precision or ("fp16" if args.nn_dtype == "fp16" else "fp32")
     dt = torch.bfloat16 if args.nn_dtype == "bf16" else torch.float32
     if args.library_trunk:
         from alphazero_quoridor_amd.policy_value_net import LeafEvaluator
@@ -344,7 +348,7 @@ def line_at_4096_boards(args, dev, qdist):
             "note": "same desync / settle phases as the headline + 1,280 warm-up rounds, then 2,560 rounds timed by this process; its own budget of 1,000 us"}
 
 
-def second_line(args, dev, qdist):
+def second_line(args, dev, qdist, nn_precision="fp32"):
     """The target-reaching mode, timed by the same process: a winning move backed up as +1 (NOT the reference's mcts.py:125, which
     backs it up as -1 and makes searches avoid winning).  Games then last ~300 plies, so REAL finished games / wall time is a
     stationary quantity: boards desynchronised with short searches, warmed up for a few game lengths at the full playout count,
@@ -354,7 +358,7 @@ def second_line(args, dev, qdist):
     torch.manual_seed(args.seed)
     net = PolicyValueNet(use_gpu=True, device=dev)
     B2 = min(args.boards, 4096)  # (round 3's board count: with fewer boards a board gets more of the network and the population ages faster towards its steady state)
-    eng = make_engine(args, net, dev, qdist.shard_seed(args.seed + 1, 0), True, boards=B2)
+    eng = make_engine(args, net, dev, qdist.shard_seed(args.seed + 1, 0), True, boards=B2, nn_precision=nn_precision)
     kw = dict(max_playouts=args.max_playouts, budget_us=args.second_line_budget_us)
     lens = []
 
@@ -387,21 +391,34 @@ def second_line(args, dev, qdist):
     st1 = eng.stats()
     d = {k: st1[k] - st0[k] for k in st1}
     eng.close()
-    open_s = d["open_rounds"] * dt / max(d["rounds"], 1)
-    return {"label": "NOT the headline and NOT the reference's arithmetic: terminal sign fixed (a won position backed up as +1; mcts.py:125 backs it up as -1)",
-            "value": games / dt, "unit": "games/s", "games_finished": games, "seconds": dt, "boards": B2, "n_playout": args.playouts,
-            "mean_plies_per_game": float(np.mean(lens)) if lens else None, "plies_per_s": d["plies_played"] / dt, "playouts_per_s": d["playouts"] / dt,
+    # The raw count is a TRANSIENT (the games that finish inside a short window are the ones the desync phase left close to their
+    # end: followed for seven minutes the same engine sinks from 300 to 146 games/s, profiles/round4/second_line_time_course_4096boards.json).
+    # `value` is therefore the stationary estimate, built like the headline's: boards / E[wall time of a game], plies per phase from the
+    # committed SIGN-FIXED length sample (benchmarks/r5_length_fix_job.sh), board-seconds per ply of each phase measured here.
+    rounds = max(d["rounds"], 1)
+    open_board_s = d["open_rounds"] * dt / rounds
+    end_board_s = max(B2 * rounds - d["open_rounds"], 0) * dt / rounds
+    length_file = _latest_profile("game_length_%dplayouts_sign_fixed.json" % args.playouts)
+    ss = steady_state_two_phase(B2, d["open_plies"], d["plies_played"] - d["open_plies"], open_board_s, end_board_s, length_file)
+    raw = games / dt
+    parity = nn_precision == "fp32"
+    return {"label": ("NOT the headline and NOT the reference's arithmetic: terminal sign fixed (a won position backed up as +1; mcts.py:125 backs it up as -1)"
+                      + ("" if parity else "; NON_PARITY network precision: ONE fp16 MFMA per product (p / v ~1e-3 from the reference instead of 1e-5)")),
+            "value": ss["value"] if ss else raw, "unit": "games/s",
+            "value_is": ("stationary estimate: boards / E[wall time of a game], plies per phase from %s, cost per ply of each phase measured in this run" % os.path.relpath(length_file, ROOT))
+                        if ss else "NO committed sign-fixed length sample: the raw (transient) count",
+            "value_transient": raw, "value_low": (ss or {}).get("value_low"), "value_high": (ss or {}).get("value_high"),
+            "length_estimate_converged": (ss or {}).get("length_estimate_converged"), "games_per_s_steady_state": ss,
+            "games_finished": games, "seconds": dt, "boards": B2, "n_playout": args.playouts,
+            "mean_plies_per_game_of_the_finished": float(np.mean(lens)) if lens else None, "plies_per_s": d["plies_played"] / dt, "playouts_per_s": d["playouts"] / dt,
             "nn_evaluations_per_s": d["nn_evals"] / dt, "memo_hit_rate": d["memo_hits"] / max(d["playouts"], 1),
-            "board_seconds_per_open_ply": open_s / max(d["open_plies"], 1), "nn_precision": "fp32 (parity: three fp16 MFMAs per product)",
-            "budget_us": args.second_line_budget_us, "nn_evaluations_per_game": d["nn_evals"] / max(games, 1),
-            "plies_per_s_over_mean_length_of_the_finished": (d["plies_played"] / dt / float(np.mean(lens))) if lens else None,  # an UPPER figure: the games that finish in a short window are the short ones
-            "note": "network-bound: with the sign fixed a game is ~150 plies of the open phase (the mover has walls: nearly every leaf is new) at 400 evaluations "
-                    "each; evaluations per game x games/s = the network's throughput.  Round 3's 409 games/s counted the games the 4-playout desync phase had left "
-                    "close to their end (a transient); this line is taken after the population has played at 400 playouts for --second-line-warm-seconds -- "
-                    "and is STILL a transient: over seven minutes the same engine goes from 300 to 146 games/s while the finished games' mean length grows from 500 to "
-                    "1,450 plies and plies/s settles at 308 k (profiles/round4/second_line_time_course_4096boards.json)",
-            "measured": "real finished games / wall time after %d desync plies at %d playouts and %.0f s of warm-up at %d playouts"
-                        % (args.desync_plies, args.desync_playouts, args.second_line_warm_seconds, args.playouts)}
+            "board_seconds_per_open_ply": open_board_s / max(d["open_plies"], 1),
+            "nn_precision": "fp32 (parity: three fp16 MFMAs per product)" if parity else "fp16 operands, ONE MFMA per product (NON_PARITY)",
+            "budget_us": args.second_line_budget_us, "nn_evaluations_per_game_transient": d["nn_evals"] / max(games, 1),
+            "note": "network-bound: with the sign fixed a game spends most of its board time in the open phase (the mover has walls: nearly every leaf is new) at 400 "
+                    "evaluations per ply; evaluations per game x games/s = the network's throughput",
+            "measured": "after %d desync plies at %d playouts and %.0f s of warm-up at %d playouts; %.0f s counted"
+                        % (args.desync_plies, args.desync_playouts, args.second_line_warm_seconds, args.playouts, dt)}
 
 
 # ------------------------------------------------------------------------------ the asynchronous loop (default)
@@ -653,15 +670,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--boards", type=int, default=10240, help="concurrent boards per GPU (8,192 = eight k_advance wavefronts per SIMD; same box, 1.8-ms budget: 8,192 / 9,216 / 9,728 / 10,240 / 11,264 boards = 294 / 306 / 312 / 313 / 284 M playouts/s; 4,096 = BASELINE configs[3]'s number)")
+    ap.add_argument("--boards", type=int, default=10240, help="concurrent boards per GPU (8,192 = eight k_advance wavefronts per SIMD; 4,096 = BASELINE configs[3]'s number; the sweep behind the default: profiles/round4/SUMMARY.md section 2)")
     ap.add_argument("--playouts", type=int, default=400)
     ap.add_argument("--groups", type=int, default=1, help="split the boards of a GPU into this many independent groups on their own HIP streams")
     ap.add_argument("--mode", default="async", choices=["async", "lockstep"])
     ap.add_argument("--rounds-per-step", type=int, default=256, help="async: rounds of the loop per step")
-    ap.add_argument("--budget-us", type=int, default=2400, help="async: wall-clock budget of a k_advance launch (8,192 boards, same box: 1000 / 1400 / 1800 / 2400 us = 271 / 285 / 291 / 287 M playouts/s; 9,728 boards: 1800 / 2400 / 3000 / 3600 us = 301 / 305 / 292 / 282 M; 10,240 boards at 2400 us: 310 M)")
+    ap.add_argument("--budget-us", type=int, default=2400, help="async: wall-clock budget of a k_advance launch in microseconds (the sweep behind the default: profiles/round4/SUMMARY.md section 2)")
     ap.add_argument("--max-playouts", type=int, default=4096, help="async: playouts a board may start per round")
     ap.add_argument("--graph-rounds", type=int, default=0, help="async: capture this many (even) rounds per HIP graph (0 = eager launches, per-kernel events)")
-    ap.add_argument("--event-every", type=int, default=64, help="async: every n-th round of group 0 is issued in pieces with HIP events around them (those rounds run their pieces one after the other: every 8th / 32nd / 64th / 256th = 308.3 / 312.7 / 313.7 / 314.7 M playouts/s)")
+    ap.add_argument("--event-every", type=int, default=64, help="async: every n-th round of group 0 (at least one per step) is issued in pieces with HIP events around them; those rounds run their pieces one after the other (cost of the timing: profiles/round4/SUMMARY.md section 1)")
     ap.add_argument("--max-depth", type=int, default=992, help="drop a game whose playout descends more than this many levels (0 = never): where the reference's "
                                                               "recursive backup (mcts.py:55-62) overflows Python's recursion limit and ends the run")
     ap.add_argument("--no-memo", action="store_true", help="async A/B: no leaf-evaluation memo (every leaf goes to the network)")
@@ -679,6 +696,7 @@ def main():
     ap.add_argument("--second-line-seconds", type=float, default=5.0, help="async, 1 GPU: length of the labelled second run with the terminal sign fixed (0 = skip it)")
     ap.add_argument("--second-line-warm-seconds", type=float, default=12.0)
     ap.add_argument("--second-line-budget-us", type=int, default=500, help="budget of a k_advance launch in the second line (its boards wait for the network nearly every playout)")
+    ap.add_argument("--no-non-parity-line", action="store_true", help="skip the labelled NON_PARITY second line (sign fixed + one fp16 MFMA per product)")
     ap.add_argument("--no-c3", action="store_true", help="skip the 32,768-board microbenchmark line (roofline_c3)")
     ap.add_argument("--no-planes", action="store_true", help="lockstep: the rules op only produces the legal sets (the evaluator reads the leaf boards)")
     ap.add_argument("--library-trunk", action="store_true", help="lockstep A/B: trunk convolutions through MIOpen instead of the split-fp16 MFMA kernel")

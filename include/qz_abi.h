@@ -443,19 +443,23 @@ int qz_nn_evaluate_w(const qz_boards* boards /*[dev] arrays*/, const uint8_t* te
  *                 qz_stats.waiting_boards == 0).  Non-zero: from then on the engine's boards are on their own clocks -- one
  *                 may be waiting for an evaluation or hold a move whose subtree copy is left for its next launch -- and
  *                 the lock-step tree entry points (qz_mcts_descend / select* / expand_backup* / update_with_move /
- *                 finish_move) return QZ_E_INVALID until qz_engine_reset or qz_engine_set_boards(reset_trees) */
+ *                 finish_move) return QZ_E_INVALID until qz_engine_reset or qz_engine_set_boards(reset_trees).  So does
+ *                 qz_selfplay_advance / qz_selfplay_round with auto_finish = 0 on such an engine: a board may be sitting
+ *                 out of k_advance with a subtree copy that only the moves' launch (auto_finish) continues, and would
+ *                 sit out for ever */
 int qz_selfplay_advance(qz_engine* e, int max_playouts, int budget_us, int auto_finish, void* stream);
 int qz_selfplay_leaf_rules(qz_engine* e, void* stream);
 int qz_selfplay_evaluate(qz_engine* e, const qz_nn_weights* w, void* stream);
 int qz_selfplay_round_tail(qz_engine* e, void* stream);
 int qz_selfplay_round(qz_engine* e, const qz_nn_weights* w, int max_playouts, int budget_us, int auto_finish, void* stream);
+/* which of the engine's two miss counters the NEXT qz_selfplay_advance uses (0 | 1; qz_selfplay_round_tail flips it,
+ * qz_engine_reset / qz_engine_set_boards(reset_trees) set it to 0).  A HIP graph captured over whole rounds bakes the
+ * counter's address in: replay it only while this value is what it was at capture time (SelfPlayEngine.capture_rounds
+ * keeps one graph per value). */
+int qz_selfplay_parity(qz_engine* e);
 /* the miss list of the round in progress (between qz_selfplay_advance and qz_selfplay_round_tail), engine-owned
  * device memory: boards, *n_dev = how many, their legal sets / network outputs once the two calls above have run.
  * For callers that evaluate the list themselves (another network) and for the tests. */
-/* which of the engine's two miss counters the NEXT qz_selfplay_advance uses (0 | 1; qz_selfplay_round_tail flips it,
- * qz_engine_reset / qz_engine_set_boards(reset_trees) set it to 0).  A HIP graph captured over whole rounds bakes the
- * counter's address in: replay it only while this value is what it was at capture time (run one eager round otherwise). */
-int qz_selfplay_parity(qz_engine* e);
 int qz_selfplay_misses(qz_engine* e, qz_boards* boards_out, const int32_t** n_dev_out, uint32_t** mask5_out /*[n][5]*/,
                        float** p_out /*[n][140]*/, float** v_out /*[n]*/);
 /* the weights changed (training step, checkpoint load): every stored evaluation is dead.  O(1): bumps the epoch the

@@ -390,6 +390,12 @@ def test_a_leftover_of_eager_rounds_does_not_break_a_captured_graph(gpu_device):
         assert sg["miss_overflow"] == 0 and sg["playouts"] == se["playouts"] and sg["nn_evals"] == se["nn_evals"] and sg["plies_played"] == se["plies_played"]
         # a reset between the pieces of a round leaves no stale counter behind
         from alphazero_quoridor_amd import _cabi
+        # an engine whose boards play their moves on the device refuses launches WITHOUT the moves' kernel: a board with a
+        # pending subtree copy sits out of k_advance and would never be continued
+        with pytest.raises(_cabi.QzError):
+            _cabi.check(g.L.qz_selfplay_advance(g.h, 4, 0, 0, g._s()))
+        with pytest.raises(_cabi.QzError):
+            g.selfplay_round(ev, 4, 0, auto_finish=False)
         _cabi.check(g.L.qz_selfplay_advance(g.h, 4, 0, 1, g._s()))
         g.reset()
         assert g.round_parity() == 0
