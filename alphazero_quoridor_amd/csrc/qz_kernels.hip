@@ -16,6 +16,7 @@
 //
 // Reference semantics: see qz_rules.h (rules) and the per-kernel comments (mcts.py).
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 
 #include "qz_rules.h"
@@ -371,20 +372,13 @@ union MasksEncShared {
 // Second launch of the pooled pipeline: mask groups (issue-bound: slot tests, floods) and
 // encoder groups (HBM-bound) are independent of each other, so they share one grid and
 // overlap on the CUs.
-template <int NB, int NBE>
-__global__ __launch_bounds__(256) void k_pool_masks_enc(const PoolHand* __restrict__ hands, int n,
-                                                        uint32_t* __restrict__ mask5, int n_mask_groups, int enc_tile0,
-                                                        const uint64_t* __restrict__ hb, const uint64_t* __restrict__ vb,
-                                                        const uint64_t* __restrict__ meta, const uint8_t* __restrict__ terminal,
-                                                        float* __restrict__ planes) {
-    __shared__ MasksEncShared<NB, NBE> smu;
-    const int tid = (int)threadIdx.x, lane = tid & 63;
-    if ((int)blockIdx.x >= n_mask_groups) {
-        encoder_group<NBE>(smu.enc, hb, vb, meta, n, terminal, planes, (enc_tile0 + (int)blockIdx.x - n_mask_groups) * NBE, tid);
-        return;
-    }
-    MasksShared<NB>& sm = smu.m;
-    const int b0 = (int)blockIdx.x * NB;
+// one mask group: the tile of NB boards from b0 (P2 slot tests -> pooled work list, P3 floods, P4 masks) from the hand-off
+// records of launch 1 / the path groups
+template <int NB>
+__device__ __forceinline__ void mask_group(MasksShared<NB>& sm, const PoolHand* __restrict__ hands, int n, uint32_t* __restrict__ mask5,
+                                           const uint64_t* __restrict__ hb, const uint64_t* __restrict__ vb, const uint64_t* __restrict__ meta,
+                                           const int b0, const int tid) {
+    const int lane = tid & 63;
     const int nb = (n - b0) < NB ? (n - b0) : NB;
     if (tid == 0) sm.n_items = 0u;
     {  // the tile's hand-off records into LDS (coalesced dword copy); srcpos tables cleared
@@ -436,6 +430,73 @@ __global__ __launch_bounds__(256) void k_pool_masks_enc(const PoolHand* __restri
 #pragma unroll
         for (int w = 0; w < 5; w++) mask5[(size_t)(b0 + tid) * 5 + w] = m5[w];
     }
+}
+template <int NB, int NBE>
+__global__ __launch_bounds__(256) void k_pool_masks_enc(const PoolHand* __restrict__ hands, int n,
+                                                        uint32_t* __restrict__ mask5, int n_mask_groups, int enc_tile0,
+                                                        const uint64_t* __restrict__ hb, const uint64_t* __restrict__ vb,
+                                                        const uint64_t* __restrict__ meta, const uint8_t* __restrict__ terminal,
+                                                        float* __restrict__ planes) {
+    __shared__ MasksEncShared<NB, NBE> smu;
+    const int tid = (int)threadIdx.x;
+    if ((int)blockIdx.x >= n_mask_groups) {
+        encoder_group<NBE>(smu.enc, hb, vb, meta, n, terminal, planes, (enc_tile0 + (int)blockIdx.x - n_mask_groups) * NBE, tid);
+        return;
+    }
+    mask_group<NB>(smu.m, hands, n, mask5, hb, vb, meta, (int)blockIdx.x * NB, tid);
+}
+
+// The pooled pipeline as ONE launch (round 5; the default from 8,192 boards on).  Workgroups by role, in grid order:
+//   [path groups][encoder tiles A][mask groups][encoder tiles B]
+// The chip hands out workgroups in grid order, so every path group is resident before any later workgroup starts.  A path
+// group publishes its 128 boards' hand-off records with a release at device scope and sets ready[group] = tag; a mask group
+// waits (one lane, s_sleep between polls, acquire at device scope) for the one or two path groups its tile of boards comes
+// from.  What the two-launch form loses at the launch boundary -- ~5 us of gap, and the second half of the encoder tiles
+// queued BEHIND the mask groups of a launch that cannot start before the first is completely done -- is gone: the mask
+// groups are placed (and wait) while encoder tiles A still run, encoder tiles B fill the slots beside them.
+// `tag` is unique per launch (a process-wide counter spread over 64 bits), so the flags need no reset and no particular
+// initial content; a launch captured into a HIP graph would replay its tag: the launcher keeps the two-launch form there.
+template <int NB, int NBE>
+__global__ __launch_bounds__(256) void k_pool_fused(const uint64_t* __restrict__ hb, const uint64_t* __restrict__ vb,
+                                                    const uint64_t* __restrict__ meta, int n, const uint8_t* __restrict__ terminal,
+                                                    PoolHand* __restrict__ hands, unsigned long long* __restrict__ ready, unsigned long long tag,
+                                                    uint32_t* __restrict__ mask5, float* __restrict__ planes, int n_path_groups, int enc_a,
+                                                    int n_mask_groups, int detour_mode) {
+    __shared__ MasksEncShared<NB, NBE> smu;
+    const int tid = (int)threadIdx.x;
+    int bid = (int)blockIdx.x;
+    if (bid < n_path_groups) {
+        const int task = bid * 256 + tid;
+        const int b = task >> 1, p = (task & 1) + 1;
+        if (b < n) {
+            Board bd = unpack(hb[b], vb[b], meta[b]);
+            bool term = terminal ? (terminal[b] != 0) : false;
+            pool_k1_hand(bd, term, p, hands[b], detour_mode);
+        }
+        __threadfence();   // every lane's record is on its way out of this XCD's L2 ...
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(ready + bid, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);  // ... before the flag says so
+        return;
+    }
+    bid -= n_path_groups;
+    if (bid < enc_a) {
+        encoder_group<NBE>(smu.enc, hb, vb, meta, n, terminal, planes, bid * NBE, tid);
+        return;
+    }
+    bid -= enc_a;
+    if (bid < n_mask_groups) {
+        const int b0 = bid * NB;
+        const int b1 = (b0 + NB < n ? b0 + NB : n) - 1;  // last board of the tile
+        if (tid == 0) {
+            for (int j = (2 * b0) >> 8; j <= (2 * b1 + 1) >> 8; j++)
+                while (__hip_atomic_load(ready + j, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != tag) __builtin_amdgcn_s_sleep(16);
+        }
+        __syncthreads();
+        mask_group<NB>(smu.m, hands, n, mask5, hb, vb, meta, b0, tid);
+        return;
+    }
+    bid -= n_mask_groups;
+    encoder_group<NBE>(smu.enc, hb, vb, meta, n, terminal, planes, (enc_a + bid) * NBE, tid);
 }
 
 // Quoridor.step() + has_a_winner(): one thread per board, fully coalesced SoA traffic
@@ -826,6 +887,14 @@ __device__ __forceinline__ void select_core(EngineDev& E, BoardRegs& S, const in
         uint32_t* const we = pe0 + (size_t)R * CAP;  // this descent (what the backup reads)
         unsigned long long* const wb = pb0 + (size_t)R * CAP;
         const bool use = (E.select_opts & 1) == 0;
+#ifndef QZ_SCAN_AT_END
+#define QZ_SCAN_AT_END 1
+#endif
+        // `scanned` (edge records looked at: a statistic, the roofline's algorithmic bytes) = the sum of the descent's nodes'
+        // child counts.  Every level's block entry (base << 8 | count) is in the descent buffer when the descent ends, so with
+        // the LDS mirror (k_advance) ONE pass lane = level adds them up at the leaf -- instead of four ballots + popcounts in
+        // every replay round and an add per walked level, all on the scalar unit of an issue-bound kernel.
+        const bool scan_at_end = QZ_SCAN_AT_END && PM.cap > 0u;
         // lane r < R keeps record r's length and the time it was last useful
         if (!use) S.rlen = 0u;
         uint32_t& rlen = S.rlen;      // (ONE copy: a second one lived in a register of its own across the whole descent)
@@ -996,7 +1065,7 @@ __device__ __forceinline__ void select_core(EngineDev& E, BoardRegs& S, const in
                     }
                     used |= 1u << cur;
                     done = apply_actions_wave(bd, lact, nconf, lane);
-                    {   // edge records scanned by the confirmed levels (statistics): lne is 1..8, four ballots
+                    if (!scan_at_end) {   // edge records scanned by the confirmed levels (statistics): lne is 1..8, four ballots
                         const uint64_t inm = nconf >= 64 ? ~0ull : ((1ull << nconf) - 1ull);
                         const uint32_t l1 = (uint32_t)lne - 1u;  // 0..7
                         scanned += (uint32_t)nconf + (uint32_t)__popcll(__ballot((l1 & 1u) != 0u) & inm) + 2u * (uint32_t)__popcll(__ballot((l1 & 2u) != 0u) & inm) +
@@ -1044,7 +1113,7 @@ __device__ __forceinline__ void select_core(EngineDev& E, BoardRegs& S, const in
             uint32_t recorded = QZ_NONE;
             if (sel_valid) recorded = sel_rec;
             else if (cur != QZ_NONE && plen < cur_len) recorded = pe0[(size_t)cur * CAP + plen];  // uniform load, in flight during the scan
-            scanned += (uint32_t)ne;
+            if (!scan_at_end) scanned += (uint32_t)ne;
             int kk;
             uint32_t misc, w_coff;
             double w_sq;  // of the winning edge: act | cne << 8 | rid << 16, its child block, sqrt(its visit count) = the next level's sqrt(N_parent)
@@ -1188,6 +1257,12 @@ __device__ __forceinline__ void select_core(EngineDev& E, BoardRegs& S, const in
         }
         QZ_TS(1)
         at_leaf_hook(bd, done);
+        if (scan_at_end) {
+            const uint32_t nrec = plen < CAP ? plen : CAP;
+            uint32_t sc = 0u;
+            for (uint32_t i = (uint32_t)lane; i < nrec; i += 64u) sc += (uint32_t)((i < PM.cap ? PM.wb[i] : wb[i]) & 0xFFull);
+            scanned = wave_sum_u32(sc);
+        }
         // (all wave-uniform by construction; said so explicitly, or the compiler carries them -- and the record bookkeeping
         // derived from them -- in vector registers it does not have: their scratch reloads each drain the store queue)
         cur = rfl(cur);
@@ -2213,7 +2288,25 @@ __global__ __launch_bounds__(TPB) void k_finish_move(EngineDev E, const uint8_t*
 
 // ---------------------------------------------------------------------------- leaf-evaluation memo
 // (layout: qz_device.h, MemoDev)
+#ifndef QZ_MEMO_HASH32
+#define QZ_MEMO_HASH32 1
+#endif
+// (which bucket a board's evaluation lives in: any function of the key will do -- a hit is decided by the compare of all 24 bytes)
 __device__ __forceinline__ uint64_t memo_hash(uint64_t hb, uint64_t vb, uint64_t meta) {
+#if QZ_MEMO_HASH32
+    // Six 32-bit multiplies of the key's words + a 32-bit finaliser: ~20 scalar instructions.  Round 4's form -- five 64 x 64-bit
+    // multiplies, each six scalar instructions on this chip -- was ~50 of the ~1,100 instructions of every playout of k_advance
+    // (the board is wave-uniform: the hash runs on the scalar unit), and the kernel is issue-bound.  The bucket index is the
+    // hash's low bits (at most 24): every output bit depends on every input bit after the three xor-shift / multiply steps.
+    uint32_t x = ((uint32_t)hb * 0x9E3779B1u) ^ ((uint32_t)(hb >> 32) * 0x85EBCA77u) ^ ((uint32_t)vb * 0xC2B2AE3Du) ^ ((uint32_t)(vb >> 32) * 0x27D4EB2Fu) ^
+                 ((uint32_t)meta * 0x165667B1u) ^ ((uint32_t)(meta >> 32) * 0xD6E8FEB9u);
+    x ^= x >> 15;
+    x *= 0x2C1B3C6Du;
+    x ^= x >> 12;
+    x *= 0x297A2D39u;
+    x ^= x >> 15;
+    return (uint64_t)x;
+#else
     uint64_t x = (hb * 0x9E3779B97F4A7C15ull) ^ ((vb + 0xD1B54A32D192ED03ull) * 0xC2B2AE3D27D4EB4Full) ^ (meta * 0x165667B19E3779F9ull);
     x ^= x >> 32;
     x *= 0xD6E8FEB86659FD93ull;
@@ -2221,6 +2314,7 @@ __device__ __forceinline__ uint64_t memo_hash(uint64_t hb, uint64_t vb, uint64_t
     x *= 0xD6E8FEB86659FD93ull;
     x ^= x >> 32;
     return x;
+#endif
 }
 // the key dword a lane compares its loaded dword with: entry dwords 0..5 = hb, vb, meta | epoch << 48
 __device__ __forceinline__ uint32_t memo_key_dword(int pos, uint64_t hb, uint64_t vb, uint64_t mk) {
@@ -2896,6 +2990,14 @@ static inline dim3 wave_grid(int n) { return dim3((unsigned)((n + WPB - 1) / WPB
 constexpr int NBE = QZ_NBE;  // boards per encoder group (8 and 32 measured at 32,768 boards: see DESIGN 9.2)
 
 template <int NB>
+static void launch_fused(const uint64_t* hb, const uint64_t* vb, const uint64_t* meta, int n, const uint8_t* terminal, PoolHand* hands,
+                         unsigned long long* ready, unsigned long long tag, uint32_t* mask5, float* planes, int n_path_groups, int enc_a, int enc_b,
+                         int detour_mode, hipStream_t s) {
+    const int n_mask_groups = (n + NB - 1) / NB;
+    hipLaunchKernelGGL((k_pool_fused<NB, NBE>), dim3((unsigned)(n_path_groups + enc_a + n_mask_groups + enc_b)), dim3(256), 0, s, hb, vb, meta, n, terminal,
+                       hands, ready, tag, mask5, planes, n_path_groups, enc_a, n_mask_groups, detour_mode);
+}
+template <int NB>
 static void launch_masks_enc(const PoolHand* hands, int n, uint32_t* mask5, const uint64_t* hb,
                              const uint64_t* vb, const uint64_t* meta, const uint8_t* terminal, float* planes, int enc_tile0,
                              int n_enc_groups, hipStream_t s) {
@@ -2905,7 +3007,10 @@ static void launch_masks_enc(const PoolHand* hands, int n, uint32_t* mask5, cons
                        mask5, n_mask_groups, enc_tile0, hb, vb, meta, terminal, planes);
 }
 
-size_t movegen_scratch_bytes(int n) { return (size_t)n * sizeof(PoolHand); }  // 184 B per board (round 3: 1,522)
+// 184 B per board (round 3: 1,522) + one 8-byte ready flag per path group of 128 boards (k_pool_fused)
+static inline size_t hands_bytes(int n) { return (((size_t)n * sizeof(PoolHand)) + 15u) & ~(size_t)15u; }
+size_t movegen_scratch_bytes(int n) { return hands_bytes(n) + 8u * (size_t)((2 * n + 255) / 256 + 1); }
+static std::atomic<unsigned long long> g_fused_launches{0};
 
 hipError_t movegen_encode(const uint64_t* hb, const uint64_t* vb, const uint64_t* meta, int n, uint32_t* mask5,
                           float* planes, const uint8_t* terminal, void* scratch, const RulesOpts& ro, hipStream_t s, const int* n_dev) {
@@ -2914,7 +3019,7 @@ hipError_t movegen_encode(const uint64_t* hb, const uint64_t* vb, const uint64_t
     // Small batches are latency-bound: one launch, a wavefront per board, no hand-off through
     // HBM (k_wave_rules).  From ~8k boards on the chip is saturated and the pooled two-launch
     // pipeline, which packs lanes better, wins.
-    if (n_dev || (ro.variant >= 2 && ro.variant <= 6) || (ro.variant == 0 && n < 8192)) {
+    if (n_dev || (ro.variant >= 2 && ro.variant <= 6) || ((ro.variant == 0 || ro.variant == 7) && n < 8192)) {
         const int n_enc_groups = planes ? (n + NBE - 1) / NBE : 0;
         // boards per wavefront: on bench trees (late-game boards, many without walls left) one board per
         // wavefront measured 29.1 us vs 33.0 (two) / 34.6 (four) at 4,096 boards; on the synthetic
@@ -2940,12 +3045,32 @@ hipError_t movegen_encode(const uint64_t* hb, const uint64_t* vb, const uint64_t
     // 72.4 / 77.3, 60 % 67.5 / 71.9 / 78.6, 70 % 67.8 / 73.7 / 80.5 (70 % was the optimum of round 1's kernels).
     const int enc_total = planes ? (n + NBE - 1) / NBE : 0;
     const int enc_a = mask5 ? (enc_total * ro.enc_split_pct) / 100 : 0;
+    int nbt = ro.variant >= 8 ? ro.variant : (n >= 16384 ? 24 : (n >= 8192 ? 16 : 8));
+    // ONE launch (k_pool_fused) unless asked for the two-launch form (variant 7: its A/B and parity partner) or the stream is
+    // being captured into a HIP graph (a replay would repeat the launch's tag: the ready flags would already carry it)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess) {
+        (void)hipGetLastError();
+        cap = hipStreamCaptureStatusActive;
+    }
+    if (mask5 && ro.variant != 7 && cap == hipStreamCaptureStatusNone) {
+        const int n_path_groups = (2 * n + 255) / 256;
+        unsigned long long* ready = reinterpret_cast<unsigned long long*>(reinterpret_cast<uint8_t*>(scratch) + hands_bytes(n));
+        const unsigned long long k = g_fused_launches.fetch_add(1ull) + 1ull;
+        const unsigned long long tag = (k * 0x9E3779B97F4A7C15ull) | 1ull;  // odd, distinct for 2^63 launches; fresh memory equals it with probability 2^-63
+        const int enc_b = enc_total - enc_a;
+        if (nbt >= 32) launch_fused<32>(hb, vb, meta, n, terminal, hands, ready, tag, mask5, planes, n_path_groups, enc_a, enc_b, ro.detour_pooled, s);
+        else if (nbt >= 24) launch_fused<24>(hb, vb, meta, n, terminal, hands, ready, tag, mask5, planes, n_path_groups, enc_a, enc_b, ro.detour_pooled, s);
+        else if (nbt >= 16) launch_fused<16>(hb, vb, meta, n, terminal, hands, ready, tag, mask5, planes, n_path_groups, enc_a, enc_b, ro.detour_pooled, s);
+        else if (nbt >= 12) launch_fused<12>(hb, vb, meta, n, terminal, hands, ready, tag, mask5, planes, n_path_groups, enc_a, enc_b, ro.detour_pooled, s);
+        else launch_fused<8>(hb, vb, meta, n, terminal, hands, ready, tag, mask5, planes, n_path_groups, enc_a, enc_b, ro.detour_pooled, s);
+        return hipGetLastError();
+    }
     if (mask5) {
         const int n_path_groups = (2 * n + 255) / 256;
         hipLaunchKernelGGL((k_pool_paths_enc<NBE>), dim3((unsigned)(n_path_groups + enc_a)), dim3(256), 0, s, hb, vb, meta, n,
                            terminal, hands, n_path_groups, planes, ro.detour_pooled);
     }
-    int nbt = ro.variant >= 8 ? ro.variant : (n >= 16384 ? 24 : (n >= 8192 ? 16 : 8));
     const int enc_b = enc_total - enc_a;
     if (nbt >= 32) launch_masks_enc<32>(hands, n, mask5, hb, vb, meta, terminal, planes, enc_a, enc_b, s);
     else if (nbt >= 24) launch_masks_enc<24>(hands, n, mask5, hb, vb, meta, terminal, planes, enc_a, enc_b, s);

@@ -585,6 +585,14 @@ def test_steady_state_estimator_of_the_bench_line(tmp_path):
     d = json.load(open(committed))
     assert d["n_playout"] == 400 and d["mean_open_plies_per_game"] > 0 and d["restricted_mean"] < d["mean_plies_per_game"]
     assert d["mean_ci95"][0] < d["mean_plies_per_game"] < d["mean_ci95"][1] and d["games_censored"] <= d["boards"]
+    # ... and so does the SIGN-FIXED sample behind the second line's stationary `value`: the estimator the
+    # second line uses is this one, on that file
+    fixed = bench._latest_profile("game_length_400playouts_sign_fixed.json")
+    assert fixed is not None
+    df = json.load(open(fixed))
+    assert df["n_playout"] == 400 and df["mean_open_plies_per_game"] > 0 and df["restricted_mean"] < df["mean_plies_per_game"] < d["mean_plies_per_game"]
+    s3 = bench.steady_state_two_phase(4096, 1000.0, 50000.0, 40.0, 60.0, fixed)
+    assert s3["value_low"] < s3["value"] < s3["value_high"] and s3["length_source"].endswith("game_length_400playouts_sign_fixed.json")
     # benchmarks/game_length.py's estimators on a hand-made sample: Kaplan-Meier with right-censored observations, and the
     # window-doubling comparison the bench line quotes
     sys.path.insert(0, os.path.join(ROOT, "benchmarks"))
