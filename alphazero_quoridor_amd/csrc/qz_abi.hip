@@ -113,7 +113,11 @@ static RulesOpts rules_opts(const qz_rules_opts* o) {
     r.variant = o->variant;
     if (o->detour_pooled > 0) r.detour_pooled = o->detour_pooled - 1;
     if (o->detour_wave > 0) r.detour_wave = o->detour_wave - 1;
-    if (o->enc_split_pct > 0) r.enc_split_pct = o->enc_split_pct > 100 ? 100 : o->enc_split_pct;
+    if (o->enc_split_pct > 0) {  // split + 1000 x (1 + first): see qz_rules_opts
+        const int split = o->enc_split_pct % 1000, first = o->enc_split_pct / 1000 - 1;
+        if (split > 0) r.enc_split_pct = split > 100 ? 100 : split;
+        if (first >= 0) r.enc_first_pct = first > 100 ? 100 : first;
+    }
     return r;
 }
 

@@ -107,6 +107,7 @@ struct RulesOpts {
     int variant = 0;
     int detour_pooled = 1, detour_wave = 0;  // pool_k1's detour_mode per kernel family
     int enc_split_pct = 50;                  // share of the encoder tiles beside the path groups
+    int enc_first_pct = 0;                   // share of the second launch's encoder tiles placed in FRONT of its mask groups in the grid
 };
 
 // Leaf-evaluation memo.  policy_value_fn on a batch of one (policy_value_net.py:145-164, BatchNorm in training mode)

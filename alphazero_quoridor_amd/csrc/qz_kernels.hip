@@ -16,7 +16,6 @@
 //
 // Reference semantics: see qz_rules.h (rules) and the per-kernel comments (mcts.py).
 #include <hip/hip_runtime.h>
-#include <atomic>
 #include <stdint.h>
 
 #include "qz_rules.h"
@@ -436,67 +435,21 @@ __global__ __launch_bounds__(256) void k_pool_masks_enc(const PoolHand* __restri
                                                         uint32_t* __restrict__ mask5, int n_mask_groups, int enc_tile0,
                                                         const uint64_t* __restrict__ hb, const uint64_t* __restrict__ vb,
                                                         const uint64_t* __restrict__ meta, const uint8_t* __restrict__ terminal,
-                                                        float* __restrict__ planes) {
+                                                        float* __restrict__ planes, int n_enc_first) {
     __shared__ MasksEncShared<NB, NBE> smu;
     const int tid = (int)threadIdx.x;
-    if ((int)blockIdx.x >= n_mask_groups) {
-        encoder_group<NBE>(smu.enc, hb, vb, meta, n, terminal, planes, (enc_tile0 + (int)blockIdx.x - n_mask_groups) * NBE, tid);
-        return;
-    }
-    mask_group<NB>(smu.m, hands, n, mask5, hb, vb, meta, (int)blockIdx.x * NB, tid);
-}
-
-// The pooled pipeline as ONE launch (round 5; the default from 8,192 boards on).  Workgroups by role, in grid order:
-//   [path groups][encoder tiles A][mask groups][encoder tiles B]
-// The chip hands out workgroups in grid order, so every path group is resident before any later workgroup starts.  A path
-// group publishes its 128 boards' hand-off records with a release at device scope and sets ready[group] = tag; a mask group
-// waits (one lane, s_sleep between polls, acquire at device scope) for the one or two path groups its tile of boards comes
-// from.  What the two-launch form loses at the launch boundary -- ~5 us of gap, and the second half of the encoder tiles
-// queued BEHIND the mask groups of a launch that cannot start before the first is completely done -- is gone: the mask
-// groups are placed (and wait) while encoder tiles A still run, encoder tiles B fill the slots beside them.
-// `tag` is unique per launch (a process-wide counter spread over 64 bits), so the flags need no reset and no particular
-// initial content; a launch captured into a HIP graph would replay its tag: the launcher keeps the two-launch form there.
-template <int NB, int NBE>
-__global__ __launch_bounds__(256) void k_pool_fused(const uint64_t* __restrict__ hb, const uint64_t* __restrict__ vb,
-                                                    const uint64_t* __restrict__ meta, int n, const uint8_t* __restrict__ terminal,
-                                                    PoolHand* __restrict__ hands, unsigned long long* __restrict__ ready, unsigned long long tag,
-                                                    uint32_t* __restrict__ mask5, float* __restrict__ planes, int n_path_groups, int enc_a,
-                                                    int n_mask_groups, int detour_mode) {
-    __shared__ MasksEncShared<NB, NBE> smu;
-    const int tid = (int)threadIdx.x;
+    // grid order = dispatch order: [n_enc_first encoder tiles][mask groups][the other encoder tiles]
     int bid = (int)blockIdx.x;
-    if (bid < n_path_groups) {
-        const int task = bid * 256 + tid;
-        const int b = task >> 1, p = (task & 1) + 1;
-        if (b < n) {
-            Board bd = unpack(hb[b], vb[b], meta[b]);
-            bool term = terminal ? (terminal[b] != 0) : false;
-            pool_k1_hand(bd, term, p, hands[b], detour_mode);
-        }
-        __threadfence();   // every lane's record is on its way out of this XCD's L2 ...
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(ready + bid, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);  // ... before the flag says so
+    if (bid < n_enc_first) {
+        encoder_group<NBE>(smu.enc, hb, vb, meta, n, terminal, planes, (enc_tile0 + bid) * NBE, tid);
         return;
     }
-    bid -= n_path_groups;
-    if (bid < enc_a) {
-        encoder_group<NBE>(smu.enc, hb, vb, meta, n, terminal, planes, bid * NBE, tid);
+    bid -= n_enc_first;
+    if (bid >= n_mask_groups) {
+        encoder_group<NBE>(smu.enc, hb, vb, meta, n, terminal, planes, (enc_tile0 + n_enc_first + bid - n_mask_groups) * NBE, tid);
         return;
     }
-    bid -= enc_a;
-    if (bid < n_mask_groups) {
-        const int b0 = bid * NB;
-        const int b1 = (b0 + NB < n ? b0 + NB : n) - 1;  // last board of the tile
-        if (tid == 0) {
-            for (int j = (2 * b0) >> 8; j <= (2 * b1 + 1) >> 8; j++)
-                while (__hip_atomic_load(ready + j, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != tag) __builtin_amdgcn_s_sleep(16);
-        }
-        __syncthreads();
-        mask_group<NB>(smu.m, hands, n, mask5, hb, vb, meta, b0, tid);
-        return;
-    }
-    bid -= n_mask_groups;
-    encoder_group<NBE>(smu.enc, hb, vb, meta, n, terminal, planes, (enc_a + bid) * NBE, tid);
+    mask_group<NB>(smu.m, hands, n, mask5, hb, vb, meta, bid * NB, tid);
 }
 
 // Quoridor.step() + has_a_winner(): one thread per board, fully coalesced SoA traffic
@@ -2990,27 +2943,17 @@ static inline dim3 wave_grid(int n) { return dim3((unsigned)((n + WPB - 1) / WPB
 constexpr int NBE = QZ_NBE;  // boards per encoder group (8 and 32 measured at 32,768 boards: see DESIGN 9.2)
 
 template <int NB>
-static void launch_fused(const uint64_t* hb, const uint64_t* vb, const uint64_t* meta, int n, const uint8_t* terminal, PoolHand* hands,
-                         unsigned long long* ready, unsigned long long tag, uint32_t* mask5, float* planes, int n_path_groups, int enc_a, int enc_b,
-                         int detour_mode, hipStream_t s) {
-    const int n_mask_groups = (n + NB - 1) / NB;
-    hipLaunchKernelGGL((k_pool_fused<NB, NBE>), dim3((unsigned)(n_path_groups + enc_a + n_mask_groups + enc_b)), dim3(256), 0, s, hb, vb, meta, n, terminal,
-                       hands, ready, tag, mask5, planes, n_path_groups, enc_a, n_mask_groups, detour_mode);
-}
-template <int NB>
 static void launch_masks_enc(const PoolHand* hands, int n, uint32_t* mask5, const uint64_t* hb,
                              const uint64_t* vb, const uint64_t* meta, const uint8_t* terminal, float* planes, int enc_tile0,
-                             int n_enc_groups, hipStream_t s) {
+                             int n_enc_groups, hipStream_t s, int enc_first_pct = 0) {
     const int n_mask_groups = mask5 ? (n + NB - 1) / NB : 0;
     if (n_mask_groups + n_enc_groups == 0) return;
+    const int n_enc_first = n_mask_groups ? (n_enc_groups * enc_first_pct) / 100 : 0;
     hipLaunchKernelGGL((k_pool_masks_enc<NB, NBE>), dim3((unsigned)(n_mask_groups + n_enc_groups)), dim3(256), 0, s, hands, n,
-                       mask5, n_mask_groups, enc_tile0, hb, vb, meta, terminal, planes);
+                       mask5, n_mask_groups, enc_tile0, hb, vb, meta, terminal, planes, n_enc_first);
 }
 
-// 184 B per board (round 3: 1,522) + one 8-byte ready flag per path group of 128 boards (k_pool_fused)
-static inline size_t hands_bytes(int n) { return (((size_t)n * sizeof(PoolHand)) + 15u) & ~(size_t)15u; }
-size_t movegen_scratch_bytes(int n) { return hands_bytes(n) + 8u * (size_t)((2 * n + 255) / 256 + 1); }
-static std::atomic<unsigned long long> g_fused_launches{0};
+size_t movegen_scratch_bytes(int n) { return (size_t)n * sizeof(PoolHand); }  // 184 B per board (round 3: 1,522)
 
 hipError_t movegen_encode(const uint64_t* hb, const uint64_t* vb, const uint64_t* meta, int n, uint32_t* mask5,
                           float* planes, const uint8_t* terminal, void* scratch, const RulesOpts& ro, hipStream_t s, const int* n_dev) {
@@ -3046,37 +2989,17 @@ hipError_t movegen_encode(const uint64_t* hb, const uint64_t* vb, const uint64_t
     const int enc_total = planes ? (n + NBE - 1) / NBE : 0;
     const int enc_a = mask5 ? (enc_total * ro.enc_split_pct) / 100 : 0;
     int nbt = ro.variant >= 8 ? ro.variant : (n >= 16384 ? 24 : (n >= 8192 ? 16 : 8));
-    // ONE launch (k_pool_fused) unless asked for the two-launch form (variant 7: its A/B and parity partner) or the stream is
-    // being captured into a HIP graph (a replay would repeat the launch's tag: the ready flags would already carry it)
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &cap) != hipSuccess) {
-        (void)hipGetLastError();
-        cap = hipStreamCaptureStatusActive;
-    }
-    if (mask5 && ro.variant != 7 && cap == hipStreamCaptureStatusNone) {
-        const int n_path_groups = (2 * n + 255) / 256;
-        unsigned long long* ready = reinterpret_cast<unsigned long long*>(reinterpret_cast<uint8_t*>(scratch) + hands_bytes(n));
-        const unsigned long long k = g_fused_launches.fetch_add(1ull) + 1ull;
-        const unsigned long long tag = (k * 0x9E3779B97F4A7C15ull) | 1ull;  // odd, distinct for 2^63 launches; fresh memory equals it with probability 2^-63
-        const int enc_b = enc_total - enc_a;
-        if (nbt >= 32) launch_fused<32>(hb, vb, meta, n, terminal, hands, ready, tag, mask5, planes, n_path_groups, enc_a, enc_b, ro.detour_pooled, s);
-        else if (nbt >= 24) launch_fused<24>(hb, vb, meta, n, terminal, hands, ready, tag, mask5, planes, n_path_groups, enc_a, enc_b, ro.detour_pooled, s);
-        else if (nbt >= 16) launch_fused<16>(hb, vb, meta, n, terminal, hands, ready, tag, mask5, planes, n_path_groups, enc_a, enc_b, ro.detour_pooled, s);
-        else if (nbt >= 12) launch_fused<12>(hb, vb, meta, n, terminal, hands, ready, tag, mask5, planes, n_path_groups, enc_a, enc_b, ro.detour_pooled, s);
-        else launch_fused<8>(hb, vb, meta, n, terminal, hands, ready, tag, mask5, planes, n_path_groups, enc_a, enc_b, ro.detour_pooled, s);
-        return hipGetLastError();
-    }
     if (mask5) {
         const int n_path_groups = (2 * n + 255) / 256;
         hipLaunchKernelGGL((k_pool_paths_enc<NBE>), dim3((unsigned)(n_path_groups + enc_a)), dim3(256), 0, s, hb, vb, meta, n,
                            terminal, hands, n_path_groups, planes, ro.detour_pooled);
     }
     const int enc_b = enc_total - enc_a;
-    if (nbt >= 32) launch_masks_enc<32>(hands, n, mask5, hb, vb, meta, terminal, planes, enc_a, enc_b, s);
-    else if (nbt >= 24) launch_masks_enc<24>(hands, n, mask5, hb, vb, meta, terminal, planes, enc_a, enc_b, s);
-    else if (nbt >= 16) launch_masks_enc<16>(hands, n, mask5, hb, vb, meta, terminal, planes, enc_a, enc_b, s);
-    else if (nbt >= 12) launch_masks_enc<12>(hands, n, mask5, hb, vb, meta, terminal, planes, enc_a, enc_b, s);
-    else launch_masks_enc<8>(hands, n, mask5, hb, vb, meta, terminal, planes, enc_a, enc_b, s);
+    if (nbt >= 32) launch_masks_enc<32>(hands, n, mask5, hb, vb, meta, terminal, planes, enc_a, enc_b, s, ro.enc_first_pct);
+    else if (nbt >= 24) launch_masks_enc<24>(hands, n, mask5, hb, vb, meta, terminal, planes, enc_a, enc_b, s, ro.enc_first_pct);
+    else if (nbt >= 16) launch_masks_enc<16>(hands, n, mask5, hb, vb, meta, terminal, planes, enc_a, enc_b, s, ro.enc_first_pct);
+    else if (nbt >= 12) launch_masks_enc<12>(hands, n, mask5, hb, vb, meta, terminal, planes, enc_a, enc_b, s, ro.enc_first_pct);
+    else launch_masks_enc<8>(hands, n, mask5, hb, vb, meta, terminal, planes, enc_a, enc_b, s, ro.enc_first_pct);
     return hipGetLastError();
 }
 hipError_t step(uint64_t* hb, uint64_t* vb, uint64_t* meta, const uint8_t* action, int n, uint8_t* done, uint8_t* winner,

@@ -216,7 +216,7 @@ def c3_microbench(dev, launches=60):
     t = _load_json(tf or "")
     return {"workload": "BASELINE configs[2] microbenchmark: 32,768 boards (S-mid: 0..20 plies of random legal play, mover has a wall), actions() + state(), "
                         "inputs resident in HBM, NOT part of the timed region",
-            "kernel": "k_pool_fused (pooled pipeline in ONE launch: path groups, encoder tiles, mask groups waiting on ready flags; 184-byte hand-off record per board)",
+            "kernel": "k_pool_paths_enc + k_pool_masks_enc (pooled pipeline, two launches, 184-byte hand-off record per board)",
             "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
             "traffic": t.get("traffic_bytes_per_launch") if t else None, "traffic_source": ("profiles: " + os.path.relpath(tf, ROOT)) if t else None,
             "traffic_over_algorithmic": (t["traffic_bytes_per_launch"] / (n * BYTES_PER_BOARD)) if t else None,

@@ -77,13 +77,13 @@ int qz_movegen_encode(const qz_boards* boards, int n, uint32_t* mask5 /*[dev]*/,
  *                  there on), 2 | 3 | 4 = k_wave_rules with 2 | 1 | 4 boards per wavefront (3 = what 0
  *                  picks for small batches: base paths searched on nine lanes per player, planes as
  *                  streaming stores), 5 = 3 with one base-path search per lane, 6 = 3 with ordinary
- *                  stores (parity / A-B partners), 7 = the pooled pipeline as the two launches of rounds 1-4
- *                  (A-B / parity partner of the single launch 0 picks from 8,192 boards on; also what a
- *                  stream under HIP-graph capture gets), 8 | 12 | 16 | 24 | 32 = pooled pipeline with that
+ *                  stores (parity / A-B partners), 8 | 12 | 16 | 24 | 32 = pooled pipeline with that
  *                  many boards per mask workgroup
  *   detour_pooled  group-detour mode of the pooled pipeline: 0 = default (one group), else 1 + mode
  *   detour_wave    ... of k_wave_rules: 0 = default (off), else 1 + mode (mode 0 | 1 | 2)
- *   enc_split_pct  0 = default (50): percent of the encoder groups beside the path groups */
+ *   enc_split_pct  0 = default (50): percent of the encoder groups beside the path groups (first launch of the pooled
+ *                  pipeline); + 1000 x (1 + f): f percent of the SECOND launch's encoder groups are placed in front of its
+ *                  mask groups in the grid (= dispatch) order, the rest behind them (default: see RulesOpts in qz_device.h) */
 typedef struct {
     int32_t variant, detour_pooled, detour_wave, enc_split_pct;
 } qz_rules_opts;
