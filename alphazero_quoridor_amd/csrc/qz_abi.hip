@@ -116,7 +116,7 @@ static RulesOpts rules_opts(const qz_rules_opts* o) {
     if (o->enc_split_pct > 0) {  // split + 1000 x (1 + first): see qz_rules_opts
         const int split = o->enc_split_pct % 1000, first = o->enc_split_pct / 1000 - 1;
         if (split > 0) r.enc_split_pct = split > 100 ? 100 : split;
-        if (first >= 0) r.enc_first_pct = first > 100 ? 100 : first;
+        if (first >= 0) r.enc_first_pct = first > 800 ? 800 : first;
     }
     return r;
 }

@@ -435,18 +435,26 @@ __global__ __launch_bounds__(256) void k_pool_masks_enc(const PoolHand* __restri
                                                         uint32_t* __restrict__ mask5, int n_mask_groups, int enc_tile0,
                                                         const uint64_t* __restrict__ hb, const uint64_t* __restrict__ vb,
                                                         const uint64_t* __restrict__ meta, const uint8_t* __restrict__ terminal,
-                                                        float* __restrict__ planes, int n_enc_first) {
+                                                        float* __restrict__ planes, int n_enc_first, int n_enc_tiles) {
     __shared__ MasksEncShared<NB, NBE> smu;
     const int tid = (int)threadIdx.x;
-    // grid order = dispatch order: [n_enc_first encoder tiles][mask groups][the other encoder tiles]
+    // grid order = dispatch order: [n_enc_first PERSISTENT encoder workgroups][mask groups][one workgroup per remaining encoder tile]
+    // A persistent encoder workgroup writes tiles enc_tile0 + bid, + n_enc_first, ... of the launch's n_enc_tiles: a FEW of them
+    // per CU keep the HBM write path busy from the launch's first microsecond to its last while the mask groups -- the long pole:
+    // issue-bound, 29 KB of LDS each -- have the rest of the CU.  (One workgroup per tile in front of the mask groups takes their
+    // slots for the whole launch -- an encoder workgroup lives as long as the bandwidth it shares lets it: measured +5..17 us --
+    // and behind them it only starts when they are done: 22 + 20 us in sequence, round 4.)
     int bid = (int)blockIdx.x;
     if (bid < n_enc_first) {
-        encoder_group<NBE>(smu.enc, hb, vb, meta, n, terminal, planes, (enc_tile0 + bid) * NBE, tid);
+        for (int t = bid; t < n_enc_tiles; t += n_enc_first) {
+            if (t != bid) __syncthreads();  // the tile before has left the LDS bitmaps
+            encoder_group<NBE>(smu.enc, hb, vb, meta, n, terminal, planes, (enc_tile0 + t) * NBE, tid);
+        }
         return;
     }
     bid -= n_enc_first;
-    if (bid >= n_mask_groups) {
-        encoder_group<NBE>(smu.enc, hb, vb, meta, n, terminal, planes, (enc_tile0 + n_enc_first + bid - n_mask_groups) * NBE, tid);
+    if (bid >= n_mask_groups) {  // (only without persistent encoder workgroups)
+        encoder_group<NBE>(smu.enc, hb, vb, meta, n, terminal, planes, (enc_tile0 + bid - n_mask_groups) * NBE, tid);
         return;
     }
     mask_group<NB>(smu.m, hands, n, mask5, hb, vb, meta, bid * NB, tid);
@@ -2948,9 +2956,12 @@ static void launch_masks_enc(const PoolHand* hands, int n, uint32_t* mask5, cons
                              int n_enc_groups, hipStream_t s, int enc_first_pct = 0) {
     const int n_mask_groups = mask5 ? (n + NB - 1) / NB : 0;
     if (n_mask_groups + n_enc_groups == 0) return;
-    const int n_enc_first = n_mask_groups ? (n_enc_groups * enc_first_pct) / 100 : 0;
-    hipLaunchKernelGGL((k_pool_masks_enc<NB, NBE>), dim3((unsigned)(n_mask_groups + n_enc_groups)), dim3(256), 0, s, hands, n,
-                       mask5, n_mask_groups, enc_tile0, hb, vb, meta, terminal, planes, n_enc_first);
+    // enc_first_pct: persistent encoder workgroups in front of the mask groups, in hundredths of a workgroup per CU (256 CUs)
+    int n_enc_first = (n_mask_groups && n_enc_groups) ? (256 * enc_first_pct + 99) / 100 : 0;
+    if (n_enc_first > n_enc_groups) n_enc_first = n_enc_groups;
+    const int grid = n_enc_first ? n_enc_first + n_mask_groups : n_mask_groups + n_enc_groups;
+    hipLaunchKernelGGL((k_pool_masks_enc<NB, NBE>), dim3((unsigned)grid), dim3(256), 0, s, hands, n,
+                       mask5, n_mask_groups, enc_tile0, hb, vb, meta, terminal, planes, n_enc_first, n_enc_groups);
 }
 
 size_t movegen_scratch_bytes(int n) { return (size_t)n * sizeof(PoolHand); }  // 184 B per board (round 3: 1,522)

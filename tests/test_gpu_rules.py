@@ -197,7 +197,7 @@ def test_c3_size_kernel_families_agree_and_match_oracle_sample(gpu_device):
         mask, planes = rules.movegen_encode(db)          # pooled pipeline, one detour group (the default)
         mask2, planes2 = rules.movegen_encode(db)
         assert torch.equal(mask, mask2) and torch.equal(planes, planes2)
-        for first, split in ((0, 50), (100, 35), (50, 70)):   # where the encoder tiles sit in the two launches' grids changes nothing
+        for first, split in ((0, 50), (100, 35), (250, 70), (800, 1)):   # where the encoder tiles sit in the two launches' grids changes nothing
             m, p = rules.movegen_encode(db, opts=rules.rules_opts(0, enc_split_pct=split, enc_first_pct=first))
             assert torch.equal(m, mask) and torch.equal(p, planes), (name, first, split)
         for mode in (0, 2):                               # no detours / three detour groups
