@@ -722,14 +722,35 @@ struct BoardRegs {
 enum { LC_PLAYOUTS = 0, LC_TERMINAL, LC_OVERFLOW, LC_NONFINITE, LC_MAXDEPTH, LC_HITS, LC_EVALS, LC_SPARE, LC_LEVELS /*u64*/ = 8, LC_SCANNED /*u64*/ = 10,
        LC_EXPANDED /*u64*/ = 12, LC_RSTAMP = 16 /* .. 31: the descent records' last-use stamps */, LC_WORDS = 32 };
 static_assert(QZ_PATH_RECS <= 16, "LC_RSTAMP holds sixteen stamps");
-__device__ __forceinline__ void lc_add(const BoardRegs& S, int i, uint32_t v, int lane) {
+#ifndef QZ_LC_IN_VGPR
+#define QZ_LC_IN_VGPR 1
+#endif
+// The counters' deltas of a launch.  Round 4: LDS words bumped by lane 0 (compare, exec save, move, ds_add, exec restore: six to
+// eight instructions a time, seven times per playout of an issue-bound kernel).  Now: lane LC_LANE0 + i of the register that
+// holds the record lengths in its lanes 0..15 IS counter i -- compare + select + add, no exec games, no LDS -- and the sixteen
+// lanes go to the LDS words once, in regs_store (which adds them to the per-board counters in memory as before).  A launch's
+// deltas fit 32 bits (<= 4,096 playouts of <= 2,048 levels): the high words of the 64-bit slots stay zero.
+constexpr int LC_LANE0 = 32;
+__device__ __forceinline__ void lc_add(BoardRegs& S, int i, uint32_t v, int lane) {
+#if QZ_LC_IN_VGPR
+    S.rlen += lane == LC_LANE0 + i ? v : 0u;
+#else
     if (lane == 0) __hip_atomic_fetch_add(S.lc + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#endif
 }
-__device__ __forceinline__ void lc_add64(const BoardRegs& S, int i, unsigned long long v, int lane) {
+__device__ __forceinline__ void lc_add64(BoardRegs& S, int i, unsigned long long v, int lane) {
+#if QZ_LC_IN_VGPR
+    S.rlen += lane == LC_LANE0 + i ? (uint32_t)v : 0u;
+#else
     if (lane == 0) __hip_atomic_fetch_add(reinterpret_cast<lds_u64*>(S.lc + i), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#endif
 }
-__device__ __forceinline__ void lc_max(const BoardRegs& S, int i, uint32_t v, int lane) {
+__device__ __forceinline__ void lc_max(BoardRegs& S, int i, uint32_t v, int lane) {
+#if QZ_LC_IN_VGPR
+    S.rlen = (lane == LC_LANE0 + i && v > S.rlen) ? v : S.rlen;
+#else
     if (lane == 0) __hip_atomic_fetch_max(S.lc + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#endif
 }
 // the first `cap` levels of the current descent once more in LDS (we: chosen edges, wb: blocks); nullptr: none
 struct PathMirror {
@@ -779,6 +800,9 @@ __device__ __forceinline__ void regs_store(const EngineDev& E, const int b, cons
         E.rec_len[(size_t)b * QZ_PATH_RECS + lane] = R.rlen;
         E.rec_stamp[(size_t)b * QZ_PATH_RECS + lane] = R.lc[LC_RSTAMP + lane];
     }
+#if QZ_LC_IN_VGPR
+    if (lane >= LC_LANE0 && lane < LC_LANE0 + LC_RSTAMP) R.lc[lane - LC_LANE0] = R.rlen;  // the counter lanes -> the LDS words lane 0 reads below
+#endif
     wave_sync();
     if (lane == 0) {
         // the counters: all loads first, then all stores (one round trip, not one per counter)
@@ -856,8 +880,31 @@ __device__ __forceinline__ void select_core(EngineDev& E, BoardRegs& S, const in
         // the LDS mirror (k_advance) ONE pass lane = level adds them up at the leaf -- instead of four ballots + popcounts in
         // every replay round and an add per walked level, all on the scalar unit of an issue-bound kernel.
         const bool scan_at_end = QZ_SCAN_AT_END && PM.cap > 0u;
+#ifndef QZ_APPLY_AT_LEAF
+#define QZ_APPLY_AT_LEAF 1
+#endif
+        // The scratch board is only needed AT THE LEAF (the selection never looks at it), so with the LDS mirror (k_advance) the
+        // descent does not replay its moves level by level (game.step(action), mcts.py:113): every block entry of the descent
+        // buffer carries the level's move in its top byte, and the leaf's board is the root's + all of them in ONE wave reduction
+        // (apply_actions_wave, lane = level) -- round 4 ran that reduction after every replay round and a scalar apply_action per
+        // walked level, and kept the board's nine scalars alive across the whole descent of a kernel that has 78 of them.
+        // Levels from QZ_PATH_CAP on have no entry: the board is brought up to date there and stepped level by level from then on.
+        bool lazy = QZ_APPLY_AT_LEAF && PM.cap > 0u;
+        auto board_from_path = [&](const uint32_t upto) -> uint32_t {  // bd = the root's board + the moves of levels [0, upto); returns the levels' child counts summed
+            wave_sync();
+            uint32_t sc = 0u;
+            for (uint32_t i0 = 0u; i0 < upto; i0 += 64u) {
+                const uint32_t i = i0 + (uint32_t)lane;
+                unsigned long long w = 0ull;
+                if (i < upto) w = i < PM.cap ? PM.wb[i] : wb[i];
+                const uint32_t left = upto - i0;
+                done = apply_actions_wave(bd, (uint32_t)(w >> 56), (int)(left < 64u ? left : 64u), lane);
+                sc += (uint32_t)(w & 0xFFull);
+            }
+            return wave_sum_u32(sc);
+        };
         // lane r < R keeps record r's length and the time it was last useful
-        if (!use) S.rlen = 0u;
+        if (!use && lane < (int)R) S.rlen = 0u;  // (lanes LC_LANE0.. of the same register are the launch's counters)
         uint32_t& rlen = S.rlen;      // (ONE copy: a second one lived in a register of its own across the whole descent)
         const uint32_t src = S.rec_last & (R - 1u);  // the record of the previous descent
         const uint32_t src_len = rdl(rlen, (int)src);
@@ -1017,15 +1064,15 @@ __device__ __forceinline__ void select_core(EngineDev& E, BoardRegs& S, const in
                         if (i < PM.cap) {
                             if (!mir) {  // (replayed FROM the mirror: the entries are there)
                                 PM.we[i] = chosen;
-                                PM.wb[i] = ((unsigned long long)lbase << 8) | (unsigned long long)lne;  // (= the record's entry: this lane is ok)
+                                PM.wb[i] = ((unsigned long long)lact << 56) | ((unsigned long long)lbase << 8) | (unsigned long long)lne;  // (the record's entry -- this lane is ok -- + the move)
                             }
                         } else {
                             we[i] = chosen;
-                            wb[i] = ((unsigned long long)lbase << 8) | (unsigned long long)lne;
+                            wb[i] = ((unsigned long long)lact << 56) | ((unsigned long long)lbase << 8) | (unsigned long long)lne;
                         }
                     }
                     used |= 1u << cur;
-                    done = apply_actions_wave(bd, lact, nconf, lane);
+                    if (!lazy) done = apply_actions_wave(bd, lact, nconf, lane);
                     if (!scan_at_end) {   // edge records scanned by the confirmed levels (statistics): lne is 1..8, four ballots
                         const uint64_t inm = nconf >= 64 ? ~0ull : ((1ull << nconf) - 1ull);
                         const uint32_t l1 = (uint32_t)lne - 1u;  // 0..7
@@ -1169,9 +1216,13 @@ __device__ __forceinline__ void select_core(EngineDev& E, BoardRegs& S, const in
             }
             const uint32_t e = base + (uint32_t)kk;
             const int a = (int)(misc & 0xFFu);
-            done = apply_action(bd, a);  // game.step(action), mcts.py:113
+            if (lazy && plen >= CAP) {  // (rare: deeper than the descent buffer)
+                board_from_path(CAP);
+                lazy = false;
+            }
+            if (!lazy) done = apply_action(bd, a);  // game.step(action), mcts.py:113
             if (lane == 0 && plen < CAP) {
-                const unsigned long long blk = ((unsigned long long)base << 8) | (unsigned long long)(ne > 255 ? 255 : ne);
+                const unsigned long long blk = ((unsigned long long)a << 56) | ((unsigned long long)base << 8) | (unsigned long long)(ne > 255 ? 255 : ne);
                 if (plen < PM.cap) {  // (the mirror's levels reach memory only if the leaf has to wait for the network: k_advance)
                     PM.we[plen] = e;
                     PM.wb[plen] = blk;
@@ -1217,13 +1268,16 @@ __device__ __forceinline__ void select_core(EngineDev& E, BoardRegs& S, const in
             ne = cne;
         }
         QZ_TS(1)
-        at_leaf_hook(bd, done);
-        if (scan_at_end) {
+        if (lazy) {
+            const uint32_t sc = board_from_path(plen);  // (plen <= CAP here)
+            if (scan_at_end) scanned = sc;
+        } else if (scan_at_end) {
             const uint32_t nrec = plen < CAP ? plen : CAP;
             uint32_t sc = 0u;
             for (uint32_t i = (uint32_t)lane; i < nrec; i += 64u) sc += (uint32_t)((i < PM.cap ? PM.wb[i] : wb[i]) & 0xFFull);
             scanned = wave_sum_u32(sc);
         }
+        at_leaf_hook(bd, done);
         // (all wave-uniform by construction; said so explicitly, or the compiler carries them -- and the record bookkeeping
         // derived from them -- in vector registers it does not have: their scratch reloads each drain the store queue)
         cur = rfl(cur);
