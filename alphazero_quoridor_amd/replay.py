@@ -236,9 +236,23 @@ class ReplayBuffer:
     # ---- the deque's sequence protocol, so that code written against the reference's buffer -- `random.sample(
     # self.data_buffer, self.batch_size)` (train.py:67), indexing, iteration -- runs unchanged.  Every entry comes back in
     # the reference's shape; TrainPipeline.policy_update itself uses sample() (same positions, no host round trip).
+    # COST: one element = one device gather + one qz_encode launch + three device-to-host copies, so `random.sample(buffer,
+    # 512)` -- which indexes element by element -- is ~1,500 host round trips.  Batched forms, one gather + one launch each:
+    # buffer[[i, j, ...]] / buffer[slice], reference_sample(k) (= random.sample(buffer, k): same positions, same consumption of
+    # the `random` module's state), sample(k) (device tensors, what TrainPipeline.policy_update uses), iteration (chunks of 256).
+    def reference_sample(self, k, rng=random):
+        """random.sample(buffer, k) in ONE device round trip: the same positions in the same order"""
+        return self.reference_tuples(self.sample_indices(k, rng))
+
     def __getitem__(self, i):
         if isinstance(i, slice):
             return self.reference_tuples(range(*i.indices(self._size)))
+        if isinstance(i, (list, tuple, np.ndarray, torch.Tensor)):  # an index list: one gather for all of them
+            idx = [int(j) for j in (i.tolist() if hasattr(i, "tolist") else i)]
+            idx = [j + self._size if j < 0 else j for j in idx]
+            if any(not 0 <= j < self._size for j in idx):
+                raise IndexError("ReplayBuffer index out of range")
+            return self.reference_tuples(idx)
         i = int(i)
         if i < 0:
             i += self._size

@@ -386,6 +386,14 @@ def test_replay_buffer_answers_like_the_reference_deque(monkeypatch):
     random.seed(11)
     mini = random.sample(buf, 128)  # ... and unchanged on the device ring
     assert all(same(a, e) for a, e in zip(mini, want))
+    # the batched forms (random.sample indexes element by element, ~1,500 host round trips per minibatch): the same
+    # positions in ONE gather -- reference_sample(k), and indexing with a list of positions
+    random.seed(11)
+    fast = buf.reference_sample(128)
+    assert all(same(a, e) for a, e in zip(fast, want))
+    assert all(same(a, e) for a, e in zip(buf[[3, -1, 250, 0]], [ref[3], ref[-1], ref[250], ref[0]]))
+    with pytest.raises(IndexError):
+        buf[[0, 300]]
     # the reference's next three lines (train.py:68-70) work on what comes back
     state_batch = [data[0] for data in mini]
     assert np.asarray(state_batch).shape == (128, 26, 9, 9) and np.asarray([data[1] for data in mini]).shape == (128, 140)
