@@ -357,7 +357,9 @@ def second_line(args, dev, qdist, nn_precision="fp32"):
 
     torch.manual_seed(args.seed)
     net = PolicyValueNet(use_gpu=True, device=dev)
-    B2 = min(args.boards, 4096)  # (round 3's board count: with fewer boards a board gets more of the network and the population ages faster towards its steady state)
+    # (round 5 sweep, stationary estimate on one box, boards / budget: 4,096 / 500 us 100 games/s, 8,192 / 500 116, 16,384 / 500 114,
+    # 16,384 / 1,000 153, 32,768 / 1,000 135 -- profiles/round5/second_line_board_sweep.txt)
+    B2 = args.second_line_boards
     eng = make_engine(args, net, dev, qdist.shard_seed(args.seed + 1, 0), True, boards=B2, nn_precision=nn_precision)
     kw = dict(max_playouts=args.max_playouts, budget_us=args.second_line_budget_us)
     lens = []
@@ -695,7 +697,8 @@ def main():
     ap.add_argument("--fix-terminal-sign", action="store_true", help="NOT the headline: back a winning move up as +1 (the reference backs it up as -1, mcts.py:125)")
     ap.add_argument("--second-line-seconds", type=float, default=5.0, help="async, 1 GPU: length of the labelled second run with the terminal sign fixed (0 = skip it)")
     ap.add_argument("--second-line-warm-seconds", type=float, default=12.0)
-    ap.add_argument("--second-line-budget-us", type=int, default=500, help="budget of a k_advance launch in the second line (its boards wait for the network nearly every playout)")
+    ap.add_argument("--second-line-budget-us", type=int, default=1000, help="budget of a k_advance launch in the second line")
+    ap.add_argument("--second-line-boards", type=int, default=16384, help="boards of the second line's engine")
     ap.add_argument("--no-non-parity-line", action="store_true", help="skip the labelled NON_PARITY second line (sign fixed + one fp16 MFMA per product)")
     ap.add_argument("--no-c3", action="store_true", help="skip the 32,768-board microbenchmark line (roofline_c3)")
     ap.add_argument("--no-planes", action="store_true", help="lockstep: the rules op only produces the legal sets (the evaluator reads the leaf boards)")

@@ -81,7 +81,7 @@ def test_bench_single_gpu_line_carries_the_contract(gpu_device):
         return json.loads(lines[0])
 
     # the default route: the asynchronous self-play loop
-    a = run("--rounds-per-step", "64")
+    a = run("--rounds-per-step", "64", "--second-line-boards", "256", "--second-line-warm-seconds", "3", "--second-line-seconds", "2")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in a, k
@@ -95,6 +95,13 @@ def test_bench_single_gpu_line_carries_the_contract(gpu_device):
     assert a["engine_stats"]["node_overflow"] == 0 and a["engine_stats"]["runaway_descents"] == 0
     assert a["cpu_baseline"]["kind"] == "port" and a["cpu_baseline"]["value"] > 0
     assert "games_per_s_steady_state" in a and "games_in_timed_region" in a and len(a["ms_per_step_series"]) == 2
+    # the headline names its tracked scalar; the second line's `value` is the stationary estimate from the
+    # committed sign-fixed length sample with the raw count beside it; the throughput-precision network has a labelled line of its own
+    assert a["tracked_scalar"] == "plies_per_s" and a["plies_per_s"] > 0
+    for key, parity in (("second_line_fix_terminal_sign", True), ("second_line_NON_PARITY_fp16", False)):
+        s2 = a[key]
+        assert s2["unit"] == "games/s" and s2["value_transient"] >= 0 and s2["value"] > 0 and "game_length_400playouts_sign_fixed.json" in s2["value_is"]
+        assert s2["value_low"] < s2["value"] < s2["value_high"] and ("NON_PARITY" in s2["label"]) == (not parity) and "NOT the headline" in s2["label"]
     # with the rounds captured in HIP graphs the step's first round is still issued piece by piece: the line keeps its roofline
     g = run("--rounds-per-step", "32", "--graph-rounds", "8", "--no-c3", "--no-cpu-baseline", "--second-line-seconds", "0")
     assert g["config"]["graph_rounds"] == 8 and g["roofline"]["launches_timed"] == 2 and 0 < g["roofline"]["frac"] < 1 and g["rounds"] == 2 * 32
