@@ -100,8 +100,11 @@ def test_bench_single_gpu_line_carries_the_contract(gpu_device):
     assert a["tracked_scalar"] == "plies_per_s" and a["plies_per_s"] > 0
     for key, parity in (("second_line_fix_terminal_sign", True), ("second_line_NON_PARITY_fp16", False)):
         s2 = a[key]
-        assert s2["unit"] == "games/s" and s2["value_transient"] >= 0 and s2["value"] > 0 and "game_length_400playouts_sign_fixed.json" in s2["value_is"]
-        assert s2["value_low"] < s2["value"] < s2["value_high"] and ("NON_PARITY" in s2["label"]) == (not parity) and "NOT the headline" in s2["label"]
+        # (this run plays 16 playouts per move: no committed length sample for that count, so `value` falls back to the raw count and
+        # says so; with the default 400 playouts it is the stationary estimate -- the estimator itself: tests/test_host_logic.py)
+        assert s2["unit"] == "games/s" and s2["value_transient"] >= 0 and s2["value"] == s2["value_transient"] and "NO committed" in s2["value_is"]
+        assert s2["games_per_s_steady_state"] is None and ("NON_PARITY" in s2["label"]) == (not parity) and "NOT the headline" in s2["label"]
+        assert s2["boards"] == 256 and s2["plies_per_s"] > 0 and s2["nn_evaluations_per_s"] > 0
     # with the rounds captured in HIP graphs the step's first round is still issued piece by piece: the line keeps its roofline
     g = run("--rounds-per-step", "32", "--graph-rounds", "8", "--no-c3", "--no-cpu-baseline", "--second-line-seconds", "0")
     assert g["config"]["graph_rounds"] == 8 and g["roofline"]["launches_timed"] == 2 and 0 < g["roofline"]["frac"] < 1 and g["rounds"] == 2 * 32
