@@ -2309,17 +2309,24 @@ __global__ __launch_bounds__(TPB) void k_finish_move(EngineDev E, const uint8_t*
 // (which bucket a board's evaluation lives in: any function of the key will do -- a hit is decided by the compare of all 24 bytes)
 __device__ __forceinline__ uint64_t memo_hash(uint64_t hb, uint64_t vb, uint64_t meta) {
 #if QZ_MEMO_HASH32
-    // Six 32-bit multiplies of the key's words + a 32-bit finaliser: ~20 scalar instructions.  Round 4's form -- five 64 x 64-bit
-    // multiplies, each six scalar instructions on this chip -- was ~50 of the ~1,100 instructions of every playout of k_advance
-    // (the board is wave-uniform: the hash runs on the scalar unit), and the kernel is issue-bound.  The bucket index is the
-    // hash's low bits (at most 24): every output bit depends on every input bit after the three xor-shift / multiply steps.
-    uint32_t x = ((uint32_t)hb * 0x9E3779B1u) ^ ((uint32_t)(hb >> 32) * 0x85EBCA77u) ^ ((uint32_t)vb * 0xC2B2AE3Du) ^ ((uint32_t)(vb >> 32) * 0x27D4EB2Fu) ^
-                 ((uint32_t)meta * 0x165667B1u) ^ ((uint32_t)(meta >> 32) * 0xD6E8FEB9u);
+    // Every 32-bit word of the key times an odd constant, the product's two halves folded together (s_mul_i32 + s_mul_hi_u32: a
+    // product's low half only depends on the operand's bits below it, the high half brings the upper bits down), xor of the six,
+    // one xor-shift / multiply / xor-shift: 27 scalar instructions.  Round 4's form -- five 64 x 64-bit multiplies, six scalar
+    // instructions each -- was ~50 of the ~1,100 instructions of every playout of k_advance (the board is wave-uniform: the hash
+    // runs on the scalar unit), and the kernel is issue-bound.  Checked offline on 780,000 leaf boards two plies around 1,024
+    // synthetic positions: buckets of 2^17 and 2^20 fill like a Poisson process (overfull buckets 122,610 / 41,630 against 122,657 /
+    // 41,620 expected; round 4's hash: the same).  A first version WITHOUT the high halves left 20 % more overfull buckets at 2^20.
+    const uint32_t w[6] = {(uint32_t)hb, (uint32_t)(hb >> 32), (uint32_t)vb, (uint32_t)(vb >> 32), (uint32_t)meta, (uint32_t)(meta >> 32)};
+    const uint32_t c[6] = {0x9E3779B1u, 0x85EBCA77u, 0xC2B2AE3Du, 0x27D4EB2Fu, 0x165667B1u, 0xD6E8FEB9u};
+    uint32_t x = 0u;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        const uint64_t p = (uint64_t)w[i] * (uint64_t)c[i];
+        x ^= (uint32_t)p ^ (uint32_t)(p >> 32);
+    }
     x ^= x >> 15;
     x *= 0x2C1B3C6Du;
-    x ^= x >> 12;
-    x *= 0x297A2D39u;
-    x ^= x >> 15;
+    x ^= x >> 13;
     return (uint64_t)x;
 #else
     uint64_t x = (hb * 0x9E3779B97F4A7C15ull) ^ ((vb + 0xD1B54A32D192ED03ull) * 0xC2B2AE3D27D4EB4Full) ^ (meta * 0x165667B19E3779F9ull);

@@ -369,8 +369,11 @@ def test_a_leftover_of_eager_rounds_does_not_break_a_captured_graph(gpu_device):
     net.policy_value_net.load_state_dict(det_fill_state_dict(net.policy_value_net.state_dict(), 6))
     ev = net.evaluator("per_leaf")
     boards = synth_positions(512, seed=13, max_walls=12, mover_has_walls=True)  # opening-phase boards: nearly every board misses every round
-    g = make_engine(boards, 16, seed=2)
-    e = make_engine(boards, 16, seed=2)
+    # (no memo: the test compares two engines after the same NUMBER OF ROUNDS, and with the memo the round in which a board gets an
+    # evaluation can depend on timing -- two inserters of one bucket in one tail: the loser skips, it is a cache -- though never
+    # WHAT the board computes; the miss counters this test is about do not care)
+    g = make_engine(boards, 16, seed=2, memo=False)
+    e = make_engine(boards, 16, seed=2, memo=False)
     try:
         n0 = g.capture_rounds(ev, rounds=4, max_playouts=4, warmup=2)
         e.run_rounds(ev, n0, max_playouts=4)   # the eager rounds capture_rounds has run (warm-up + one between its two captures)
