@@ -7,10 +7,11 @@
 
 Workload (config.workload): BASELINE.json configs[3] per GPU -- n_playout=400, 9x9, reference defaults (10 walls, c_puct=5,
 temp=1, Dirichlet 0.3/0.25), random-init policy_value_net in fp32 with the reference's per-leaf BatchNorm statistics; weak
-scaling, finished tuples all-gathered every step.  --boards concurrent boards per GPU (default 10,240: the chip holds 8,192
-wavefronts of k_advance, eight per SIMD, and about a seventh of the boards -- those whose mover still has walls -- leave a launch
-after one playout: their slots go to the boards beyond the 8,192nd; configs[3] names 4,096 as the per-GPU minimum of concurrent
-boards and `--boards 4096` runs exactly that).
+scaling, finished tuples all-gathered every step.  --boards concurrent boards per GPU (default 13,312: the chip holds 8,192
+wavefronts of k_advance, eight per SIMD; a board leaves its launch when it meets a leaf for the network -- a seventh of them, those
+whose mover still has walls, after one playout -- and its slot goes to the next board: with ONE deadline per launch (--select-opts 8)
+the boards beyond the 8,192nd take the slots in turn; configs[3] names 4,096 as the per-GPU minimum of concurrent boards and
+`--boards 4096` runs exactly that; `--boards 10240 --budget-us 2400 --select-opts 0` is round 4's shape).
 
 DEFAULT ROUTE (--mode async): the asynchronous self-play loop (qz_selfplay_*, include/qz_abi.h): every board runs its 400
 playouts per move on its own clock; a leaf whose evaluation is in the leaf-evaluation memo is expanded from the memo, every
@@ -203,7 +204,8 @@ class Run:
 
         name = "BASELINE configs[2] as an engine run" if B == 32768 else ("BASELINE configs[1]" if a.playouts == 100 else (
             "BASELINE configs[3] per GPU" if B == 4096 else "BASELINE configs[3]'s per-GPU workload with %d instead of 4,096 boards per GPU (the engine keeps eight "
-            "k_advance wavefronts per SIMD busy, and the slots of boards that leave a launch early go to the boards beyond the 8,192nd; same_loop_at_4096_boards is the literal board count)" % B))
+            "k_advance wavefronts per SIMD busy, and the slots of boards that leave a launch early go to the boards beyond the 8,192nd%s; same_loop_at_4096_boards is the literal board count)"
+            % (B, ", one deadline per launch" if (a.select_opts & 8) else "")))
         label = ("NON-PARITY THROUGHPUT MODE (network products on fp16 operands, p / v ~1e-3 from the reference) -- " if a.nn_dtype == "fp16" else "") + \
                 ("TERMINAL SIGN FIXED (not the reference's mcts.py:125) -- " if a.fix_terminal_sign else "")
         cfg = {"workload": label + "%s: %d concurrent boards/GPU, n_playout=%d, 9x9, 10 walls/player, c_puct=5, temp=1.0, %s" % (name, B, a.playouts, workload_tail),
@@ -298,7 +300,7 @@ def hbm_line(kernel, us, nbytes, note, launches, traffic=None, src=None):
             "traffic_source": src, "avg_launch_us": us, "launches_timed": launches, "algorithmic_bytes_per_launch": nbytes, "note": note}
 
 
-def make_engine(args, net, dev, seed, fix_sign, boards=None, nn_precision=None):
+def make_engine(args, net, dev, seed, fix_sign, boards=None, nn_precision=None, select_opts=None):
     from alphazero_quoridor_amd.engine import BoardGroups
 
     prec = nn_precision or ("fp16" if args.nn_dtype == "fp16" else "fp32")
@@ -310,7 +312,8 @@ def make_engine(args, net, dev, seed, fix_sign, boards=None, nn_precision=None):
     else:
         make_ev = lambda: net.evaluator(args.bn, dt, bool(args.channels_last), nn_precision=prec)  # noqa: E731
     return BoardGroups(boards or args.boards, args.groups, make_ev, seed=seed, device=dev, n_playout=args.playouts, c_puct=5, temp=1.0, is_selfplay=1,
-                       fix_terminal_sign=fix_sign, select_opts=args.select_opts, memo=not args.no_memo, max_depth=args.max_depth)
+                       fix_terminal_sign=fix_sign, select_opts=args.select_opts if select_opts is None else select_opts, memo=not args.no_memo,
+                       max_depth=args.max_depth)
 
 
 def line_at_4096_boards(args, dev, qdist):
@@ -320,7 +323,7 @@ def line_at_4096_boards(args, dev, qdist):
 
     torch.manual_seed(args.seed)
     net = PolicyValueNet(use_gpu=True, device=dev)
-    eng = make_engine(args, net, dev, qdist.shard_seed(args.seed, 0), False, boards=4096)
+    eng = make_engine(args, net, dev, qdist.shard_seed(args.seed, 0), False, boards=4096, select_opts=0)  # (per-board budgets: every board has its slot)
     kw = dict(max_playouts=args.max_playouts, budget_us=1000)  # (4,096 boards, no board beyond the slots: 1,000 / 1,800 / 2,400 us = 214 / 205 / 181 M playouts/s)
     eng.set_playouts(args.desync_playouts)
     for _ in range(0, args.desync_plies * (args.desync_playouts + 1), 64):
@@ -360,7 +363,7 @@ def second_line(args, dev, qdist, nn_precision="fp32"):
     # (round 5 sweep, stationary estimate on one box, boards / budget: 4,096 / 500 us 100 games/s, 8,192 / 500 116, 16,384 / 500 114,
     # 16,384 / 1,000 153, 32,768 / 1,000 135 -- profiles/round5/second_line_board_sweep.txt)
     B2 = args.second_line_boards
-    eng = make_engine(args, net, dev, qdist.shard_seed(args.seed + 1, 0), True, boards=B2, nn_precision=nn_precision)
+    eng = make_engine(args, net, dev, qdist.shard_seed(args.seed + 1, 0), True, boards=B2, nn_precision=nn_precision, select_opts=0)  # (the shape the sweep was run in)
     kw = dict(max_playouts=args.max_playouts, budget_us=args.second_line_budget_us)
     lens = []
 
@@ -672,12 +675,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--boards", type=int, default=10240, help="concurrent boards per GPU (8,192 = eight k_advance wavefronts per SIMD; 4,096 = BASELINE configs[3]'s number; the sweep behind the default: profiles/round4/SUMMARY.md section 2)")
+    ap.add_argument("--boards", type=int, default=13312, help="concurrent boards per GPU (8,192 = eight k_advance wavefronts per SIMD; 4,096 = BASELINE configs[3]'s number; the sweep behind the default: profiles/round4/SUMMARY.md section 2)")
     ap.add_argument("--playouts", type=int, default=400)
     ap.add_argument("--groups", type=int, default=1, help="split the boards of a GPU into this many independent groups on their own HIP streams")
     ap.add_argument("--mode", default="async", choices=["async", "lockstep"])
     ap.add_argument("--rounds-per-step", type=int, default=256, help="async: rounds of the loop per step")
-    ap.add_argument("--budget-us", type=int, default=2400, help="async: wall-clock budget of a k_advance launch in microseconds (the sweep behind the default: profiles/round4/SUMMARY.md section 2)")
+    ap.add_argument("--budget-us", type=int, default=3000, help="async: wall-clock budget of a k_advance launch in microseconds (the sweep behind the default: profiles/round4/SUMMARY.md section 2)")
     ap.add_argument("--max-playouts", type=int, default=4096, help="async: playouts a board may start per round")
     ap.add_argument("--graph-rounds", type=int, default=0, help="async: capture this many (even) rounds per HIP graph (0 = eager launches, per-kernel events)")
     ap.add_argument("--event-every", type=int, default=64, help="async: every n-th round of group 0 (at least one per step) is issued in pieces with HIP events around them; those rounds run their pieces one after the other (cost of the timing: profiles/round4/SUMMARY.md section 1)")
@@ -704,7 +707,9 @@ def main():
     ap.add_argument("--no-planes", action="store_true", help="lockstep: the rules op only produces the legal sets (the evaluator reads the leaf boards)")
     ap.add_argument("--library-trunk", action="store_true", help="lockstep A/B: trunk convolutions through MIOpen instead of the split-fp16 MFMA kernel")
     ap.add_argument("--separate-descent", action="store_true", help="lockstep A/B: k_select as its own launch")
-    ap.add_argument("--select-opts", type=int, default=0, help="A/B switches of the descent (qz_config.select_opts)")
+    ap.add_argument("--select-opts", type=int, default=8, help="switches of the descent / the launch (qz_config.select_opts); 8 = ONE deadline per k_advance launch, counted from its first "
+                                                                 "wavefront, boards take the first slots in turn (round 5's default: 13,312 boards at 3,000 us = +6 %% over 10,240 boards with "
+                                                                 "per-board budgets of 2,400 us on the same box; 0 = per-board budgets)")
     ap.add_argument("--rules-variant", type=int, default=0, help="lockstep A/B: qz_rules_opts.variant of the engines' leaf rules op")
     ap.add_argument("--length-file", default=None, help="game-length sample for games_per_s_steady_state (default: newest profiles/round*/game_length_<n>playouts.json)")
     ap.add_argument("--clock-log", default=None, help="write the clock / power samples of the timed region to this JSON file")

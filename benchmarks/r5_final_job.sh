@@ -20,8 +20,8 @@ if has bench; then
 fi
 line() { timeout 400 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-c3 --second-line-seconds 0 "$@"; }
 if has ab; then
-  line --boards 4096 --budget-us 1000 > $O/bench_boards4096.json 2> $O/bench_boards4096.err
-  line --boards 13312 --select-opts 8 --budget-us 3000 > $O/bench_boards13312_one_deadline.json 2> $O/bench_boards13312.err
+  line --boards 4096 --budget-us 1000 --select-opts 0 > $O/bench_boards4096.json 2> $O/bench_boards4096.err
+  line --boards 10240 --budget-us 2400 --select-opts 0 > $O/bench_round4_shape_10240boards_2400us.json 2> $O/bench_round4_shape.err
   line --playouts 800 > $O/bench_c5_playouts800_1gpu.json 2> $O/bench_c5.err
   line --playouts 100 > $O/bench_c2_playouts100.json 2> $O/bench_c2.err
   line --graph-rounds 16 > $O/bench_graph_rounds16.json 2> $O/bench_graph16.err
@@ -45,14 +45,14 @@ if has pmc; then
     timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/$O/pmc_$c -- /usr/bin/python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-c3 --second-line-seconds 0 > $R/$O/pmc_$c.json 2> $R/$O/pmc_$c.err
   done
   bpb=$(python3 -c "import json; d=json.load(open('$R/$O/pmc_FETCH_SIZE.json')); print(d['roofline']['algorithmic_bytes_per_launch'] / d['config']['boards_per_gpu'])")
-  python3 $R/benchmarks/pmc_traffic.py --fetch $R/$O/pmc_FETCH_SIZE --write $R/$O/pmc_WRITE_SIZE --kernels k_advance --boards 10240 --bytes-per-board $bpb --last 200 \
-     --label "k_advance<8> (10,240 boards, n_playout=400, last 200 launches of a bench run)" --out $R/$O/pmc_traffic_advance.json > /dev/null && cat $R/$O/pmc_traffic_advance.json | head -12
+  python3 $R/benchmarks/pmc_traffic.py --fetch $R/$O/pmc_FETCH_SIZE --write $R/$O/pmc_WRITE_SIZE --kernels k_advance --boards 13312 --bytes-per-board $bpb --last 200 \
+     --label "k_advance<8> (13,312 boards, one 3,000-us deadline per launch, n_playout=400, last 200 launches of a bench run)" --out $R/$O/pmc_traffic_advance.json > /dev/null && cat $R/$O/pmc_traffic_advance.json | head -12
   rm -rf $R/$O/pmc_FETCH_SIZE $R/$O/pmc_WRITE_SIZE
 fi
 if has sq; then
-  BOARDS=10240 PLAYOUTS=400 MAXP=4096 BUDGET=2400 FIX=0 MAXD=992 ITERS=150 ROUNDS=64 EVERY=50 timeout 800 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d $R/$O/pmc_sq -- /usr/bin/python3 $R/benchmarks/async_debug.py > $R/$O/pmc_sq.log 2>&1
+  BOARDS=13312 SELECT_OPTS=8 PLAYOUTS=400 MAXP=4096 BUDGET=3000 FIX=0 MAXD=992 ITERS=150 ROUNDS=64 EVERY=50 timeout 800 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d $R/$O/pmc_sq -- /usr/bin/python3 $R/benchmarks/async_debug.py > $R/$O/pmc_sq.log 2>&1
   c=$(find $R/$O/pmc_sq -name "*counter_collection.csv" | head -1)
-  python3 $R/benchmarks/pmc_tail_stats.py "$c" 0.3 > $R/$O/pmc_sq_async_late_game_10240boards.json; head -c 1500 $R/$O/pmc_sq_async_late_game_10240boards.json
+  python3 $R/benchmarks/pmc_tail_stats.py "$c" 0.3 > $R/$O/pmc_sq_async_13312boards.json; head -c 1500 $R/$O/pmc_sq_async_13312boards.json
   rm -rf $R/$O/pmc_sq
 fi
 cd $R

@@ -1,7 +1,7 @@
 """GPU parity AT THE BENCH'S OWN SHAPES ("What's missing" 3 and 4; "Next round" 2 and 7).
 
-  * bench.py's default engine -- 10,240 boards on the 8,192 wavefront slots of k_advance<8>, the real network, the 2,400-us
-    budget -- against the oracle: every (board -> p, v) the network produced for the subtrees of 64 sampled boards is taken
+  * bench.py's default engine -- 13,312 boards on the 8,192 wavefront slots of k_advance<8>, the real network, one 3,000-us
+    deadline per launch (and round 4's shape: 10,240 boards, per-board budgets of 2,400 us) -- against the oracle: every (board -> p, v) the network produced for the subtrees of 64 sampled boards is taken
     from the miss lists (qz_selfplay_misses) and handed to oracle.OracleMCTS (the C restatement of mcts.py:103-151) as its
     policy; three plies of 400 playouts, root visits / float64 Q / float32 P bit-equal.
   * SURVEY 4 T2 at its prescribed size: 10^6 positions through the library's default kernel choice at 32,768 boards per
@@ -50,10 +50,12 @@ def oracle_masks_planes(boards, pool, want_planes=True, chunk=1024):
     return mask, status, planes
 
 
-def test_bench_shape_10240_boards_real_net_equals_the_oracle(gpu_device):
-    """`python bench.py`'s engine: 10,240 boards (more than the 8,192 wavefront slots of k_advance<8>: slots are handed from
-    boards that leave a launch to the boards beyond the 8,192nd), n_playout=400, the real network in parity precision, the
-    bench's 2,400-us budget and playout cap.  85 % late-game boards (the mover has no wall left: the memo's regime, 30 playouts
+@pytest.mark.parametrize("B,BUDGET,select_opts", [(13312, 3000, 8), (10240, 2400, 0)])
+def test_bench_shape_real_net_equals_the_oracle(gpu_device, B, BUDGET, select_opts):
+    """`python bench.py`'s engine, round 5's default shape (13,312 boards, ONE deadline of 3,000 us per launch, boards taking the
+    first slots in turn: select_opts 8) and round 4's (10,240 boards, per-board budgets of 2,400 us): more boards than the 8,192
+    wavefront slots of k_advance<8> (slots are handed from boards that leave a launch to the boards beyond the 8,192nd),
+    n_playout=400, the real network in parity precision, the bench's playout cap.  85 % late-game boards (the mover has no wall left: the memo's regime, 30 playouts
     per launch) and 15 % whose mover has walls (one network round trip per playout), as in a sustained run.  64 boards are
     followed in the oracle: mcts.py's pointer tree fed with the evaluations the ENGINE'S network produced for their subtrees
     (collected from the miss lists; a leaf of board j carries a superset of j's walls, which is what the collector filters on).
@@ -68,7 +70,7 @@ def test_bench_shape_10240_boards_real_net_equals_the_oracle(gpu_device):
     from alphazero_quoridor_amd.policy_value_net import PolicyValueNet
     from synth import synth_positions
 
-    B, NP, BUDGET = 10240, 400, 2400
+    NP = 400
     net = PolicyValueNet(use_gpu=True, device=gpu_device)
     net.policy_value_net.load_state_dict(det_fill_state_dict(net.policy_value_net.state_dict(), 2024))
     ev = net.evaluator("per_leaf")
@@ -89,7 +91,7 @@ def test_bench_shape_10240_boards_real_net_equals_the_oracle(gpu_device):
     assert S == 64
     s_hb, s_vb = boards["hbits"][samp].copy(), boards["vbits"][samp].copy()
 
-    eng = SelfPlayEngine(B, n_playout=NP, c_puct=5.0, temp=1.0, seed=3, device=gpu_device, max_depth=992)
+    eng = SelfPlayEngine(B, n_playout=NP, c_puct=5.0, temp=1.0, seed=3, device=gpu_device, max_depth=992, select_opts=select_opts)
     eng.set_boards(DeviceBoards.from_packed(boards, eng.device), reset_trees=True)
     L = eng.L
     table = {}
@@ -163,9 +165,9 @@ def test_bench_shape_10240_boards_real_net_equals_the_oracle(gpu_device):
         st = eng.stats()
         assert st["node_overflow"] == 0 and st["miss_overflow"] == 0 and st["runaway_descents"] == 0 and st["memo_hits"] > st["nn_evals"], st
         assert alive.sum() >= 32
-        print("bench shape: %d boards x 3 plies x %d playouts, %d rounds at a %d-us budget in %.0f s: %d network evaluations, %d memo hits, deepest "
+        print("bench shape (select_opts %d): %d boards x 3 plies x %d playouts, %d rounds at a %d-us budget in %.0f s: %d network evaluations, %d memo hits, deepest "
               "descent %d levels; %d boards followed in the oracle (%d evaluations of their subtrees collected): visits, Q, P bit-equal"
-              % (B, NP, rounds, BUDGET, time.time() - t0, st["nn_evals"], st["memo_hits"], st["max_depth"], S, len(table)))
+              % (select_opts, B, NP, rounds, BUDGET, time.time() - t0, st["nn_evals"], st["memo_hits"], st["max_depth"], S, len(table)))
     finally:
         eng.close()
 
