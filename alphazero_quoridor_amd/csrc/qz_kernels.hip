@@ -730,7 +730,7 @@ static_assert(QZ_PATH_RECS <= 16, "LC_RSTAMP holds sixteen stamps");
 // holds the record lengths in its lanes 0..15 IS counter i -- compare + select + add, no exec games, no LDS -- and the sixteen
 // lanes go to the LDS words once, in regs_store (which adds them to the per-board counters in memory as before).  A launch's
 // deltas fit 32 bits (<= 4,096 playouts of <= 2,048 levels): the high words of the 64-bit slots stay zero.
-constexpr int LC_LANE0 = 32;
+[[maybe_unused]] constexpr int LC_LANE0 = 32;
 __device__ __forceinline__ void lc_add(BoardRegs& S, int i, uint32_t v, int lane) {
 #if QZ_LC_IN_VGPR
     S.rlen += lane == LC_LANE0 + i ? v : 0u;
