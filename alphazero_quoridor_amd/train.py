@@ -63,7 +63,7 @@ class TrainPipeline(object):
         self.n_groups = n_groups  # board groups on separate HIP streams (engine.BoardGroups)
         self.async_loop = True        # self-play through the asynchronous loop (False: the lock-step engine, one ply of every board per harvest)
         self.rounds_per_harvest = 64  # rounds of the loop between two harvests (+ all-gathers)
-        self.budget_us = 1000         # wall-clock budget of a k_advance launch.  (bench.py runs 2,400 us: the optimum for ten thousand boards deep
+        self.budget_us = 1000         # wall-clock budget of a k_advance launch.  (bench.py runs 3,000 us with one deadline per launch: the optimum for 13,312 boards deep
                                       # in random-network games, where nearly every leaf is in the memo; a board whose mover still has walls makes
                                       # ONE playout per round, so a population of short games is better served by short rounds)
         # a game whose search descends deeper than this is DROPPED (not in the replay data; counted and logged by
