@@ -2786,22 +2786,15 @@ __global__ __launch_bounds__(TPB) void k_moves(EngineDev E, unsigned int budget)
 
 // After the network: (a) every evaluated leaf goes into the memo, (b) the OTHER miss counter is cleared for the next
 // round, (c) k_release's work: trees replaced by a re-root go back to the pool, dropped games restart.  PUSH-ONLY.
-// Grid: n_boards waves for the slots, then n_boards waves for the boards.
-__global__ __launch_bounds__(TPB) void k_round_tail(EngineDev E, int par) {
-    const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
-    const int w = (int)blockIdx.x * WPB + wave;
-    if (w < E.n_boards) {
-        const int n = (int)rfl((uint32_t)E.miss_count[par]);
-        if (w < n) memo_insert(E, rfl64(E.miss_hb[w]), rfl64(E.miss_vb[w]), rfl64(E.miss_meta[w]), E.miss_mask + (size_t)w * 5,
-                               E.miss_p + (size_t)w * QZ_N_ACT, E.miss_v[w], lane);
-        if (w == 0 && lane == 0) {
-            E.miss_count[par ^ 1] = 0;
-            E.miss_count[2] = (E.miss_count[2] + 1) & 0xFFFFF;  // rounds finished (k_advance's shared deadline, select_opts bit 3)
-        }
-        return;
-    }
-    const int b = w - E.n_boards;
-    if (b >= E.n_boards) return;
+// Grid (round 5): TAIL_SLOT_WAVES wavefronts stride over the miss list (device-side count), then one LANE per board looks
+// whether its board has anything to hand back -- almost none has -- and the wavefront serves those that do one after the
+// other.  (Round 4 launched a wavefront per slot of the list's CAPACITY and a wavefront per board: 2 x n_boards wavefronts
+// that mostly read one word and left -- 66-89 us per round for a few microseconds of work.)
+#ifndef QZ_TAIL_COMPACT
+#define QZ_TAIL_COMPACT 1
+#endif
+constexpr int TAIL_SLOT_WAVES = 4096;
+__device__ __forceinline__ void tail_board(EngineDev& E, const int b, const int lane) {
     const uint32_t rel = rfl((uint32_t)E.release[b]);
     const uint32_t half = rfl(E.tree_half[b]);
     if (rfl((uint32_t)E.status[b]) == QZ_ABORTED) {
@@ -2814,6 +2807,48 @@ __global__ __launch_bounds__(TPB) void k_round_tail(EngineDev E, int par) {
     if (rel & 1u) wave_free_tree_half(E, b, half ^ 1u, lane);
     if (rel & 2u) wave_free_tree_half(E, b, half, lane);
     if (rel && lane == 0) E.release[b] = 0;
+}
+__global__ __launch_bounds__(TPB) void k_round_tail(EngineDev E, int par) {
+    const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+    const int w = (int)blockIdx.x * WPB + wave;
+#if QZ_TAIL_COMPACT
+    if (w < TAIL_SLOT_WAVES) {
+        int n = (int)rfl((uint32_t)E.miss_count[par]);
+        n = n < E.n_boards ? n : E.n_boards;
+        for (int sl = w; sl < n; sl += TAIL_SLOT_WAVES)
+            memo_insert(E, rfl64(E.miss_hb[sl]), rfl64(E.miss_vb[sl]), rfl64(E.miss_meta[sl]), E.miss_mask + (size_t)sl * 5, E.miss_p + (size_t)sl * QZ_N_ACT,
+                        E.miss_v[sl], lane);
+        if (w == 0 && lane == 0) {
+            E.miss_count[par ^ 1] = 0;
+            E.miss_count[2] = (E.miss_count[2] + 1) & 0xFFFFF;  // rounds finished (k_advance's shared deadline, select_opts bit 3)
+        }
+        return;
+    }
+    const int b0 = (w - TAIL_SLOT_WAVES) * 64;
+    if (b0 >= E.n_boards) return;
+    const int bl = b0 + lane;
+    const bool need = bl < E.n_boards && (E.release[bl] != 0 || E.status[bl] == QZ_ABORTED);
+    uint64_t todo = __ballot(need);
+    while (todo) {  // wave-uniform: the boards of this wavefront's 64 that have pages to hand back / a game to restart
+        const int j = __ffsll((unsigned long long)todo) - 1;
+        todo &= todo - 1ull;
+        tail_board(E, b0 + j, lane);
+    }
+#else
+    if (w < E.n_boards) {
+        const int n = (int)rfl((uint32_t)E.miss_count[par]);
+        if (w < n) memo_insert(E, rfl64(E.miss_hb[w]), rfl64(E.miss_vb[w]), rfl64(E.miss_meta[w]), E.miss_mask + (size_t)w * 5,
+                               E.miss_p + (size_t)w * QZ_N_ACT, E.miss_v[w], lane);
+        if (w == 0 && lane == 0) {
+            E.miss_count[par ^ 1] = 0;
+            E.miss_count[2] = (E.miss_count[2] + 1) & 0xFFFFF;  // rounds finished (k_advance's shared deadline, select_opts bit 3)
+        }
+        return;
+    }
+    const int b = w - E.n_boards;
+    if (b >= E.n_boards) return;
+    tail_board(E, b, lane);
+#endif
 }
 // qz_memo_flush: the weights changed, every stored evaluation is dead
 __global__ void k_memo_flush(EngineDev E) {
@@ -3133,7 +3168,11 @@ hipError_t moves(const EngineDev& E, unsigned int budget_ticks, hipStream_t s) {
     return hipGetLastError();
 }
 hipError_t round_tail(const EngineDev& E, int par, hipStream_t s) {
+#if QZ_TAIL_COMPACT
+    hipLaunchKernelGGL(k_round_tail, wave_grid(TAIL_SLOT_WAVES + (E.n_boards + 63) / 64), dim3(TPB), 0, s, E, par);
+#else
     hipLaunchKernelGGL(k_round_tail, wave_grid(2 * E.n_boards), dim3(TPB), 0, s, E, par);
+#endif
     return hipGetLastError();
 }
 hipError_t memo_flush(const EngineDev& E, hipStream_t s) {
