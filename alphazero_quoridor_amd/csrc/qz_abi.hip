@@ -380,7 +380,7 @@ int qz_engine_create(const qz_config* cfg, qz_engine** out) {
     ALLOC(harvest_gid, B);
     ALLOC(status, B);
     ALLOC(winner, B);
-    ALLOC(counters, (size_t)QZ_C_COUNT);
+    ALLOC(counters, (size_t)QZ_C_TOTAL);
     ALLOC(drop_log, (size_t)QZ_DROP_LOG * 4);
     ALLOC(bc_playouts, B);
     ALLOC(bc_terminal, B);
@@ -440,7 +440,7 @@ int qz_engine_create(const qz_config* cfg, qz_engine** out) {
     }
     hipError_t he = hipMemset(d.tree_half, 0, B);
     if (he == hipSuccess) he = hipMemset(d.game_serial, 0, B * sizeof(uint32_t));
-    if (he == hipSuccess) he = hipMemset(d.counters, 0, QZ_C_COUNT * sizeof(unsigned long long));
+    if (he == hipSuccess) he = hipMemset(d.counters, 0, QZ_C_TOTAL * sizeof(unsigned long long));
     if (he == hipSuccess) he = hipMemset(d.leaf_term, 0, B);
     if (he == hipSuccess) he = hipMemset(d.path_len, 0, B * sizeof(uint32_t));
     if (he == hipSuccess) he = hipMemset(d.rec_len, 0, B * QZ_PATH_RECS * sizeof(uint32_t));
@@ -713,7 +713,7 @@ int qz_harvest(qz_engine* e, const qz_boards* t_boards, float* t_pi, float* t_z,
 int qz_engine_stats(qz_engine* e, qz_stats* out, void* stream) {
     ENGINE_CHECK(e);
     if (!out) return fail(QZ_E_INVALID, "out is null");
-    unsigned long long h[QZ_C_COUNT];
+    unsigned long long h[QZ_C_TOTAL];
     hipStream_t s = (hipStream_t)stream;
     const size_t B = (size_t)e->cfg.n_boards;
     std::vector<uint32_t> bp(B), bt(B), bo(B), nn(B), ne(B), bf(B), bd(B), mh(B), me_(B), orr(B), opl(B), ps(B);
@@ -795,8 +795,13 @@ int qz_engine_stats(qz_engine* e, qz_stats* out, void* stream) {
     out->rounds = (int64_t)h[QZ_C_ROUNDS];
     out->memo_hits = (int64_t)smh;
     out->nn_evals = (int64_t)sme;
-    out->memo_inserts = (int64_t)h[QZ_C_MEMO_INSERTS];
-    out->memo_locked = (int64_t)h[QZ_C_MEMO_LOCKED];
+    unsigned long long ins = h[QZ_C_MEMO_INSERTS], lck = h[QZ_C_MEMO_LOCKED];
+    for (int i = 0; i < QZ_C_SPREAD; i++) {  // (k_round_tail counts in QZ_C_SPREAD words each: qz_device.h)
+        ins += h[QZ_C_COUNT + i];
+        lck += h[QZ_C_COUNT + QZ_C_SPREAD + i];
+    }
+    out->memo_inserts = (int64_t)ins;
+    out->memo_locked = (int64_t)lck;
     out->open_rounds = (int64_t)sor;
     out->open_plies = (int64_t)sop;
     out->waiting_boards = (int64_t)sw;

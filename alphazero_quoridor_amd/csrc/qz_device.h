@@ -77,6 +77,9 @@ enum {
     QZ_C_DROPS_LOGGED,      // dropped games written to drop_log so far (the log keeps the last QZ_DROP_LOG of them)
     QZ_C_MISS_OVERFLOW,     // leaves that found the miss list full (a stale counter: must stay 0); their boards redo the descent next launch
     QZ_C_COUNT
+    // behind the QZ_C_COUNT words: QZ_C_SPREAD words each for the memo's inserts and lock skips -- k_round_tail's thousands of
+    // wavefronts bump the one of their index instead of ONE address (same-address atomics queue at ~10-20 ns each: 4,700 inserts
+    // a round were ~50 of the tail's 90 us); qz_engine_stats adds them to memo_inserts / memo_locked
 };
 // pool bookkeeping words (int): free-stack tops and low-water marks
 enum { QZ_P_TREE_TOP = 0, QZ_P_TREE_LOW, QZ_P_TRAJ_TOP, QZ_P_TRAJ_LOW, QZ_P_COUNT };
@@ -103,6 +106,9 @@ typedef uint32_t qz_u32x3_a16 __attribute__((ext_vector_type(3), aligned(16))); 
 // pipeline above), 2 | 3 | 4 = k_wave_rules with 2 | 1 | 4 boards per wavefront, 5 | 6 = 3 with one
 // base-path search per lane | with ordinary stores for the planes (A/B partners of 3), 8 | 12 | 16 |
 // 24 | 32 = pooled pipeline with that many boards per mask workgroup.
+constexpr int QZ_C_SPREAD = 64;
+constexpr int QZ_C_TOTAL = QZ_C_COUNT + 2 * QZ_C_SPREAD;
+
 struct RulesOpts {
     int variant = 0;
     int detour_pooled = 1, detour_wave = 0;  // pool_k1's detour_mode per kernel family

@@ -2414,9 +2414,10 @@ __device__ __forceinline__ bool memo_probe_finish(const EngineDev& E, const uint
     return true;
 }
 // store one evaluation (wave-cooperative; k_round_tail only: no probe runs at the same time)
-__device__ __forceinline__ void memo_insert(const EngineDev& E, const uint64_t hb, const uint64_t vb, const uint64_t meta, const uint32_t* __restrict__ mask,
-                                            const float* __restrict__ prow, const float v, const int lane) {
-    if (!E.memo.small) return;
+// -> 0: nothing stored (no memo, or the evaluation is already there), 1: stored, 2: another wave held the bucket's lock (skipped)
+__device__ __forceinline__ int memo_insert(const EngineDev& E, const uint64_t hb, const uint64_t vb, const uint64_t meta, const uint32_t* __restrict__ mask,
+                                           const float* __restrict__ prow, const float v, const int lane) {
+    if (!E.memo.small) return 0;
     const uint32_t epoch = rfl(*E.memo.epoch);
     const uint64_t mk = meta | ((uint64_t)epoch << 48);
     const uint64_t h = memo_hash(hb, vb, meta);
@@ -2430,29 +2431,26 @@ __device__ __forceinline__ void memo_insert(const EngineDev& E, const uint64_t h
         B = E.memo.small + (size_t)((uint32_t)h & E.memo.small_mask) * (QZ_MEMO_S_WAYS * QZ_MEMO_S_DW);
         const uint32_t d0 = B[lane], d1 = B[lane + 64];
         const uint64_t e0 = __ballot(pos >= 6 || d0 == kd), e1 = __ballot(pos >= 6 || d1 == kd);
-        if ((uint32_t)e0 == 0xFFFFFFFFu || (uint32_t)(e0 >> 32) == 0xFFFFFFFFu || (uint32_t)e1 == 0xFFFFFFFFu || (uint32_t)(e1 >> 32) == 0xFFFFFFFFu) return;
+        if ((uint32_t)e0 == 0xFFFFFFFFu || (uint32_t)(e0 >> 32) == 0xFFFFFFFFu || (uint32_t)e1 == 0xFFFFFFFFu || (uint32_t)(e1 >> 32) == 0xFFFFFFFFu) return 0;
         // first way of another epoch (empty / flushed), else a way picked by the hash
         const uint64_t l0 = __ballot(pos == 5 && (d0 >> 16) == epoch), l1 = __ballot(pos == 5 && (d1 >> 16) == epoch);
         const uint32_t livem = (uint32_t)((l0 >> 5) & 1ull) | ((uint32_t)((l0 >> 37) & 1ull) << 1) | ((uint32_t)((l1 >> 5) & 1ull) << 2) | ((uint32_t)((l1 >> 37) & 1ull) << 3);
-        way = livem == 0xFu ? (int)((h >> 40) & 3ull) : (__ffs((int)(~livem & 0xFu)) - 1);
+        way = livem == 0xFu ? (int)(((uint32_t)h >> 30) & 3u) : (__ffs((int)(~livem & 0xFu)) - 1);  // (the bucket index uses at most the hash's low 24 bits)
         lock = B + 31;
     } else {
         B = E.memo.big + (size_t)((uint32_t)h & E.memo.big_mask) * (QZ_MEMO_B_WAYS * QZ_MEMO_B_DW);
         const bool in = pos < 16;
         const uint32_t d = in ? B[(lane >> 5) * QZ_MEMO_B_DW + pos] : 0u;
         const uint64_t e0 = __ballot(pos >= 6 || d == kd);
-        if ((uint32_t)e0 == 0xFFFFFFFFu || (uint32_t)(e0 >> 32) == 0xFFFFFFFFu) return;
+        if ((uint32_t)e0 == 0xFFFFFFFFu || (uint32_t)(e0 >> 32) == 0xFFFFFFFFu) return 0;
         const uint64_t l0 = __ballot(pos == 5 && (d >> 16) == epoch);
         const uint32_t livem = (uint32_t)((l0 >> 5) & 1ull) | ((uint32_t)((l0 >> 37) & 1ull) << 1);
-        way = livem == 0x3u ? (int)((h >> 40) & 1ull) : (__ffs((int)(~livem & 0x3u)) - 1);
+        way = livem == 0x3u ? (int)(((uint32_t)h >> 31) & 1u) : (__ffs((int)(~livem & 0x3u)) - 1);
         lock = B + 15;
     }
     uint32_t got = 0u;
     if (lane == 0) got = atomicCAS(lock, 0u, 1u) == 0u ? 1u : 0u;
-    if (rfl(got) == 0u) {  // another wave is writing this bucket: skip (the memo is a cache)
-        if (lane == 0) atomicAdd(&E.counters[QZ_C_MEMO_LOCKED], 1ull);
-        return;
-    }
+    if (rfl(got) == 0u) return 2;  // another wave is writing this bucket: skip (the memo is a cache)
     if (memo_is_small(bd)) {
         uint32_t* W = B + way * QZ_MEMO_S_DW;
         if (lane < 20) {
@@ -2476,10 +2474,8 @@ __device__ __forceinline__ void memo_insert(const EngineDev& E, const uint64_t h
     }
     __threadfence();
     wave_sync();
-    if (lane == 0) {
-        atomicExch(lock, 0u);
-        atomicAdd(&E.counters[QZ_C_MEMO_INSERTS], 1ull);
-    }
+    if (lane == 0) atomicExch(lock, 0u);
+    return 1;
 }
 
 // ---------------------------------------------------------------------------- asynchronous self-play
@@ -2815,9 +2811,17 @@ __global__ __launch_bounds__(TPB) void k_round_tail(EngineDev E, int par) {
     if (w < TAIL_SLOT_WAVES) {
         int n = (int)rfl((uint32_t)E.miss_count[par]);
         n = n < E.n_boards ? n : E.n_boards;
-        for (int sl = w; sl < n; sl += TAIL_SLOT_WAVES)
-            memo_insert(E, rfl64(E.miss_hb[sl]), rfl64(E.miss_vb[sl]), rfl64(E.miss_meta[sl]), E.miss_mask + (size_t)sl * 5, E.miss_p + (size_t)sl * QZ_N_ACT,
-                        E.miss_v[sl], lane);
+        unsigned long long n_ins = 0ull, n_lck = 0ull;
+        for (int sl = w; sl < n; sl += TAIL_SLOT_WAVES) {
+            const int r = memo_insert(E, rfl64(E.miss_hb[sl]), rfl64(E.miss_vb[sl]), rfl64(E.miss_meta[sl]), E.miss_mask + (size_t)sl * 5,
+                                      E.miss_p + (size_t)sl * QZ_N_ACT, E.miss_v[sl], lane);
+            n_ins += r == 1 ? 1ull : 0ull;
+            n_lck += r == 2 ? 1ull : 0ull;
+        }
+        if (lane == 0) {  // (one of QZ_C_SPREAD addresses each: not one address for thousands of wavefronts)
+            if (n_ins) atomicAdd(&E.counters[QZ_C_COUNT + (w & (QZ_C_SPREAD - 1))], n_ins);
+            if (n_lck) atomicAdd(&E.counters[QZ_C_COUNT + QZ_C_SPREAD + (w & (QZ_C_SPREAD - 1))], n_lck);
+        }
         if (w == 0 && lane == 0) {
             E.miss_count[par ^ 1] = 0;
             E.miss_count[2] = (E.miss_count[2] + 1) & 0xFFFFF;  // rounds finished (k_advance's shared deadline, select_opts bit 3)
@@ -2837,8 +2841,11 @@ __global__ __launch_bounds__(TPB) void k_round_tail(EngineDev E, int par) {
 #else
     if (w < E.n_boards) {
         const int n = (int)rfl((uint32_t)E.miss_count[par]);
-        if (w < n) memo_insert(E, rfl64(E.miss_hb[w]), rfl64(E.miss_vb[w]), rfl64(E.miss_meta[w]), E.miss_mask + (size_t)w * 5,
-                               E.miss_p + (size_t)w * QZ_N_ACT, E.miss_v[w], lane);
+        if (w < n) {
+            const int r = memo_insert(E, rfl64(E.miss_hb[w]), rfl64(E.miss_vb[w]), rfl64(E.miss_meta[w]), E.miss_mask + (size_t)w * 5,
+                                      E.miss_p + (size_t)w * QZ_N_ACT, E.miss_v[w], lane);
+            if (lane == 0 && r) atomicAdd(&E.counters[r == 1 ? QZ_C_MEMO_INSERTS : QZ_C_MEMO_LOCKED], 1ull);
+        }
         if (w == 0 && lane == 0) {
             E.miss_count[par ^ 1] = 0;
             E.miss_count[2] = (E.miss_count[2] + 1) & 0xFFFFF;  // rounds finished (k_advance's shared deadline, select_opts bit 3)
