@@ -2414,9 +2414,15 @@ __device__ __forceinline__ bool memo_probe_finish(const EngineDev& E, const uint
     return true;
 }
 // store one evaluation (wave-cooperative; k_round_tail only: no probe runs at the same time)
-// -> 0: nothing stored (no memo, or the evaluation is already there), 1: stored, 2: another wave held the bucket's lock (skipped)
+// -> 0: nothing stored (no memo, or the evaluation is already there), 1: stored, 2: another wave has the bucket this round (skipped)
+// A bucket takes ONE insert per round: its lock word holds the number of the last round in which a wavefront wrote it (round_id =
+// the engine's count of k_advance launches, never 0), taken by compare-and-swap from the value the bucket was read with.  Nobody
+// unlocks, so there is no fence and no second atomic per insert (round 4: lock 0 / 1, __threadfence -- a write-back of the XCD's
+// whole L2 -- and an exchange to unlock, for every one of a round's thousands of inserts), and two writers can never tear an
+// entry: the next writer of the bucket is a wavefront of a LATER launch.  Probes run in k_advance only: the kernel boundary
+// publishes the entry.
 __device__ __forceinline__ int memo_insert(const EngineDev& E, const uint64_t hb, const uint64_t vb, const uint64_t meta, const uint32_t* __restrict__ mask,
-                                           const float* __restrict__ prow, const float v, const int lane) {
+                                           const float* __restrict__ prow, const float v, const int lane, const uint32_t round_id) {
     if (!E.memo.small) return 0;
     const uint32_t epoch = rfl(*E.memo.epoch);
     const uint64_t mk = meta | ((uint64_t)epoch << 48);
@@ -2427,6 +2433,7 @@ __device__ __forceinline__ int memo_insert(const EngineDev& E, const uint64_t hb
     uint32_t* B;
     int way;
     uint32_t* lock;
+    uint32_t held;  // the lock word as the bucket was read
     if (memo_is_small(bd)) {
         B = E.memo.small + (size_t)((uint32_t)h & E.memo.small_mask) * (QZ_MEMO_S_WAYS * QZ_MEMO_S_DW);
         const uint32_t d0 = B[lane], d1 = B[lane + 64];
@@ -2437,6 +2444,7 @@ __device__ __forceinline__ int memo_insert(const EngineDev& E, const uint64_t hb
         const uint32_t livem = (uint32_t)((l0 >> 5) & 1ull) | ((uint32_t)((l0 >> 37) & 1ull) << 1) | ((uint32_t)((l1 >> 5) & 1ull) << 2) | ((uint32_t)((l1 >> 37) & 1ull) << 3);
         way = livem == 0xFu ? (int)(((uint32_t)h >> 30) & 3u) : (__ffs((int)(~livem & 0xFu)) - 1);  // (the bucket index uses at most the hash's low 24 bits)
         lock = B + 31;
+        held = rdl(d0, 31);
     } else {
         B = E.memo.big + (size_t)((uint32_t)h & E.memo.big_mask) * (QZ_MEMO_B_WAYS * QZ_MEMO_B_DW);
         const bool in = pos < 16;
@@ -2447,10 +2455,12 @@ __device__ __forceinline__ int memo_insert(const EngineDev& E, const uint64_t hb
         const uint32_t livem = (uint32_t)((l0 >> 5) & 1ull) | ((uint32_t)((l0 >> 37) & 1ull) << 1);
         way = livem == 0x3u ? (int)(((uint32_t)h >> 31) & 1u) : (__ffs((int)(~livem & 0x3u)) - 1);
         lock = B + 15;
+        held = rdl(d, 15);
     }
+    if (held == round_id) return 2;  // another wave has written this bucket in this round: skip (the memo is a cache)
     uint32_t got = 0u;
-    if (lane == 0) got = atomicCAS(lock, 0u, 1u) == 0u ? 1u : 0u;
-    if (rfl(got) == 0u) return 2;  // another wave is writing this bucket: skip (the memo is a cache)
+    if (lane == 0) got = atomicCAS(lock, held, round_id) == held ? 1u : 0u;
+    if (rfl(got) == 0u) return 2;
     if (memo_is_small(bd)) {
         uint32_t* W = B + way * QZ_MEMO_S_DW;
         if (lane < 20) {
@@ -2472,9 +2482,6 @@ __device__ __forceinline__ int memo_insert(const EngineDev& E, const uint64_t hb
             if (!(way == 0 && i == 15)) W[i] = val;  // (dword 15 of way 0 is the lock)
         }
     }
-    __threadfence();
-    wave_sync();
-    if (lane == 0) atomicExch(lock, 0u);
     return 1;
 }
 
@@ -2812,9 +2819,10 @@ __global__ __launch_bounds__(TPB) void k_round_tail(EngineDev E, int par) {
         int n = (int)rfl((uint32_t)E.miss_count[par]);
         n = n < E.n_boards ? n : E.n_boards;
         unsigned long long n_ins = 0ull, n_lck = 0ull;
+        const uint32_t round_id = rfl((uint32_t)E.counters[QZ_C_ROUNDS]) | 0x80000000u;  // (this round's k_advance has counted itself; never 0)
         for (int sl = w; sl < n; sl += TAIL_SLOT_WAVES) {
             const int r = memo_insert(E, rfl64(E.miss_hb[sl]), rfl64(E.miss_vb[sl]), rfl64(E.miss_meta[sl]), E.miss_mask + (size_t)sl * 5,
-                                      E.miss_p + (size_t)sl * QZ_N_ACT, E.miss_v[sl], lane);
+                                      E.miss_p + (size_t)sl * QZ_N_ACT, E.miss_v[sl], lane, round_id);
             n_ins += r == 1 ? 1ull : 0ull;
             n_lck += r == 2 ? 1ull : 0ull;
         }
@@ -2843,7 +2851,7 @@ __global__ __launch_bounds__(TPB) void k_round_tail(EngineDev E, int par) {
         const int n = (int)rfl((uint32_t)E.miss_count[par]);
         if (w < n) {
             const int r = memo_insert(E, rfl64(E.miss_hb[w]), rfl64(E.miss_vb[w]), rfl64(E.miss_meta[w]), E.miss_mask + (size_t)w * 5,
-                                      E.miss_p + (size_t)w * QZ_N_ACT, E.miss_v[w], lane);
+                                      E.miss_p + (size_t)w * QZ_N_ACT, E.miss_v[w], lane, rfl((uint32_t)E.counters[QZ_C_ROUNDS]) | 0x80000000u);
             if (lane == 0 && r) atomicAdd(&E.counters[r == 1 ? QZ_C_MEMO_INSERTS : QZ_C_MEMO_LOCKED], 1ull);
         }
         if (w == 0 && lane == 0) {
