@@ -131,8 +131,8 @@ struct qz_engine {
     int par = 0;               // which of the two miss counters the round in progress uses
     bool async_moves = false;  // qz_selfplay_advance has run with auto_finish: boards may hold a move whose subtree copy is not done
     // qz_selfplay_round: the rules op of the miss list and the finished boards' moves run beside the network's trunk
-    hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t side = nullptr, side2 = nullptr;  // (the rules op / the moves: each on a stream of its own beside the network)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
     size_t memo_small_bytes = 0, memo_big_bytes = 0;
     unsigned flushes = 0;
     std::vector<void*> allocs;
@@ -258,8 +258,10 @@ int qz_engine_destroy(qz_engine* e) {
     (void)hipSetDevice(e->cfg.device);
     (void)hipDeviceSynchronize();
     if (e->side) (void)hipStreamDestroy(e->side);
+    if (e->side2) (void)hipStreamDestroy(e->side2);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+    if (e->ev_join2) (void)hipEventDestroy(e->ev_join2);
     for (void* p : e->allocs) (void)hipFree(p);
     delete e;
     return 0;
@@ -1008,8 +1010,10 @@ int qz_selfplay_round(qz_engine* e, const qz_nn_weights* w, int max_playouts, in
     hipStream_t s = (hipStream_t)stream;
     if (!e->side) {
         HIP_TRY(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&e->side2, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&e->ev_join2, hipEventDisableTiming));
     }
     const EngineDev& d = e->dev;
     const unsigned int ticks = budget_us > 0 ? (unsigned int)budget_us * 100u : 0xFFFFFFFFu;  // s_memrealtime: 100 MHz
@@ -1018,14 +1022,21 @@ int qz_selfplay_round(qz_engine* e, const qz_nn_weights* w, int max_playouts, in
     // (the network is queued first: its workgroups -- 4 per CU, most of the LDS -- should be placed before the side kernels'; queuing
     // the side kernels first and / or a high-priority side stream measured the same: profiles/round4/SUMMARY.md)
     if ((r = nn_evaluate(d.miss_hb, d.miss_vb, d.miss_meta, nullptr, d.n_boards, w, e->feat, d.miss_p, d.miss_v, d.miss_count + e->par, s))) return r;
+    // The rules op and the moves are independent of each other (the miss list / the boards' own trees, roots and trajectories)
+    // and each gets a stream of its own: on ONE side stream the moves queued behind the rules op, whose few workgroups wait
+    // for room beside the trunk's for most of the trunk's duration -- the moves then started when the network was nearly
+    // done, and the round's tail waited 133 us for them (rocprofv3 trace, benchmarks/trace_round_gaps.py; round 5).
     HIP_TRY(hipStreamWaitEvent(e->side, e->ev_fork, 0));
     HIP_TRY(qzl::movegen_encode(d.miss_hb, d.miss_vb, d.miss_meta, d.n_boards, d.miss_mask, nullptr, nullptr, e->scratch, e->rules, e->side, d.miss_count + e->par));
+    HIP_TRY(hipEventRecord(e->ev_join, e->side));
     if (auto_finish) {
-        HIP_TRY(qzl::moves(d, ticks, e->side));
+        HIP_TRY(hipStreamWaitEvent(e->side2, e->ev_fork, 0));
+        HIP_TRY(qzl::moves(d, ticks, e->side2));
+        HIP_TRY(hipEventRecord(e->ev_join2, e->side2));
         e->async_moves = true;
     }
-    HIP_TRY(hipEventRecord(e->ev_join, e->side));
     HIP_TRY(hipStreamWaitEvent(s, e->ev_join, 0));
+    if (auto_finish) HIP_TRY(hipStreamWaitEvent(s, e->ev_join2, 0));
     return qz_selfplay_round_tail(e, stream);
 }
 int qz_selfplay_parity(qz_engine* e) { return e ? e->par : fail(QZ_E_INVALID, "null engine"); }
