@@ -2762,8 +2762,11 @@ __global__ __launch_bounds__(64 * ADV_WPB) __attribute__((amdgpu_waves_per_eu(W,
 // compact_state[b] and goes on in the next round's launch; the board sits out of k_advance meanwhile (reroot_pend).  Round 3
 // ran the copies in k_advance's prologue: their registers and scratch were k_advance's.  POP-ONLY.
 __global__ __launch_bounds__(TPB) void k_moves(EngineDev E, unsigned int budget) {
+    // (ONE wavefront per workgroup: beside the network's trunk -- qz_selfplay_round -- every SIMD's register file is full, and a
+    // workgroup of four wavefronts needs room on all four SIMDs of a CU at once: it waited for the trunk's grid to run dry and the
+    // round's tail waited 117-133 us for the moves; a one-wavefront workgroup takes the slot of any trunk wavefront that retires)
     const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
-    const int b = __builtin_amdgcn_readfirstlane((int)blockIdx.x * WPB + wave);
+    const int b = __builtin_amdgcn_readfirstlane((int)blockIdx.x * (int)(blockDim.x >> 6) + wave);
     if (b >= E.n_boards) return;
     if (rfl(E.status[b]) != QZ_PLAYING || rfl((uint32_t)E.release[b]) != 0u) return;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -3179,7 +3182,7 @@ hipError_t advance(const EngineDev& E, int max_iters, unsigned int budget_ticks,
 }
 // the moves of the boards that have done their playouts + the subtree copies they leave (and the slices earlier moves left)
 hipError_t moves(const EngineDev& E, unsigned int budget_ticks, hipStream_t s) {
-    hipLaunchKernelGGL(k_moves, wave_grid(E.n_boards), dim3(TPB), 0, s, E, compact_budget(budget_ticks));
+    hipLaunchKernelGGL(k_moves, dim3((unsigned)E.n_boards), dim3(64), 0, s, E, compact_budget(budget_ticks));
     return hipGetLastError();
 }
 hipError_t round_tail(const EngineDev& E, int par, hipStream_t s) {
