@@ -17,6 +17,7 @@
 namespace qzl {
 hipError_t movegen_encode(const uint64_t*, const uint64_t*, const uint64_t*, int, uint32_t*, float*, const uint8_t*, void*, const RulesOpts&, hipStream_t, const int* n_dev = nullptr);
 hipError_t advance(const EngineDev&, int, unsigned int, int, int, hipStream_t);
+hipError_t advance_overlap(const EngineDev&, int, unsigned int, int, hipStream_t);
 hipError_t moves(const EngineDev&, unsigned int, hipStream_t);
 hipError_t round_tail(const EngineDev&, int, hipStream_t);
 hipError_t memo_flush(const EngineDev&, hipStream_t);
@@ -40,7 +41,7 @@ struct TrunkInput {  // qz_conv.hip
     const float *hot9, *base0, *wd, *gamma0, *beta0;
 };
 hipError_t trunk(float*, float*, long long, int, const void* const*, const float* const*, const float* const*, const float*, float, int, hipStream_t,
-                 const void*, const float*, const float*, float*, const TrunkInput*, const int* n_live = nullptr, int single_product = 0);
+                 const void*, const float*, const float*, float*, const TrunkInput*, const int* n_live = nullptr, int single_product = 0, int persist_wgs = 0);
 hipError_t head_fc(const float*, long long, const float*, const float*, const float*, const float*, const float*, const float*, float*, float*, hipStream_t,
                    const int* n_live = nullptr);
 hipError_t rollout_begin(const uint64_t*, const uint64_t*, const uint64_t*, int, uint8_t*, uint8_t*, int8_t*, int*, hipStream_t);
@@ -133,6 +134,7 @@ struct qz_engine {
     // qz_selfplay_round: the rules op of the miss list and the finished boards' moves run beside the network's trunk
     hipStream_t side = nullptr, side2 = nullptr;  // (the rules op / the moves: each on a stream of its own beside the network)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
+    int overlap_us = 0, trunk_wgs = 512;  // qz_selfplay_set_overlap: k_advance's second launch beside the network / the persistent trunk's grid
     size_t memo_small_bytes = 0, memo_big_bytes = 0;
     unsigned flushes = 0;
     std::vector<void*> allocs;
@@ -810,6 +812,9 @@ int qz_engine_stats(qz_engine* e, qz_stats* out, void* stream) {
     out->runaway_descents = (int64_t)h[QZ_C_RUNAWAY];
     out->compact_slices = (int64_t)h[QZ_C_COMPACT_SLICES];
     out->miss_overflow = (int64_t)h[QZ_C_MISS_OVERFLOW];
+    unsigned long long ovp = 0ull;
+    for (int i = 0; i < QZ_C_SPREAD; i++) ovp += h[QZ_C_OVERLAP_PLAYOUTS_0 + i];
+    out->overlap_playouts = (int64_t)ovp;
     return 0;
 }
 
@@ -918,10 +923,10 @@ static int nn_weights_check(const qz_nn_weights* w) {
 }
 // boards -> (p, v) for the first n (or *n_live) boards: the fused trunk launch + the fully connected launch
 static int nn_evaluate(const uint64_t* hb, const uint64_t* vb, const uint64_t* meta, const uint8_t* terminal, int64_t n, const qz_nn_weights* w, float* feat,
-                       float* p_out, float* v_out, const int* n_live, hipStream_t s) {
+                       float* p_out, float* v_out, const int* n_live, hipStream_t s, int persist_wgs = 0) {
     const qzl::TrunkInput in = {hb, vb, meta, terminal, w->hot9, w->base0, w->wd, w->gamma0, w->beta0};
     HIP_TRY(qzl::trunk(nullptr, nullptr, (long long)n, w->n_blocks, w->w16, w->gamma, w->beta, w->inv_scale, w->eps, 1, s, w->w6_16, w->gamma6, w->beta6, feat, &in,
-                       n_live, w->precision == 1));
+                       n_live, w->precision == 1, persist_wgs));
     HIP_TRY(qzl::head_fc(feat, (long long)n, w->w1t, w->b1, w->w2, w->b2, w->w3t, w->b3, p_out, v_out, s, n_live));
     return 0;
 }
@@ -1017,11 +1022,18 @@ int qz_selfplay_round(qz_engine* e, const qz_nn_weights* w, int max_playouts, in
     }
     const EngineDev& d = e->dev;
     const unsigned int ticks = budget_us > 0 ? (unsigned int)budget_us * 100u : 0xFFFFFFFFu;  // s_memrealtime: 100 MHz
+    // qz_selfplay_set_overlap: the boards that are not waiting for the network go on playing beside it -- the trunk as a grid of
+    // trunk_wgs persistent workgroups (two per CU = one 256-register wavefront per SIMD), k_advance's second launch in the other
+    // half of every SIMD's registers (four 64-register wavefronts), behind the moves on their stream; the tail (the memo's
+    // inserts: no probe may be in flight) waits for it.  (Needs the launch-wide deadline: select_opts bit 3, budgets >= 100 us.)
+    const bool overlap = e->overlap_us >= 100 && (d.select_opts & 8) != 0 && budget_us >= 100;
     HIP_TRY(qzl::advance(d, max_playouts, ticks, 0, e->par, s));
     HIP_TRY(hipEventRecord(e->ev_fork, s));
     // (the network is queued first: its workgroups -- 4 per CU, most of the LDS -- should be placed before the side kernels'; queuing
     // the side kernels first and / or a high-priority side stream measured the same: profiles/round4/SUMMARY.md)
-    if ((r = nn_evaluate(d.miss_hb, d.miss_vb, d.miss_meta, nullptr, d.n_boards, w, e->feat, d.miss_p, d.miss_v, d.miss_count + e->par, s))) return r;
+    if ((r = nn_evaluate(d.miss_hb, d.miss_vb, d.miss_meta, nullptr, d.n_boards, w, e->feat, d.miss_p, d.miss_v, d.miss_count + e->par, s,
+                         overlap ? e->trunk_wgs : 0)))
+        return r;
     // The rules op and the moves are independent of each other (the miss list / the boards' own trees, roots and trajectories)
     // and each gets a stream of its own: on ONE side stream the moves queued behind the rules op, whose few workgroups wait
     // for room beside the trunk's for most of the trunk's duration -- the moves then started when the network was nearly
@@ -1029,15 +1041,29 @@ int qz_selfplay_round(qz_engine* e, const qz_nn_weights* w, int max_playouts, in
     HIP_TRY(hipStreamWaitEvent(e->side, e->ev_fork, 0));
     HIP_TRY(qzl::movegen_encode(d.miss_hb, d.miss_vb, d.miss_meta, d.n_boards, d.miss_mask, nullptr, nullptr, e->scratch, e->rules, e->side, d.miss_count + e->par));
     HIP_TRY(hipEventRecord(e->ev_join, e->side));
-    if (auto_finish) {
+    if (auto_finish || overlap) {
         HIP_TRY(hipStreamWaitEvent(e->side2, e->ev_fork, 0));
-        HIP_TRY(qzl::moves(d, ticks, e->side2));
+        if (auto_finish) {
+            HIP_TRY(qzl::moves(d, ticks, e->side2));
+            e->async_moves = true;
+        }
+        if (overlap) HIP_TRY(qzl::advance_overlap(d, max_playouts, (unsigned int)e->overlap_us * 100u, e->par, e->side2));
         HIP_TRY(hipEventRecord(e->ev_join2, e->side2));
-        e->async_moves = true;
     }
     HIP_TRY(hipStreamWaitEvent(s, e->ev_join, 0));
-    if (auto_finish) HIP_TRY(hipStreamWaitEvent(s, e->ev_join2, 0));
+    if (auto_finish || overlap) HIP_TRY(hipStreamWaitEvent(s, e->ev_join2, 0));
     return qz_selfplay_round_tail(e, stream);
+}
+int qz_selfplay_set_overlap(qz_engine* e, int overlap_us, int trunk_workgroups) {
+    if (!e) return fail(QZ_E_INVALID, "null engine");
+    if (overlap_us < 0 || overlap_us > 1000000) return fail(QZ_E_INVALID, "overlap_us must be in [0, 1e6]");
+    if (overlap_us > 0 && overlap_us < 100) return fail(QZ_E_INVALID, "an overlap budget below 100 us cannot hold one playout: 0 (off) or >= 100");
+    if (trunk_workgroups < 0) return fail(QZ_E_INVALID, "trunk_workgroups < 0");
+    if (overlap_us > 0 && !(e->dev.select_opts & 8))
+        return fail(QZ_E_INVALID, "the overlap launch needs the launch-wide deadline (qz_config.select_opts bit 3)");
+    e->overlap_us = overlap_us;
+    e->trunk_wgs = trunk_workgroups > 0 ? trunk_workgroups : 512;
+    return 0;
 }
 int qz_selfplay_parity(qz_engine* e) { return e ? e->par : fail(QZ_E_INVALID, "null engine"); }
 int qz_selfplay_misses(qz_engine* e, qz_boards* boards_out, const int32_t** n_dev_out, uint32_t** mask5_out, float** p_out, float** v_out) {

@@ -290,7 +290,7 @@ struct InputArgs {
 // SPLIT = false: ONE MFMA per product on the hi halves only (fp16 operands, fp32 accumulation) -- the labelled
 // throughput mode (`nn_precision="fp16"`, bench.py --nn-dtype fp16): a third of the matrix work, p / v within ~1e-3
 // of the reference instead of 1e-5 (tests/test_gpu_conv.py states the bound); never the default.
-template <bool FROM_BOARD, bool SPLIT = true>
+template <bool FROM_BOARD, bool SPLIT = true, bool PERSIST = false>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_trunk(const float* __restrict__ x, float* __restrict__ out, TrunkArgs A, int n_layers, float eps, HeadArgs H, InputArgs I,
                                                const int* __restrict__ n_live  // or nullptr: only the first *n_live leaves are evaluated (the engine's miss list)
 #ifdef QZ_TRUNK_STAMPS
@@ -298,11 +298,17 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #endif
                                                ) {
     __shared__ TrunkShared sm;
-    if (n_live && (int)blockIdx.x >= __builtin_amdgcn_readfirstlane(*n_live)) return;
-    const int tid = (int)threadIdx.x, lane = tid & 63, nt = tid >> 6;
+    // PERSIST (qz_selfplay_round with an overlap budget): a grid of a FEW workgroups -- two per CU, one wavefront per SIMD -- strides over
+    // the leaves, so that the rest of every SIMD (half the registers, half the LDS) stays free for k_advance's wavefronts
+    const int n_lv = n_live ? __builtin_amdgcn_readfirstlane(*n_live) : 0x7FFFFFFF;
+  for (unsigned int leaf = blockIdx.x;; leaf += gridDim.x) {
+    if ((int)leaf >= n_lv) return;
+    int tid_ = (int)threadIdx.x;
+    if (PERSIST) asm volatile("" : "+v"(tid_));  // (per iteration: or every address below is hoisted out of the loop -- 179 registers' worth, to scratch)
+    const int tid = tid_, lane = tid & 63, nt = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int co = 32 * nt + r;
-    const size_t obase = (size_t)blockIdx.x * NPOS * C + (size_t)co;
+    const size_t obase = (size_t)leaf * NPOS * C + (size_t)co;
 #ifdef QZ_TRUNK_STAMPS
     unsigned long long t_stage = 0, t_loop = 0, t_stat = 0, t_hand = 0, t_mark = __builtin_amdgcn_s_memtime();
     const unsigned long long t_begin = t_mark, r_begin = __builtin_amdgcn_s_memrealtime();
@@ -317,7 +323,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     float* const s_raw = reinterpret_cast<float*>(sm.a_hi);  // input stage: conv1 before bn1, fp32 [81][64] (20,736 of the images' 23,616 B)
     bool term = false;
     if (!from_board) {   // stage the leaf (fp32 [81][64]) as fp16 hi / lo images
-        const float4* x4 = reinterpret_cast<const float4*>(x) + (size_t)blockIdx.x * NPOS * 16;
+        const float4* x4 = reinterpret_cast<const float4*>(x) + (size_t)leaf * NPOS * 16;
         _Float16* ih = reinterpret_cast<_Float16*>(sm.a_hi);
         _Float16* il = reinterpret_cast<_Float16*>(sm.a_lo);
         for (int i = tid; i < NPOS * 16; i += 128) {
@@ -343,10 +349,10 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     } else {
         // packed board, include/qz_abi.h: meta = p1 i8 | p2 i8 | walls1 u8 | walls2 u8 | current player u8
-        const uint64_t m = I.meta[blockIdx.x], bhb = I.hb[blockIdx.x], bvb = I.vb[blockIdx.x];
+        const uint64_t m = I.meta[leaf], bhb = I.hb[leaf], bvb = I.vb[leaf];
         const int p1 = (int)(int8_t)(m & 0xFF), p2 = (int)(int8_t)((m >> 8) & 0xFF);
         const int w1 = (int)((m >> 16) & 0xFF), w2 = (int)((m >> 24) & 0xFF), cur = (int)((m >> 32) & 0xFF);
-        term = I.terminal ? (I.terminal[blockIdx.x] != 0) : false;
+        term = I.terminal ? (I.terminal[leaf] != 0) : false;
         for (int q = tid; q < 576; q += 128) reinterpret_cast<float4*>(s_wd)[q] = reinterpret_cast<const float4*>(I.wd)[q];
         {
             const int wm = cur == 1 ? w1 : w2, wo = cur == 1 ? w2 : w1;
@@ -589,7 +595,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // ends up with head channel r (r < 6 are real) of its tiles' rows
         // (the wave with two tiles has twice the matrix work: alternating that role between the waves from workgroup to
         // workgroup spreads it over the SIMDs of a CU)
-        const int role = nt ^ (int)((H.role_shift < 31) ? ((blockIdx.x >> H.role_shift) & 1u) : 0u);
+        const int role = nt ^ (int)((H.role_shift < 31) ? ((leaf >> H.role_shift) & 1u) : 0u);
         const bool two = __builtin_amdgcn_readfirstlane(role) == 0;
         const int rb0 = role ? rbase[2] : rbase[0], rb1 = rbase[1];
         const uint32_t vm0 = role ? vmask[2] : vmask[0], vm1 = vmask[1];
@@ -678,16 +684,19 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
         }
         __syncthreads();
-        float* fo = H.feat + (size_t)blockIdx.x * (6 * NPOS);
+        float* fo = H.feat + (size_t)leaf * (6 * NPOS);
         for (int i = tid; i < 6 * NPOS; i += 128) fo[i] = fb[i];
     }
 #ifdef QZ_TRUNK_STAMPS
     if (lane == 0) {
-        unsigned long long* o = stamps + ((size_t)blockIdx.x * 2 + nt) * 8;
+        unsigned long long* o = stamps + ((size_t)leaf * 2 + nt) * 8;
         o[0] = t_stage; o[1] = t_loop; o[2] = t_stat; o[3] = t_hand; o[4] = __builtin_amdgcn_s_memtime() - t_begin; o[5] = t_begin;
         o[6] = __builtin_amdgcn_s_memrealtime() - r_begin; o[7] = __smid();  // o[4] / o[6] x 100 MHz = the clock this wave ran at
     }
 #endif
+    if (!PERSIST) return;
+    __syncthreads();  // the next leaf's stage writes the images this leaf's head stage read
+  }
 }
 
 }  // namespace
@@ -715,7 +724,8 @@ struct TrunkInput {
 // from the packed boards in the same launch and x is not read (may be NULL)
 hipError_t trunk(float* x, float* tmp, long long n, int n_blocks, const void* const* w16, const float* const* gamma, const float* const* beta,
                  const float* inv_scale /*[dev]*/, float eps, int fused, hipStream_t s, const void* w6 = nullptr, const float* gamma6 = nullptr,
-                 const float* beta6 = nullptr, float* feat = nullptr, const TrunkInput* in = nullptr, const int* n_live = nullptr, int single_product = 0) {
+                 const float* beta6 = nullptr, float* feat = nullptr, const TrunkInput* in = nullptr, const int* n_live = nullptr, int single_product = 0,
+                 int persist_wgs = 0) {
     if (n <= 0 || n_blocks <= 0) return hipSuccess;
     const int nl = 2 * n_blocks;
     if ((feat || in || n_live) && !(fused && nl <= MAX_TRUNK_LAYERS)) return hipErrorInvalidValue;
@@ -743,7 +753,12 @@ hipError_t trunk(float* x, float* tmp, long long n, int n_blocks, const void* co
         InputArgs I = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         if (in) I = InputArgs{in->hb, in->vb, in->meta, in->terminal, in->hot9, in->base0, in->wd, in->gamma0, in->beta0};
         if (single_product && !in) return hipErrorInvalidValue;  // (the throughput mode exists on the route from the packed boards only)
-        if (in && single_product) hipLaunchKernelGGL((k_trunk<true, false>), dim3((unsigned)n), dim3(128), 0, s, x, feat ? nullptr : x, A, nl, eps, H, I, n_live);
+        if (persist_wgs > 0) {  // (the engine's route only: from the packed boards, the count on the device)
+            if (!in || !n_live) return hipErrorInvalidValue;
+            const unsigned g = (unsigned)(persist_wgs < n ? persist_wgs : n);
+            if (single_product) hipLaunchKernelGGL((k_trunk<true, false, true>), dim3(g), dim3(128), 0, s, x, feat ? nullptr : x, A, nl, eps, H, I, n_live);
+            else hipLaunchKernelGGL((k_trunk<true, true, true>), dim3(g), dim3(128), 0, s, x, feat ? nullptr : x, A, nl, eps, H, I, n_live);
+        } else if (in && single_product) hipLaunchKernelGGL((k_trunk<true, false>), dim3((unsigned)n), dim3(128), 0, s, x, feat ? nullptr : x, A, nl, eps, H, I, n_live);
         else if (in) hipLaunchKernelGGL((k_trunk<true, true>), dim3((unsigned)n), dim3(128), 0, s, x, feat ? nullptr : x, A, nl, eps, H, I, n_live);
         else hipLaunchKernelGGL((k_trunk<false, true>), dim3((unsigned)n), dim3(128), 0, s, x, feat ? nullptr : x, A, nl, eps, H, I, n_live);
         return hipGetLastError();

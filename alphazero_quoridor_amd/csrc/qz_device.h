@@ -107,7 +107,8 @@ typedef uint32_t qz_u32x3_a16 __attribute__((ext_vector_type(3), aligned(16))); 
 // base-path search per lane | with ordinary stores for the planes (A/B partners of 3), 8 | 12 | 16 |
 // 24 | 32 = pooled pipeline with that many boards per mask workgroup.
 constexpr int QZ_C_SPREAD = 64;
-constexpr int QZ_C_TOTAL = QZ_C_COUNT + 2 * QZ_C_SPREAD;
+constexpr int QZ_C_OVERLAP_PLAYOUTS_0 = QZ_C_COUNT + 2 * QZ_C_SPREAD;  // playouts of the rounds' second launches (k_advance beside the network), QZ_C_SPREAD words
+constexpr int QZ_C_TOTAL = QZ_C_COUNT + 3 * QZ_C_SPREAD;
 
 struct RulesOpts {
     int variant = 0;

@@ -2521,6 +2521,7 @@ constexpr int ADV_WPB = QZ_ADV_WPB;
 #ifndef QZ_ADV_WAVES_SMALL
 #define QZ_ADV_WAVES_SMALL 4  // wavefronts per SIMD the build of k_advance for engines of <= 4,096 boards aims at (A/B: 8 = one build for all sizes)
 #endif
+template <bool OV>
 __device__ __forceinline__ void advance_board(EngineDev& E, const int max_iters, const unsigned int budget, const int par) {
     __shared__ uint32_t s_we[ADV_WPB][ADV_LCAP];
     __shared__ unsigned long long s_wb[ADV_WPB][ADV_LCAP];
@@ -2535,11 +2536,19 @@ __device__ __forceinline__ void advance_board(EngineDev& E, const int max_iters,
     // a multiple of 8, so a board stays on its XCD and its tree in that XCD's L2).
     // (Only with a budget of 100 us or more: under a shorter one the boards behind the first slots would never start a playout.)
     const bool shared = (E.select_opts & 8) != 0 && budget >= 10000u && budget != 0xFFFFFFFFu;
+    // OV: the round's SECOND launch (qz_selfplay_round with an overlap budget), beside the network: the boards that are not
+    // waiting for it go on playing.  Such a launch never consumes an evaluation (the network is writing them) and never adds to the
+    // miss list (the network is reading it): a board that meets a leaf for the network forgets the descent -- the tree is as it was --
+    // and repeats it in the next round's first launch.  It has a deadline of its own (tag bit 19 of the launch stamp) and the
+    // boards that got their slots LAST in the first launch (the first 8,192 in rotation order hold the chip's slots) come first.
+    // (A build of its own: as a run-time flag of the one build it cost the first launch 300 more register-spill moves.)
+    constexpr bool ov = OV;
     uint32_t seq = 0u;
     int b_ = w_;
     if (shared) {
         seq = rfl((uint32_t)E.miss_count[2]);
-        b_ = (int)(((unsigned int)w_ + (seq % 4096u) * QZ_ADV_ROT) % (unsigned int)E.n_boards);
+        b_ = (int)(((unsigned int)w_ + (seq % 4096u) * QZ_ADV_ROT + (ov ? 8192u : 0u)) % (unsigned int)E.n_boards);
+        if (ov) seq ^= 0x80000u;
     }
     const int b = __builtin_amdgcn_readfirstlane(b_);  // in an SGPR: every per-board address below is scalar arithmetic
     // The engine descriptor arrives in the kernel-argument segment and is fetched in 16-dword pieces; left alone, a piece is ONE
@@ -2555,8 +2564,8 @@ __device__ __forceinline__ void advance_board(EngineDev& E, const int max_iters,
     QZ_OWN_S(E.select_opts); QZ_OWN_S(E.node_cap); QZ_OWN_S(E.edge_cap); QZ_OWN_S(E.fix_terminal_sign); QZ_OWN_S(E.tree_pool_pages);
 #undef QZ_OWN_P
 #undef QZ_OWN_S
-    if (b == 0 && lane == 0) atomicAdd(&E.counters[QZ_C_ROUNDS], 1ull);
-    if (rfl(E.status[b]) != QZ_PLAYING) return;
+    if (b == 0 && lane == 0 && !ov) atomicAdd(&E.counters[QZ_C_ROUNDS], 1ull);
+    if (!ov && rfl(E.status[b]) != QZ_PLAYING) return;
     unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long t_it = t0;
     bool late = false;  // this wavefront's budget began before it did
@@ -2580,6 +2589,9 @@ __device__ __forceinline__ void advance_board(EngineDev& E, const int max_iters,
             }
         }
     }
+    // (the second launch: its first wavefront has left the launch's stamp above even if its own board has nothing to do -- half
+    // the boards have not, and without the stamp every wavefront of the launch would count the budget from its own start)
+    if (ov && (rfl(E.status[b]) != QZ_PLAYING || rfl(E.pend_slot[b]) != QZ_NONE)) return;
 #ifndef QZ_BUDGET_PREDICT
 #define QZ_BUDGET_PREDICT 1  // what a board expects its next playout to last: 0 = nothing, 1 = as long as its last one, 2 = the largest of its recent ones (a maximum that decays by a quarter per playout: measured no different from 1, 289.1 against 290.6 M playouts/s; nor is a margin of a quarter or a half of the last playout on top: 309.5 / 309.8 against 309.0 M, launches as long as before -- the launch's overrun of ~100 us is the extreme of ten thousand boards' playout times, not a misprediction of the typical one)
 #endif
@@ -2687,6 +2699,7 @@ __device__ __forceinline__ void advance_board(EngineDev& E, const int max_iters,
         waiting = true;
         break;
     }
+    if (ov) waiting = false;
     if (waiting) {
         uint32_t s = 0u;
         if (lane == 0) s = (uint32_t)atomicAdd(E.miss_count + par, 1);
@@ -2738,6 +2751,10 @@ __device__ __forceinline__ void advance_board(EngineDev& E, const int max_iters,
     }
 #endif
     if (lane == 0) {
+        if (ov) {  // (what the second launches add, for the accounts of the first: bench.py's roofline line)
+            const uint32_t d0 = E.pl_done[b];
+            if (done != d0) atomicAdd(&E.counters[QZ_C_OVERLAP_PLAYOUTS_0 + (b & (QZ_C_SPREAD - 1))], (unsigned long long)(done - d0));
+        }
         E.pl_done[b] = done;
         if (!waiting && slot != QZ_NONE) E.pend_slot[b] = QZ_NONE;
         if (open_rounds) E.bc_open_rounds[b] += open_rounds;
@@ -2749,9 +2766,9 @@ __device__ __forceinline__ void advance_board(EngineDev& E, const int max_iters,
 // chain is bound by its own latencies (round 3: one / two / four wavefronts per SIMD ran 78.8 / 74.0 / 66.6 playouts per board and
 // round).  k_advance<4>: 73 registers, no spill at all, for engines of up to 4,096 boards, where the extra residency buys nothing
 // and the eight-wave build's few spills cost 9 %.
-template <int W>
+template <int W, bool OV = false>
 __global__ __launch_bounds__(64 * ADV_WPB) __attribute__((amdgpu_waves_per_eu(W, W))) void k_advance(EngineDev E, int max_iters, unsigned int budget, int par) {
-    advance_board(E, max_iters, budget, par);
+    advance_board<OV>(E, max_iters, budget, par);
 }
 
 // k_moves: MCTSPlayer.choose_action's tail + one iteration of start_self_play's loop (finish_move_board) for every
@@ -3172,6 +3189,13 @@ hipError_t finish_move(const EngineDev& E, const uint8_t* forced, float* pi_out,
 // fits one slice.
 static unsigned int compact_budget(unsigned int budget_ticks) {
     return budget_ticks == 0xFFFFFFFFu ? budget_ticks : (budget_ticks / 32u > 0u ? budget_ticks / 32u : 1u);
+}
+// the round's second launch, beside the network (advance_board<true>): always the 64-register build -- four of its wavefronts fit
+// beside one of the trunk's on a SIMD
+hipError_t advance_overlap(const EngineDev& E, int max_iters, unsigned int budget_ticks, int par, hipStream_t s) {
+    const dim3 adv_grid((unsigned)((E.n_boards + ADV_WPB - 1) / ADV_WPB)), adv_block(64 * ADV_WPB);
+    hipLaunchKernelGGL((k_advance<8, true>), adv_grid, adv_block, 0, s, E, max_iters, budget_ticks, par);
+    return hipGetLastError();
 }
 hipError_t advance(const EngineDev& E, int max_iters, unsigned int budget_ticks, int auto_finish, int par, hipStream_t s) {
     if (auto_finish) hipLaunchKernelGGL(k_moves, wave_grid(E.n_boards), dim3(TPB), 0, s, E, compact_budget(budget_ticks));

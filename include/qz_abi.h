@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define QZ_ABI_VERSION 5
+#define QZ_ABI_VERSION 6
 #define QZ_N_ACTIONS 140            /* quoridor.py:12  action_space = 140            */
 #define QZ_PLANES (26 * 81)         /* quoridor.py:58-131  26x9x9 state tensor       */
 #define QZ_MASK_WORDS 5             /* 140-bit legal mask, bit a of word a/32        */
@@ -200,6 +200,8 @@ typedef struct {
                                   in the board's next launch (a 1,000-level line copies one level per memory round trip)  */
     int64_t miss_overflow;     /* leaves that found the miss list full (only a stale miss counter can do that): must be 0; the
                                   guard exists so that such a bug cannot write past the list                    */
+    int64_t overlap_playouts;  /* of `playouts`: those made by the rounds' second launches, beside the network
+                                  (qz_selfplay_set_overlap)                                                     */
 } qz_stats;
 
 /* MCTSPlayer.__init__ / MCTS.__init__ (mcts.py:89-100, 159-161) for n_boards trees +
@@ -454,6 +456,16 @@ int qz_selfplay_leaf_rules(qz_engine* e, void* stream);
 int qz_selfplay_evaluate(qz_engine* e, const qz_nn_weights* w, void* stream);
 int qz_selfplay_round_tail(qz_engine* e, void* stream);
 int qz_selfplay_round(qz_engine* e, const qz_nn_weights* w, int max_playouts, int budget_us, int auto_finish, void* stream);
+/* qz_selfplay_round with the network OFF the boards' critical path (off by default: overlap_us = 0).  With overlap_us >= 100 a
+ * round is: the launch above; then, BESIDE the network, a second launch of the same loop for overlap_us microseconds in which the
+ * boards that are not waiting for an evaluation go on playing (behind the moves, on their stream); then the tail.  The second
+ * launch never consumes an evaluation and never adds to the miss list: a board that meets a leaf for the network there forgets
+ * the descent (the tree is as it was) and repeats it in the next round's first launch -- per board the operations and their order
+ * are unchanged, so the parity statement above holds.  To make room the trunk runs as `trunk_workgroups` persistent workgroups
+ * (0 = 512: two per CU, one 256-register wavefront per SIMD) striding over the miss list, which leaves half of every SIMD's
+ * registers to four of k_advance's wavefronts.  Needs qz_config.select_opts bit 3 (the launch-wide deadline); QZ_E_INVALID
+ * otherwise.  qz_stats.overlap_playouts counts what the second launches add. */
+int qz_selfplay_set_overlap(qz_engine* e, int overlap_us, int trunk_workgroups);
 /* which of the engine's two miss counters the NEXT qz_selfplay_advance uses (0 | 1; qz_selfplay_round_tail flips it,
  * qz_engine_reset / qz_engine_set_boards(reset_trees) set it to 0).  A HIP graph captured over whole rounds bakes the
  * counter's address in: replay it only while this value is what it was at capture time (SelfPlayEngine.capture_rounds
