@@ -2565,6 +2565,9 @@ __device__ __forceinline__ void advance_board(EngineDev& E, const int max_iters,
 #undef QZ_OWN_P
 #undef QZ_OWN_S
     if (b == 0 && lane == 0 && !ov) atomicAdd(&E.counters[QZ_C_ROUNDS], 1ull);
+    // (the first launch: a board that is not playing leaves before the stamp -- if it is the first wavefront's, about one launch in
+    // 250, that launch's wavefronts count the budget from their own starts.  Moving the test behind the stamp, as the second launch
+    // has it, costs this build 59 more register-spill moves: left as it is.)
     if (!ov && rfl(E.status[b]) != QZ_PLAYING) return;
     unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long t_it = t0;
