@@ -134,7 +134,7 @@ struct qz_engine {
     // qz_selfplay_round: the rules op of the miss list and the finished boards' moves run beside the network's trunk
     hipStream_t side = nullptr, side2 = nullptr;  // (the rules op / the moves: each on a stream of its own beside the network)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
-    int overlap_us = 0, trunk_wgs = 512;  // qz_selfplay_set_overlap: k_advance's second launch beside the network / the persistent trunk's grid
+    int overlap_us = 0, trunk_wgs = 0;  // qz_selfplay_set_overlap: k_advance's second launch beside the network / the persistent trunk's grid
     size_t memo_small_bytes = 0, memo_big_bytes = 0;
     unsigned flushes = 0;
     std::vector<void*> allocs;
@@ -992,7 +992,8 @@ int qz_selfplay_evaluate(qz_engine* e, const qz_nn_weights* w, void* stream) {
     int r;
     if ((r = nn_weights_check(w))) return r;
     const EngineDev& d = e->dev;
-    return nn_evaluate(d.miss_hb, d.miss_vb, d.miss_meta, nullptr, d.n_boards, w, e->feat, d.miss_p, d.miss_v, d.miss_count + e->par, (hipStream_t)stream);
+    return nn_evaluate(d.miss_hb, d.miss_vb, d.miss_meta, nullptr, d.n_boards, w, e->feat, d.miss_p, d.miss_v, d.miss_count + e->par, (hipStream_t)stream,
+                       e->trunk_wgs > 0 ? e->trunk_wgs : 0);
 }
 int qz_selfplay_round_tail(qz_engine* e, void* stream) {
     ENGINE_CHECK(e);
@@ -1032,7 +1033,7 @@ int qz_selfplay_round(qz_engine* e, const qz_nn_weights* w, int max_playouts, in
     // (the network is queued first: its workgroups -- 4 per CU, most of the LDS -- should be placed before the side kernels'; queuing
     // the side kernels first and / or a high-priority side stream measured the same: profiles/round4/SUMMARY.md)
     if ((r = nn_evaluate(d.miss_hb, d.miss_vb, d.miss_meta, nullptr, d.n_boards, w, e->feat, d.miss_p, d.miss_v, d.miss_count + e->par, s,
-                         overlap ? e->trunk_wgs : 0)))
+                         e->trunk_wgs > 0 ? e->trunk_wgs : (overlap ? 512 : 0))))
         return r;
     // The rules op and the moves are independent of each other (the miss list / the boards' own trees, roots and trajectories)
     // and each gets a stream of its own: on ONE side stream the moves queued behind the rules op, whose few workgroups wait
@@ -1062,7 +1063,7 @@ int qz_selfplay_set_overlap(qz_engine* e, int overlap_us, int trunk_workgroups) 
     if (overlap_us > 0 && !(e->dev.select_opts & 8))
         return fail(QZ_E_INVALID, "the overlap launch needs the launch-wide deadline (qz_config.select_opts bit 3)");
     e->overlap_us = overlap_us;
-    e->trunk_wgs = trunk_workgroups > 0 ? trunk_workgroups : 512;
+    e->trunk_wgs = trunk_workgroups;  // (> 0 with overlap_us = 0: the persistent trunk alone, an A/B of the trunk's two launch shapes)
     return 0;
 }
 int qz_selfplay_parity(qz_engine* e) { return e ? e->par : fail(QZ_E_INVALID, "null engine"); }

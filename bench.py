@@ -314,8 +314,8 @@ def make_engine(args, net, dev, seed, fix_sign, boards=None, nn_precision=None, 
     so = args.select_opts if select_opts is None else select_opts
     eng = BoardGroups(boards or args.boards, args.groups, make_ev, seed=seed, device=dev, n_playout=args.playouts, c_puct=5, temp=1.0, is_selfplay=1,
                       fix_terminal_sign=fix_sign, select_opts=so, memo=not args.no_memo, max_depth=args.max_depth)
-    if args.overlap_us and (so & 8):  # (k_advance's second launch beside the network needs the launch-wide deadline)
-        eng.set_overlap(args.overlap_us, args.trunk_workgroups)
+    if (args.overlap_us and (so & 8)) or args.trunk_workgroups:  # (k_advance's second launch beside the network needs the launch-wide deadline)
+        eng.set_overlap(args.overlap_us if (so & 8) else 0, args.trunk_workgroups)
     return eng
 
 
@@ -720,7 +720,7 @@ def main():
                                                                  "per-board budgets of 2,400 us on the same box; 0 = per-board budgets)")
     ap.add_argument("--overlap-us", type=int, default=0, help="k_advance's SECOND launch per round, beside the network, for this many microseconds (qz_selfplay_set_overlap; "
                                                               "0 = off; needs --select-opts 8); the rounds timed piece by piece have none")
-    ap.add_argument("--trunk-workgroups", type=int, default=0, help="with --overlap-us: the persistent trunk's grid (0 = 512: two workgroups per CU)")
+    ap.add_argument("--trunk-workgroups", type=int, default=0, help="the trunk as this many persistent workgroups striding over the miss list (0 = one workgroup per leaf; with --overlap-us 0 = 512: two per CU)")
     ap.add_argument("--rules-variant", type=int, default=0, help="lockstep A/B: qz_rules_opts.variant of the engines' leaf rules op")
     ap.add_argument("--length-file", default=None, help="game-length sample for games_per_s_steady_state (default: newest profiles/round*/game_length_<n>playouts.json)")
     ap.add_argument("--clock-log", default=None, help="write the clock / power samples of the timed region to this JSON file")

@@ -464,7 +464,8 @@ int qz_selfplay_round(qz_engine* e, const qz_nn_weights* w, int max_playouts, in
  * are unchanged, so the parity statement above holds.  To make room the trunk runs as `trunk_workgroups` persistent workgroups
  * (0 = 512: two per CU, one 256-register wavefront per SIMD) striding over the miss list, which leaves half of every SIMD's
  * registers to four of k_advance's wavefronts.  Needs qz_config.select_opts bit 3 (the launch-wide deadline); QZ_E_INVALID
- * otherwise.  qz_stats.overlap_playouts counts what the second launches add. */
+ * otherwise.  qz_stats.overlap_playouts counts what the second launches add.  (overlap_us = 0 with trunk_workgroups > 0: no second
+ * launch, only the trunk's persistent launch shape with that grid -- an A/B switch.) */
 int qz_selfplay_set_overlap(qz_engine* e, int overlap_us, int trunk_workgroups);
 /* which of the engine's two miss counters the NEXT qz_selfplay_advance uses (0 | 1; qz_selfplay_round_tail flips it,
  * qz_engine_reset / qz_engine_set_boards(reset_trees) set it to 0).  A HIP graph captured over whole rounds bakes the
