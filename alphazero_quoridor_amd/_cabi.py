@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "libqzero_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "qz_abi.h")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 N_ACTIONS = 140
 PLANES = 26 * 81
 MASK_WORDS = 5
@@ -43,7 +43,7 @@ class qz_boards(C.Structure):
 
 
 class qz_rules_opts(C.Structure):
-    _fields_ = [("variant", C.c_int32), ("detour_pooled", C.c_int32), ("detour_wave", C.c_int32), ("enc_split_pct", C.c_int32)]
+    _fields_ = [("variant", C.c_int32), ("detour_pooled", C.c_int32), ("detour_wave", C.c_int32), ("enc_split_pct", C.c_int32), ("pool_dependent", C.c_int32)]
 
 
 class qz_config(C.Structure):
@@ -125,7 +125,6 @@ class qz_stats(C.Structure):
         ("runaway_descents", C.c_int64),
         ("compact_slices", C.c_int64),
         ("miss_overflow", C.c_int64),
-        ("overlap_playouts", C.c_int64),
     ]
 
 
@@ -202,7 +201,6 @@ _SIGNATURES = {
     "qz_selfplay_evaluate": (C.c_int, [_P, C.POINTER(qz_nn_weights), _P]),
     "qz_selfplay_round_tail": (C.c_int, [_P, _P]),
     "qz_selfplay_round": (C.c_int, [_P, C.POINTER(qz_nn_weights), C.c_int, C.c_int, C.c_int, _P]),
-    "qz_selfplay_set_overlap": (C.c_int, [_P, C.c_int, C.c_int]),
     "qz_selfplay_parity": (C.c_int, [_P]),
     "qz_selfplay_misses": (C.c_int, [_P, C.POINTER(qz_boards), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
     "qz_memo_flush": (C.c_int, [_P, _P]),

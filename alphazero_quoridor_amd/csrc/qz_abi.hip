@@ -15,13 +15,15 @@
 #include "qz_device.h"
 
 namespace qzl {
-hipError_t movegen_encode(const uint64_t*, const uint64_t*, const uint64_t*, int, uint32_t*, float*, const uint8_t*, void*, const RulesOpts&, hipStream_t, const int* n_dev = nullptr);
+hipError_t movegen_encode(const uint64_t*, const uint64_t*, const uint64_t*, int, uint32_t*, float*, const uint8_t*, void*, const RulesOpts&, hipStream_t, const int* n_dev = nullptr,
+                          const PoolAsync* pa = nullptr);
 hipError_t advance(const EngineDev&, int, unsigned int, int, int, hipStream_t);
-hipError_t advance_overlap(const EngineDev&, int, unsigned int, int, hipStream_t);
+hipError_t advance_lanes(const EngineDev&, int, unsigned int, int, hipStream_t);
 hipError_t moves(const EngineDev&, unsigned int, hipStream_t);
 hipError_t round_tail(const EngineDev&, int, hipStream_t);
 hipError_t memo_flush(const EngineDev&, hipStream_t);
 size_t movegen_scratch_bytes(int);
+size_t movegen_scratch_header_bytes();
 hipError_t step(uint64_t*, uint64_t*, uint64_t*, const uint8_t*, int, uint8_t*, uint8_t*, hipStream_t);
 hipError_t select(const EngineDev&, hipStream_t);
 hipError_t expand_backup(const EngineDev&, const float*, const float*, hipStream_t);
@@ -41,7 +43,7 @@ struct TrunkInput {  // qz_conv.hip
     const float *hot9, *base0, *wd, *gamma0, *beta0;
 };
 hipError_t trunk(float*, float*, long long, int, const void* const*, const float* const*, const float* const*, const float*, float, int, hipStream_t,
-                 const void*, const float*, const float*, float*, const TrunkInput*, const int* n_live = nullptr, int single_product = 0, int persist_wgs = 0);
+                 const void*, const float*, const float*, float*, const TrunkInput*, const int* n_live = nullptr, int single_product = 0);
 hipError_t head_fc(const float*, long long, const float*, const float*, const float*, const float*, const float*, const float*, float*, float*, hipStream_t,
                    const int* n_live = nullptr);
 hipError_t rollout_begin(const uint64_t*, const uint64_t*, const uint64_t*, int, uint8_t*, uint8_t*, int8_t*, int*, hipStream_t);
@@ -82,9 +84,10 @@ static std::mutex g_scratch_mu;
 struct ScratchBuf {
     void* p = nullptr;
     size_t bytes = 0;
+    PoolAsync pa;  // the pooled pipeline's second stream + fork / join events (created with the buffer)
 };
 static std::map<std::pair<int, void*>, ScratchBuf> g_scratch;
-static int get_scratch(int n, void* stream, void** out) {
+static int get_scratch(int n, void* stream, void** out, const PoolAsync** pa_out = nullptr) {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     size_t need = qzl::movegen_scratch_bytes(n);
@@ -94,17 +97,27 @@ static int get_scratch(int n, void* stream, void** out) {
         if (sb.p) {
             HIP_TRY(hipDeviceSynchronize());
             (void)hipFree(sb.p);
-            sb = ScratchBuf();
+            sb.p = nullptr;
+            sb.bytes = 0;
         }
         hipError_t e = hipMalloc(&sb.p, need);
         if (e != hipSuccess) {
             (void)hipGetLastError();
-            sb = ScratchBuf();
+            sb.p = nullptr;
             return fail(QZ_E_OOM, "hipMalloc(%zu) for move-generation scratch failed: %s", need, hipGetErrorString(e));
         }
         sb.bytes = need;
+        HIP_TRY(hipMemset(sb.p, 0, qzl::movegen_scratch_header_bytes()));  // (the ready flags / deferred list: call numbers only, from here on)
+        if (!sb.pa.side) {  // (optional: without them the pipeline's launches simply follow each other)
+            if (hipStreamCreateWithFlags(&sb.pa.side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&sb.pa.fork, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&sb.pa.join, hipEventDisableTiming) != hipSuccess) {
+                (void)hipGetLastError();
+                sb.pa = PoolAsync();
+            }
+        }
     }
     *out = sb.p;
+    if (pa_out) *pa_out = sb.pa.side ? &sb.pa : nullptr;
     return 0;
 }
 
@@ -114,11 +127,8 @@ static RulesOpts rules_opts(const qz_rules_opts* o) {
     r.variant = o->variant;
     if (o->detour_pooled > 0) r.detour_pooled = o->detour_pooled - 1;
     if (o->detour_wave > 0) r.detour_wave = o->detour_wave - 1;
-    if (o->enc_split_pct > 0) {  // split + 1000 x (1 + first): see qz_rules_opts
-        const int split = o->enc_split_pct % 1000, first = o->enc_split_pct / 1000 - 1;
-        if (split > 0) r.enc_split_pct = split > 100 ? 100 : split;
-        if (first >= 0) r.enc_first_pct = first > 800 ? 800 : first;
-    }
+    if (o->enc_split_pct > 0) r.enc_split_pct = o->enc_split_pct > 100 ? 100 : o->enc_split_pct;
+    r.pool_dependent = o->pool_dependent != 0;
     return r;
 }
 
@@ -134,7 +144,8 @@ struct qz_engine {
     // qz_selfplay_round: the rules op of the miss list and the finished boards' moves run beside the network's trunk
     hipStream_t side = nullptr, side2 = nullptr;  // (the rules op / the moves: each on a stream of its own beside the network)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
-    int overlap_us = 0, trunk_wgs = 0;  // qz_selfplay_set_overlap: k_advance's second launch beside the network / the persistent trunk's grid
+    hipStream_t lanes = nullptr;           // k_lanes (select_opts bit 4) runs beside k_advance on a stream of its own
+    hipEvent_t ev_lfork = nullptr, ev_ljoin = nullptr;
     size_t memo_small_bytes = 0, memo_big_bytes = 0;
     unsigned flushes = 0;
     std::vector<void*> allocs;
@@ -193,9 +204,10 @@ int qz_movegen_encode_opts(const qz_boards* boards, int n, uint32_t* mask5, floa
     if (n > 0 && !mask5 && !planes) return fail(QZ_E_INVALID, "mask5 and planes are both null");
     if (n == 0) return 0;
     void* scratch = nullptr;
-    if ((r = get_scratch(n, stream, &scratch))) return r;
+    const PoolAsync* pa = nullptr;
+    if ((r = get_scratch(n, stream, &scratch, &pa))) return r;
     HIP_TRY(qzl::movegen_encode(boards->hbits, boards->vbits, boards->meta, n, mask5, planes, nullptr, scratch, rules_opts(opts),
-                                (hipStream_t)stream));
+                                (hipStream_t)stream, nullptr, pa));
     return 0;
 }
 int qz_movegen(const qz_boards* boards, int n, uint32_t* mask5, void* stream) {
@@ -261,6 +273,9 @@ int qz_engine_destroy(qz_engine* e) {
     (void)hipDeviceSynchronize();
     if (e->side) (void)hipStreamDestroy(e->side);
     if (e->side2) (void)hipStreamDestroy(e->side2);
+    if (e->lanes) (void)hipStreamDestroy(e->lanes);
+    if (e->ev_lfork) (void)hipEventDestroy(e->ev_lfork);
+    if (e->ev_ljoin) (void)hipEventDestroy(e->ev_ljoin);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     if (e->ev_join2) (void)hipEventDestroy(e->ev_join2);
@@ -437,6 +452,7 @@ int qz_engine_create(const qz_config* cfg, qz_engine** out) {
         uint8_t* sc = nullptr;
         rc = dev_alloc(e, &sc, qzl::movegen_scratch_bytes(c.n_boards));
         e->scratch = sc;
+        if (!rc && hipMemset(sc, 0, qzl::movegen_scratch_header_bytes()) != hipSuccess) rc = fail(QZ_E_HIP, "scratch init failed");
     }
     if (rc) {
         qz_engine_destroy(e);
@@ -812,9 +828,6 @@ int qz_engine_stats(qz_engine* e, qz_stats* out, void* stream) {
     out->runaway_descents = (int64_t)h[QZ_C_RUNAWAY];
     out->compact_slices = (int64_t)h[QZ_C_COMPACT_SLICES];
     out->miss_overflow = (int64_t)h[QZ_C_MISS_OVERFLOW];
-    unsigned long long ovp = 0ull;
-    for (int i = 0; i < QZ_C_SPREAD; i++) ovp += h[QZ_C_OVERLAP_PLAYOUTS_0 + i];
-    out->overlap_playouts = (int64_t)ovp;
     return 0;
 }
 
@@ -923,10 +936,10 @@ static int nn_weights_check(const qz_nn_weights* w) {
 }
 // boards -> (p, v) for the first n (or *n_live) boards: the fused trunk launch + the fully connected launch
 static int nn_evaluate(const uint64_t* hb, const uint64_t* vb, const uint64_t* meta, const uint8_t* terminal, int64_t n, const qz_nn_weights* w, float* feat,
-                       float* p_out, float* v_out, const int* n_live, hipStream_t s, int persist_wgs = 0) {
+                       float* p_out, float* v_out, const int* n_live, hipStream_t s) {
     const qzl::TrunkInput in = {hb, vb, meta, terminal, w->hot9, w->base0, w->wd, w->gamma0, w->beta0};
     HIP_TRY(qzl::trunk(nullptr, nullptr, (long long)n, w->n_blocks, w->w16, w->gamma, w->beta, w->inv_scale, w->eps, 1, s, w->w6_16, w->gamma6, w->beta6, feat, &in,
-                       n_live, w->precision == 1, persist_wgs));
+                       n_live, w->precision == 1));
     HIP_TRY(qzl::head_fc(feat, (long long)n, w->w1t, w->b1, w->w2, w->b2, w->w3t, w->b3, p_out, v_out, s, n_live));
     return 0;
 }
@@ -967,6 +980,27 @@ int qz_nn_evaluate_w(const qz_boards* boards, const uint8_t* terminal, int64_t n
 }
 
 // ------------------------------------------------------------------ asynchronous self-play
+// k_moves (auto_finish), then the playouts: k_advance for every board -- or, with select_opts bit 4, k_advance for the boards that
+// still have walls and k_lanes (one LANE per board, qz_lanes.h) for the others, side by side on two streams (independent boards;
+// the miss list's counter and the page pool are shared through atomics).  Fork / join by events: captures into a HIP graph.
+static int launch_advance(qz_engine* e, int max_playouts, unsigned int ticks, int auto_finish, hipStream_t s) {
+    const EngineDev& d = e->dev;
+    if (!(d.select_opts & 16)) {
+        HIP_TRY(qzl::advance(d, max_playouts, ticks, auto_finish, e->par, s));
+        return 0;
+    }
+    if (!e->lanes) HIP_TRY(hipStreamCreateWithFlags(&e->lanes, hipStreamNonBlocking));
+    if (!e->ev_lfork) HIP_TRY(hipEventCreateWithFlags(&e->ev_lfork, hipEventDisableTiming));
+    if (!e->ev_ljoin) HIP_TRY(hipEventCreateWithFlags(&e->ev_ljoin, hipEventDisableTiming));
+    if (auto_finish) HIP_TRY(qzl::moves(d, ticks, s));
+    HIP_TRY(hipEventRecord(e->ev_lfork, s));
+    HIP_TRY(hipStreamWaitEvent(e->lanes, e->ev_lfork, 0));
+    HIP_TRY(qzl::advance_lanes(d, max_playouts, ticks, e->par, e->lanes));
+    HIP_TRY(hipEventRecord(e->ev_ljoin, e->lanes));
+    HIP_TRY(qzl::advance(d, max_playouts, ticks, 0, e->par, s));
+    HIP_TRY(hipStreamWaitEvent(s, e->ev_ljoin, 0));
+    return 0;
+}
 int qz_selfplay_advance(qz_engine* e, int max_playouts, int budget_us, int auto_finish, void* stream) {
     ENGINE_CHECK(e);
     if (max_playouts <= 0) return fail(QZ_E_INVALID, "max_playouts must be > 0");
@@ -976,7 +1010,8 @@ int qz_selfplay_advance(qz_engine* e, int max_playouts, int budget_us, int auto_
         return fail(QZ_E_INVALID, "engine is in asynchronous self-play (boards may hold a move whose subtree copy only a launch with auto_finish continues): "
                                   "keep auto_finish set, or reset the engine (qz_engine_reset / qz_engine_set_boards with reset_trees) first");
     const unsigned int ticks = budget_us > 0 ? (unsigned int)budget_us * 100u : 0xFFFFFFFFu;  // s_memrealtime: 100 MHz
-    HIP_TRY(qzl::advance(e->dev, max_playouts, ticks, auto_finish, e->par, (hipStream_t)stream));
+    int r;
+    if ((r = launch_advance(e, max_playouts, ticks, auto_finish, (hipStream_t)stream))) return r;
     if (auto_finish) e->async_moves = true;
     return 0;
 }
@@ -992,8 +1027,7 @@ int qz_selfplay_evaluate(qz_engine* e, const qz_nn_weights* w, void* stream) {
     int r;
     if ((r = nn_weights_check(w))) return r;
     const EngineDev& d = e->dev;
-    return nn_evaluate(d.miss_hb, d.miss_vb, d.miss_meta, nullptr, d.n_boards, w, e->feat, d.miss_p, d.miss_v, d.miss_count + e->par, (hipStream_t)stream,
-                       e->trunk_wgs > 0 ? e->trunk_wgs : 0);
+    return nn_evaluate(d.miss_hb, d.miss_vb, d.miss_meta, nullptr, d.n_boards, w, e->feat, d.miss_p, d.miss_v, d.miss_count + e->par, (hipStream_t)stream);
 }
 int qz_selfplay_round_tail(qz_engine* e, void* stream) {
     ENGINE_CHECK(e);
@@ -1023,17 +1057,11 @@ int qz_selfplay_round(qz_engine* e, const qz_nn_weights* w, int max_playouts, in
     }
     const EngineDev& d = e->dev;
     const unsigned int ticks = budget_us > 0 ? (unsigned int)budget_us * 100u : 0xFFFFFFFFu;  // s_memrealtime: 100 MHz
-    // qz_selfplay_set_overlap: the boards that are not waiting for the network go on playing beside it -- the trunk as a grid of
-    // trunk_wgs persistent workgroups (two per CU = one 256-register wavefront per SIMD), k_advance's second launch in the other
-    // half of every SIMD's registers (four 64-register wavefronts), behind the moves on their stream; the tail (the memo's
-    // inserts: no probe may be in flight) waits for it.  (Needs the launch-wide deadline: select_opts bit 3, budgets >= 100 us.)
-    const bool overlap = e->overlap_us >= 100 && (d.select_opts & 8) != 0 && budget_us >= 100;
-    HIP_TRY(qzl::advance(d, max_playouts, ticks, 0, e->par, s));
+    if ((r = launch_advance(e, max_playouts, ticks, 0, s))) return r;
     HIP_TRY(hipEventRecord(e->ev_fork, s));
     // (the network is queued first: its workgroups -- 4 per CU, most of the LDS -- should be placed before the side kernels'; queuing
     // the side kernels first and / or a high-priority side stream measured the same: profiles/round4/SUMMARY.md)
-    if ((r = nn_evaluate(d.miss_hb, d.miss_vb, d.miss_meta, nullptr, d.n_boards, w, e->feat, d.miss_p, d.miss_v, d.miss_count + e->par, s,
-                         e->trunk_wgs > 0 ? e->trunk_wgs : (overlap ? 512 : 0))))
+    if ((r = nn_evaluate(d.miss_hb, d.miss_vb, d.miss_meta, nullptr, d.n_boards, w, e->feat, d.miss_p, d.miss_v, d.miss_count + e->par, s)))
         return r;
     // The rules op and the moves are independent of each other (the miss list / the boards' own trees, roots and trajectories)
     // and each gets a stream of its own: on ONE side stream the moves queued behind the rules op, whose few workgroups wait
@@ -1042,29 +1070,15 @@ int qz_selfplay_round(qz_engine* e, const qz_nn_weights* w, int max_playouts, in
     HIP_TRY(hipStreamWaitEvent(e->side, e->ev_fork, 0));
     HIP_TRY(qzl::movegen_encode(d.miss_hb, d.miss_vb, d.miss_meta, d.n_boards, d.miss_mask, nullptr, nullptr, e->scratch, e->rules, e->side, d.miss_count + e->par));
     HIP_TRY(hipEventRecord(e->ev_join, e->side));
-    if (auto_finish || overlap) {
+    if (auto_finish) {
         HIP_TRY(hipStreamWaitEvent(e->side2, e->ev_fork, 0));
-        if (auto_finish) {
-            HIP_TRY(qzl::moves(d, ticks, e->side2));
-            e->async_moves = true;
-        }
-        if (overlap) HIP_TRY(qzl::advance_overlap(d, max_playouts, (unsigned int)e->overlap_us * 100u, e->par, e->side2));
+        HIP_TRY(qzl::moves(d, ticks, e->side2));
+        e->async_moves = true;
         HIP_TRY(hipEventRecord(e->ev_join2, e->side2));
     }
     HIP_TRY(hipStreamWaitEvent(s, e->ev_join, 0));
-    if (auto_finish || overlap) HIP_TRY(hipStreamWaitEvent(s, e->ev_join2, 0));
+    if (auto_finish) HIP_TRY(hipStreamWaitEvent(s, e->ev_join2, 0));
     return qz_selfplay_round_tail(e, stream);
-}
-int qz_selfplay_set_overlap(qz_engine* e, int overlap_us, int trunk_workgroups) {
-    if (!e) return fail(QZ_E_INVALID, "null engine");
-    if (overlap_us < 0 || overlap_us > 1000000) return fail(QZ_E_INVALID, "overlap_us must be in [0, 1e6]");
-    if (overlap_us > 0 && overlap_us < 100) return fail(QZ_E_INVALID, "an overlap budget below 100 us cannot hold one playout: 0 (off) or >= 100");
-    if (trunk_workgroups < 0) return fail(QZ_E_INVALID, "trunk_workgroups < 0");
-    if (overlap_us > 0 && !(e->dev.select_opts & 8))
-        return fail(QZ_E_INVALID, "the overlap launch needs the launch-wide deadline (qz_config.select_opts bit 3)");
-    e->overlap_us = overlap_us;
-    e->trunk_wgs = trunk_workgroups;  // (> 0 with overlap_us = 0: the persistent trunk alone, an A/B of the trunk's two launch shapes)
-    return 0;
 }
 int qz_selfplay_parity(qz_engine* e) { return e ? e->par : fail(QZ_E_INVALID, "null engine"); }
 int qz_selfplay_misses(qz_engine* e, qz_boards* boards_out, const int32_t** n_dev_out, uint32_t** mask5_out, float** p_out, float** v_out) {

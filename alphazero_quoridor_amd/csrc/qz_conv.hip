@@ -290,7 +290,7 @@ struct InputArgs {
 // SPLIT = false: ONE MFMA per product on the hi halves only (fp16 operands, fp32 accumulation) -- the labelled
 // throughput mode (`nn_precision="fp16"`, bench.py --nn-dtype fp16): a third of the matrix work, p / v within ~1e-3
 // of the reference instead of 1e-5 (tests/test_gpu_conv.py states the bound); never the default.
-template <bool FROM_BOARD, bool SPLIT = true, bool PERSIST = false>
+template <bool FROM_BOARD, bool SPLIT = true>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_trunk(const float* __restrict__ x, float* __restrict__ out, TrunkArgs A, int n_layers, float eps, HeadArgs H, InputArgs I,
                                                const int* __restrict__ n_live  // or nullptr: only the first *n_live leaves are evaluated (the engine's miss list)
 #ifdef QZ_TRUNK_STAMPS
@@ -298,14 +298,13 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #endif
                                                ) {
     __shared__ TrunkShared sm;
-    // PERSIST (qz_selfplay_round with an overlap budget): a grid of a FEW workgroups -- two per CU, one wavefront per SIMD -- strides over
-    // the leaves, so that the rest of every SIMD (half the registers, half the LDS) stays free for k_advance's wavefronts
+    // one workgroup per leaf (a grid of a few persistent workgroups striding over the list measured 3 % slower: profiles/round5/SUMMARY.md 6);
+    // the count of live leaves may sit on the device (the engine's miss list): workgroups beyond it leave at once
     const int n_lv = n_live ? __builtin_amdgcn_readfirstlane(*n_live) : 0x7FFFFFFF;
-  for (unsigned int leaf = blockIdx.x;; leaf += gridDim.x) {
+  {
+    const unsigned int leaf = blockIdx.x;
     if ((int)leaf >= n_lv) return;
-    int tid_ = (int)threadIdx.x;
-    if (PERSIST) asm volatile("" : "+v"(tid_));  // (per iteration: or every address below is hoisted out of the loop -- 179 registers' worth, to scratch)
-    const int tid = tid_, lane = tid & 63, nt = tid >> 6;
+    const int tid = (int)threadIdx.x, lane = tid & 63, nt = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int co = 32 * nt + r;
     const size_t obase = (size_t)leaf * NPOS * C + (size_t)co;
@@ -694,8 +693,6 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         o[6] = __builtin_amdgcn_s_memrealtime() - r_begin; o[7] = __smid();  // o[4] / o[6] x 100 MHz = the clock this wave ran at
     }
 #endif
-    if (!PERSIST) return;
-    __syncthreads();  // the next leaf's stage writes the images this leaf's head stage read
   }
 }
 
@@ -724,8 +721,7 @@ struct TrunkInput {
 // from the packed boards in the same launch and x is not read (may be NULL)
 hipError_t trunk(float* x, float* tmp, long long n, int n_blocks, const void* const* w16, const float* const* gamma, const float* const* beta,
                  const float* inv_scale /*[dev]*/, float eps, int fused, hipStream_t s, const void* w6 = nullptr, const float* gamma6 = nullptr,
-                 const float* beta6 = nullptr, float* feat = nullptr, const TrunkInput* in = nullptr, const int* n_live = nullptr, int single_product = 0,
-                 int persist_wgs = 0) {
+                 const float* beta6 = nullptr, float* feat = nullptr, const TrunkInput* in = nullptr, const int* n_live = nullptr, int single_product = 0) {
     if (n <= 0 || n_blocks <= 0) return hipSuccess;
     const int nl = 2 * n_blocks;
     if ((feat || in || n_live) && !(fused && nl <= MAX_TRUNK_LAYERS)) return hipErrorInvalidValue;
@@ -753,12 +749,7 @@ hipError_t trunk(float* x, float* tmp, long long n, int n_blocks, const void* co
         InputArgs I = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         if (in) I = InputArgs{in->hb, in->vb, in->meta, in->terminal, in->hot9, in->base0, in->wd, in->gamma0, in->beta0};
         if (single_product && !in) return hipErrorInvalidValue;  // (the throughput mode exists on the route from the packed boards only)
-        if (persist_wgs > 0) {  // (the engine's route only: from the packed boards, the count on the device)
-            if (!in || !n_live) return hipErrorInvalidValue;
-            const unsigned g = (unsigned)(persist_wgs < n ? persist_wgs : n);
-            if (single_product) hipLaunchKernelGGL((k_trunk<true, false, true>), dim3(g), dim3(128), 0, s, x, feat ? nullptr : x, A, nl, eps, H, I, n_live);
-            else hipLaunchKernelGGL((k_trunk<true, true, true>), dim3(g), dim3(128), 0, s, x, feat ? nullptr : x, A, nl, eps, H, I, n_live);
-        } else if (in && single_product) hipLaunchKernelGGL((k_trunk<true, false>), dim3((unsigned)n), dim3(128), 0, s, x, feat ? nullptr : x, A, nl, eps, H, I, n_live);
+        if (in && single_product) hipLaunchKernelGGL((k_trunk<true, false>), dim3((unsigned)n), dim3(128), 0, s, x, feat ? nullptr : x, A, nl, eps, H, I, n_live);
         else if (in) hipLaunchKernelGGL((k_trunk<true, true>), dim3((unsigned)n), dim3(128), 0, s, x, feat ? nullptr : x, A, nl, eps, H, I, n_live);
         else hipLaunchKernelGGL((k_trunk<false, true>), dim3((unsigned)n), dim3(128), 0, s, x, feat ? nullptr : x, A, nl, eps, H, I, n_live);
         return hipGetLastError();

@@ -107,15 +107,21 @@ typedef uint32_t qz_u32x3_a16 __attribute__((ext_vector_type(3), aligned(16))); 
 // base-path search per lane | with ordinary stores for the planes (A/B partners of 3), 8 | 12 | 16 |
 // 24 | 32 = pooled pipeline with that many boards per mask workgroup.
 constexpr int QZ_C_SPREAD = 64;
-constexpr int QZ_C_OVERLAP_PLAYOUTS_0 = QZ_C_COUNT + 2 * QZ_C_SPREAD;  // playouts of the rounds' second launches (k_advance beside the network), QZ_C_SPREAD words
-constexpr int QZ_C_TOTAL = QZ_C_COUNT + 3 * QZ_C_SPREAD;
+constexpr int QZ_C_TOTAL = QZ_C_COUNT + 2 * QZ_C_SPREAD;
 
 struct RulesOpts {
     int variant = 0;
     int detour_pooled = 1, detour_wave = 0;  // pool_k1's detour_mode per kernel family
     int enc_split_pct = 50;                  // share of the encoder tiles beside the path groups
-    int enc_first_pct = 0;                   // share of the second launch's encoder tiles placed in FRONT of its mask groups in the grid
+    int pool_dependent = 0;                  // 1: the pooled pipeline's two launches one after the other on the caller's stream (A/B partner of the two-stream form)
 };
+#if defined(__HIPCC__)
+// a second stream + fork / join events for the pooled pipeline's two launches side by side (qzl::movegen_encode)
+struct PoolAsync {
+    hipStream_t side = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+#endif
 
 // Leaf-evaluation memo.  policy_value_fn on a batch of one (policy_value_net.py:145-164, BatchNorm in training mode)
 // is a pure function of the 24-byte board, and a long game revisits the same few thousand boards millions of times

@@ -17,6 +17,7 @@
 // Reference semantics: see qz_rules.h (rules) and the per-kernel comments (mcts.py).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 #include "qz_rules.h"
 #include "qz_movegen_pool.h"
@@ -116,7 +117,7 @@ template <int NBE>
 __global__ __launch_bounds__(256) void k_pool_paths_enc(const uint64_t* __restrict__ hb, const uint64_t* __restrict__ vb,
                                                         const uint64_t* __restrict__ meta, int n, const uint8_t* __restrict__ terminal,
                                                         PoolHand* __restrict__ hands, int n_path_groups,
-                                                        float* __restrict__ planes, int detour_mode) {
+                                                        float* __restrict__ planes, int detour_mode, uint32_t* __restrict__ ready, uint32_t epoch) {
     __shared__ EncShared<NBE> sm;
     const int tid = (int)threadIdx.x;
     if ((int)blockIdx.x < n_path_groups) {
@@ -125,10 +126,19 @@ __global__ __launch_bounds__(256) void k_pool_paths_enc(const uint64_t* __restri
         // Long dependent chains, no LDS: latency-bound, ~1 wave per SIMD chip-wide.
         const int task = (int)blockIdx.x * 256 + tid;
         const int b = task >> 1, p = (task & 1) + 1;
-        if (b >= n) return;
-        Board bd = unpack(hb[b], vb[b], meta[b]);
-        bool term = terminal ? (terminal[b] != 0) : false;
-        pool_k1_hand(bd, term, p, hands[b], detour_mode);
+        if (b < n) {
+            Board bd = unpack(hb[b], vb[b], meta[b]);
+            bool term = terminal ? (terminal[b] != 0) : false;
+            pool_k1_hand(bd, term, p, hands[b], detour_mode);
+        }
+        if (ready) {
+            // The second launch runs BESIDE this one (another stream, no stream dependency: movegen_encode): its mask groups take the
+            // records of their 128-board path group when this flag carries the call's number.  Release at device scope: the
+            // records of all four wavefronts are out of this XCD's L2 before the flag is.
+            __threadfence();
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(ready + blockIdx.x, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
         return;
     }
     encoder_group<NBE>(sm, hb, vb, meta, n, terminal, planes, ((int)blockIdx.x - n_path_groups) * NBE, tid);
@@ -430,34 +440,91 @@ __device__ __forceinline__ void mask_group(MasksShared<NB>& sm, const PoolHand* 
         for (int w = 0; w < 5; w++) mask5[(size_t)(b0 + tid) * 5 + w] = m5[w];
     }
 }
+// The mask groups of a launch that does NOT wait for the path groups' launch (movegen_encode, two streams): a group takes its
+// boards' records when the flags of the path groups that write them (128 boards each) carry this call's number -- acquire at
+// device scope.  Normally they do when the group is placed (the encoder tiles in front of it in the grid have run beside the path
+// groups meanwhile); a group that waits longer than POOL_SPIN_TICKS gives its slot back -- spinning workgroups must never keep the
+// path groups off the chip -- and leaves its number in the call's deferred list, which k_pool_masks_fixup (a third, dependent
+// launch: at once empty-handed in the normal case) works off.
+constexpr unsigned long long POOL_SPIN_TICKS = 20000ull;  // 200 us of s_memrealtime (100 MHz)
+__device__ __forceinline__ bool pool_wait_ready(const uint32_t* __restrict__ ready, unsigned long long* __restrict__ defer, const uint32_t epoch,
+                                                const int group, const int b0, const int nb, const int tid, int* const ok_s) {
+    if (tid == 0) {
+        const int pg0 = (2 * b0) >> 8, pg1 = (2 * (b0 + nb) - 1) >> 8;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        int ok = 0;
+        for (;;) {
+            const uint32_t a = __hip_atomic_load(ready + pg0, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t c = __hip_atomic_load(ready + pg1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            if (a == epoch && c == epoch) {
+                ok = 1;
+                break;
+            }
+            if (__builtin_amdgcn_s_memrealtime() - t0 > POOL_SPIN_TICKS) break;
+            __builtin_amdgcn_s_sleep(16);
+        }
+        if (!ok) {  // defer[0] = call number << 32 | entries of this call; defer[1 + i / 2] holds two group numbers
+            unsigned long long old = __hip_atomic_load(defer, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (;;) {
+                const unsigned long long cnt = (uint32_t)(old >> 32) == epoch ? (old & 0xFFFFFFFFull) : 0ull;
+                const unsigned long long neu = ((unsigned long long)epoch << 32) | (cnt + 1ull);
+                const unsigned long long seen = atomicCAS(defer, old, neu);
+                if (seen == old) {
+                    reinterpret_cast<uint32_t*>(defer + 1)[cnt] = (uint32_t)group;
+                    break;
+                }
+                old = seen;
+            }
+        }
+        *ok_s = ok;
+    }
+    __syncthreads();
+    const bool ok = *ok_s != 0;
+    if (ok) __atomic_thread_fence(__ATOMIC_ACQUIRE);  // (every thread reads the records: nothing stale from this CU's L1 / this XCD's L2)
+    return ok;
+}
 template <int NB, int NBE>
 __global__ __launch_bounds__(256) void k_pool_masks_enc(const PoolHand* __restrict__ hands, int n,
                                                         uint32_t* __restrict__ mask5, int n_mask_groups, int enc_tile0,
                                                         const uint64_t* __restrict__ hb, const uint64_t* __restrict__ vb,
                                                         const uint64_t* __restrict__ meta, const uint8_t* __restrict__ terminal,
-                                                        float* __restrict__ planes, int n_enc_first, int n_enc_tiles) {
+                                                        float* __restrict__ planes, int n_enc_tiles, int enc_first,
+                                                        const uint32_t* __restrict__ ready, unsigned long long* __restrict__ defer, uint32_t epoch) {
     __shared__ MasksEncShared<NB, NBE> smu;
+    __shared__ int s_ok;
     const int tid = (int)threadIdx.x;
-    // grid order = dispatch order: [n_enc_first PERSISTENT encoder workgroups][mask groups][one workgroup per remaining encoder tile]
-    // A persistent encoder workgroup writes tiles enc_tile0 + bid, + n_enc_first, ... of the launch's n_enc_tiles: a FEW of them
-    // per CU keep the HBM write path busy from the launch's first microsecond to its last while the mask groups -- the long pole:
-    // issue-bound, 29 KB of LDS each -- have the rest of the CU.  (One workgroup per tile in front of the mask groups takes their
-    // slots for the whole launch -- an encoder workgroup lives as long as the bandwidth it shares lets it: measured +5..17 us --
-    // and behind them it only starts when they are done: 22 + 20 us in sequence, round 4.)
+    // grid order = dispatch order.  Dependent launch (behind the path groups' launch on the same stream): [mask groups][encoder
+    // tiles] -- the mask groups are the long pole.  Concurrent launch (enc_first, ready != nullptr): [encoder tiles][mask groups] --
+    // the encoder tiles do not depend on the path groups and run BESIDE them from the first microsecond; the mask groups are
+    // placed as those drain, by when the path groups' flags are normally up.
     int bid = (int)blockIdx.x;
-    if (bid < n_enc_first) {
-        for (int t = bid; t < n_enc_tiles; t += n_enc_first) {
-            if (t != bid) __syncthreads();  // the tile before has left the LDS bitmaps
-            encoder_group<NBE>(smu.enc, hb, vb, meta, n, terminal, planes, (enc_tile0 + t) * NBE, tid);
+    if (enc_first) {
+        if (bid < n_enc_tiles) {
+            encoder_group<NBE>(smu.enc, hb, vb, meta, n, terminal, planes, (enc_tile0 + bid) * NBE, tid);
+            return;
         }
-        return;
-    }
-    bid -= n_enc_first;
-    if (bid >= n_mask_groups) {  // (only without persistent encoder workgroups)
+        bid -= n_enc_tiles;
+    } else if (bid >= n_mask_groups) {
         encoder_group<NBE>(smu.enc, hb, vb, meta, n, terminal, planes, (enc_tile0 + bid - n_mask_groups) * NBE, tid);
         return;
     }
-    mask_group<NB>(smu.m, hands, n, mask5, hb, vb, meta, bid * NB, tid);
+    const int b0 = bid * NB;
+    if (ready && !pool_wait_ready(ready, defer, epoch, bid, b0, (n - b0) < NB ? (n - b0) : NB, tid, &s_ok)) return;
+    mask_group<NB>(smu.m, hands, n, mask5, hb, vb, meta, b0, tid);
+}
+// the mask groups a concurrent launch gave up on (pool_wait_ready), after both launches: stream-ordered, no flags
+template <int NB>
+__global__ __launch_bounds__(256) void k_pool_masks_fixup(const PoolHand* __restrict__ hands, int n, uint32_t* __restrict__ mask5,
+                                                          const uint64_t* __restrict__ hb, const uint64_t* __restrict__ vb,
+                                                          const uint64_t* __restrict__ meta, const unsigned long long* __restrict__ defer, uint32_t epoch) {
+    const unsigned long long w = defer[0];
+    if ((uint32_t)(w >> 32) != epoch) return;
+    __shared__ MasksShared<NB> sm;
+    const uint32_t cnt = (uint32_t)w;
+    for (uint32_t i = blockIdx.x; i < cnt; i += gridDim.x) {
+        if (i != blockIdx.x) __syncthreads();
+        mask_group<NB>(sm, hands, n, mask5, hb, vb, meta, (int)reinterpret_cast<const uint32_t*>(defer + 1)[i] * NB, (int)threadIdx.x);
+    }
 }
 
 // Quoridor.step() + has_a_winner(): one thread per board, fully coalesced SoA traffic
@@ -2521,7 +2588,6 @@ constexpr int ADV_WPB = QZ_ADV_WPB;
 #ifndef QZ_ADV_WAVES_SMALL
 #define QZ_ADV_WAVES_SMALL 4  // wavefronts per SIMD the build of k_advance for engines of <= 4,096 boards aims at (A/B: 8 = one build for all sizes)
 #endif
-template <bool OV>
 __device__ __forceinline__ void advance_board(EngineDev& E, const int max_iters, const unsigned int budget, const int par) {
     __shared__ uint32_t s_we[ADV_WPB][ADV_LCAP];
     __shared__ unsigned long long s_wb[ADV_WPB][ADV_LCAP];
@@ -2536,19 +2602,11 @@ __device__ __forceinline__ void advance_board(EngineDev& E, const int max_iters,
     // a multiple of 8, so a board stays on its XCD and its tree in that XCD's L2).
     // (Only with a budget of 100 us or more: under a shorter one the boards behind the first slots would never start a playout.)
     const bool shared = (E.select_opts & 8) != 0 && budget >= 10000u && budget != 0xFFFFFFFFu;
-    // OV: the round's SECOND launch (qz_selfplay_round with an overlap budget), beside the network: the boards that are not
-    // waiting for it go on playing.  Such a launch never consumes an evaluation (the network is writing them) and never adds to the
-    // miss list (the network is reading it): a board that meets a leaf for the network forgets the descent -- the tree is as it was --
-    // and repeats it in the next round's first launch.  It has a deadline of its own (tag bit 19 of the launch stamp) and the
-    // boards that got their slots LAST in the first launch (the first 8,192 in rotation order hold the chip's slots) come first.
-    // (A build of its own: as a run-time flag of the one build it cost the first launch 300 more register-spill moves.)
-    constexpr bool ov = OV;
     uint32_t seq = 0u;
     int b_ = w_;
     if (shared) {
         seq = rfl((uint32_t)E.miss_count[2]);
-        b_ = (int)(((unsigned int)w_ + (seq % 4096u) * QZ_ADV_ROT + (ov ? 8192u : 0u)) % (unsigned int)E.n_boards);
-        if (ov) seq ^= 0x80000u;
+        b_ = (int)(((unsigned int)w_ + (seq % 4096u) * QZ_ADV_ROT) % (unsigned int)E.n_boards);
     }
     const int b = __builtin_amdgcn_readfirstlane(b_);  // in an SGPR: every per-board address below is scalar arithmetic
     // The engine descriptor arrives in the kernel-argument segment and is fetched in 16-dword pieces; left alone, a piece is ONE
@@ -2564,11 +2622,11 @@ __device__ __forceinline__ void advance_board(EngineDev& E, const int max_iters,
     QZ_OWN_S(E.select_opts); QZ_OWN_S(E.node_cap); QZ_OWN_S(E.edge_cap); QZ_OWN_S(E.fix_terminal_sign); QZ_OWN_S(E.tree_pool_pages);
 #undef QZ_OWN_P
 #undef QZ_OWN_S
-    if (b == 0 && lane == 0 && !ov) atomicAdd(&E.counters[QZ_C_ROUNDS], 1ull);
+    if (b == 0 && lane == 0) atomicAdd(&E.counters[QZ_C_ROUNDS], 1ull);
     // (the first launch: a board that is not playing leaves before the stamp -- if it is the first wavefront's, about one launch in
     // 250, that launch's wavefronts count the budget from their own starts.  Moving the test behind the stamp, as the second launch
     // has it, costs this build 59 more register-spill moves: left as it is.)
-    if (!ov && rfl(E.status[b]) != QZ_PLAYING) return;
+    if (rfl(E.status[b]) != QZ_PLAYING) return;
     unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long t_it = t0;
     bool late = false;  // this wavefront's budget began before it did
@@ -2592,9 +2650,8 @@ __device__ __forceinline__ void advance_board(EngineDev& E, const int max_iters,
             }
         }
     }
-    // (the second launch: its first wavefront has left the launch's stamp above even if its own board has nothing to do -- half
-    // the boards have not, and without the stamp every wavefront of the launch would count the budget from its own start)
-    if (ov && (rfl(E.status[b]) != QZ_PLAYING || rfl(E.pend_slot[b]) != QZ_NONE)) return;
+    // select_opts bit 4: the boards on which neither player has a wall left are k_lanes' (qz_lanes.h: one LANE per board, beside this launch)
+    if ((E.select_opts & 16) && ((rfl64(E.root_meta[b]) >> 16) & 0xFFFFull) == 0ull) return;
 #ifndef QZ_BUDGET_PREDICT
 #define QZ_BUDGET_PREDICT 1  // what a board expects its next playout to last: 0 = nothing, 1 = as long as its last one, 2 = the largest of its recent ones (a maximum that decays by a quarter per playout: measured no different from 1, 289.1 against 290.6 M playouts/s; nor is a margin of a quarter or a half of the last playout on top: 309.5 / 309.8 against 309.0 M, launches as long as before -- the launch's overrun of ~100 us is the extreme of ten thousand boards' playout times, not a misprediction of the typical one)
 #endif
@@ -2702,7 +2759,6 @@ __device__ __forceinline__ void advance_board(EngineDev& E, const int max_iters,
         waiting = true;
         break;
     }
-    if (ov) waiting = false;
     if (waiting) {
         uint32_t s = 0u;
         if (lane == 0) s = (uint32_t)atomicAdd(E.miss_count + par, 1);
@@ -2754,10 +2810,6 @@ __device__ __forceinline__ void advance_board(EngineDev& E, const int max_iters,
     }
 #endif
     if (lane == 0) {
-        if (ov) {  // (what the second launches add, for the accounts of the first: bench.py's roofline line)
-            const uint32_t d0 = E.pl_done[b];
-            if (done != d0) atomicAdd(&E.counters[QZ_C_OVERLAP_PLAYOUTS_0 + (b & (QZ_C_SPREAD - 1))], (unsigned long long)(done - d0));
-        }
         E.pl_done[b] = done;
         if (!waiting && slot != QZ_NONE) E.pend_slot[b] = QZ_NONE;
         if (open_rounds) E.bc_open_rounds[b] += open_rounds;
@@ -2769,9 +2821,9 @@ __device__ __forceinline__ void advance_board(EngineDev& E, const int max_iters,
 // chain is bound by its own latencies (round 3: one / two / four wavefronts per SIMD ran 78.8 / 74.0 / 66.6 playouts per board and
 // round).  k_advance<4>: 73 registers, no spill at all, for engines of up to 4,096 boards, where the extra residency buys nothing
 // and the eight-wave build's few spills cost 9 %.
-template <int W, bool OV = false>
+template <int W>
 __global__ __launch_bounds__(64 * ADV_WPB) __attribute__((amdgpu_waves_per_eu(W, W))) void k_advance(EngineDev E, int max_iters, unsigned int budget, int par) {
-    advance_board<OV>(E, max_iters, budget, par);
+    advance_board(E, max_iters, budget, par);
 }
 
 // k_moves: MCTSPlayer.choose_action's tail + one iteration of start_self_play's loop (finish_move_board) for every
@@ -3072,6 +3124,8 @@ __global__ void k_sqrt_table(double* out, int n) {  // self-test helper: device 
     if (i < n) out[i] = sqrt_count((uint32_t)i);  // (what the descents use)
 }
 
+#include "qz_lanes.h"
+
 }  // namespace
 
 // ============================================================================ launchers
@@ -3084,30 +3138,46 @@ static inline dim3 wave_grid(int n) { return dim3((unsigned)((n + WPB - 1) / WPB
 #endif
 constexpr int NBE = QZ_NBE;  // boards per encoder group (8 and 32 measured at 32,768 boards: see DESIGN 9.2)
 
+// what a caller that can run the pooled pipeline's two launches side by side hands to movegen_encode: a second stream, two events
+// (fork / join: captures into a HIP graph), and -- behind the hand-off records in the scratch buffer -- the path groups' ready
+// flags and the deferred list (movegen_scratch_bytes; zeroed once, at allocation: flags and list are tagged with the call's number)
+std::atomic<uint32_t> g_pool_epoch{0};
+
 template <int NB>
 static void launch_masks_enc(const PoolHand* hands, int n, uint32_t* mask5, const uint64_t* hb,
                              const uint64_t* vb, const uint64_t* meta, const uint8_t* terminal, float* planes, int enc_tile0,
-                             int n_enc_groups, hipStream_t s, int enc_first_pct = 0) {
+                             int n_enc_groups, hipStream_t s, const uint32_t* ready, unsigned long long* defer, uint32_t epoch) {
     const int n_mask_groups = mask5 ? (n + NB - 1) / NB : 0;
     if (n_mask_groups + n_enc_groups == 0) return;
-    // enc_first_pct: persistent encoder workgroups in front of the mask groups, in hundredths of a workgroup per CU (256 CUs)
-    int n_enc_first = (n_mask_groups && n_enc_groups) ? (256 * enc_first_pct + 99) / 100 : 0;
-    if (n_enc_first > n_enc_groups) n_enc_first = n_enc_groups;
-    const int grid = n_enc_first ? n_enc_first + n_mask_groups : n_mask_groups + n_enc_groups;
-    hipLaunchKernelGGL((k_pool_masks_enc<NB, NBE>), dim3((unsigned)grid), dim3(256), 0, s, hands, n,
-                       mask5, n_mask_groups, enc_tile0, hb, vb, meta, terminal, planes, n_enc_first, n_enc_groups);
+    hipLaunchKernelGGL((k_pool_masks_enc<NB, NBE>), dim3((unsigned)(n_mask_groups + n_enc_groups)), dim3(256), 0, s, hands, n,
+                       mask5, n_mask_groups, enc_tile0, hb, vb, meta, terminal, planes, n_enc_groups, ready ? 1 : 0, ready, defer, epoch);
+}
+template <int NB>
+static void launch_masks_fixup(const PoolHand* hands, int n, uint32_t* mask5, const uint64_t* hb, const uint64_t* vb, const uint64_t* meta,
+                               const unsigned long long* defer, uint32_t epoch, hipStream_t s) {
+    hipLaunchKernelGGL((k_pool_masks_fixup<NB>), dim3(64), dim3(256), 0, s, hands, n, mask5, hb, vb, meta, defer, epoch);
 }
 
-size_t movegen_scratch_bytes(int n) { return (size_t)n * sizeof(PoolHand); }  // 184 B per board (round 3: 1,522)
+// Scratch layout: [header: ready flags | deferred list][hand-off records].  The header has a FIXED size and place (whatever n: a
+// buffer is reused by calls of different sizes, and a flag word must never be memory an earlier call used for records -- a stale
+// word equal to a later call's number would release a mask group early); it is zeroed once, when the buffer is allocated, and only
+// ever holds call numbers afterwards.  Calls of more than POOL_ASYNC_MAX_N boards run their two launches one after the other.
+constexpr int POOL_ASYNC_MAX_N = 1 << 20;
+constexpr size_t POOL_READY_BYTES = (size_t)(2 * POOL_ASYNC_MAX_N / 256) * 4;         // one word per path group (128 boards)
+constexpr size_t POOL_DEFER_BYTES = 16 + (size_t)(POOL_ASYNC_MAX_N / 8) * 4;           // call number | count, then one word per mask group (>= 8 boards)
+constexpr size_t POOL_HEADER_BYTES = (POOL_READY_BYTES + POOL_DEFER_BYTES + 255) & ~(size_t)255;
+size_t movegen_scratch_header_bytes() { return POOL_HEADER_BYTES; }
+size_t movegen_scratch_bytes(int n) { return POOL_HEADER_BYTES + (size_t)n * sizeof(PoolHand); }  // + 184 B per board (round 3: 1,522)
 
 hipError_t movegen_encode(const uint64_t* hb, const uint64_t* vb, const uint64_t* meta, int n, uint32_t* mask5,
-                          float* planes, const uint8_t* terminal, void* scratch, const RulesOpts& ro, hipStream_t s, const int* n_dev) {
+                          float* planes, const uint8_t* terminal, void* scratch, const RulesOpts& ro, hipStream_t s, const int* n_dev,
+                          const PoolAsync* pa) {
     if (n <= 0) return hipSuccess;
     if (n_dev && planes) return hipErrorInvalidValue;  // a device-side count: k_wave_rules, legal sets only (no encoder tiles)
     // Small batches are latency-bound: one launch, a wavefront per board, no hand-off through
     // HBM (k_wave_rules).  From ~8k boards on the chip is saturated and the pooled two-launch
     // pipeline, which packs lanes better, wins.
-    if (n_dev || (ro.variant >= 2 && ro.variant <= 6) || ((ro.variant == 0 || ro.variant == 7) && n < 8192)) {
+    if (n_dev || (ro.variant >= 2 && ro.variant <= 6) || (ro.variant == 0 && n < 8192)) {
         const int n_enc_groups = planes ? (n + NBE - 1) / NBE : 0;
         // boards per wavefront: on bench trees (late-game boards, many without walls left) one board per
         // wavefront measured 29.1 us vs 33.0 (two) / 34.6 (four) at 4,096 boards; on the synthetic
@@ -3125,26 +3195,52 @@ hipError_t movegen_encode(const uint64_t* hb, const uint64_t* vb, const uint64_t
         else hipLaunchKernelGGL((k_wave_rules<NBE, 2, false>), grid, dim3(256), 0, s, hb, vb, meta, n, terminal, mask5, planes, n_mg_groups, ro.detour_wave, n_dev);
         return hipGetLastError();
     }
-    PoolHand* hands = reinterpret_cast<PoolHand*>(scratch);
-    // encoder tiles are split over the two launches: half of them ride beside the path search (a
-    // latency-bound dependent chain of ~27 us that leaves issue slots and the memory pipe idle),
-    // the rest beside the mask groups (~22 us alone).  Sweep at 32,768 boards on the final kernels
-    // (S-open / S-mid / S-dense, us): 40 % 67.0 / 74.9 / 79.1, 50 % 66.6 / 72.3 / 76.8, 55 % 67.6 /
-    // 72.4 / 77.3, 60 % 67.5 / 71.9 / 78.6, 70 % 67.8 / 73.7 / 80.5 (70 % was the optimum of round 1's kernels).
+    PoolHand* hands = reinterpret_cast<PoolHand*>(reinterpret_cast<char*>(scratch) + POOL_HEADER_BYTES);
+    // Encoder tiles are split over the two launches: enc_split_pct percent ride beside the path search (a latency-bound
+    // dependent chain of ~27 us that leaves issue slots and the memory pipe idle), the rest in the mask groups' launch.
+    // Dependent launches (round 4's sweep at 32,768 boards, S-open / S-mid / S-dense, us): 40 % 67.0 / 74.9 / 79.1, 50 % 66.6 / 72.3 /
+    // 76.8, 60 % 67.5 / 71.9 / 78.6, 70 % 67.8 / 73.7 / 80.5.
     const int enc_total = planes ? (n + NBE - 1) / NBE : 0;
     const int enc_a = mask5 ? (enc_total * ro.enc_split_pct) / 100 : 0;
-    int nbt = ro.variant >= 8 ? ro.variant : (n >= 16384 ? 24 : (n >= 8192 ? 16 : 8));
+    const int enc_b = enc_total - enc_a;
+    const int nbt = ro.variant >= 8 ? ro.variant : (n >= 16384 ? 24 : (n >= 8192 ? 16 : 8));
+    // Two streams (pa != nullptr, mask5 != nullptr, not switched off): the second launch does not wait for the first -- its encoder
+    // tiles (first in its grid) run beside the path groups, its mask groups take their records when the path groups' flags are up
+    // (k_pool_masks_enc) -- and a third, dependent launch serves the mask groups that gave up waiting (normally none).
+    const bool two = pa && pa->side && mask5 && !ro.pool_dependent && n <= POOL_ASYNC_MAX_N;
+    uint32_t epoch = 0u;
+    uint32_t* ready = nullptr;
+    unsigned long long* defer = nullptr;
+    hipStream_t s2 = s;
+    if (two) {
+        do epoch = ++g_pool_epoch; while (epoch == 0u);
+        ready = reinterpret_cast<uint32_t*>(scratch);
+        defer = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(scratch) + POOL_READY_BYTES);
+        s2 = pa->side;
+        hipError_t e = hipEventRecord(pa->fork, s);
+        if (e == hipSuccess) e = hipStreamWaitEvent(s2, pa->fork, 0);
+        if (e != hipSuccess) return e;
+    }
     if (mask5) {
         const int n_path_groups = (2 * n + 255) / 256;
         hipLaunchKernelGGL((k_pool_paths_enc<NBE>), dim3((unsigned)(n_path_groups + enc_a)), dim3(256), 0, s, hb, vb, meta, n,
-                           terminal, hands, n_path_groups, planes, ro.detour_pooled);
+                           terminal, hands, n_path_groups, planes, ro.detour_pooled, ready, epoch);
     }
-    const int enc_b = enc_total - enc_a;
-    if (nbt >= 32) launch_masks_enc<32>(hands, n, mask5, hb, vb, meta, terminal, planes, enc_a, enc_b, s, ro.enc_first_pct);
-    else if (nbt >= 24) launch_masks_enc<24>(hands, n, mask5, hb, vb, meta, terminal, planes, enc_a, enc_b, s, ro.enc_first_pct);
-    else if (nbt >= 16) launch_masks_enc<16>(hands, n, mask5, hb, vb, meta, terminal, planes, enc_a, enc_b, s, ro.enc_first_pct);
-    else if (nbt >= 12) launch_masks_enc<12>(hands, n, mask5, hb, vb, meta, terminal, planes, enc_a, enc_b, s, ro.enc_first_pct);
-    else launch_masks_enc<8>(hands, n, mask5, hb, vb, meta, terminal, planes, enc_a, enc_b, s, ro.enc_first_pct);
+    if (nbt >= 32) launch_masks_enc<32>(hands, n, mask5, hb, vb, meta, terminal, planes, enc_a, enc_b, s2, ready, defer, epoch);
+    else if (nbt >= 24) launch_masks_enc<24>(hands, n, mask5, hb, vb, meta, terminal, planes, enc_a, enc_b, s2, ready, defer, epoch);
+    else if (nbt >= 16) launch_masks_enc<16>(hands, n, mask5, hb, vb, meta, terminal, planes, enc_a, enc_b, s2, ready, defer, epoch);
+    else if (nbt >= 12) launch_masks_enc<12>(hands, n, mask5, hb, vb, meta, terminal, planes, enc_a, enc_b, s2, ready, defer, epoch);
+    else launch_masks_enc<8>(hands, n, mask5, hb, vb, meta, terminal, planes, enc_a, enc_b, s2, ready, defer, epoch);
+    if (two) {
+        hipError_t e = hipEventRecord(pa->join, s2);
+        if (e == hipSuccess) e = hipStreamWaitEvent(s, pa->join, 0);
+        if (e != hipSuccess) return e;
+        if (nbt >= 32) launch_masks_fixup<32>(hands, n, mask5, hb, vb, meta, defer, epoch, s);
+        else if (nbt >= 24) launch_masks_fixup<24>(hands, n, mask5, hb, vb, meta, defer, epoch, s);
+        else if (nbt >= 16) launch_masks_fixup<16>(hands, n, mask5, hb, vb, meta, defer, epoch, s);
+        else if (nbt >= 12) launch_masks_fixup<12>(hands, n, mask5, hb, vb, meta, defer, epoch, s);
+        else launch_masks_fixup<8>(hands, n, mask5, hb, vb, meta, defer, epoch, s);
+    }
     return hipGetLastError();
 }
 hipError_t step(uint64_t* hb, uint64_t* vb, uint64_t* meta, const uint8_t* action, int n, uint8_t* done, uint8_t* winner,
@@ -3193,18 +3289,16 @@ hipError_t finish_move(const EngineDev& E, const uint8_t* forced, float* pi_out,
 static unsigned int compact_budget(unsigned int budget_ticks) {
     return budget_ticks == 0xFFFFFFFFu ? budget_ticks : (budget_ticks / 32u > 0u ? budget_ticks / 32u : 1u);
 }
-// the round's second launch, beside the network (advance_board<true>): always the 64-register build -- four of its wavefronts fit
-// beside one of the trunk's on a SIMD
-hipError_t advance_overlap(const EngineDev& E, int max_iters, unsigned int budget_ticks, int par, hipStream_t s) {
-    const dim3 adv_grid((unsigned)((E.n_boards + ADV_WPB - 1) / ADV_WPB)), adv_block(64 * ADV_WPB);
-    hipLaunchKernelGGL((k_advance<8, true>), adv_grid, adv_block, 0, s, E, max_iters, budget_ticks, par);
-    return hipGetLastError();
-}
 hipError_t advance(const EngineDev& E, int max_iters, unsigned int budget_ticks, int auto_finish, int par, hipStream_t s) {
     if (auto_finish) hipLaunchKernelGGL(k_moves, wave_grid(E.n_boards), dim3(TPB), 0, s, E, compact_budget(budget_ticks));
     const dim3 adv_grid((unsigned)((E.n_boards + ADV_WPB - 1) / ADV_WPB)), adv_block(64 * ADV_WPB);
     if (E.n_boards > 4096 * QZ_ADV_WAVES_SMALL / 4 || (E.select_opts & 4)) hipLaunchKernelGGL(k_advance<8>, adv_grid, adv_block, 0, s, E, max_iters, budget_ticks, par);
     else hipLaunchKernelGGL(k_advance<QZ_ADV_WAVES_SMALL>, adv_grid, adv_block, 0, s, E, max_iters, budget_ticks, par);
+    return hipGetLastError();
+}
+// k_lanes (qz_lanes.h): the boards without walls, 64 per wavefront, beside k_advance's launch for the others (select_opts bit 4)
+hipError_t advance_lanes(const EngineDev& E, int max_iters, unsigned int budget_ticks, int par, hipStream_t s) {
+    hipLaunchKernelGGL(k_lanes, dim3((unsigned)((E.n_boards + 63) / 64)), dim3(64), 0, s, E, max_iters, budget_ticks, par);
     return hipGetLastError();
 }
 // the moves of the boards that have done their playouts + the subtree copies they leave (and the slices earlier moves left)

@@ -357,15 +357,6 @@ class SelfPlayEngine:
         _cabi.check(self.L.qz_selfplay_round(self.h, C.byref(evaluator.nn_weights()), int(max_playouts), int(budget_us), int(bool(auto_finish)),
                                              self._s()))
 
-    def set_overlap(self, overlap_us, trunk_workgroups=0):
-        """selfplay_round with the network off the boards' critical path (qz_selfplay_set_overlap, include/qz_abi.h): beside
-        the network the boards that are not waiting for it go on playing for `overlap_us` microseconds (0 = off, the
-        default); the trunk then runs as `trunk_workgroups` persistent workgroups (0 = 512).  Needs select_opts bit 3.
-        Drops a captured graph of rounds (it holds the old schedule)."""
-        _cabi.check(self.L.qz_selfplay_set_overlap(self.h, int(overlap_us), int(trunk_workgroups)))
-        self.overlap_us = int(overlap_us)
-        self._round_graph = None
-
     def capture_rounds(self, evaluator, rounds=16, max_playouts=64, budget_us=0, auto_finish=True, warmup=2):
         """Capture `rounds` (even: the two miss counters alternate) rounds into HIP graphs for run_rounds -- ONE GRAPH PER
         MISS-COUNTER PARITY: a graph bakes in which of the two counters its first round appends to (a kernel argument), and a
@@ -653,10 +644,6 @@ class BoardGroups:
         for eng in self.engines:
             eng.set_playouts(n_playout)
         self.n_playout = int(n_playout)
-
-    def set_overlap(self, overlap_us, trunk_workgroups=0):
-        for eng in self.engines:
-            eng.set_overlap(overlap_us, trunk_workgroups)
 
     def capture_rounds(self, rounds=16, **kw):
         for _, eng, ev in self._each():

@@ -314,8 +314,6 @@ def make_engine(args, net, dev, seed, fix_sign, boards=None, nn_precision=None, 
     so = args.select_opts if select_opts is None else select_opts
     eng = BoardGroups(boards or args.boards, args.groups, make_ev, seed=seed, device=dev, n_playout=args.playouts, c_puct=5, temp=1.0, is_selfplay=1,
                       fix_terminal_sign=fix_sign, select_opts=so, memo=not args.no_memo, max_depth=args.max_depth)
-    if (args.overlap_us and (so & 8)) or args.trunk_workgroups:  # (k_advance's second launch beside the network needs the launch-wide deadline)
-        eng.set_overlap(args.overlap_us if (so & 8) else 0, args.trunk_workgroups)
     return eng
 
 
@@ -519,10 +517,7 @@ def run_async(R):
     if not evs:
         raise SystemExit("bench.py: the timed region issued no timed round (rounds_per_step=%d, event_every=%d, graph_rounds=%d): no roofline, no line" % (NR, args.event_every, args.graph_rounds))
     adv_us, rules_us, nn_us, tail_us = (sum(p[i][0].elapsed_time(p[i][1]) for p in evs) / len(evs) * 1e3 for i in range(4))
-    # (with --overlap-us a round has a second k_advance launch beside the network; the timed rounds are issued piece by piece and have
-    # none, so the work of a FIRST launch is the run's minus the second launches' share: qz_stats.overlap_playouts)
-    main_share = 1.0 - d.get("overlap_playouts", 0) / max(d["playouts"], 1)
-    per_launch = {k: d[k] / (rounds * G) * main_share for k in ("edges_scanned", "edges_expanded", "descent_levels", "playouts", "memo_hits", "nn_evals")}
+    per_launch = {k: d[k] / (rounds * G) for k in ("edges_scanned", "edges_expanded", "descent_levels", "playouts", "memo_hits", "nn_evals")}
     # k_advance's algorithmic bytes: every level of a descent reads the node's edge records (32 B each) and its 12-byte record entry,
     # the backup rewrites 24 B per level, a new leaf probes one 512-byte memo bucket and its expansion writes 32 B per legal move
     adv_bytes = (per_launch["edges_scanned"] * 32 + per_launch["descent_levels"] * (12 + 24) + (per_launch["memo_hits"] + per_launch["nn_evals"]) * 512
@@ -535,8 +530,6 @@ def run_async(R):
                 % os.path.relpath(length_file, ROOT)) if ss else "games finished inside the timed region / wall time (no committed length sample with a phase split)"
     out = R.base_line(elapsed, ss["value"] if ss else games_all / elapsed, value_is, ss, games_all, plies_all, playouts_all, term_all, step_ms, desync_s,
                       {"mode": "async", "rounds_per_step": NR, "budget_us": args.budget_us, "max_playouts_per_round": args.max_playouts, "graph_rounds": args.graph_rounds,
-                       "overlap_us": args.overlap_us if (args.select_opts & 8) else 0,
-                       "overlap_playouts_share": d.get("overlap_playouts", 0) / max(d["playouts"], 1),
                        "step": "%d rounds; a round = k_advance (every board: playouts until it needs the network, %d us budget) + network on the leaves the memo does "
                                "not know (actions() of those leaves and k_moves on a second stream beside the trunk) + memo insert; every %d-th round is issued piece by "
                                "piece with HIP events around the pieces" % (NR, args.budget_us, ev_every)},
@@ -718,9 +711,6 @@ def main():
     ap.add_argument("--select-opts", type=int, default=8, help="switches of the descent / the launch (qz_config.select_opts); 8 = ONE deadline per k_advance launch, counted from its first "
                                                                  "wavefront, boards take the first slots in turn (round 5's default: 13,312 boards at 3,000 us = +6 %% over 10,240 boards with "
                                                                  "per-board budgets of 2,400 us on the same box; 0 = per-board budgets)")
-    ap.add_argument("--overlap-us", type=int, default=0, help="k_advance's SECOND launch per round, beside the network, for this many microseconds (qz_selfplay_set_overlap; "
-                                                              "0 = off; needs --select-opts 8); the rounds timed piece by piece have none")
-    ap.add_argument("--trunk-workgroups", type=int, default=0, help="the trunk as this many persistent workgroups striding over the miss list (0 = one workgroup per leaf; with --overlap-us 0 = 512: two per CU)")
     ap.add_argument("--rules-variant", type=int, default=0, help="lockstep A/B: qz_rules_opts.variant of the engines' leaf rules op")
     ap.add_argument("--length-file", default=None, help="game-length sample for games_per_s_steady_state (default: newest profiles/round*/game_length_<n>playouts.json)")
     ap.add_argument("--clock-log", default=None, help="write the clock / power samples of the timed region to this JSON file")

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define QZ_ABI_VERSION 6
+#define QZ_ABI_VERSION 7
 #define QZ_N_ACTIONS 140            /* quoridor.py:12  action_space = 140            */
 #define QZ_PLANES (26 * 81)         /* quoridor.py:58-131  26x9x9 state tensor       */
 #define QZ_MASK_WORDS 5             /* 140-bit legal mask, bit a of word a/32        */
@@ -81,11 +81,14 @@ int qz_movegen_encode(const qz_boards* boards, int n, uint32_t* mask5 /*[dev]*/,
  *                  many boards per mask workgroup
  *   detour_pooled  group-detour mode of the pooled pipeline: 0 = default (one group), else 1 + mode
  *   detour_wave    ... of k_wave_rules: 0 = default (off), else 1 + mode (mode 0 | 1 | 2)
- *   enc_split_pct  0 = default (50): percent of the encoder groups beside the path groups (first launch of the pooled
- *                  pipeline); + 1000 x (1 + f): f percent of the SECOND launch's encoder groups are placed in front of its
- *                  mask groups in the grid (= dispatch) order, the rest behind them (default: see RulesOpts in qz_device.h) */
+ *   enc_split_pct  0 = default (50): percent of the encoder groups beside the path groups (first launch of the pooled pipeline)
+ *   pool_dependent 0 = default: the pooled pipeline's two launches run SIDE BY SIDE on two streams -- the second launch's encoder
+ *                  tiles beside the path groups, its mask groups released by per-path-group ready flags (release / acquire at
+ *                  device scope), a third launch for the mask groups that gave up waiting (normally none) -- where the entry point
+ *                  has a second stream (qz_movegen* / qz_encode: one per caller stream); 1 = one after the other on the caller's
+ *                  stream (the A/B and parity partner) */
 typedef struct {
-    int32_t variant, detour_pooled, detour_wave, enc_split_pct;
+    int32_t variant, detour_pooled, detour_wave, enc_split_pct, pool_dependent;
 } qz_rules_opts;
 /* qz_movegen / qz_encode / qz_movegen_encode with explicit options: mask5 or planes may be NULL
  * (not both), opts may be NULL (defaults). */
@@ -139,7 +142,11 @@ typedef struct {
                                   kernel (eight wavefronts per SIMD: what engines above 4,096 boards run) whatever the engine's size,
                                   bit 3 = qz_selfplay_advance's budget (if >= 100 us) counts from the launch's FIRST wavefront -- one
                                   deadline for all boards -- and the boards take the first slots in turn: for engines of more boards
-                                  than the chip holds wavefronts (8,192), where a board may get its slot in the middle of a launch */
+                                  than the chip holds wavefronts (8,192), where a board may get its slot in the middle of a launch,
+                                  bit 4 = the boards on which NEITHER player has a wall left are played by k_lanes (csrc/qz_lanes.h: one
+                                  LANE per board, the backup folded into the next descent) beside k_advance's launch for the others --
+                                  same search results bit for bit (tests/test_gpu_lanes.py); measured 4x slower than k_advance at
+                                  13,312 boards (profiles/round6/SUMMARY.md): the prototype of the other mapping, off by default */
     /* Leaf-evaluation memo (qz_selfplay_*): log2 of the number of buckets of its two tables; 0 = auto (16,384 small entries
      * -- at most 8 GB -- and 512 big entries per board, rounded up to a power of two), < 0 = no memo (every leaf goes to the network).
      * small: leaves whose mover has no wall left, 4 entries of 128 B per bucket; big: all others, 2 x 640 B. */
@@ -200,8 +207,6 @@ typedef struct {
                                   in the board's next launch (a 1,000-level line copies one level per memory round trip)  */
     int64_t miss_overflow;     /* leaves that found the miss list full (only a stale miss counter can do that): must be 0; the
                                   guard exists so that such a bug cannot write past the list                    */
-    int64_t overlap_playouts;  /* of `playouts`: those made by the rounds' second launches, beside the network
-                                  (qz_selfplay_set_overlap)                                                     */
 } qz_stats;
 
 /* MCTSPlayer.__init__ / MCTS.__init__ (mcts.py:89-100, 159-161) for n_boards trees +
@@ -456,17 +461,6 @@ int qz_selfplay_leaf_rules(qz_engine* e, void* stream);
 int qz_selfplay_evaluate(qz_engine* e, const qz_nn_weights* w, void* stream);
 int qz_selfplay_round_tail(qz_engine* e, void* stream);
 int qz_selfplay_round(qz_engine* e, const qz_nn_weights* w, int max_playouts, int budget_us, int auto_finish, void* stream);
-/* qz_selfplay_round with the network OFF the boards' critical path (off by default: overlap_us = 0).  With overlap_us >= 100 a
- * round is: the launch above; then, BESIDE the network, a second launch of the same loop for overlap_us microseconds in which the
- * boards that are not waiting for an evaluation go on playing (behind the moves, on their stream); then the tail.  The second
- * launch never consumes an evaluation and never adds to the miss list: a board that meets a leaf for the network there forgets
- * the descent (the tree is as it was) and repeats it in the next round's first launch -- per board the operations and their order
- * are unchanged, so the parity statement above holds.  To make room the trunk runs as `trunk_workgroups` persistent workgroups
- * (0 = 512: two per CU, one 256-register wavefront per SIMD) striding over the miss list, which leaves half of every SIMD's
- * registers to four of k_advance's wavefronts.  Needs qz_config.select_opts bit 3 (the launch-wide deadline); QZ_E_INVALID
- * otherwise.  qz_stats.overlap_playouts counts what the second launches add.  (overlap_us = 0 with trunk_workgroups > 0: no second
- * launch, only the trunk's persistent launch shape with that grid -- an A/B switch.) */
-int qz_selfplay_set_overlap(qz_engine* e, int overlap_us, int trunk_workgroups);
 /* which of the engine's two miss counters the NEXT qz_selfplay_advance uses (0 | 1; qz_selfplay_round_tail flips it,
  * qz_engine_reset / qz_engine_set_boards(reset_trees) set it to 0).  A HIP graph captured over whole rounds bakes the
  * counter's address in: replay it only while this value is what it was at capture time (SelfPlayEngine.capture_rounds

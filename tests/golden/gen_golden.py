@@ -6,7 +6,7 @@ GPU box).  It imports the reference's quoridor.py / mcts.py / policy_value_net.p
 drives them on seeded inputs and stores inputs + expected outputs as small .npz
 files.  No reference source is copied: fixtures are data.
 
-    python tests/golden/gen_golden.py [--only rules,pawn,positions,steps,mcts,episodes,net,train,rollouts,no_move]
+    python tests/golden/gen_golden.py [--only rules,pawn,positions,steps,mcts,episodes,net,train,rollouts,no_move,real_net_search]
 
 The oracle (oracle/) and the HIP path are both checked against these files.
 """
@@ -789,6 +789,116 @@ def gen_no_move(out_dir):
                                                           int(sum(int(b["w1"] if b["cur"] == 1 else b["w2"]) > 0 for b in boards))))
 
 
+# --------------------------------------------------------------------------- F9: the reference's search WITH ITS OWN NETWORK
+def _real_net_worker(job):
+    """One get_move_probs of the reference's MCTS (mcts.py:129-144) with the reference's PolicyValueNet(use_gpu=False) as
+    the policy, weights from det_fill_state_dict(seed).  Under torch >= 0.4 `value.data[0][0]` (policy_value_net.py:163) is a
+    0-dim float32 TENSOR, so TreeNode._Q becomes a float32 tensor after its first update (mcts.py:53) and Q + u is
+    compared in float32 -- the SURVEY 8(c) hazard.  Everything the network returned during the search is recorded (board ->
+    legal actions, priors, value), so that a search fed with exactly these evaluations can be compared with this one."""
+    rec, n_playout, seed = job
+    import warnings
+
+    import torch
+
+    warnings.filterwarnings("ignore")
+    torch.set_num_threads(1)
+    import mcts as ref_mcts
+    from policy_value_net import PolicyValueNet
+
+    pvn = PolicyValueNet(use_gpu=False)
+    pvn.policy_value_net.load_state_dict(det_fill_state_dict(pvn.policy_value_net.state_dict(), seed=seed))
+    table = {}
+
+    def policy(game):
+        ap, val = pvn.policy_value_fn(game)
+        ap = list(ap)
+        key = pack_game(game).tobytes()
+        v32 = np.float32(float(val))
+        assert float(v32) == float(val)  # (a float32 tensor: nothing is lost)
+        ent = (np.array([a for a, _ in ap], dtype=np.uint8), np.array([q for _, q in ap], dtype=np.float32), v32)
+        old = table.get(key)
+        if old is not None:  # the evaluation is a pure function of the board (batch of one, train-mode BN): the memo's premise
+            assert np.array_equal(old[0], ent[0]) and np.array_equal(old[1], ent[1]) and old[2] == ent[2]
+        table[key] = ent
+        return ap, val
+
+    g = game_from_packed(rec)
+    m = ref_mcts.MCTS(policy, c_puct=5, n_playout=n_playout)
+    try:
+        with quiet():
+            acts, probs = m.get_move_probs(g, temp=1.0)
+    except IndexError:  # quirk Q5: the reference's own crash on an off-board winning jump inside a playout
+        return None
+    ch = m._root._children
+    visits = np.array([ch[a]._n_visits for a in acts], dtype=np.int32)
+    qs = np.array([float(ch[a]._Q) for a in acts], dtype=np.float64)
+    q_is_tensor = any(isinstance(ch[a]._Q, torch.Tensor) for a in acts)
+    k = len(acts)
+    pad = lambda x, dt: np.concatenate([np.asarray(x, dtype=dt), np.zeros(140 - k, dtype=dt)])  # noqa: E731
+    keys = list(table.keys())
+    return dict(
+        board=rec, k=k, acts=pad(acts, np.int16), visits=pad(visits, np.int32), q32=pad(qs, np.float64), root_visits=m._root._n_visits,
+        q_is_tensor=q_is_tensor,
+        t_board=np.frombuffer(b"".join(keys), dtype=PACKED_DTYPE).copy(),
+        t_k=np.array([len(table[x][0]) for x in keys], dtype=np.int32),
+        t_acts=np.concatenate([table[x][0] for x in keys]), t_p=np.concatenate([table[x][1] for x in keys]),
+        t_v=np.array([table[x][2] for x in keys], dtype=np.float32),
+    )
+
+
+def gen_real_net_search(out_dir, procs, n_playout=400, seed=2024):
+    """real_net_search.npz: >= 64 searches of the reference with the reference's network: 64 late-game
+    positions (nobody has a wall left: the regime of the leaf-evaluation memo and of k_lanes), 8 where only the mover is out of
+    walls, 8 with walls in hand (140-wide nodes).  Stored: root visits / actions / root visit count, Q as the reference held it
+    (float32 tensors, widened), and the evaluation table of every search as ragged arrays."""
+    from synth import synth_positions
+
+    q = _ref()
+
+    def live(rec):
+        g = game_from_packed(rec)
+        return not g.has_a_winner()[0] and int(rec["p1"]) != int(rec["p2"]) and len(g.actions()) > 0
+
+    late = synth_positions(200, seed=77, max_walls=14)
+    late["w1"] = 0
+    late["w2"] = 0
+    mover_out = synth_positions(60, seed=78, max_walls=12)
+    for r in mover_out:
+        if int(r["cur"]) == 1:
+            r["w1"], r["w2"] = 0, max(1, int(r["w2"]))
+        else:
+            r["w2"], r["w1"] = 0, max(1, int(r["w1"]))
+    walls = synth_positions(60, seed=79, max_walls=10, mover_has_walls=True)
+    jobs = []
+    for group, want in ((walls, 8), (mover_out, 8), (late, 64)):
+        jobs.append([(r.copy(), n_playout, seed) for r in group if live(r)][: want + 6])  # (a few spares for Q5 crashes)
+    t0 = time.time()
+    ctx = get_context("fork")
+    res, kinds = [], []
+    with ctx.Pool(procs) as pool:
+        for kind, (grp, want) in enumerate(zip(jobs, (8, 8, 64))):
+            out = [r for r in pool.map(_real_net_worker, grp, chunksize=1) if r is not None][:want]
+            assert len(out) == want, (kind, len(out))
+            res += out
+            kinds += [kind] * want
+    assert all(r["q_is_tensor"] for r in res)
+    toff = np.concatenate([[0], np.cumsum([len(r["t_board"]) for r in res])]).astype(np.int64)
+    np.savez_compressed(
+        os.path.join(out_dir, "real_net_search.npz"),
+        board=np.array([r["board"] for r in res], dtype=PACKED_DTYPE), kind=np.array(kinds, dtype=np.int8),
+        n_playout=np.array(n_playout), c_puct=np.array(5.0), fill_seed=np.array(seed),
+        k=np.array([r["k"] for r in res], dtype=np.int32), acts=np.stack([r["acts"] for r in res]),
+        visits=np.stack([r["visits"] for r in res]), q32=np.stack([r["q32"] for r in res]),
+        root_visits=np.array([r["root_visits"] for r in res], dtype=np.int32),
+        t_off=toff, t_board=np.concatenate([r["t_board"] for r in res]), t_k=np.concatenate([r["t_k"] for r in res]),
+        t_acts=np.concatenate([r["t_acts"] for r in res]), t_p=np.concatenate([r["t_p"] for r in res]),
+        t_v=np.concatenate([r["t_v"] for r in res]),
+    )
+    print("real_net_search: %d searches x %d playouts of the reference with its own network (%d evaluations recorded) in %.0fs"
+          % (len(res), n_playout, int(toff[-1]), time.time() - t0))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="rules,positions,steps,mcts,episodes,net,train,net_more,rollouts,no_move")
@@ -817,6 +927,8 @@ def main():
         gen_rollouts(HERE, args.procs)
     if "no_move" in only:
         gen_no_move(HERE)
+    if "real_net_search" in only:  # (not in the default list: ~10 minutes of the reference on 8 cores)
+        gen_real_net_search(HERE, args.procs)
 
 
 if __name__ == "__main__":

@@ -106,8 +106,8 @@ def _games_by_slot(batches):
     return out
 
 
-@pytest.mark.parametrize("compact_edges,budget_us,pool_pages,overlap_us", [(0, 0, 0, 0), (-1, 0, 0, 0), (0, 300, 192 * 60, 0), (-1, 1, 0, 0), (-1, 150, 0, 150)])
-def test_asynchronous_games_equal_lockstep_games(gpu_device, compact_edges, budget_us, pool_pages, overlap_us):
+@pytest.mark.parametrize("compact_edges,budget_us,pool_pages,select_opts", [(0, 0, 0, 0), (-1, 0, 0, 0), (0, 300, 192 * 60, 0), (-1, 1, 0, 0), (-1, 150, 0, 8), (0, 0, 0, 16), (-1, 1, 0, 16)])
+def test_asynchronous_games_equal_lockstep_games(gpu_device, compact_edges, budget_us, pool_pages, select_opts):
     """Complete self-play games (Dirichlet noise, sampled moves, subtree reuse, continuous refill) from the
     asynchronous loop -- boards on their own clocks, several playouts and whole moves per launch, memo on --
     against the lock-step engine with the same seed: for every board slot the games come out in the same
@@ -117,10 +117,9 @@ def test_asynchronous_games_equal_lockstep_games(gpu_device, compact_edges, budg
     engine does), and a large pool whose threshold (20 pages) these trees rarely reach: moves in place, under a
     wall-clock budget per launch.  Last: always copied under a budget of 1 us -- one playout per launch, and every subtree
     copy stops after its first window of 64 edges and goes on, window by window, in the board's next launches
-    (qz_stats.compact_slices).  The fifth case: the network OFF the boards' critical path (qz_selfplay_set_overlap) -- every round has
-    a second k_advance launch beside the persistent trunk, behind the moves (always copied, in slices of 4.7 us), in which the boards
-    that are not waiting go on playing and a board that meets a leaf for the network forgets the descent and repeats it in the next
-    round.  Afterwards the engine refuses lock-step calls until it is reset."""
+    (qz_stats.compact_slices).  The fifth case: one deadline per launch (select_opts 8); the last two: the boards without walls on
+    k_lanes (select_opts 16, csrc/qz_lanes.h) beside k_advance's launch for the others.  Afterwards the engine refuses lock-step
+    calls until it is reset."""
     from alphazero_quoridor_amd import _cabi
     from alphazero_quoridor_amd.engine import SelfPlayEngine
 
@@ -128,9 +127,7 @@ def test_asynchronous_games_equal_lockstep_games(gpu_device, compact_edges, budg
     ev = _net(gpu_device, 7).evaluator("per_leaf")
     lock = SelfPlayEngine(B, n_playout=NP, seed=77, device=gpu_device, fix_terminal_sign=True)
     asyn = SelfPlayEngine(B, n_playout=NP, seed=77, device=gpu_device, fix_terminal_sign=True, compact_edges=compact_edges,
-                          tree_pool_pages=pool_pages, select_opts=8 if overlap_us else 0)
-    if overlap_us:
-        asyn.set_overlap(overlap_us)
+                          tree_pool_pages=pool_pages, select_opts=select_opts)
     try:
         lb, ab = [], []
         for _ in range(260):
@@ -160,11 +157,6 @@ def test_asynchronous_games_equal_lockstep_games(gpu_device, compact_edges, budg
               % (compared, st["rounds"], st["playouts"], st["memo_hits"], st["nn_evals"]))
         assert compared >= n_lock // 2, (compared, n_lock)
         assert st["node_overflow"] == 0 and st["runaway_descents"] == 0
-        if overlap_us:
-            assert st["overlap_playouts"] > 0, st
-            print("playouts of the rounds' second launches, beside the network: %d of %d" % (st["overlap_playouts"], st["playouts"]))
-        else:
-            assert st["overlap_playouts"] == 0, st
         if budget_us == 1:
             assert st["compact_slices"] > 0, st
             print("subtree copies suspended and resumed: %d" % st["compact_slices"])
@@ -179,21 +171,19 @@ def test_asynchronous_games_equal_lockstep_games(gpu_device, compact_edges, budg
         asyn.close()
 
 
-@pytest.mark.parametrize("select_opts,overlap_us", [(0, 0), (8, 0), (8, 200)])
-def test_more_boards_than_wavefront_slots_play_the_lockstep_games(gpu_device, select_opts, overlap_us):
+@pytest.mark.parametrize("select_opts", [0, 8, 24])
+def test_more_boards_than_wavefront_slots_play_the_lockstep_games(gpu_device, select_opts):
     """The bench's shape: MORE boards (8,704) than the chip holds wavefronts of k_advance<8> (8,192), one wavefront per workgroup --
     the boards behind the 8,192nd start when a board that needs the network has left -- against the lock-step engine with the
     same seed and board count: every slot's games in the same order with identical (board, pi, z) tuples.  select_opts 8: one
-    deadline per launch, boards rotating through the first slots; with overlap_us the rounds' second launches beside the persistent
-    trunk as well (qz_selfplay_set_overlap).  Short games (terminal sign fixed, 12 playouts)."""
+    deadline per launch, boards rotating through the first slots; 24: the boards without walls on k_lanes as well.  Short games
+    (terminal sign fixed, 12 playouts)."""
     from alphazero_quoridor_amd.engine import SelfPlayEngine
 
     B, NP = 8704, 12
     ev = _net(gpu_device, 7).evaluator("per_leaf")
     lock = SelfPlayEngine(B, n_playout=NP, seed=41, device=gpu_device, fix_terminal_sign=True)
     asyn = SelfPlayEngine(B, n_playout=NP, seed=41, device=gpu_device, fix_terminal_sign=True, select_opts=select_opts)
-    if overlap_us:
-        asyn.set_overlap(overlap_us)
     try:
         lb, ab = [], []
         for _ in range(150):
@@ -224,7 +214,6 @@ def test_more_boards_than_wavefront_slots_play_the_lockstep_games(gpu_device, se
               % (compared, late, st["rounds"], st["playouts"], st["memo_hits"]))
         assert compared >= n_lock // 2 and late > 0, (compared, late, n_lock)
         assert st["node_overflow"] == 0 and st["runaway_descents"] == 0 and st["miss_overflow"] == 0
-        assert (st["overlap_playouts"] > 0) == bool(overlap_us), st["overlap_playouts"]
     finally:
         lock.close()
         asyn.close()

@@ -106,11 +106,8 @@ def test_bench_single_gpu_line_carries_the_contract(gpu_device):
         assert s2["games_per_s_steady_state"] is None and ("NON_PARITY" in s2["label"]) == (not parity) and "NOT the headline" in s2["label"]
         assert s2["boards"] == 256 and s2["plies_per_s"] > 0 and s2["nn_evaluations_per_s"] > 0
     # with the rounds captured in HIP graphs the step's first round is still issued piece by piece: the line keeps its roofline
-    # (here with the opt-in second k_advance launch beside a persistent trunk in every captured round: qz_selfplay_set_overlap)
-    g = run("--rounds-per-step", "32", "--graph-rounds", "8", "--no-c3", "--no-cpu-baseline", "--second-line-seconds", "0", "--overlap-us", "150")
+    g = run("--rounds-per-step", "32", "--graph-rounds", "8", "--no-c3", "--no-cpu-baseline", "--second-line-seconds", "0")
     assert g["config"]["graph_rounds"] == 8 and g["roofline"]["launches_timed"] == 2 and 0 < g["roofline"]["frac"] < 1 and g["rounds"] == 2 * 32
-    assert g["config"]["overlap_us"] == 150 and 0 < g["config"]["overlap_playouts_share"] < 1
-    assert a["config"]["overlap_us"] == 0 and a["config"]["overlap_playouts_share"] == 0
     # round 2's route, kept for A/B
     d = run("--mode", "lockstep")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",

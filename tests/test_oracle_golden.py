@@ -320,6 +320,52 @@ def test_roots_without_a_legal_move():
         assert acts == [] and t.root_visits() == 4 and t.node_count() == 0
 
 
+def real_net_tables(d):
+    """real_net_search.npz -> per search {packed board bytes: (dense p[140], v)}: what the REFERENCE's network returned during it"""
+    out = []
+    aoff = np.concatenate([[0], np.cumsum(d["t_k"])]).astype(np.int64)
+    for i in range(len(d["board"])):
+        tab = {}
+        for t in range(int(d["t_off"][i]), int(d["t_off"][i + 1])):
+            p = np.zeros(140, dtype=np.float32)
+            p[d["t_acts"][aoff[t]:aoff[t + 1]].astype(int)] = d["t_p"][aoff[t]:aoff[t + 1]]
+            tab[d["t_board"][t].tobytes()] = (p, np.float32(d["t_v"][t]), d["t_acts"][aoff[t]:aoff[t + 1]].astype(int).tolist())
+        out.append(tab)
+    return out
+
+
+def test_real_network_search_of_the_reference():
+    """tests/golden/real_net_search.npz (gen_golden.py:gen_real_net_search): 80 searches of the reference's MCTS at 400
+    playouts with the reference's OWN PolicyValueNet as the policy -- there `value.data[0][0]` (policy_value_net.py:163) is a
+    0-dim float32 tensor under torch >= 0.4, TreeNode._Q (mcts.py:53) turns into a float32 tensor and Q + u (mcts.py:70) is
+    compared in float32; the build follows the code as written for torch 0.3 (Q a Python float: float64).  Fed with exactly the
+    evaluations the reference's network produced, the oracle must visit the root's children exactly as often: the float32 / float64
+    difference of Q never changes a selection on these 80 searches (64 late-game, 8 mover out of walls, 8 with walls in hand).  If
+    a case ever differs, the engines need a q_dtype compatibility switch -- this test is the tripwire."""
+    d = load("real_net_search.npz")
+    tabs = real_net_tables(d)
+    n, diff, qerr = len(d["board"]), 0, 0.0
+    assert n >= 80 and (d["kind"] == 0).sum() >= 8 and (d["kind"] == 2).sum() >= 64
+    for i in range(n):
+        tab = tabs[i]
+
+        def policy(g, legal, tab=tab):
+            p, v, acts = tab[g.packed().tobytes()]
+            assert acts == list(legal)  # the reference's actions() order = the oracle's
+            return legal, p[legal], float(v)
+
+        m = oracle.OracleMCTS(policy, c_puct=float(d["c_puct"]), n_playout=int(d["n_playout"]))
+        acts, visits, _ = m.get_move_probs(oracle.OracleGame.from_packed(d["board"][i]), 1.0)
+        k = int(d["k"][i])
+        assert acts == d["acts"][i][:k].astype(int).tolist(), i
+        diff += int(not np.array_equal(visits, d["visits"][i][:k]))
+        assert m.root_visits() == int(d["root_visits"][i])
+        qerr = max(qerr, float(np.abs(np.asarray(m.root_children()[2]) - d["q32"][i][:k]).max()))
+    assert diff == 0, "%d of %d searches differ from the reference's (float32 tensor Q): add a q_dtype switch" % (diff, n)
+    assert qerr < 1e-5, qerr  # float32 running means against float64 ones
+    print("%d reference searches with the reference's network: root visits identical; max |Q64 - Q32| = %.2e" % (n, qerr))
+
+
 def test_oracle_under_address_and_ub_sanitizers():
     """`make -C oracle libqz_oracle_asan.so` (gcc -fsanitize=address,undefined) really runs: the
     rules fixtures, a slice of the position fixtures, MCTS searches with subtree reuse and the
