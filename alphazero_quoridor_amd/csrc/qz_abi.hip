@@ -15,15 +15,13 @@
 #include "qz_device.h"
 
 namespace qzl {
-hipError_t movegen_encode(const uint64_t*, const uint64_t*, const uint64_t*, int, uint32_t*, float*, const uint8_t*, void*, const RulesOpts&, hipStream_t, const int* n_dev = nullptr,
-                          const PoolAsync* pa = nullptr);
+hipError_t movegen_encode(const uint64_t*, const uint64_t*, const uint64_t*, int, uint32_t*, float*, const uint8_t*, void*, const RulesOpts&, hipStream_t, const int* n_dev = nullptr);
 hipError_t advance(const EngineDev&, int, unsigned int, int, int, hipStream_t);
 hipError_t advance_lanes(const EngineDev&, int, unsigned int, int, hipStream_t);
 hipError_t moves(const EngineDev&, unsigned int, hipStream_t);
 hipError_t round_tail(const EngineDev&, int, hipStream_t);
 hipError_t memo_flush(const EngineDev&, hipStream_t);
 size_t movegen_scratch_bytes(int);
-size_t movegen_scratch_header_bytes();
 hipError_t step(uint64_t*, uint64_t*, uint64_t*, const uint8_t*, int, uint8_t*, uint8_t*, hipStream_t);
 hipError_t select(const EngineDev&, hipStream_t);
 hipError_t expand_backup(const EngineDev&, const float*, const float*, hipStream_t);
@@ -84,10 +82,9 @@ static std::mutex g_scratch_mu;
 struct ScratchBuf {
     void* p = nullptr;
     size_t bytes = 0;
-    PoolAsync pa;  // the pooled pipeline's second stream + fork / join events (created with the buffer)
 };
 static std::map<std::pair<int, void*>, ScratchBuf> g_scratch;
-static int get_scratch(int n, void* stream, void** out, const PoolAsync** pa_out = nullptr) {
+static int get_scratch(int n, void* stream, void** out) {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     size_t need = qzl::movegen_scratch_bytes(n);
@@ -107,17 +104,8 @@ static int get_scratch(int n, void* stream, void** out, const PoolAsync** pa_out
             return fail(QZ_E_OOM, "hipMalloc(%zu) for move-generation scratch failed: %s", need, hipGetErrorString(e));
         }
         sb.bytes = need;
-        HIP_TRY(hipMemset(sb.p, 0, qzl::movegen_scratch_header_bytes()));  // (the ready flags / deferred list: call numbers only, from here on)
-        if (!sb.pa.side) {  // (optional: without them the pipeline's launches simply follow each other)
-            if (hipStreamCreateWithFlags(&sb.pa.side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&sb.pa.fork, hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&sb.pa.join, hipEventDisableTiming) != hipSuccess) {
-                (void)hipGetLastError();
-                sb.pa = PoolAsync();
-            }
-        }
     }
     *out = sb.p;
-    if (pa_out) *pa_out = sb.pa.side ? &sb.pa : nullptr;
     return 0;
 }
 
@@ -128,7 +116,6 @@ static RulesOpts rules_opts(const qz_rules_opts* o) {
     if (o->detour_pooled > 0) r.detour_pooled = o->detour_pooled - 1;
     if (o->detour_wave > 0) r.detour_wave = o->detour_wave - 1;
     if (o->enc_split_pct > 0) r.enc_split_pct = o->enc_split_pct > 100 ? 100 : o->enc_split_pct;
-    r.pool_dependent = o->pool_dependent != 0;
     return r;
 }
 
@@ -204,10 +191,9 @@ int qz_movegen_encode_opts(const qz_boards* boards, int n, uint32_t* mask5, floa
     if (n > 0 && !mask5 && !planes) return fail(QZ_E_INVALID, "mask5 and planes are both null");
     if (n == 0) return 0;
     void* scratch = nullptr;
-    const PoolAsync* pa = nullptr;
-    if ((r = get_scratch(n, stream, &scratch, &pa))) return r;
+    if ((r = get_scratch(n, stream, &scratch))) return r;
     HIP_TRY(qzl::movegen_encode(boards->hbits, boards->vbits, boards->meta, n, mask5, planes, nullptr, scratch, rules_opts(opts),
-                                (hipStream_t)stream, nullptr, pa));
+                                (hipStream_t)stream));
     return 0;
 }
 int qz_movegen(const qz_boards* boards, int n, uint32_t* mask5, void* stream) {
@@ -452,7 +438,6 @@ int qz_engine_create(const qz_config* cfg, qz_engine** out) {
         uint8_t* sc = nullptr;
         rc = dev_alloc(e, &sc, qzl::movegen_scratch_bytes(c.n_boards));
         e->scratch = sc;
-        if (!rc && hipMemset(sc, 0, qzl::movegen_scratch_header_bytes()) != hipSuccess) rc = fail(QZ_E_HIP, "scratch init failed");
     }
     if (rc) {
         qz_engine_destroy(e);

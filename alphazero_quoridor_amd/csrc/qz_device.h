@@ -113,15 +113,7 @@ struct RulesOpts {
     int variant = 0;
     int detour_pooled = 1, detour_wave = 0;  // pool_k1's detour_mode per kernel family
     int enc_split_pct = 50;                  // share of the encoder tiles beside the path groups
-    int pool_dependent = 0;                  // 1: the pooled pipeline's two launches one after the other on the caller's stream (A/B partner of the two-stream form)
 };
-#if defined(__HIPCC__)
-// a second stream + fork / join events for the pooled pipeline's two launches side by side (qzl::movegen_encode)
-struct PoolAsync {
-    hipStream_t side = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
-};
-#endif
 
 // Leaf-evaluation memo.  policy_value_fn on a batch of one (policy_value_net.py:145-164, BatchNorm in training mode)
 // is a pure function of the 24-byte board, and a long game revisits the same few thousand boards millions of times

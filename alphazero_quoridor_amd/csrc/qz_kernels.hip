@@ -17,7 +17,6 @@
 // Reference semantics: see qz_rules.h (rules) and the per-kernel comments (mcts.py).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <atomic>
 
 #include "qz_rules.h"
 #include "qz_movegen_pool.h"
@@ -117,7 +116,7 @@ template <int NBE>
 __global__ __launch_bounds__(256) void k_pool_paths_enc(const uint64_t* __restrict__ hb, const uint64_t* __restrict__ vb,
                                                         const uint64_t* __restrict__ meta, int n, const uint8_t* __restrict__ terminal,
                                                         PoolHand* __restrict__ hands, int n_path_groups,
-                                                        float* __restrict__ planes, int detour_mode, uint32_t* __restrict__ ready, uint32_t epoch) {
+                                                        float* __restrict__ planes, int detour_mode) {
     __shared__ EncShared<NBE> sm;
     const int tid = (int)threadIdx.x;
     if ((int)blockIdx.x < n_path_groups) {
@@ -130,14 +129,6 @@ __global__ __launch_bounds__(256) void k_pool_paths_enc(const uint64_t* __restri
             Board bd = unpack(hb[b], vb[b], meta[b]);
             bool term = terminal ? (terminal[b] != 0) : false;
             pool_k1_hand(bd, term, p, hands[b], detour_mode);
-        }
-        if (ready) {
-            // The second launch runs BESIDE this one (another stream, no stream dependency: movegen_encode): its mask groups take the
-            // records of their 128-board path group when this flag carries the call's number.  Release at device scope: the
-            // records of all four wavefronts are out of this XCD's L2 before the flag is.
-            __threadfence();
-            __syncthreads();
-            if (tid == 0) __hip_atomic_store(ready + blockIdx.x, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
         return;
     }
@@ -440,91 +431,24 @@ __device__ __forceinline__ void mask_group(MasksShared<NB>& sm, const PoolHand* 
         for (int w = 0; w < 5; w++) mask5[(size_t)(b0 + tid) * 5 + w] = m5[w];
     }
 }
-// The mask groups of a launch that does NOT wait for the path groups' launch (movegen_encode, two streams): a group takes its
-// boards' records when the flags of the path groups that write them (128 boards each) carry this call's number -- acquire at
-// device scope.  Normally they do when the group is placed (the encoder tiles in front of it in the grid have run beside the path
-// groups meanwhile); a group that waits longer than POOL_SPIN_TICKS gives its slot back -- spinning workgroups must never keep the
-// path groups off the chip -- and leaves its number in the call's deferred list, which k_pool_masks_fixup (a third, dependent
-// launch: at once empty-handed in the normal case) works off.
-constexpr unsigned long long POOL_SPIN_TICKS = 20000ull;  // 200 us of s_memrealtime (100 MHz)
-__device__ __forceinline__ bool pool_wait_ready(const uint32_t* __restrict__ ready, unsigned long long* __restrict__ defer, const uint32_t epoch,
-                                                const int group, const int b0, const int nb, const int tid, int* const ok_s) {
-    if (tid == 0) {
-        const int pg0 = (2 * b0) >> 8, pg1 = (2 * (b0 + nb) - 1) >> 8;
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        int ok = 0;
-        for (;;) {
-            const uint32_t a = __hip_atomic_load(ready + pg0, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t c = __hip_atomic_load(ready + pg1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-            if (a == epoch && c == epoch) {
-                ok = 1;
-                break;
-            }
-            if (__builtin_amdgcn_s_memrealtime() - t0 > POOL_SPIN_TICKS) break;
-            __builtin_amdgcn_s_sleep(16);
-        }
-        if (!ok) {  // defer[0] = call number << 32 | entries of this call; defer[1 + i / 2] holds two group numbers
-            unsigned long long old = __hip_atomic_load(defer, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (;;) {
-                const unsigned long long cnt = (uint32_t)(old >> 32) == epoch ? (old & 0xFFFFFFFFull) : 0ull;
-                const unsigned long long neu = ((unsigned long long)epoch << 32) | (cnt + 1ull);
-                const unsigned long long seen = atomicCAS(defer, old, neu);
-                if (seen == old) {
-                    reinterpret_cast<uint32_t*>(defer + 1)[cnt] = (uint32_t)group;
-                    break;
-                }
-                old = seen;
-            }
-        }
-        *ok_s = ok;
-    }
-    __syncthreads();
-    const bool ok = *ok_s != 0;
-    if (ok) __atomic_thread_fence(__ATOMIC_ACQUIRE);  // (every thread reads the records: nothing stale from this CU's L1 / this XCD's L2)
-    return ok;
-}
 template <int NB, int NBE>
 __global__ __launch_bounds__(256) void k_pool_masks_enc(const PoolHand* __restrict__ hands, int n,
                                                         uint32_t* __restrict__ mask5, int n_mask_groups, int enc_tile0,
                                                         const uint64_t* __restrict__ hb, const uint64_t* __restrict__ vb,
                                                         const uint64_t* __restrict__ meta, const uint8_t* __restrict__ terminal,
-                                                        float* __restrict__ planes, int n_enc_tiles, int enc_first,
-                                                        const uint32_t* __restrict__ ready, unsigned long long* __restrict__ defer, uint32_t epoch) {
+                                                        float* __restrict__ planes) {
     __shared__ MasksEncShared<NB, NBE> smu;
-    __shared__ int s_ok;
     const int tid = (int)threadIdx.x;
-    // grid order = dispatch order.  Dependent launch (behind the path groups' launch on the same stream): [mask groups][encoder
-    // tiles] -- the mask groups are the long pole.  Concurrent launch (enc_first, ready != nullptr): [encoder tiles][mask groups] --
-    // the encoder tiles do not depend on the path groups and run BESIDE them from the first microsecond; the mask groups are
-    // placed as those drain, by when the path groups' flags are normally up.
-    int bid = (int)blockIdx.x;
-    if (enc_first) {
-        if (bid < n_enc_tiles) {
-            encoder_group<NBE>(smu.enc, hb, vb, meta, n, terminal, planes, (enc_tile0 + bid) * NBE, tid);
-            return;
-        }
-        bid -= n_enc_tiles;
-    } else if (bid >= n_mask_groups) {
+    // grid order = dispatch order: [mask groups][encoder tiles] -- the mask groups are the launch's long pole (issue-bound, 29 KB of
+    // LDS each).  Measured and rejected: encoder tiles in front of them (rounds 5: +2..17 us), a few persistent encoder workgroups
+    // per CU (round 5: +3..11 us), and this launch running BESIDE the path groups' launch with its mask groups released by
+    // per-path-group ready flags (round 6: +22..120 us, profiles/round6/rules/).
+    const int bid = (int)blockIdx.x;
+    if (bid >= n_mask_groups) {
         encoder_group<NBE>(smu.enc, hb, vb, meta, n, terminal, planes, (enc_tile0 + bid - n_mask_groups) * NBE, tid);
         return;
     }
-    const int b0 = bid * NB;
-    if (ready && !pool_wait_ready(ready, defer, epoch, bid, b0, (n - b0) < NB ? (n - b0) : NB, tid, &s_ok)) return;
-    mask_group<NB>(smu.m, hands, n, mask5, hb, vb, meta, b0, tid);
-}
-// the mask groups a concurrent launch gave up on (pool_wait_ready), after both launches: stream-ordered, no flags
-template <int NB>
-__global__ __launch_bounds__(256) void k_pool_masks_fixup(const PoolHand* __restrict__ hands, int n, uint32_t* __restrict__ mask5,
-                                                          const uint64_t* __restrict__ hb, const uint64_t* __restrict__ vb,
-                                                          const uint64_t* __restrict__ meta, const unsigned long long* __restrict__ defer, uint32_t epoch) {
-    const unsigned long long w = defer[0];
-    if ((uint32_t)(w >> 32) != epoch) return;
-    __shared__ MasksShared<NB> sm;
-    const uint32_t cnt = (uint32_t)w;
-    for (uint32_t i = blockIdx.x; i < cnt; i += gridDim.x) {
-        if (i != blockIdx.x) __syncthreads();
-        mask_group<NB>(sm, hands, n, mask5, hb, vb, meta, (int)reinterpret_cast<const uint32_t*>(defer + 1)[i] * NB, (int)threadIdx.x);
-    }
+    mask_group<NB>(smu.m, hands, n, mask5, hb, vb, meta, bid * NB, tid);
 }
 
 // Quoridor.step() + has_a_winner(): one thread per board, fully coalesced SoA traffic
@@ -3138,40 +3062,20 @@ static inline dim3 wave_grid(int n) { return dim3((unsigned)((n + WPB - 1) / WPB
 #endif
 constexpr int NBE = QZ_NBE;  // boards per encoder group (8 and 32 measured at 32,768 boards: see DESIGN 9.2)
 
-// what a caller that can run the pooled pipeline's two launches side by side hands to movegen_encode: a second stream, two events
-// (fork / join: captures into a HIP graph), and -- behind the hand-off records in the scratch buffer -- the path groups' ready
-// flags and the deferred list (movegen_scratch_bytes; zeroed once, at allocation: flags and list are tagged with the call's number)
-std::atomic<uint32_t> g_pool_epoch{0};
-
 template <int NB>
 static void launch_masks_enc(const PoolHand* hands, int n, uint32_t* mask5, const uint64_t* hb,
                              const uint64_t* vb, const uint64_t* meta, const uint8_t* terminal, float* planes, int enc_tile0,
-                             int n_enc_groups, hipStream_t s, const uint32_t* ready, unsigned long long* defer, uint32_t epoch) {
+                             int n_enc_groups, hipStream_t s) {
     const int n_mask_groups = mask5 ? (n + NB - 1) / NB : 0;
     if (n_mask_groups + n_enc_groups == 0) return;
     hipLaunchKernelGGL((k_pool_masks_enc<NB, NBE>), dim3((unsigned)(n_mask_groups + n_enc_groups)), dim3(256), 0, s, hands, n,
-                       mask5, n_mask_groups, enc_tile0, hb, vb, meta, terminal, planes, n_enc_groups, ready ? 1 : 0, ready, defer, epoch);
-}
-template <int NB>
-static void launch_masks_fixup(const PoolHand* hands, int n, uint32_t* mask5, const uint64_t* hb, const uint64_t* vb, const uint64_t* meta,
-                               const unsigned long long* defer, uint32_t epoch, hipStream_t s) {
-    hipLaunchKernelGGL((k_pool_masks_fixup<NB>), dim3(64), dim3(256), 0, s, hands, n, mask5, hb, vb, meta, defer, epoch);
+                       mask5, n_mask_groups, enc_tile0, hb, vb, meta, terminal, planes);
 }
 
-// Scratch layout: [header: ready flags | deferred list][hand-off records].  The header has a FIXED size and place (whatever n: a
-// buffer is reused by calls of different sizes, and a flag word must never be memory an earlier call used for records -- a stale
-// word equal to a later call's number would release a mask group early); it is zeroed once, when the buffer is allocated, and only
-// ever holds call numbers afterwards.  Calls of more than POOL_ASYNC_MAX_N boards run their two launches one after the other.
-constexpr int POOL_ASYNC_MAX_N = 1 << 20;
-constexpr size_t POOL_READY_BYTES = (size_t)(2 * POOL_ASYNC_MAX_N / 256) * 4;         // one word per path group (128 boards)
-constexpr size_t POOL_DEFER_BYTES = 16 + (size_t)(POOL_ASYNC_MAX_N / 8) * 4;           // call number | count, then one word per mask group (>= 8 boards)
-constexpr size_t POOL_HEADER_BYTES = (POOL_READY_BYTES + POOL_DEFER_BYTES + 255) & ~(size_t)255;
-size_t movegen_scratch_header_bytes() { return POOL_HEADER_BYTES; }
-size_t movegen_scratch_bytes(int n) { return POOL_HEADER_BYTES + (size_t)n * sizeof(PoolHand); }  // + 184 B per board (round 3: 1,522)
+size_t movegen_scratch_bytes(int n) { return (size_t)n * sizeof(PoolHand); }  // 184 B per board (round 3: 1,522)
 
 hipError_t movegen_encode(const uint64_t* hb, const uint64_t* vb, const uint64_t* meta, int n, uint32_t* mask5,
-                          float* planes, const uint8_t* terminal, void* scratch, const RulesOpts& ro, hipStream_t s, const int* n_dev,
-                          const PoolAsync* pa) {
+                          float* planes, const uint8_t* terminal, void* scratch, const RulesOpts& ro, hipStream_t s, const int* n_dev) {
     if (n <= 0) return hipSuccess;
     if (n_dev && planes) return hipErrorInvalidValue;  // a device-side count: k_wave_rules, legal sets only (no encoder tiles)
     // Small batches are latency-bound: one launch, a wavefront per board, no hand-off through
@@ -3195,7 +3099,7 @@ hipError_t movegen_encode(const uint64_t* hb, const uint64_t* vb, const uint64_t
         else hipLaunchKernelGGL((k_wave_rules<NBE, 2, false>), grid, dim3(256), 0, s, hb, vb, meta, n, terminal, mask5, planes, n_mg_groups, ro.detour_wave, n_dev);
         return hipGetLastError();
     }
-    PoolHand* hands = reinterpret_cast<PoolHand*>(reinterpret_cast<char*>(scratch) + POOL_HEADER_BYTES);
+    PoolHand* hands = reinterpret_cast<PoolHand*>(scratch);
     // Encoder tiles are split over the two launches: enc_split_pct percent ride beside the path search (a latency-bound
     // dependent chain of ~27 us that leaves issue slots and the memory pipe idle), the rest in the mask groups' launch.
     // Dependent launches (round 4's sweep at 32,768 boards, S-open / S-mid / S-dense, us): 40 % 67.0 / 74.9 / 79.1, 50 % 66.6 / 72.3 /
@@ -3204,43 +3108,16 @@ hipError_t movegen_encode(const uint64_t* hb, const uint64_t* vb, const uint64_t
     const int enc_a = mask5 ? (enc_total * ro.enc_split_pct) / 100 : 0;
     const int enc_b = enc_total - enc_a;
     const int nbt = ro.variant >= 8 ? ro.variant : (n >= 16384 ? 24 : (n >= 8192 ? 16 : 8));
-    // Two streams (pa != nullptr, mask5 != nullptr, not switched off): the second launch does not wait for the first -- its encoder
-    // tiles (first in its grid) run beside the path groups, its mask groups take their records when the path groups' flags are up
-    // (k_pool_masks_enc) -- and a third, dependent launch serves the mask groups that gave up waiting (normally none).
-    const bool two = pa && pa->side && mask5 && !ro.pool_dependent && n <= POOL_ASYNC_MAX_N;
-    uint32_t epoch = 0u;
-    uint32_t* ready = nullptr;
-    unsigned long long* defer = nullptr;
-    hipStream_t s2 = s;
-    if (two) {
-        do epoch = ++g_pool_epoch; while (epoch == 0u);
-        ready = reinterpret_cast<uint32_t*>(scratch);
-        defer = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(scratch) + POOL_READY_BYTES);
-        s2 = pa->side;
-        hipError_t e = hipEventRecord(pa->fork, s);
-        if (e == hipSuccess) e = hipStreamWaitEvent(s2, pa->fork, 0);
-        if (e != hipSuccess) return e;
-    }
     if (mask5) {
         const int n_path_groups = (2 * n + 255) / 256;
         hipLaunchKernelGGL((k_pool_paths_enc<NBE>), dim3((unsigned)(n_path_groups + enc_a)), dim3(256), 0, s, hb, vb, meta, n,
-                           terminal, hands, n_path_groups, planes, ro.detour_pooled, ready, epoch);
+                           terminal, hands, n_path_groups, planes, ro.detour_pooled);
     }
-    if (nbt >= 32) launch_masks_enc<32>(hands, n, mask5, hb, vb, meta, terminal, planes, enc_a, enc_b, s2, ready, defer, epoch);
-    else if (nbt >= 24) launch_masks_enc<24>(hands, n, mask5, hb, vb, meta, terminal, planes, enc_a, enc_b, s2, ready, defer, epoch);
-    else if (nbt >= 16) launch_masks_enc<16>(hands, n, mask5, hb, vb, meta, terminal, planes, enc_a, enc_b, s2, ready, defer, epoch);
-    else if (nbt >= 12) launch_masks_enc<12>(hands, n, mask5, hb, vb, meta, terminal, planes, enc_a, enc_b, s2, ready, defer, epoch);
-    else launch_masks_enc<8>(hands, n, mask5, hb, vb, meta, terminal, planes, enc_a, enc_b, s2, ready, defer, epoch);
-    if (two) {
-        hipError_t e = hipEventRecord(pa->join, s2);
-        if (e == hipSuccess) e = hipStreamWaitEvent(s, pa->join, 0);
-        if (e != hipSuccess) return e;
-        if (nbt >= 32) launch_masks_fixup<32>(hands, n, mask5, hb, vb, meta, defer, epoch, s);
-        else if (nbt >= 24) launch_masks_fixup<24>(hands, n, mask5, hb, vb, meta, defer, epoch, s);
-        else if (nbt >= 16) launch_masks_fixup<16>(hands, n, mask5, hb, vb, meta, defer, epoch, s);
-        else if (nbt >= 12) launch_masks_fixup<12>(hands, n, mask5, hb, vb, meta, defer, epoch, s);
-        else launch_masks_fixup<8>(hands, n, mask5, hb, vb, meta, defer, epoch, s);
-    }
+    if (nbt >= 32) launch_masks_enc<32>(hands, n, mask5, hb, vb, meta, terminal, planes, enc_a, enc_b, s);
+    else if (nbt >= 24) launch_masks_enc<24>(hands, n, mask5, hb, vb, meta, terminal, planes, enc_a, enc_b, s);
+    else if (nbt >= 16) launch_masks_enc<16>(hands, n, mask5, hb, vb, meta, terminal, planes, enc_a, enc_b, s);
+    else if (nbt >= 12) launch_masks_enc<12>(hands, n, mask5, hb, vb, meta, terminal, planes, enc_a, enc_b, s);
+    else launch_masks_enc<8>(hands, n, mask5, hb, vb, meta, terminal, planes, enc_a, enc_b, s);
     return hipGetLastError();
 }
 hipError_t step(uint64_t* hb, uint64_t* vb, uint64_t* meta, const uint8_t* action, int n, uint8_t* done, uint8_t* winner,

@@ -37,12 +37,11 @@ def encode(boards: DeviceBoards, out: torch.Tensor | None = None) -> torch.Tenso
     return out
 
 
-def rules_opts(variant=0, detour_pooled=None, detour_wave=None, enc_split_pct=None, pool_dependent=False) -> _cabi.qz_rules_opts:
+def rules_opts(variant=0, detour_pooled=None, detour_wave=None, enc_split_pct=None) -> _cabi.qz_rules_opts:
     """qz_rules_opts (include/qz_abi.h): which formulation of the rules op to run.  None = the
-    library default; detour modes are 0 | 1 | 2; pool_dependent = the pooled pipeline's two launches one after
-    the other (the A/B and parity partner of the two-stream form)."""
+    library default; detour modes are 0 | 1 | 2."""
     return _cabi.qz_rules_opts(int(variant), 0 if detour_pooled is None else 1 + int(detour_pooled),
-                               0 if detour_wave is None else 1 + int(detour_wave), int(enc_split_pct or 0), int(bool(pool_dependent)))
+                               0 if detour_wave is None else 1 + int(detour_wave), int(enc_split_pct or 0))
 
 
 def movegen_encode(boards: DeviceBoards, mask: torch.Tensor | None = None, planes: torch.Tensor | None = None, opts=None):

@@ -50,7 +50,7 @@ sys.path.insert(0, ROOT)
 CONV_FLOPS = 2.0 * 81 * 9 * (10 * 64 * 64 + 64 * 6 + 26 * 64) + 2.0 * (324 * 128 + 128 + 162 * 140)  # fp32-equivalent FLOPs per leaf
 
 sys.path.insert(0, os.path.join(ROOT, "benchmarks"))
-from bench_support import BYTES_PER_BOARD, HBM_PEAK_GBS, ClockSampler, _latest_profile, _load_json, c3_microbench, cpu_baseline, usable_cores  # noqa: E402,F401
+from bench_support import BYTES_PER_BOARD, HBM_PEAK_GBS, ClockSampler, _latest_profile, _load_json, c3_microbench, cpu_baseline, file_sha256, tree_sha, usable_cores  # noqa: E402,F401
 
 
 def launch_ranks(n_gpus, argv):
@@ -91,7 +91,7 @@ def _length_fields(d, length_file, rate):
     wd = d.get("window_doubling") or {}
     out = {"n_games_in_length_sample": d.get("games_finished"), "n_games_censored": d.get("games_censored"),
            "n_games_dropped_as_censored": d.get("games_dropped_as_censored"), "length_estimator": d.get("estimator"),
-           "length_source": os.path.relpath(length_file, ROOT), "restricted_mean_plies": rm, "observation_window_plies": d.get("T"),
+           "length_source": os.path.relpath(length_file, ROOT), "length_source_sha256": file_sha256(length_file), "restricted_mean_plies": rm, "observation_window_plies": d.get("T"),
            "survival_at_window": ST, "upper_bound": rate(float(rm)) if rm else None,
            "value_high": rate(float(rm)) if rm else None,
            "value_low": rate(float(rm) + 2.0 * float(ST) / float(lam)) if rm and ST is not None and lam else None,
@@ -187,6 +187,25 @@ class Run:
                         "max over ranks of each rank's mean / maximum; inside the timed region and inside ms_per_step"}
         return self.exch
 
+    def per_rank(self, elapsed, plies, playouts):
+        """What EACH rank did, gathered on every rank: an N > 1 line shows N distinct devices each doing its share.
+        On RCCL the PCI bus ids must differ (one process per GPU); under gloo two ranks may share a device (the CPU-box test shape)."""
+        try:
+            bus = torch.cuda.get_device_properties(self.dev)
+            bus_id = "%04x:%02x:%02x" % (int(getattr(bus, "pci_domain_id", 0)), int(getattr(bus, "pci_bus_id", -1)), int(getattr(bus, "pci_device_id", 0)))
+        except Exception:  # noqa: BLE001
+            bus_id = "unknown"
+        mine = {"rank": self.rank, "local_device": int(self.dev.index or 0), "pci_bus_id": bus_id, "plies": float(plies), "playouts": float(playouts),
+                "ms_per_step": elapsed / self.args.steps * 1e3}
+        if self.world == 1:
+            return [mine]
+        allr = [None] * self.world
+        torch.distributed.all_gather_object(allr, mine)
+        if torch.distributed.get_backend() == "nccl":
+            ids = [r["pci_bus_id"] for r in allr]
+            assert len(set(ids)) == self.world, "two ranks of an RCCL job on one device: %s" % ids
+        return allr
+
     def reduce(self, elapsed, totals):
         el = torch.tensor([elapsed], dtype=torch.float64, device=self.dev)
         tot = torch.tensor(totals, dtype=torch.float64, device=self.dev)
@@ -242,6 +261,7 @@ class Run:
         out["clocks"] = sampler.summary() if sampler else None
         if self.world > 1:
             out["allgather_ms"] = self.exch
+        out["provenance"] = tree_sha()
         if a.clock_log and sampler:
             with open(a.clock_log, "w") as f:
                 json.dump({"step_ms": step_ms, "samples": sampler.samples}, f)
@@ -266,7 +286,7 @@ class Run:
                 seen = self.lengths["timed"] + self.lengths["warmup"] + self.lengths["desync"]
                 L_cpu = float(np.mean(seen)) if seen else None
                 L_src = "NO length sample for n_playout=%d: mean length of the %d games finished in this run (mostly desync games)" % (a.playouts, len(seen))
-            out["cpu_baseline"] = cpu_baseline(a.cpu_seconds, a.playouts, L_cpu, L_src)
+            out["cpu_baseline"] = cpu_baseline(a.cpu_seconds, a.playouts, L_cpu, L_src, open_share=(out.get("open_phase") or {}).get("share_of_board_time"))
         print(json.dumps(out))
 
 
@@ -292,12 +312,14 @@ def round_schedule(rounds_per_step, event_every, graph_rounds=0):
     return out
 
 
-def hbm_line(kernel, us, nbytes, note, launches, traffic=None, src=None):
+def hbm_line(kernel, us, nbytes, note, launches, traffic=None, src=None, src_file=None):
     if us is None or not launches:
         raise SystemExit("bench.py: no timed launch of '%s' -- a line without its roofline is unmeasured (round_schedule must time >= 1 round per step)" % kernel[:40])
     gbs = nbytes / (us * 1e-6) / 1e9
     return {"kernel": kernel, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
-            "traffic_source": src, "avg_launch_us": us, "launches_timed": launches, "algorithmic_bytes_per_launch": nbytes, "note": note}
+            "traffic_source": src, "traffic_source_sha256": file_sha256(src_file) if src_file else None,
+            "traffic_measured_on_these_kernels": ((_load_json(src_file) or {}).get("kernel_sources_sha256") == tree_sha()["kernel_sources_sha256"]) if src_file else None,
+            "avg_launch_us": us, "launches_timed": launches, "algorithmic_bytes_per_launch": nbytes, "note": note}
 
 
 def make_engine(args, net, dev, seed, fix_sign, boards=None, nn_precision=None, select_opts=None):
@@ -503,6 +525,10 @@ def run_async(R):
     st1 = eng.stats()
     d = {k: st1[k] - st0[k] for k in st1}
     exch = R.exchange_summary()
+    ranks = R.per_rank(elapsed, d["plies_played"], d["playouts"])
+    if args.dump_roots and rank == 0:  # the steady-state population's root positions (cpu_baseline's workload: tests/golden/steady_state_roots.npz)
+        roots = np.concatenate([e.get_boards().to_packed() for e in eng.engines])
+        np.savez_compressed(args.dump_roots, board=roots, boards_per_gpu=B, n_playout=args.playouts, rounds_played=int(st1["rounds"]), seed=args.seed)
     elapsed, (games_all, plies_all, playouts_all, term_all, evals_all, hits_all, open_plies_all, open_rounds_all) = R.reduce(
         elapsed, [games, d["plies_played"], d["playouts"], d["leaf_terminal"], d["nn_evals"], d["memo_hits"], d["open_plies"], d["open_rounds"]])
     if rank != 0:
@@ -535,7 +561,7 @@ def run_async(R):
                                "piece with HIP events around the pieces" % (NR, args.budget_us, ev_every)},
                       "asynchronous self-play loop with leaf-evaluation memo, finished tuples all-gathered every step")
     out.update({
-        "games_per_s_plies_over_mean_length": ss_simple, "nn_evaluations_per_s": evals_all / elapsed, "leaf_evals_per_s": evals_all / elapsed,
+        "per_rank": ranks, "games_per_s_plies_over_mean_length": ss_simple, "nn_evaluations_per_s": evals_all / elapsed, "leaf_evals_per_s": evals_all / elapsed,
         "memo_hit_rate": hits_all / max(playouts_all, 1.0),
         "open_phase": {"plies": open_plies_all, "share_of_board_time": open_rounds_all / max(B * world * rounds, 1), "note": "root's mover still has walls"},
         "mean_descent_depth": d["descent_levels"] / max(d["playouts"], 1), "rounds": rounds, "ms_per_round": round_s * 1e3,
@@ -546,7 +572,7 @@ def run_async(R):
             "dependent-load latency and instruction issue, not bandwidth: a playout is a chain of memory round trips (record -> edge blocks -> memo bucket -> "
             "backup) of a single wavefront; %.0f playouts per launch, mean depth %.1f.  The launch lasts its time budget + the last playouts; see DESIGN 3.0"
             % (per_launch["playouts"], d["descent_levels"] / max(d["playouts"], 1)), len(evs),
-            traffic=(t_adv or {}).get("traffic_bytes_per_launch"), src=("profiles: " + os.path.relpath(t_adv_f, ROOT)) if t_adv else None),
+            traffic=(t_adv or {}).get("traffic_bytes_per_launch"), src=("profiles: " + os.path.relpath(t_adv_f, ROOT)) if t_adv else None, src_file=t_adv_f if t_adv else None),
         "roofline_rules": hbm_line("k_wave_rules on the miss list (Quoridor.actions() of the leaves the memo does not know; legal sets only)", rules_us, miss_per_round * 44,
                                    "%.0f leaves per launch: a launch lasts as long as one board's dependent chain" % miss_per_round, len(evs)),
         "roofline_nn": None if nn_us is None else {
@@ -627,6 +653,7 @@ def run_lockstep(R):
     st1 = eng.stats()
     d = {kk: st1[kk] - st0[kk] for kk in st1}
     exch = R.exchange_summary()
+    ranks = R.per_rank(elapsed, d["plies_played"], d["playouts"])
     elapsed, (games_all, plies_all, playouts_all, term_all) = R.reduce(elapsed, [games, d["plies_played"], d["playouts"], d["leaf_terminal"]])
     if rank != 0:
         return
@@ -654,7 +681,7 @@ def run_lockstep(R):
                        "step": "one ply of every board (n_playout playout steps + finish_move + harvest)"},
                       "lock-step engine: leaf batch=%d, every leaf through the network, finished tuples all-gathered every ply" % args.boards)
     out.update({
-        "leaf_evals_per_s": playouts_all / elapsed, "mean_descent_depth": d["descent_levels"] / max(d["playouts"], 1),
+        "per_rank": ranks, "leaf_evals_per_s": playouts_all / elapsed, "mean_descent_depth": d["descent_levels"] / max(d["playouts"], 1),
         "roofline": dict(hbm_line("the rules op on the leaf batch (Quoridor.actions() + state(): k_wave_rules below 8,192 boards, the pooled two-launch pipeline above; "
                                   "qz_rules_opts.variant %d)" % args.rules_variant, rules_us, gb * bpb, "planes written: %s" % planes_written, n_evs, traffic=traffic),
                          planes_written=planes_written, planes_consumed_by_evaluator=bool(planes_consumed)),
@@ -714,6 +741,7 @@ def main():
     ap.add_argument("--rules-variant", type=int, default=0, help="lockstep A/B: qz_rules_opts.variant of the engines' leaf rules op")
     ap.add_argument("--length-file", default=None, help="game-length sample for games_per_s_steady_state (default: newest profiles/round*/game_length_<n>playouts.json)")
     ap.add_argument("--clock-log", default=None, help="write the clock / power samples of the timed region to this JSON file")
+    ap.add_argument("--dump-roots", default=None, help="async: after the timed region write every board's root position to this .npz (the steady-state sample behind cpu_baseline.by_phase)")
     args = ap.parse_args()
     if args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and "RANK" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))

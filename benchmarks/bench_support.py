@@ -34,6 +34,34 @@ def _load_json(path):
         return None
 
 
+def file_sha256(path):
+    """sha256 of a committed file a bench line rests on (length samples, PMC traffic files): the line names what it read."""
+    import hashlib
+
+    try:
+        with open(path, "rb") as f:
+            return hashlib.sha256(f.read()).hexdigest()
+    except (OSError, TypeError):
+        return None
+
+
+def tree_sha():
+    """the git commit of this tree (None on a box without .git: gpurun snapshots do not carry it) + a hash of the kernel sources,
+    which travels everywhere: a profile file recorded with the same `kernel_sources_sha256` was measured on these kernels."""
+    import hashlib
+
+    try:
+        commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip() or None
+    except (OSError, subprocess.SubprocessError):
+        commit = None
+    h = hashlib.sha256()
+    for p in sorted(glob.glob(os.path.join(ROOT, "alphazero_quoridor_amd", "csrc", "*.h*"))):
+        h.update(os.path.basename(p).encode())
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return {"git_commit": commit, "kernel_sources_sha256": h.hexdigest()}
+
+
 # ------------------------------------------------------------------------------ clocks / power
 class ClockSampler(threading.Thread):
     """Samples shader clock, power and temperature while the timed region runs (sysfs when readable, else `rocm-smi --json`
@@ -147,16 +175,26 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(seconds, n_playout, mean_plies_per_game, length_source):
-    """The oracle port on this host: 1 process, then one process per usable core side by side (python -m oracle.cpu_baseline:
-    one torch thread each).  playouts/s is the measured quantity; games/s divides it by n_playout and by the SAME plies per
-    game the GPU's steady-state estimate uses."""
-    cores = usable_cores()
-    half = max(seconds / 2.0, 2.0)
-    env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1")
-    cmd = [sys.executable, "-m", "oracle.cpu_baseline", "--seconds", "%.1f" % half, "--n-playout", str(n_playout)]
+STEADY_ROOTS = os.path.join(ROOT, "tests", "golden", "steady_state_roots.npz")
 
-    def run_many(k):
+
+def cpu_baseline(seconds, n_playout, mean_plies_per_game, length_source, open_share=None):
+    """The oracle port on this host: 1 process, then one process per usable core side by side (python -m oracle.cpu_baseline:
+    one torch thread each), ON THE WORKLOAD THE GPU NUMBER IS QUOTED ON: the searches of a steady-state population's root
+    positions (tests/golden/steady_state_roots.npz: roots harvested from a sustained run of this engine), split by phase -- roots
+    whose mover still has walls (`open`: 100+ legal moves, a double BFS per candidate wall: the slow class of the reference's
+    actions(), quoridor.py:138-157) and the others (`late`) -- and weighted by the share of its board time the GPU run spent in
+    each phase (`open_share` = the line's open_phase.share_of_board_time).  The first ply from the opening (131 legal moves: the
+    figure of rounds 1-5) stays in by_phase as `opening_ply`.  playouts/s is the measured quantity; games/s divides it by
+    n_playout and by the SAME plies per game the GPU's steady-state estimate uses."""
+    cores = usable_cores()
+    env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    have_roots = os.path.exists(STEADY_ROOTS)
+    phases = ["opening"] + (["open", "late"] if have_roots else [])
+    per = max(seconds / (2.0 * len(phases)), 2.0)
+
+    def run_many(k, phase):
+        cmd = [sys.executable, "-m", "oracle.cpu_baseline", "--seconds", "%.1f" % per, "--n-playout", str(n_playout), "--phase", phase]
         procs = [subprocess.Popen(cmd + ["--seed", str(i)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env, cwd=ROOT) for i in range(k)]
         res = []
         for p in procs:
@@ -165,28 +203,48 @@ def cpu_baseline(seconds, n_playout, mean_plies_per_game, length_source):
                 res.append(json.loads(lines[-1]))
         return res
 
-    one, many = run_many(1), run_many(cores)
-    if not one or not many:
-        return {"value": None, "unit": "games/s", "cores": cores, "kind": "port", "sample": "oracle.cpu_baseline failed to run"}
-    pps1 = one[0]["playouts"] / one[0]["seconds"]
-    ppsN = sum(r["playouts"] / r["seconds"] for r in many)
+    by_phase = {}
+    for ph in phases:
+        one, many = run_many(1, ph), run_many(cores, ph)
+        if not one or not many:
+            return {"value": None, "unit": "games/s", "cores": cores, "kind": "port", "sample": "oracle.cpu_baseline --phase %s failed to run" % ph}
+        by_phase["opening_ply" if ph == "opening" else "steady_" + ph] = {
+            "playouts_per_s_1core": one[0]["playouts"] / one[0]["seconds"], "playouts_per_s_allcores": sum(r["playouts"] / r["seconds"] for r in many),
+            "processes": len(many), "playouts_timed": int(sum(r["playouts"] for r in many)), "positions": many[0].get("positions"),
+            "mean_legal_moves_at_the_roots": many[0].get("mean_root_moves"), "seconds_per_process": per}
+    n_proc = by_phase["opening_ply"]["processes"]
+    if have_roots and open_share is not None:
+        w_open = min(max(float(open_share), 0.0), 1.0)
+        pps1 = w_open * by_phase["steady_open"]["playouts_per_s_1core"] + (1.0 - w_open) * by_phase["steady_late"]["playouts_per_s_1core"]
+        ppsN = w_open * by_phase["steady_open"]["playouts_per_s_allcores"] + (1.0 - w_open) * by_phase["steady_late"]["playouts_per_s_allcores"]
+        basis = ("steady-state roots (tests/golden/steady_state_roots.npz, sha256 %s...): %.3f x the open-phase rate + %.3f x the late-phase rate -- the shares of its "
+                 "board time the GPU run spent in each phase (open_phase.share_of_board_time)" % ((file_sha256(STEADY_ROOTS) or "?")[:12], w_open, 1.0 - w_open))
+    else:
+        pps1, ppsN = by_phase["opening_ply"]["playouts_per_s_1core"], by_phase["opening_ply"]["playouts_per_s_allcores"]
+        basis = "the first ply from the opening only (no steady-state root sample / no phase split in this run)"
     L = mean_plies_per_game
     out = {
-        "value": (ppsN / n_playout / L) if L else None, "unit": "games/s", "cores": len(many), "host_hardware_threads": os.cpu_count(), "kind": "port",
-        "sample": "%d + %d x %d playouts (%.0f s on 1 core, then %.0f s on %d cores as independent processes) of the first ply at n_playout=%d from the "
-                  "opening (131 legal moves): oracle C port + batch-1 fp32 torch-CPU forward per leaf, 1 torch thread per process; games/s = playouts/s / "
-                  "%d / %s plies per game (%s)" % (one[0]["playouts"], len(many), int(np.mean([r["playouts"] for r in many])), half, half, len(many),
-                                                   n_playout, n_playout, "%.0f" % L if L else "?", length_source),
+        "value": (ppsN / n_playout / L) if L else None, "unit": "games/s", "cores": n_proc, "host_hardware_threads": os.cpu_count(), "kind": "port",
+        "sample": "oracle C port + batch-1 fp32 torch-CPU forward per leaf, 1 torch thread per process, %d-playout searches from fresh trees: %.0f s on 1 core, then %.0f s on "
+                  "%d cores as independent processes, per phase (%s); weighted: %s; games/s = playouts/s / %d / %s plies per game (%s)"
+                  % (n_playout, per, per, n_proc, ", ".join(by_phase), basis, n_playout, "%.0f" % L if L else "?", length_source),
         "compare_on": "playouts_per_s (length-independent)", "playouts_per_s_1core": pps1, "playouts_per_s_allcores": ppsN,
-        "games_per_s_1core": (pps1 / n_playout / L) if L else None,
+        "games_per_s_1core": (pps1 / n_playout / L) if L else None, "by_phase": by_phase, "open_share_used": open_share if have_roots else None,
     }
     cal = _load_json(_latest_profile("cpu_calibration.json") or "")
     if cal and cal.get("port_over_reference"):
-        r = float(cal["port_over_reference"])
-        out["reference_estimate"] = {
-            "playouts_per_s_1core": pps1 / r, "playouts_per_s_allcores": ppsN / r, "port_over_reference": r,
-            "calibration": "pure-Python reference vs this C port on the build container's host (%s; %.2f vs %.1f playouts/s): benchmarks/calibrate_cpu_port.py"
-                           % (cal.get("host_cpu", "?"), cal["reference_playouts_per_s"], cal["port_playouts_per_s"])}
+        r_open = float(cal["port_over_reference"])
+        r_late = float(cal.get("port_over_reference_late") or r_open)
+        est = {"port_over_reference_opening": r_open, "port_over_reference_late": r_late,
+               "calibration": "pure-Python reference vs this C port on the build container's host (%s): benchmarks/calibrate_cpu_port.py; the opening ratio is applied to "
+                              "the open phase, the late-game ratio to the late phase" % cal.get("host_cpu", "?")}
+        if have_roots and open_share is not None:
+            w = min(max(float(open_share), 0.0), 1.0)
+            est["playouts_per_s_1core"] = w * by_phase["steady_open"]["playouts_per_s_1core"] / r_open + (1.0 - w) * by_phase["steady_late"]["playouts_per_s_1core"] / r_late
+            est["playouts_per_s_allcores"] = w * by_phase["steady_open"]["playouts_per_s_allcores"] / r_open + (1.0 - w) * by_phase["steady_late"]["playouts_per_s_allcores"] / r_late
+        else:
+            est["playouts_per_s_1core"], est["playouts_per_s_allcores"] = pps1 / r_open, ppsN / r_open
+        out["reference_estimate"] = est
     return out
 
 

@@ -96,11 +96,10 @@ def main():
     ap.add_argument("--only", default="S-open,S-mid,S-dense")
     ap.add_argument("--variant", type=int, default=0, help="qz_rules_opts.variant: 0 by size (default), 2|3|4 wave-per-board, 8..32 pooled tile size")
     ap.add_argument("--enc-split", type=int, default=-1, help="A/B: percent of the encoder tiles launched beside the path search")
-    ap.add_argument("--dependent", action="store_true", help="A/B: the pooled pipeline's two launches one after the other (qz_rules_opts.pool_dependent)")
     ap.add_argument("--detour", type=int, default=-1, help="A/B: pool_k1 detour_mode, pooled + 3 * wave-per-board (0..8)")
     args = ap.parse_args()
     opts = rules.rules_opts(args.variant, None if args.detour < 0 else args.detour % 3, None if args.detour < 0 else args.detour // 3,
-                            None if args.enc_split < 0 else max(args.enc_split, 1), args.dependent)
+                            None if args.enc_split < 0 else max(args.enc_split, 1))
     dev = torch.device("cuda:0")
     n = args.boards
     mask = torch.empty((n, 5), dtype=torch.int32, device=dev)
@@ -121,7 +120,7 @@ def main():
         meta = db.meta
         placed = (20 - ((meta >> 16) & 0xFF) - ((meta >> 24) & 0xFF)).float()
         gbs = n * BYTES / us / 1e3
-        print(json.dumps({"set": name, "variant": args.variant, "pool_dependent": bool(args.dependent), "enc_split": args.enc_split, "boards": n, "launches": args.launches, "avg_launch_us": us,
+        print(json.dumps({"set": name, "variant": args.variant, "enc_split": args.enc_split, "boards": n, "launches": args.launches, "avg_launch_us": us,
                           "algorithmic_GBps": gbs, "frac_of_8TBps": gbs / 8000.0, "boards_per_s": n / us * 1e6,
                           "mean_legal_actions": float(legal.mean()), "mean_walls_placed": float(placed.mean())}))
 

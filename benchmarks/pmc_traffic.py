@@ -8,7 +8,10 @@ section: on gfx950 FETCH_SIZE reports half the bytes of wide streaming reads -- 
 kernels --, WRITE_SIZE is exact; Infinity-Cache hits are counted).  Kernels named in --kernels are summed per launch
 (the pooled pipeline is two launches); only the last `--last` launches of every kernel count (the script's timed loop of
 mask + planes calls; what precedes it is warm-up and mask-only calls)."""
-import argparse, csv, glob, json, os, collections
+import argparse, csv, glob, json, os, collections, sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from bench_support import tree_sha  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--fetch", required=True)
@@ -49,7 +52,7 @@ out = {"boards": a.boards, "planes": bool(a.planes), "kernel": a.label, "fetch_s
        "correction": "FETCH_SIZE x2 (gfx950 reports half the bytes of wide streaming reads; an upper bound here: the reads are small gathers), "
                      "WRITE_SIZE as is; x1024 B (MI355X_MICROARCH.md, HBM section); summed over the launches of one call",
        "traffic_bytes_per_launch": traffic, "algorithmic_bytes_per_launch": alg, "ratio": traffic / alg,
-       "launches_averaged": {"fetch": n_f, "write": n_w},
+       "launches_averaged": {"fetch": n_f, "write": n_w}, **tree_sha(),
        "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), benchmarks/r2_final_job.sh; parsed by benchmarks/pmc_traffic.py"}
 json.dump(out, open(a.out, "w"), indent=1)
 if a.rows_out:

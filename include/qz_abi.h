@@ -81,14 +81,9 @@ int qz_movegen_encode(const qz_boards* boards, int n, uint32_t* mask5 /*[dev]*/,
  *                  many boards per mask workgroup
  *   detour_pooled  group-detour mode of the pooled pipeline: 0 = default (one group), else 1 + mode
  *   detour_wave    ... of k_wave_rules: 0 = default (off), else 1 + mode (mode 0 | 1 | 2)
- *   enc_split_pct  0 = default (50): percent of the encoder groups beside the path groups (first launch of the pooled pipeline)
- *   pool_dependent 0 = default: the pooled pipeline's two launches run SIDE BY SIDE on two streams -- the second launch's encoder
- *                  tiles beside the path groups, its mask groups released by per-path-group ready flags (release / acquire at
- *                  device scope), a third launch for the mask groups that gave up waiting (normally none) -- where the entry point
- *                  has a second stream (qz_movegen* / qz_encode: one per caller stream); 1 = one after the other on the caller's
- *                  stream (the A/B and parity partner) */
+ *   enc_split_pct  0 = default (50): percent of the encoder groups beside the path groups (first launch of the pooled pipeline) */
 typedef struct {
-    int32_t variant, detour_pooled, detour_wave, enc_split_pct, pool_dependent;
+    int32_t variant, detour_pooled, detour_wave, enc_split_pct;
 } qz_rules_opts;
 /* qz_movegen / qz_encode / qz_movegen_encode with explicit options: mask5 or planes may be NULL
  * (not both), opts may be NULL (defaults). */

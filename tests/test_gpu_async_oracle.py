@@ -357,6 +357,57 @@ def test_real_network_search_equals_the_oracle_fed_with_the_miss_list_evaluation
         eng.close()
 
 
+@pytest.mark.parametrize("select_opts", [0, 4, 16])
+def test_reference_search_with_its_own_network_through_the_loop(gpu_device, golden_dir, select_opts):
+    """tests/golden/real_net_search.npz (gen_golden.py:gen_real_net_search): 80 searches of the REFERENCE's MCTS
+    at 400 playouts with the reference's own PolicyValueNet as the policy -- under torch >= 0.4 its leaf value is a 0-dim float32
+    tensor (policy_value_net.py:163), TreeNode._Q turns into one (mcts.py:53) and Q + u is compared in float32, where the build
+    follows the code as written for torch 0.3 (float64).  The loop -- k_advance's two builds, and k_lanes for the 64 boards without
+    walls (select_opts 16) -- is fed, through the miss list, EXACTLY the (p, v) the reference's network returned for each board
+    (a leaf the reference never evaluated would be a search that went another way: KeyError), memo on: root visit counts and
+    root visits must equal the reference's on all 80.  (The oracle passes the same check on the CPU: tests/test_oracle_golden.py.)"""
+    from alphazero_quoridor_amd import _cabi
+    from test_oracle_golden import real_net_tables
+
+    d = np.load(golden_dir + "/real_net_search.npz")
+    tabs = real_net_tables(d)
+    n, NP = len(d["board"]), int(d["n_playout"])
+    table = {}
+    for t in tabs:
+        for k, (p, v, _) in t.items():
+            if k in table:  # the evaluation is a pure function of the board: searches that meet the same board got the same answer
+                assert np.array_equal(table[k][0], p) and table[k][1] == v
+            table[k] = (p, v)
+    eng = make_engine(d["board"], NP, c_puct=float(d["c_puct"]), select_opts=select_opts)
+    L = eng.L
+    try:
+        for _ in range(100000):
+            _cabi.check(L.qz_selfplay_advance(eng.h, 4096, 0, 0, eng._s()))
+            _cabi.check(L.qz_selfplay_leaf_rules(eng.h, eng._s()))
+            packed, mask, _, _ = eng.misses()
+            if len(packed):
+                p = np.stack([table[b.tobytes()][0] for b in packed])
+                v = np.array([table[b.tobytes()][1] for b in packed], dtype=np.float32)
+                eng.set_miss_outputs(torch.from_numpy(p), torch.from_numpy(v))
+            _cabi.check(L.qz_selfplay_round_tail(eng.h, eng._s()))
+            st = eng.stats()
+            if st["waiting_boards"] == 0 and st["playouts"] >= n * NP:
+                break
+        assert st["playouts"] == n * NP and st["node_overflow"] == 0 and st["miss_overflow"] == 0, st
+        visits, q, prior, root_n = (t.cpu().numpy() for t in eng.root_children())
+        for i in range(n):
+            k = int(d["k"][i])
+            acts = d["acts"][i][:k].astype(int)
+            assert [a for a in ORDER if visits[i, a] >= 0] == acts.tolist(), i
+            assert np.array_equal(visits[i, acts], d["visits"][i][:k]), (i, visits[i, acts], d["visits"][i][:k])
+            assert root_n[i] == d["root_visits"][i]
+            assert np.abs(q[i, acts] - d["q32"][i][:k]).max() < 1e-5  # the reference's float32 running means against float64 ones
+        print("80 searches of the reference with its own network through the loop (select_opts %d): root visits identical; %d evaluations, %d memo hits"
+              % (select_opts, st["nn_evals"], st["memo_hits"]))
+    finally:
+        eng.close()
+
+
 def test_a_leftover_of_eager_rounds_does_not_break_a_captured_graph(gpu_device):
     """a HIP graph of rounds bakes in which of the two miss counters its first round uses.  An odd number of
     eager rounds between two replays (a leftover of run_rounds, the n_playout + 1 rounds of run_playouts_memo) must not

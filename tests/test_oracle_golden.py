@@ -323,13 +323,15 @@ def test_roots_without_a_legal_move():
 def real_net_tables(d):
     """real_net_search.npz -> per search {packed board bytes: (dense p[140], v)}: what the REFERENCE's network returned during it"""
     out = []
-    aoff = np.concatenate([[0], np.cumsum(d["t_k"])]).astype(np.int64)
-    for i in range(len(d["board"])):
+    t_k, t_off, t_acts, t_p, t_v, t_board = (d[k] for k in ("t_k", "t_off", "t_acts", "t_p", "t_v", "t_board"))  # (an NpzFile decompresses on every access)
+    aoff = np.concatenate([[0], np.cumsum(t_k)]).astype(np.int64)
+    for i in range(len(t_off) - 1):
         tab = {}
-        for t in range(int(d["t_off"][i]), int(d["t_off"][i + 1])):
+        for t in range(int(t_off[i]), int(t_off[i + 1])):
+            acts = t_acts[aoff[t]:aoff[t + 1]].astype(int)
             p = np.zeros(140, dtype=np.float32)
-            p[d["t_acts"][aoff[t]:aoff[t + 1]].astype(int)] = d["t_p"][aoff[t]:aoff[t + 1]]
-            tab[d["t_board"][t].tobytes()] = (p, np.float32(d["t_v"][t]), d["t_acts"][aoff[t]:aoff[t + 1]].astype(int).tolist())
+            p[acts] = t_p[aoff[t]:aoff[t + 1]]
+            tab[t_board[t].tobytes()] = (p, np.float32(t_v[t]), acts.tolist())
         out.append(tab)
     return out
 
