@@ -124,9 +124,16 @@ struct RulesOpts {
 //                [8..19] p of pawn codes 0..11   [31] of entry 0: the bucket's insert lock
 //   big table:   every other live leaf: buckets of 2 entries x 160 dwords (640 B): [0..5] key  [6] v  [8..12] mask5
 //                [15] of entry 0: lock   [16..155] p[140]
-// Probes (k_advance) and inserts (k_round_tail) never run at the same time (same stream, different launches), so
-// readers need no protocol; concurrent inserters of one bucket exclude each other through the lock word (the loser
-// skips its insert: the memo is a cache).
+// Probes (k_advance / k_lanes) and inserts (k_round_tail) never run at the same time (same stream, different launches), so
+// readers need no protocol.  Inserters: a bucket takes ONE insert per round -- its lock word holds the number of the last
+// round in which a wavefront wrote it (QZ_C_ROUNDS | 2^31: never 0), taken by compare-and-swap from the value the bucket was read
+// with; nobody unlocks (memo_insert).  Consequences, all of them about WHEN a board gets an answer, never about what it
+// computes: (a) two different boards hashing to one bucket in the same round -- the loser is skipped (qz_stats.memo_locked) and
+// evaluated again the next time it is met; WHICH of the two loses is a race, so run-level counters (nn_evals, memo_hits, the
+// round a board gets its answer in) differ between otherwise identical runs -- search results, games and tuples do not
+// (tests/test_gpu_async.py compares tuples, not counters; the one test that compares two engines round for round runs without the
+// memo); (b) round numbers come from k_advance's launches: two tails without an advance between them (the split entry points
+// called out of order) carry the same number, and the second one's inserts into buckets the first wrote are skipped.
 #define QZ_MEMO_S_DW 32
 #define QZ_MEMO_S_WAYS 4
 #define QZ_MEMO_B_DW 160

@@ -1768,7 +1768,7 @@ __device__ __forceinline__ void translate_records(EngineDev& E, int b, int lane,
                 const uint32_t nvalid = bad ? (uint32_t)(__ffsll((unsigned long long)bad) - 1) : 64u;
                 if (in && (uint32_t)lane < nvalid) {
                     re[i - 1u] = fe;
-                    rb[i - 1u] = ((unsigned long long)fb << 8) | (bo & 0xFFull);
+                    rb[i - 1u] = ((unsigned long long)fb << 8) | (bo & 0xFF000000000000FFull);  // (the level's move -- top byte -- stays with its entry: board_from_path)
                 }
                 if (bad) {
                     newlen = c - 1u + nvalid;
@@ -2757,13 +2757,7 @@ __global__ __launch_bounds__(64 * ADV_WPB) __attribute__((amdgpu_waves_per_eu(W,
 // has not finished when `budget` (s_memrealtime ticks since the launch began) is spent saves its position in
 // compact_state[b] and goes on in the next round's launch; the board sits out of k_advance meanwhile (reroot_pend).  Round 3
 // ran the copies in k_advance's prologue: their registers and scratch were k_advance's.  POP-ONLY.
-__global__ __launch_bounds__(TPB) void k_moves(EngineDev E, unsigned int budget) {
-    // (ONE wavefront per workgroup: beside the network's trunk -- qz_selfplay_round -- every SIMD's register file is full, and a
-    // workgroup of four wavefronts needs room on all four SIMDs of a CU at once: it waited for the trunk's grid to run dry and the
-    // round's tail waited 117-133 us for the moves; a one-wavefront workgroup takes the slot of any trunk wavefront that retires)
-    const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
-    const int b = __builtin_amdgcn_readfirstlane((int)blockIdx.x * (int)(blockDim.x >> 6) + wave);
-    if (b >= E.n_boards) return;
+__device__ __forceinline__ void moves_board(EngineDev& E, const int b, const int lane, const unsigned int budget) {
     if (rfl(E.status[b]) != QZ_PLAYING || rfl((uint32_t)E.release[b]) != 0u) return;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     uint32_t rp = rfl(E.reroot_pend[b]);
@@ -2785,7 +2779,15 @@ __global__ __launch_bounds__(TPB) void k_moves(EngineDev E, unsigned int budget)
     }
     if (lane == 0) E.reroot_pend[b] = 0u;
 }
-
+__global__ __launch_bounds__(TPB) void k_moves(EngineDev E, unsigned int budget) {
+    // (ONE wavefront per workgroup: beside the network's trunk -- qz_selfplay_round -- every SIMD's register file is full, and a
+    // workgroup of four wavefronts needs room on all four SIMDs of a CU at once: it waited for the trunk's grid to run dry and the
+    // round's tail waited 117-133 us for the moves; a one-wavefront workgroup takes the slot of any trunk wavefront that retires)
+    const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+    const int b = __builtin_amdgcn_readfirstlane((int)blockIdx.x * (int)(blockDim.x >> 6) + wave);
+    if (b >= E.n_boards) return;
+    moves_board(E, b, lane, budget);
+}
 // After the network: (a) every evaluated leaf goes into the memo, (b) the OTHER miss counter is cleared for the next
 // round, (c) k_release's work: trees replaced by a re-root go back to the pool, dropped games restart.  PUSH-ONLY.
 // Grid (round 5): TAIL_SLOT_WAVES wavefronts stride over the miss list (device-side count), then one LANE per board looks
