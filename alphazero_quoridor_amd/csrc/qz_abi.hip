@@ -411,6 +411,7 @@ int qz_engine_create(const qz_config* cfg, qz_engine** out) {
     ALLOC(bc_evals, B);
     ALLOC(bc_open_rounds, B);
     ALLOC(bc_open_plies, B);
+    ALLOC(rows_list, B + 2);
     ALLOC(memo.epoch, (size_t)1);
     if (!rc) rc = dev_alloc(e, &e->feat, B * 486);
     if (!rc) rc = dev_alloc(e, &e->dev_mem, (size_t)1);
@@ -473,6 +474,7 @@ int qz_engine_create(const qz_config* cfg, qz_engine** out) {
     if (he == hipSuccess) he = hipMemset(d.bc_evals, 0, B * sizeof(uint32_t));
     if (he == hipSuccess) he = hipMemset(d.bc_open_rounds, 0, B * sizeof(uint32_t));
     if (he == hipSuccess) he = hipMemset(d.bc_open_plies, 0, B * sizeof(uint32_t));
+    if (he == hipSuccess) he = hipMemset(d.rows_list, 0, (B + 2) * sizeof(uint32_t));
     if (he == hipSuccess) {
         const uint32_t one = 1u;  // epoch 0 never matches: an all-zero entry is dead
         he = hipMemcpy(d.memo.epoch, &one, sizeof(one), hipMemcpyHostToDevice);
@@ -970,7 +972,7 @@ int qz_nn_evaluate_w(const qz_boards* boards, const uint8_t* terminal, int64_t n
 // the miss list's counter and the page pool are shared through atomics).  Fork / join by events: captures into a HIP graph.
 static int launch_advance(qz_engine* e, int max_playouts, unsigned int ticks, int auto_finish, hipStream_t s) {
     const EngineDev& d = e->dev;
-    if (!(d.select_opts & 16)) {
+    if (!(d.select_opts & 48)) {
         HIP_TRY(qzl::advance(d, max_playouts, ticks, auto_finish, e->par, s));
         return 0;
     }

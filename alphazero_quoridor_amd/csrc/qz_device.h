@@ -207,6 +207,7 @@ struct EngineDev {
     float *miss_p, *miss_v;   // [B][140], [B] the network's output per slot
     uint32_t *bc_memo_hits, *bc_evals;  // [B] leaves answered by the memo / sent to the network
     uint32_t *bc_open_rounds, *bc_open_plies;  // [B] launches / plies with a root whose mover still has walls
+    uint32_t* rows_list;      // [2 + B] k_rows' boards of this round, compacted by k_rows_scout: [0] count, [1] the queue's cursor (both cleared in front of every scout), then the boards
 };
 
 #if defined(__HIPCC__)

@@ -17,6 +17,7 @@
 // Reference semantics: see qz_rules.h (rules) and the per-kernel comments (mcts.py).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "qz_rules.h"
 #include "qz_movegen_pool.h"
@@ -2574,8 +2575,9 @@ __device__ __forceinline__ void advance_board(EngineDev& E, const int max_iters,
             }
         }
     }
-    // select_opts bit 4: the boards on which neither player has a wall left are k_lanes' (qz_lanes.h: one LANE per board, beside this launch)
-    if ((E.select_opts & 16) && ((rfl64(E.root_meta[b]) >> 16) & 0xFFFFull) == 0ull) return;
+    // select_opts bit 4 / 5: the boards on which neither player has a wall left are k_lanes' (qz_lanes.h: one LANE per board) / k_rows'
+    // (qz_rows.h: sixteen lanes per board, four boards per wavefront), beside this launch
+    if ((E.select_opts & 48) && ((rfl64(E.root_meta[b]) >> 16) & 0xFFFFull) == 0ull) return;
 #ifndef QZ_BUDGET_PREDICT
 #define QZ_BUDGET_PREDICT 1  // what a board expects its next playout to last: 0 = nothing, 1 = as long as its last one, 2 = the largest of its recent ones (a maximum that decays by a quarter per playout: measured no different from 1, 289.1 against 290.6 M playouts/s; nor is a margin of a quarter or a half of the last playout on top: 309.5 / 309.8 against 309.0 M, launches as long as before -- the launch's overrun of ~100 us is the extreme of ten thousand boards' playout times, not a misprediction of the typical one)
 #endif
@@ -3051,6 +3053,7 @@ __global__ void k_sqrt_table(double* out, int n) {  // self-test helper: device 
 }
 
 #include "qz_lanes.h"
+#include "qz_rows.h"
 
 }  // namespace
 
@@ -3177,7 +3180,24 @@ hipError_t advance(const EngineDev& E, int max_iters, unsigned int budget_ticks,
 }
 // k_lanes (qz_lanes.h): the boards without walls, 64 per wavefront, beside k_advance's launch for the others (select_opts bit 4)
 hipError_t advance_lanes(const EngineDev& E, int max_iters, unsigned int budget_ticks, int par, hipStream_t s) {
-    hipLaunchKernelGGL(k_lanes, dim3((unsigned)((E.n_boards + 63) / 64)), dim3(64), 0, s, E, max_iters, budget_ticks, par);
+    if (E.select_opts & 32) {
+        // three wavefronts per SIMD (168 registers, no scratch) hold 12 boards per SIMD = 12,288 at a time: the boards without walls of an engine
+        // of up to ~14,000; four (128 registers, 124 bytes of scratch per lane) hold 16,384.  (A/B: QZ_ROWS_WEU)
+        static const int weu = getenv("QZ_ROWS_WEU") ? atoi(getenv("QZ_ROWS_WEU")) : 4;
+        hipError_t me = hipMemsetAsync(E.rows_list, 0, 2 * sizeof(uint32_t), s);  // (the list is rebuilt for every launch: a board must never be listed twice)
+        if (me != hipSuccess) return me;
+        hipLaunchKernelGGL(k_rows_scout, dim3((unsigned)((E.n_boards + 63) / 64)), dim3(64), 0, s, E);
+        // as many wavefronts as the chip holds at once (every wavefront of the grid must start at the launch's beginning: the
+        // deadline counts from a wavefront's own start); the boards beyond 4 x that are taken from the queue by rows whose boards left
+        static const int cap_env = getenv("QZ_ROWS_WAVES") ? atoi(getenv("QZ_ROWS_WAVES")) : 0;
+        const int cap = cap_env > 0 ? cap_env : 1024 * (weu >= 4 ? 4 : 2);
+        const int need = (E.n_boards + rows::NR - 1) / rows::NR;
+        const dim3 g((unsigned)(need < cap ? need : cap));
+        if (weu >= 4) hipLaunchKernelGGL(k_rows<4>, g, dim3(64), 0, s, E, max_iters, budget_ticks, par);
+        else if (weu == 3) hipLaunchKernelGGL(k_rows<3>, g, dim3(64), 0, s, E, max_iters, budget_ticks, par);
+        else hipLaunchKernelGGL(k_rows<2>, g, dim3(64), 0, s, E, max_iters, budget_ticks, par);
+    }
+    else hipLaunchKernelGGL(k_lanes, dim3((unsigned)((E.n_boards + 63) / 64)), dim3(64), 0, s, E, max_iters, budget_ticks, par);
     return hipGetLastError();
 }
 // the moves of the boards that have done their playouts + the subtree copies they leave (and the slices earlier moves left)
@@ -3255,6 +3275,16 @@ extern "C" int qzt_advance_stamps_read(void* host_out, int clear) {  // [4096 bo
     if (e == hipSuccess && clear) {
         static unsigned long long zeros[4096][16];
         e = hipMemcpyToSymbol(HIP_SYMBOL(g_adv_stamps), zeros, sizeof(zeros));
+    }
+    return (int)e;
+}
+#endif
+#ifdef QZ_ROWS_STAMPS
+extern "C" int qzt_rows_stamps_read(void* host_out, int clear) {  // [24] u64: cycles per section of k_rows, summed over wavefronts and launches
+    hipError_t e = hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_rows_stamps), sizeof(g_rows_stamps));
+    if (e == hipSuccess && clear) {
+        static unsigned long long zeros[24];
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_rows_stamps), zeros, sizeof(zeros));
     }
     return (int)e;
 }

@@ -106,7 +106,7 @@ def _games_by_slot(batches):
     return out
 
 
-@pytest.mark.parametrize("compact_edges,budget_us,pool_pages,select_opts", [(0, 0, 0, 0), (-1, 0, 0, 0), (0, 300, 192 * 60, 0), (-1, 1, 0, 0), (-1, 150, 0, 8), (0, 0, 0, 16), (-1, 1, 0, 16)])
+@pytest.mark.parametrize("compact_edges,budget_us,pool_pages,select_opts", [(0, 0, 0, 0), (-1, 0, 0, 0), (0, 300, 192 * 60, 0), (-1, 1, 0, 0), (-1, 150, 0, 8), (0, 0, 0, 16), (-1, 1, 0, 16), (0, 0, 0, 32), (-1, 1, 0, 32)])
 def test_asynchronous_games_equal_lockstep_games(gpu_device, compact_edges, budget_us, pool_pages, select_opts):
     """Complete self-play games (Dirichlet noise, sampled moves, subtree reuse, continuous refill) from the
     asynchronous loop -- boards on their own clocks, several playouts and whole moves per launch, memo on --
@@ -171,7 +171,7 @@ def test_asynchronous_games_equal_lockstep_games(gpu_device, compact_edges, budg
         asyn.close()
 
 
-@pytest.mark.parametrize("select_opts", [0, 8, 24])
+@pytest.mark.parametrize("select_opts", [0, 8, 24, 40])
 def test_more_boards_than_wavefront_slots_play_the_lockstep_games(gpu_device, select_opts):
     """The bench's shape: MORE boards (8,704) than the chip holds wavefronts of k_advance<8> (8,192), one wavefront per workgroup --
     the boards behind the 8,192nd start when a board that needs the network has left -- against the lock-step engine with the

@@ -357,7 +357,7 @@ def test_real_network_search_equals_the_oracle_fed_with_the_miss_list_evaluation
         eng.close()
 
 
-@pytest.mark.parametrize("select_opts", [0, 4, 16])
+@pytest.mark.parametrize("select_opts", [0, 4, 16, 32])
 def test_reference_search_with_its_own_network_through_the_loop(gpu_device, golden_dir, select_opts):
     """tests/golden/real_net_search.npz (gen_golden.py:gen_real_net_search): 80 searches of the REFERENCE's MCTS
     at 400 playouts with the reference's own PolicyValueNet as the policy -- under torch >= 0.4 its leaf value is a 0-dim float32

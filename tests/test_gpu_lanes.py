@@ -1,6 +1,8 @@
-"""GPU parity of k_lanes (csrc/qz_lanes.h, qz_config.select_opts bit 4): the asynchronous loop's kernel with ONE LANE PER
-BOARD, for the boards on which neither player has a wall left -- against oracle.OracleMCTS (the C restatement of mcts.py:12-151)
-and against the wavefront-per-board kernel k_advance, which is pinned on the reference's fixtures by test_gpu_async_oracle.py.
+"""GPU parity of the two other mappings of the asynchronous loop's kernel, for the boards on which neither player has a wall left:
+k_rows (csrc/qz_rows.h, qz_config.select_opts bit 5: SIXTEEN LANES per board, four boards per wavefront -- k_advance's algorithm with
+what was wave-uniform held row-uniform) and k_lanes (csrc/qz_lanes.h, bit 4: ONE LANE per board) -- against oracle.OracleMCTS (the C
+restatement of mcts.py:12-151) and against the wavefront-per-board kernel k_advance, which is pinned on the reference's fixtures by
+test_gpu_async_oracle.py.
 
 What differs from k_advance inside a board's search is only WHEN an edge's (N, Q) reaches memory: k_lanes folds the backup of
 playout i into the descent of playout i + 1 (update_recursive, mcts.py:44-62, applied top-down to the edge of each level just before
@@ -21,7 +23,9 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "gol
 
 from test_gpu_async_oracle import ORDER, make_engine, stub_round  # noqa: E402
 
-LANES = 16  # qz_config.select_opts bit 4
+LANES = 16  # qz_config.select_opts bit 4: k_lanes
+ROWS = 32   # bit 5: k_rows
+MAPPINGS = [ROWS, LANES]
 
 
 def _late_boards(n, seed, near_goal=False):
@@ -91,24 +95,26 @@ def _search_plies(boards, name, n_playout, max_playouts, budget_us, memo, select
 LANE_REGIMES = [(True, 1, 0), (True, 4096, 0), (False, 4096, 0), (True, 4096, 1), (True, 3, 0), (True, 4096, 40)]
 
 
+@pytest.mark.parametrize("mapping", MAPPINGS)
 @pytest.mark.parametrize("memo,max_playouts,budget_us", LANE_REGIMES)
-def test_lane_kernel_search_equals_the_oracle(gpu_device, memo, max_playouts, budget_us):
+def test_lane_kernel_search_equals_the_oracle(gpu_device, memo, max_playouts, budget_us, mapping):
     """200 late-game boards (no walls left: every board is k_lanes'), hash stub policy, 60 playouts per move, four plies with
     the kept subtrees carried over (in-place re-roots): visits, Q, P, root visits bit-equal with oracle.OracleMCTS."""
     boards = _late_boards(200, seed=5)
-    st = _search_plies(boards, "hash", 60, max_playouts, budget_us, memo, LANES, plies=4)
+    st = _search_plies(boards, "hash", 60, max_playouts, budget_us, memo, mapping, plies=4)
     assert (st["memo_hits"] > 0) == memo
-    print("k_lanes, %d boards x 4 plies x 60 playouts (memo %s, %d per launch, %d us): %d evaluations, %d memo hits, deepest %d"
-          % (len(boards), memo, max_playouts, budget_us, st["nn_evals"], st["memo_hits"], st["max_depth"]))
+    print("select_opts %d, %d boards x 4 plies x 60 playouts (memo %s, %d per launch, %d us): %d evaluations, %d memo hits, deepest %d"
+          % (mapping, len(boards), memo, max_playouts, budget_us, st["nn_evals"], st["memo_hits"], st["max_depth"]))
 
 
+@pytest.mark.parametrize("mapping", MAPPINGS)
 @pytest.mark.parametrize("fix_sign", [False, True])
-def test_lane_kernel_terminal_leaves_inside_the_trees(gpu_device, fix_sign):
+def test_lane_kernel_terminal_leaves_inside_the_trees(gpu_device, fix_sign, mapping):
     """pawns close to their goal rows: winning moves are in reach of the search, so terminal leaves are backed up with the
     reference's sign (mcts.py:119-126: +1 for the side that did NOT move) or the fixed one; 150 playouts, three plies, both
     kernels side by side (select_opts 0: k_advance) with identical counters."""
     boards = _late_boards(160, seed=9, near_goal=True)
-    a = _search_plies(boards, "hash", 150, 4096, 0, True, LANES, plies=3, fix_sign=fix_sign)
+    a = _search_plies(boards, "hash", 150, 4096, 0, True, mapping, plies=3, fix_sign=fix_sign)
     b = _search_plies(boards, "hash", 150, 4096, 0, True, 0, plies=3, fix_sign=fix_sign)
     assert a["leaf_terminal"] > 0, a
     for k in ("playouts", "leaf_terminal", "descent_levels", "edges_expanded", "max_depth", "edges_scanned"):
@@ -116,15 +122,17 @@ def test_lane_kernel_terminal_leaves_inside_the_trees(gpu_device, fix_sign):
     print("terminal leaves inside the trees (sign fixed: %s): %d of %d playouts ended on one; counters equal k_advance's" % (fix_sign, a["leaf_terminal"], a["playouts"]))
 
 
-def test_lane_kernel_uniform_policy_and_deep_trees(gpu_device):
+@pytest.mark.parametrize("mapping", MAPPINGS)
+def test_lane_kernel_uniform_policy_and_deep_trees(gpu_device, mapping):
     """the uniform stub (pure_mcts.py:13-16: equal priors, value 0 -- every comparison a tie broken by the first maximum) at 400
     playouts, c_puct 2.5"""
     boards = _late_boards(64, seed=21)
-    st = _search_plies(boards, "uniform", 400, 4096, 0, True, LANES, plies=2, c_puct=2.5)
+    st = _search_plies(boards, "uniform", 400, 4096, 0, True, mapping, plies=2, c_puct=2.5)
     print("uniform stub, 400 playouts: deepest descent %d levels" % st["max_depth"])
 
 
-def test_boards_cross_from_the_wavefront_kernel_to_the_lane_kernel(gpu_device):
+@pytest.mark.parametrize("mapping", MAPPINGS)
+def test_boards_cross_from_the_wavefront_kernel_to_the_lane_kernel(gpu_device, mapping):
     """Games the loop plays ON ITS OWN (moves sampled on the device, subtrees kept in place or compacted) from positions where
     the players hold one or two walls between them: the boards start on k_advance and move to k_lanes with the ply that places the
     last wall, their trees and pending state as they are.  Every harvested game replays in oracle.OracleMCTS ply by ply (pi pins
@@ -140,7 +148,7 @@ def test_boards_cross_from_the_wavefront_kernel_to_the_lane_kernel(gpu_device):
     keep = [r for r in b if not oracle.OracleGame.from_packed(r).has_a_winner()[0] and len(oracle.OracleGame.from_packed(r).actions()) > 0]
     boards = np.array(keep[:96], dtype=b.dtype)
     B = len(boards)
-    eng = make_engine(boards, NP, seed=5, fix_terminal_sign=True, select_opts=LANES, is_selfplay=1)
+    eng = make_engine(boards, NP, seed=5, fix_terminal_sign=True, select_opts=mapping, is_selfplay=1)
     batches = []
     try:
         rounds = 0
@@ -188,9 +196,10 @@ def test_boards_cross_from_the_wavefront_kernel_to_the_lane_kernel(gpu_device):
     print("%d games / %d plies replayed in the oracle, %d plies of them on boards without walls (k_lanes)" % (games, plies, late_plies))
 
 
-def test_lane_kernel_real_network_search_equals_the_oracle(gpu_device):
+@pytest.mark.parametrize("mapping", MAPPINGS)
+def test_lane_kernel_real_network_search_equals_the_oracle(gpu_device, mapping):
     """test_gpu_async_oracle's real-network search (64 late-game boards, 400 playouts, three plies, evaluations collected from the
     miss lists and fed to oracle.OracleMCTS) on k_lanes."""
     import test_gpu_async_oracle as T
 
-    T.test_real_network_search_equals_the_oracle_fed_with_the_miss_list_evaluations(gpu_device, LANES)
+    T.test_real_network_search_equals_the_oracle_fed_with_the_miss_list_evaluations(gpu_device, mapping)
