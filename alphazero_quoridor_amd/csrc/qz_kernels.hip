@@ -3187,10 +3187,12 @@ hipError_t advance_lanes(const EngineDev& E, int max_iters, unsigned int budget_
         hipError_t me = hipMemsetAsync(E.rows_list, 0, 2 * sizeof(uint32_t), s);  // (the list is rebuilt for every launch: a board must never be listed twice)
         if (me != hipSuccess) return me;
         hipLaunchKernelGGL(k_rows_scout, dim3((unsigned)((E.n_boards + 63) / 64)), dim3(64), 0, s, E);
-        // as many wavefronts as the chip holds at once (every wavefront of the grid must start at the launch's beginning: the
-        // deadline counts from a wavefront's own start); the boards beyond 4 x that are taken from the queue by rows whose boards left
+        // As many wavefronts as the chip HOLDS AT ONCE -- every wavefront of the grid must start at the launch's beginning: the deadline
+        // counts from a wavefront's own start --; the boards beyond 4 x that are taken from the queue by rows whose boards left.  Measured
+        // (benchmarks/hip/occupancy_probe.hip, profiles/round6/occupancy_probe_mi355x.txt): an MI355X keeps 3,072 one-wavefront workgroups
+        // of 74..128 registers resident (three per SIMD), not the 4,096 the register file's size suggests.  (A/B: QZ_ROWS_WAVES)
         static const int cap_env = getenv("QZ_ROWS_WAVES") ? atoi(getenv("QZ_ROWS_WAVES")) : 0;
-        const int cap = cap_env > 0 ? cap_env : 1024 * (weu >= 4 ? 4 : 2);
+        const int cap = cap_env > 0 ? cap_env : (weu >= 3 ? 3072 : 2048);
         const int need = (E.n_boards + rows::NR - 1) / rows::NR;
         const dim3 g((unsigned)(need < cap ? need : cap));
         if (weu >= 4) hipLaunchKernelGGL(k_rows<4>, g, dim3(64), 0, s, E, max_iters, budget_ticks, par);

@@ -19,8 +19,12 @@
 //     the updated values; where the new path leaves the old one, the levels of the old path below that point (a different
 //     subtree: nothing the descent will read) are flushed four per trip.  Per board the arithmetic and its order are the
 //     reference's: an edge's (N, Q) is rewritten before anything reads it again, with the same float64 expression.
-// Parity: tests/test_gpu_async_oracle.py and tests/test_gpu_bench_shape.py run their regimes on this kernel as well
-// (select_opts bit 4) -- root visits, float64 Q, float32 P bit-equal with the reference fixtures / oracle.OracleMCTS.
+// Parity: tests/test_gpu_lanes.py and tests/test_gpu_async*.py run their regimes on this kernel as well (select_opts bit 4) -- root
+// visits, float64 Q, float32 P bit-equal with the reference fixtures / oracle.OracleMCTS.
+// MEASURED (profiles/round6/SUMMARY.md 1): 88 M playouts/s against k_advance's 344 M at 13,312 boards.  Every iteration of the
+// wavefront's loop executes the code of EVERY phase some lane is in (~2,000 instructions for one step of each lane), so a lane's
+// playout takes ~112 us against 9 us for a wavefront of k_advance: the prototype of the other mapping VERDICT r5 asked to cost out,
+// kept as the parity partner of k_rows (same boards, a third formulation), off by default.
 #pragma once
 
 constexpr int LN_PT = 32;      // page-table entries per lane held in LDS (trees beyond 65,536 edge records read the table in memory)

@@ -1,24 +1,36 @@
 // qz_rows.h -- k_rows: the asynchronous loop (MCTS._playout, mcts.py:103-127) with SIXTEEN LANES PER BOARD -- four boards per
 // wavefront -- for the boards on which neither player has a wall left (the regime a reference-faithful game spends 99 % of its
-// plies in).  Included by qz_kernels.hip.  qz_config.select_opts bit 5.
+// plies in).  Included by qz_kernels.hip.  qz_config.select_opts bit 5; off by default (measured: below).
 //
-// k_advance gives a board a whole wavefront and keeps everything that is the same for the board's 64 lanes in scalar registers:
-// 64 vector registers per lane = eight wavefronts = EIGHT BOARDS per SIMD, whatever the board count -- and its throughput is
-// (boards resident) / (time of a board's playout chain): 8,192 chains of ~18 us.  A late-game descent is ~15 levels of nodes with
-// two to six children: it uses a quarter of the 64 lanes of a replay round.  Here a board has a ROW of 16 lanes (what the DPP row
-// operations address), a wavefront carries four boards, and what was wave-uniform is row-uniform: a value every lane of the row
-// holds in a vector register.  At 128 registers per lane four wavefronts fit a SIMD: SIXTEEN boards resident per SIMD, every
-// board of a 13,312-board engine at once; and the four rows of a wavefront share every instruction they execute in the same
-// phase -- the loop is written so that they mostly are: all rows start a playout together, replay together (a row whose record
-// confirmed less idles for a round), walk a level together, probe, expand and back up together.
+// k_advance gives a board a whole wavefront and keeps everything that is the same for the board's 64 lanes in scalar registers.
+// Its throughput is (boards resident) / (time of a board's playout chain), and an MI355X keeps ~4,100-4,600 one-wavefront workgroups
+// of 64 registers + 3.9 KB of LDS resident -- not the 8,192 the register file's size suggests (benchmarks/hip/occupancy_probe.hip,
+// profiles/round6/occupancy_probe_mi355x.txt) -- at ~9 us per playout, 93 % of its SIMDs' vector-issue slots taken (SQ counters:
+// 993 vector + 903 scalar instructions per playout).  A late-game descent is ~15 levels of nodes with two to six children: it uses a
+// quarter of the 64 lanes of a replay round.  Here a board has a ROW of 16 lanes (what the DPP row operations address), a wavefront
+// carries four boards, and what was wave-uniform is row-uniform: a value every lane of the row holds in a vector register or -- the
+// launch-level state -- one LDS word per row.  128 registers, no scratch, 3.75 KB of LDS per wavefront: the chip holds 3,072 such
+// wavefronts = 12,288 boards at once, three times k_advance's; and the four rows of a wavefront share every instruction they execute
+// in the same phase -- the loop is written so that they mostly are: all rows start a playout together, replay together (a row whose
+// record confirmed less idles for a round), walk a level together, probe, expand and back up together: 595 vector + 483 scalar
+// instructions per playout.  A row whose board leaves the launch (a leaf for the network, its n_playout playouts done) stores it and
+// takes the next board from the round's queue (k_rows_scout's list + one atomic), like a wavefront slot of k_advance: an engine holds
+// more boards than the chip holds rows.
+//
+// MEASURED (profiles/round6/SUMMARY.md 2): a wavefront's iteration -- four playouts -- takes ~28 us with three wavefronts per SIMD
+// (22 k cycles alone: it is bound by instruction issue as well, at half k_advance's utilisation: three wavefronts hide less latency
+// than k_advance's four and a half), so 12,288 busy rows make 444 M playouts/s inside the launch -- k_advance's 448 M, at 20,480
+// boards instead of 13,312 -- and 322 M per second of a whole round (k_advance: 343 M at 13,312 boards).  Parity with the default at
+// 1.5 x the boards is not a reason to switch: the default stays k_advance.
 //
 // The algorithm is k_advance's, piece for piece (select_core / expand_node / backup_leaf / the memo, qz_kernels.hip): sixteen descent
 // records per board (lane r of the row holds record r's length), replay rounds of 16 levels (lane = level) instead of 64, the
 // first level that does not come out as recorded selected by its own lane, the hint per edge (Edge::rid) that names the record
-// to go on in, the descent's first 128 levels mirrored in LDS, the leaf's board from the path's moves in one row reduction, the
+// to go on in, the descent's first 40 levels mirrored in LDS, the leaf's board from the path's moves in one row reduction, the
 // memo's small table, the miss list.  Records, trees and pending evaluations are k_advance's own formats: a board moves from
 // k_advance to k_rows with the ply that places the last wall, as it is.  Per board the operations and their float64 / float32
-// arithmetic are the lock-step engine's: tests/test_gpu_lanes.py runs every regime on this kernel against oracle.OracleMCTS.
+// arithmetic are the lock-step engine's: tests/test_gpu_lanes.py runs every regime on this kernel against oracle.OracleMCTS, and
+// tests/test_gpu_async*.py their games and the reference's fixtures.
 #pragma once
 
 #ifdef QZ_ROWS_STAMPS  // diagnostic build only (benchmarks/rows_stamps.py): where a wavefront's time goes, by code section
@@ -34,7 +46,7 @@ __device__ unsigned long long g_rows_stamps[24];
 namespace rows {
 constexpr int W = 16;             // lanes per board
 constexpr int NR = 64 / W;        // boards per wavefront
-constexpr uint32_t LCAP = 48;     // levels of a descent mirrored in LDS per board (576 B; deeper levels live in the descent buffer in memory): a row's LDS is 1 KB, a wavefront's 4 KB -- sixteen wavefronts fit the 64 KB a CU gives a kernel here
+constexpr uint32_t LCAP = 40;     // levels of a descent mirrored in LDS per board (576 B; deeper levels live in the descent buffer in memory): a row's LDS is 1 KB, a wavefront's 4 KB -- sixteen wavefronts fit the 64 KB a CU gives a kernel here
 constexpr uint32_t RMASK = (1u << W) - 1u;
 
 __device__ __forceinline__ int rbase(const int lane) { return lane & (64 - W); }
@@ -106,7 +118,7 @@ __device__ __forceinline__ void rows_boards(EngineDev& E, const int max_iters, c
         uint32_t we[LCAP];            // ... and the chosen edge
         uint32_t pt[64];              // the board's page table (entries 0..63; beyond: the table in memory)
         uint32_t lc[RC_WORDS];        // counter deltas of the launch + the records' last-use stamps
-        uint32_t st[16];              // the board's launch state (row-uniform words every lane of the row reads / writes alike): as loop-carried registers they spilled
+        uint32_t st[24];              // the board's launch state (row-uniform words every lane of the row reads / writes alike): as loop-carried registers they spilled
     };
     __shared__ RowShared s_row[NR];   // (one structure per board: one base address per lane, the fields at constant offsets)
     const int lane = lane_id();
@@ -115,10 +127,10 @@ __device__ __forceinline__ void rows_boards(EngineDev& E, const int max_iters, c
     // with list entry (wavefront, row); when its board leaves the launch -- a leaf for the network, its n_playout playouts done -- it
     // stores the board and takes the next entry nobody has taken (one atomic), like a wavefront slot of k_advance: an engine holds
     // more boards than the chip holds rows, and no row idles while a board waits.
-    const uint32_t n_list = min(E.rows_list[0], (uint32_t)E.n_boards);
-    const uint32_t first_free = gridDim.x * (uint32_t)NR;
-    uint32_t li = blockIdx.x * (uint32_t)NR + (uint32_t)row;
-    if (__ballot(li < n_list) == 0ull) return;
+    {
+        const uint32_t n_list0 = min(E.rows_list[0], (uint32_t)E.n_boards);
+        if (__ballot(blockIdx.x * (uint32_t)NR + (uint32_t)row < n_list0) == 0ull) return;
+    }
     typedef __attribute__((address_space(3))) RowShared lds_row;
     lds_row* const sh = (lds_row*)&s_row[row];
 #define pt (sh->pt)
@@ -139,6 +151,13 @@ __device__ __forceinline__ void rows_boards(EngineDev& E, const int max_iters, c
 #define st_t_it (sh->st[11])
 #define st_mvalid (sh->st[12])
 #define st_slot0 (sh->st[13])
+#define st_epoch (sh->st[14])
+#define st_pool_edges (sh->st[15])
+#define st_n_list (sh->st[16])
+#define st_first_free (sh->st[17])
+#define st_t0 (sh->st[18])
+#define st_rpos (sh->st[19])
+#define st_li (sh->st[20])
     Edge* const pool = E.edge_pool;
     // (the board's arrays in memory: addresses computed where they are used from `bb`, a copy of the board index the optimiser cannot
     // see through -- held as pointers they were ten registers of a kernel that has 128)
@@ -148,10 +167,13 @@ __device__ __forceinline__ void rows_boards(EngineDev& E, const int max_iters, c
 #define pb0 (E.path_blocks + (size_t)bb * (R + 1u) * CAP)
 #define gwe (pe0 + (size_t)R * CAP)   /* this descent beyond the mirror / for the backup of a later launch */
 #define gwb (pb0 + (size_t)R * CAP)
-    const uint32_t pool_edges = (uint32_t)E.tree_pool_pages * QZ_PAGE_EDGES;
-    const uint32_t epoch = *E.memo.epoch;
+    // (launch constants every row uses now and then: in LDS, not in registers -- the four-wavefront build has 128 and needs them all)
+    st_pool_edges = (uint32_t)E.tree_pool_pages * QZ_PAGE_EDGES;
+    st_epoch = *E.memo.epoch;
+    st_n_list = min(E.rows_list[0], (uint32_t)E.n_boards);
+    st_first_free = gridDim.x * (uint32_t)NR;
+    st_li = blockIdx.x * (uint32_t)NR + (uint32_t)row;   // the list entry the row takes next
     uint32_t rlen = 0u;            // lane r: record r's length
-    uint32_t rpos = 0u;            // the root's pawns and side to move: p1 | p2 << 8 | cur << 16
 
     auto phys = [&](const uint32_t e) -> uint32_t {  // physical index of logical edge e (per lane)
         const uint32_t pg = e >> QZ_PAGE_SHIFT;
@@ -264,7 +286,7 @@ __device__ __forceinline__ void rows_boards(EngineDev& E, const int max_iters, c
     auto load_board = [&]() {
         asm volatile("" : "+v"(bb));
         const uint64_t rmeta = E.root_meta[bb];
-        rpos = (uint32_t)(rmeta & 0xFFFFull) | ((uint32_t)((rmeta >> 32) & 0xFFull) << 16);
+        st_rpos = (uint32_t)(rmeta & 0xFFFFull) | ((uint32_t)((rmeta >> 32) & 0xFFull) << 16);
         const uint32_t half = E.tree_half[bb];
         st_half = half;
         st_rootN = E.root_N[bb];
@@ -317,9 +339,8 @@ __device__ __forceinline__ void rows_boards(EngineDev& E, const int max_iters, c
         wave_sync();
     };
 
-    const unsigned int t0 = (unsigned int)__builtin_amdgcn_s_memrealtime();  // (100 MHz: 32 bits wrap after 43 s; the launch's deadline counts from here)
+    st_t0 = (unsigned int)__builtin_amdgcn_s_memrealtime();  // (100 MHz: 32 bits wrap after 43 s; the launch's deadline counts from here)
     bool have = false, first_board = true;
-    uint32_t pedge = QZ_NONE, plen = 0u;
     QZ_RS_DECL
     for (;;) {
         QZ_RS(0)  // 0: leaf handling of the iteration before
@@ -328,12 +349,12 @@ __device__ __forceinline__ void rows_boards(EngineDev& E, const int max_iters, c
             if (!first_board) {
                 uint32_t t = 0u;
                 if (rl == 0) t = atomicAdd(E.rows_list + 1, 1u);
-                li = first_free + rread(t, 0, lane);
-                if ((unsigned int)__builtin_amdgcn_s_memrealtime() - t0 > budget) break;  // (a row's FIRST board always gets a playout: the 1-us regimes)
+                st_li = st_first_free + rread(t, 0, lane);
+                if ((unsigned int)__builtin_amdgcn_s_memrealtime() - st_t0 > budget) break;  // (a row's FIRST board always gets a playout: the 1-us regimes)
             }
             first_board = false;
-            if (li >= n_list) break;
-            bb = (int)E.rows_list[2u + li];
+            if (st_li >= st_n_list) break;
+            bb = (int)E.rows_list[2u + st_li];
             load_board();
             // the evaluation this board was waiting for: TreeNode.expand + update_recursive with the network's answer (path from memory)
             const uint32_t slot0 = st_slot0;
@@ -341,11 +362,10 @@ __device__ __forceinline__ void rows_boards(EngineDev& E, const int max_iters, c
                 const uint32_t m0 = E.miss_mask[(size_t)slot0 * 5];
                 const float pr = E.miss_p[(size_t)slot0 * QZ_N_ACT + (rl < 12 ? rl : 0)];
                 const double value = (double)E.miss_v[slot0];
-                pedge = E.leaf_pedge[bb];
-                plen = E.path_len[bb];
-                const unsigned long long blk = expand(pedge, m0 & 0xFFFu, pr);
-                note(plen, blk, false);
-                backup(value, pedge, plen, 0u, false);
+                const uint32_t pedge0 = E.leaf_pedge[bb], plen0 = E.path_len[bb];
+                const unsigned long long blk = expand(pedge0, m0 & 0xFFFu, pr);
+                note(plen0, blk, false);
+                backup(value, pedge0, plen0, 0u, false);
                 st_done++;
                 wave_sync();
             }
@@ -361,7 +381,7 @@ __device__ __forceinline__ void rows_boards(EngineDev& E, const int max_iters, c
                 const unsigned int now = (unsigned int)__builtin_amdgcn_s_memrealtime();
                 const unsigned int last = now - st_t_it;
                 st_t_it = now;
-                if (st_iters > 0u && (now - t0) + last > budget) stop = true;
+                if (st_iters > 0u && (now - st_t0) + last > budget) stop = true;
             }
             if (stop) {
                 store_board(false);
@@ -371,9 +391,8 @@ __device__ __forceinline__ void rows_boards(EngineDev& E, const int max_iters, c
         }
         st_iters++;
         // ================================================================ the descent (select_core)
-        int p1 = (int)(int8_t)(rpos & 0xFFu), p2 = (int)(int8_t)((rpos >> 8) & 0xFFu), cur_pl = (int)((rpos >> 16) & 0xFFu);
-        pedge = QZ_NONE;
-        plen = 0u;
+        int p1 = (int)(int8_t)(st_rpos & 0xFFu), p2 = (int)(int8_t)((st_rpos >> 8) & 0xFFu), cur_pl = (int)((st_rpos >> 16) & 0xFFu);
+        uint32_t pedge = QZ_NONE, plen = 0u;
         int ne = (int)st_root_ne;
         bool gdone = false, nonfinite = false;
         uint32_t scanned = 0u;
@@ -417,13 +436,13 @@ __device__ __forceinline__ void rows_boards(EngineDev& E, const int max_iters, c
                         lne = (int)(w & 0xFFull);
                     }
                     // nothing in a record is believed before the link test below; an entry that cannot be a block of this pool is not even loaded from
-                    ok = ok && lne >= 1 && lne <= 8 && lbase <= pool_edges - 8u;
+                    ok = ok && lne >= 1 && lne <= 8 && lbase <= st_pool_edges - 8u;
                     if (!ok) {
                         lbase = 0u;
                         lne = 1;
                     }
-                    const uint32_t* const pp = reinterpret_cast<const uint32_t*>(&pool[(rl > 0 && prev < pool_edges) ? prev : 0u]);
-                    const uint32_t* const cq = reinterpret_cast<const uint32_t*>(&pool[(ok && rec && chosen < pool_edges) ? chosen : 0u]);
+                    const uint32_t* const pp = reinterpret_cast<const uint32_t*>(&pool[(rl > 0 && prev < st_pool_edges) ? prev : 0u]);
+                    const uint32_t* const cq = reinterpret_cast<const uint32_t*>(&pool[(ok && rec && chosen < st_pool_edges) ? chosen : 0u]);
                     const uint32_t last_child = (uint32_t)lne - 1u;
                     const bool any5 = __ballot(lne >= 5) != 0ull;
                     const uint32_t pN = pp[2], pcoff = pp[4], pmisc = pp[5];
@@ -765,7 +784,7 @@ __device__ __forceinline__ void rows_boards(EngineDev& E, const int max_iters, c
         }
         QZ_RS(6)  // 6: counters, the terminal leaves' backups
         // the memo: entry e of the bucket lives in dwords 32 e .. 32 e + 31 = registers 2 e, 2 e + 1; its key in lanes 0..5 of register 2 e
-        const uint32_t mlo = ((uint32_t)p1 & 0xFFu) | (((uint32_t)p2 & 0xFFu) << 8), mhi = (uint32_t)cur_pl | (epoch << 16);
+        const uint32_t mlo = ((uint32_t)p1 & 0xFFu) | (((uint32_t)p2 & 0xFFu) << 8), mhi = (uint32_t)cur_pl | (st_epoch << 16);
         int way = -1;
         if (E.memo.small) {
             const uint64_t rhb = E.root_hb[bb], rvb = E.root_vb[bb];
@@ -841,6 +860,13 @@ __device__ __forceinline__ void rows_boards(EngineDev& E, const int max_iters, c
 #undef st_t_it
 #undef st_mvalid
 #undef st_slot0
+#undef st_epoch
+#undef st_pool_edges
+#undef st_n_list
+#undef st_first_free
+#undef st_t0
+#undef st_rpos
+#undef st_li
 #undef pt
 #undef we
 #undef wb
