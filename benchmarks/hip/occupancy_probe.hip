@@ -61,5 +61,11 @@ int main() {
     probe<100, 4096, 128>("~128 VGPR, 4 KB LDS per workgroup", out);
     probe<100, 4096, 256>("~128 VGPR, 4 KB LDS per workgroup", out);
     probe<20, 0, 64>("~32 VGPR, no LDS", out);
+    probe<46, 4096>("~48 VGPR, 4 KB LDS", out);
+    probe<52, 4096>("~56 VGPR, 4 KB LDS", out);
+    probe<58, 4096>("~60 VGPR, 4 KB LDS", out);
+    probe<62, 4096>("~64 VGPR, 4 KB LDS", out);
+    probe<66, 4096>("~68 VGPR, 4 KB LDS", out);
+    probe<70, 4096>("~72 VGPR, 4 KB LDS", out);
     return 0;
 }
