@@ -32,6 +32,13 @@ def test_bench_multi_rank_path_on_one_gpu(gpu_device):
     assert d["roofline"]["launches_timed"] == 2  # --rounds-per-step 48 below the default --event-every 64: one timed round per step (round 4: none, and no line)
     ag = d["allgather_ms"]  # the exchange is timed
     assert ag["calls"] >= 2 and 0 < ag["mean"] <= ag["max"] and ag["unit"] == "ms"
+    # the line shows what EACH rank did -- rank, device, PCI bus id, plies, playouts, ms per step -- and the
+    # ranks' shares add up to the aggregate (on RCCL the bus ids must differ: bench.py asserts it; here two gloo ranks share the GPU)
+    pr = d["per_rank"]
+    assert len(pr) == 2 and sorted(r["rank"] for r in pr) == [0, 1] and all(r["plies"] > 0 and r["playouts"] > 0 and r["ms_per_step"] > 0 for r in pr)
+    assert sum(r["plies"] for r in pr) == pytest.approx(d["plies_per_s"] * d["ms_per_step"] * 2 / 1e3, rel=1e-6)
+    assert sum(r["playouts"] for r in pr) == pytest.approx(d["playouts_per_s"] * d["ms_per_step"] * 2 / 1e3, rel=1e-6)
+    assert all(":" in r["pci_bus_id"] for r in pr) and d["provenance"]["kernel_sources_sha256"]
     # both ranks' work is in the aggregate: every round advances every board of both ranks, a move needs 16 playouts
     plies = d["plies_per_s"] * d["ms_per_step"] * 2 / 1e3
     assert 2 * 256 * 2 <= plies and d["playouts_per_s"] / d["plies_per_s"] == pytest.approx(16, rel=0.2)
@@ -93,7 +100,15 @@ def test_bench_single_gpu_line_carries_the_contract(gpu_device):
     assert a["roofline_nn"]["bound"] == "mfma" and a["roofline_nn"]["avg_launch_us"] > 0 and "k_advance" in a["roofline"]["kernel"]
     assert 0 <= a["memo_hit_rate"] <= 1 and a["nn_evaluations_per_s"] > 0 and a["playouts_per_s"] > a["nn_evaluations_per_s"]
     assert a["engine_stats"]["node_overflow"] == 0 and a["engine_stats"]["runaway_descents"] == 0
-    assert a["cpu_baseline"]["kind"] == "port" and a["cpu_baseline"]["value"] > 0
+    cb = a["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0
+    # the CPU leg runs the workload the GPU number is quoted on -- steady-state roots by phase, weighted by the
+    # line's own open-phase share of board time -- next to the opening ply of rounds 1-5
+    assert set(cb["by_phase"]) == {"opening_ply", "steady_open", "steady_late"} and all(v["playouts_per_s_allcores"] > 0 for v in cb["by_phase"].values())
+    assert cb["open_share_used"] == pytest.approx(a["open_phase"]["share_of_board_time"]) and cb["by_phase"]["steady_open"]["mean_legal_moves_at_the_roots"] > 20 > cb["by_phase"]["steady_late"]["mean_legal_moves_at_the_roots"]
+    w = cb["open_share_used"]
+    assert cb["playouts_per_s_allcores"] == pytest.approx(w * cb["by_phase"]["steady_open"]["playouts_per_s_allcores"] + (1 - w) * cb["by_phase"]["steady_late"]["playouts_per_s_allcores"])
+    assert len(a["per_rank"]) == 1 and a["per_rank"][0]["rank"] == 0 and a["provenance"]["kernel_sources_sha256"]
     assert "games_per_s_steady_state" in a and "games_in_timed_region" in a and len(a["ms_per_step_series"]) == 2
     # the headline names its tracked scalar; the second line's `value` is the stationary estimate from the
     # committed sign-fixed length sample with the raw count beside it; the throughput-precision network has a labelled line of its own
