@@ -1035,13 +1035,12 @@ int qz_selfplay_round(qz_engine* e, const qz_nn_weights* w, int max_playouts, in
         return fail(QZ_E_INVALID, "engine is in asynchronous self-play: keep auto_finish set, or reset the engine first");
     if ((r = nn_weights_check(w))) return r;
     hipStream_t s = (hipStream_t)stream;
-    if (!e->side) {
-        HIP_TRY(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
-        HIP_TRY(hipStreamCreateWithFlags(&e->side2, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&e->ev_join2, hipEventDisableTiming));
-    }
+    // (every handle on its own: after a partial failure the next call creates what is missing instead of using a null stream -- ADVICE r5)
+    if (!e->side) HIP_TRY(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+    if (!e->side2) HIP_TRY(hipStreamCreateWithFlags(&e->side2, hipStreamNonBlocking));
+    if (!e->ev_fork) HIP_TRY(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+    if (!e->ev_join) HIP_TRY(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+    if (!e->ev_join2) HIP_TRY(hipEventCreateWithFlags(&e->ev_join2, hipEventDisableTiming));
     const EngineDev& d = e->dev;
     const unsigned int ticks = budget_us > 0 ? (unsigned int)budget_us * 100u : 0xFFFFFFFFu;  // s_memrealtime: 100 MHz
     if ((r = launch_advance(e, max_playouts, ticks, 0, s))) return r;
