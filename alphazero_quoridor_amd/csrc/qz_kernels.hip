@@ -2513,6 +2513,12 @@ constexpr int ADV_WPB = QZ_ADV_WPB;
 #ifndef QZ_ADV_WAVES_SMALL
 #define QZ_ADV_WAVES_SMALL 4  // wavefronts per SIMD the build of k_advance for engines of <= 4,096 boards aims at (A/B: 8 = one build for all sizes)
 #endif
+// A field of the engine descriptor FETCHED by a scalar load of its own from the kernel-argument segment (`kp_`; EngineDev is the
+// first argument of k_advance / k_rows: offset 0) into the kernel's copy `E`.  A field read from the by-value argument is a
+// sub-register of an 8- or 16-dword piece, which the register allocator keeps, spills and reloads WHOLE (eight or sixteen
+// v_readlane for one pointer); an empty asm on a copy does not help, the coalescer joins the copy back into the piece.
+#define QZ_KARG_P(T, f) { unsigned long long a_; asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a_) : "s"(kp_), "n"(offsetof(EngineDev, f))); E.f = (T*)(__attribute__((address_space(1))) T*)a_; }
+#define QZ_KARG_S(f) { uint32_t a_; asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a_) : "s"(kp_), "n"(offsetof(EngineDev, f))); static_assert(sizeof(E.f) == 4, "32-bit field"); __builtin_memcpy(&E.f, &a_, 4); }
 __device__ __forceinline__ void advance_board(EngineDev& E, const int max_iters, const unsigned int budget, const int par) {
     __shared__ uint32_t s_we[ADV_WPB][ADV_LCAP];
     __shared__ unsigned long long s_wb[ADV_WPB][ADV_LCAP];
@@ -2539,14 +2545,18 @@ __device__ __forceinline__ void advance_board(EngineDev& E, const int max_iters,
     // it is used.  The fields the loop uses are made values of their own here.
     // (A pointer goes through the asm as an integer and comes back as a pointer to GLOBAL memory -- address space 1 --
     // explicitly: left generic, every access through it becomes a FLAT instruction, whose wait is vmcnt(0) lgkmcnt(0).)
-#define QZ_OWN_S(x) asm volatile("" : "+s"(x))
-#define QZ_OWN_P(T, x) { unsigned long long a_ = (unsigned long long)(x); QZ_OWN_S(a_); (x) = (T*)(__attribute__((address_space(1))) T*)a_; }
-    QZ_OWN_P(Edge, E.edge_pool); QZ_OWN_P(uint32_t, E.path_edges); QZ_OWN_P(unsigned long long, E.path_blocks); QZ_OWN_P(uint32_t, E.memo.small);
-    QZ_OWN_P(uint32_t, E.memo.big); QZ_OWN_P(uint32_t, E.free_tree); QZ_OWN_P(int, E.pool_words); QZ_OWN_P(unsigned long long, E.counters);
-    QZ_OWN_S(E.memo.small_mask); QZ_OWN_S(E.memo.big_mask); QZ_OWN_S(E.c_puct); QZ_OWN_S(E.n_playout); QZ_OWN_S(E.max_depth);
-    QZ_OWN_S(E.select_opts); QZ_OWN_S(E.node_cap); QZ_OWN_S(E.edge_cap); QZ_OWN_S(E.fix_terminal_sign); QZ_OWN_S(E.tree_pool_pages);
-#undef QZ_OWN_P
-#undef QZ_OWN_S
+    // Round 6: "made values of their own" through an empty asm was not enough -- the register coalescer joins such a copy back into
+    // the piece it was copied from, and the piece (E.edge_pool's: eight dwords) was still spilled and reloaded WHOLE, eight
+    // v_readlane for one pointer, at six places of the descent (38 such places in the loop, 8 or 16 lanes each).  So every field the
+    // loop uses is FETCHED by a scalar load of its own from the kernel-argument segment (EngineDev is the kernel's first argument:
+    // offset 0), which no piece is ever part of; the fields only the prologue and the epilogue use are fetched again behind the loop
+    // (QZ_KARG_COLD) so that nothing of the descriptor lives across it.
+    const unsigned long long kp_ = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    QZ_KARG_P(Edge, edge_pool); QZ_KARG_P(uint32_t, path_edges); QZ_KARG_P(unsigned long long, path_blocks); QZ_KARG_P(uint32_t, memo.small);
+    QZ_KARG_P(uint32_t, memo.big); QZ_KARG_P(uint32_t, free_tree); QZ_KARG_P(int, pool_words); QZ_KARG_P(unsigned long long, counters);
+    QZ_KARG_P(uint64_t, root_hb); QZ_KARG_P(uint64_t, root_vb); QZ_KARG_P(uint64_t, root_meta);
+    QZ_KARG_S(memo.small_mask); QZ_KARG_S(memo.big_mask); QZ_KARG_S(c_puct); QZ_KARG_S(n_playout); QZ_KARG_S(max_depth);
+    QZ_KARG_S(select_opts); QZ_KARG_S(node_cap); QZ_KARG_S(edge_cap); QZ_KARG_S(fix_terminal_sign); QZ_KARG_S(tree_pool_pages);
     if (b == 0 && lane == 0) atomicAdd(&E.counters[QZ_C_ROUNDS], 1ull);
     // (the first launch: a board that is not playing leaves before the stamp -- if it is the first wavefront's, about one launch in
     // 250, that launch's wavefronts count the budget from their own starts.  Moving the test behind the stamp, as the second launch
@@ -2650,7 +2660,10 @@ __device__ __forceinline__ void advance_board(EngineDev& E, const int max_iters,
         uint32_t term;
         MemoProbe MP;  // the memo bucket of the leaf, requested the moment the leaf is known: in flight under the record commit
         select_core(E, S, bb, ln, PM, leaf, pedge, plen, term, [&](const Board& lf, bool) { MP = memo_probe_issue(E, lf, ln); });
-        if (drop_if_too_deep(E, bb, ln, plen)) break;
+        if (E.max_depth > 0 && plen > (uint32_t)E.max_depth) {  // (rare: its fields are fetched here)
+            QZ_KARG_P(uint8_t, status); QZ_KARG_P(unsigned long long, drop_log); QZ_KARG_P(uint32_t, ply);
+            if (drop_if_too_deep(E, bb, ln, plen)) break;
+        }
         PM.valid = plen < ADV_LCAP ? plen : ADV_LCAP;
         wave_sync();  // the descent buffer (lane 0 / other lanes) before the backup reads it
         QZ_AS_MARK(4)  // 4: descent
@@ -2685,6 +2698,15 @@ __device__ __forceinline__ void advance_board(EngineDev& E, const int max_iters,
         waiting = true;
         break;
     }
+    // what the epilogue writes to: fetched here, not carried through the loop
+    QZ_KARG_S(n_boards);
+    QZ_KARG_P(int, miss_count); QZ_KARG_P(uint64_t, miss_hb); QZ_KARG_P(uint64_t, miss_vb); QZ_KARG_P(uint64_t, miss_meta); QZ_KARG_P(uint32_t, pend_slot);
+    QZ_KARG_P(uint32_t, leaf_pedge); QZ_KARG_P(uint32_t, path_len); QZ_KARG_P(uint32_t, rec_len); QZ_KARG_P(uint32_t, rec_stamp); QZ_KARG_P(uint32_t, rec_last);
+    QZ_KARG_P(uint32_t, rec_clock); QZ_KARG_P(uint32_t, bc_playouts); QZ_KARG_P(uint32_t, bc_terminal); QZ_KARG_P(uint32_t, bc_overflow);
+    QZ_KARG_P(uint32_t, bc_nonfinite); QZ_KARG_P(uint32_t, bc_maxdepth); QZ_KARG_P(uint32_t, bc_memo_hits); QZ_KARG_P(uint32_t, bc_evals);
+    QZ_KARG_P(unsigned long long, bc_levels); QZ_KARG_P(unsigned long long, bc_scanned); QZ_KARG_P(unsigned long long, bc_expanded);
+    QZ_KARG_P(uint32_t, root_N); QZ_KARG_P(uint32_t, root_ne); QZ_KARG_P(uint32_t, root_eoff); QZ_KARG_P(uint32_t, n_nodes); QZ_KARG_P(uint32_t, n_edges);
+    QZ_KARG_P(uint32_t, tree_npages); QZ_KARG_P(uint32_t, pl_done); QZ_KARG_P(uint32_t, bc_open_rounds);
     if (waiting) {
         uint32_t s = 0u;
         if (lane == 0) s = (uint32_t)atomicAdd(E.miss_count + par, 1);
@@ -3171,8 +3193,18 @@ hipError_t finish_move(const EngineDev& E, const uint8_t* forced, float* pi_out,
 static unsigned int compact_budget(unsigned int budget_ticks) {
     return budget_ticks == 0xFFFFFFFFu ? budget_ticks : (budget_ticks / 32u > 0u ? budget_ticks / 32u : 1u);
 }
+// one wavefront that sleeps: holds a stream back for `ticks` of s_memrealtime (100 MHz) without taking anything from the chip
+__global__ __launch_bounds__(64) void k_hold(unsigned int ticks) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
 hipError_t advance(const EngineDev& E, int max_iters, unsigned int budget_ticks, int auto_finish, int par, hipStream_t s) {
     if (auto_finish) hipLaunchKernelGGL(k_moves, wave_grid(E.n_boards), dim3(TPB), 0, s, E, compact_budget(budget_ticks));
+    if (E.select_opts & 32) {
+        // A/B (advance_lanes): k_rows' wavefronts placed BEFORE this launch's, so that they find contiguous registers
+        static const int hold_us = getenv("QZ_ADV_HOLD_US") ? atoi(getenv("QZ_ADV_HOLD_US")) : 0;
+        if (hold_us > 0) hipLaunchKernelGGL(k_hold, dim3(1), dim3(64), 0, s, (unsigned int)hold_us * 100u);
+    }
     const dim3 adv_grid((unsigned)((E.n_boards + ADV_WPB - 1) / ADV_WPB)), adv_block(64 * ADV_WPB);
     if (E.n_boards > 4096 * QZ_ADV_WAVES_SMALL / 4 || (E.select_opts & 4)) hipLaunchKernelGGL(k_advance<8>, adv_grid, adv_block, 0, s, E, max_iters, budget_ticks, par);
     else hipLaunchKernelGGL(k_advance<QZ_ADV_WAVES_SMALL>, adv_grid, adv_block, 0, s, E, max_iters, budget_ticks, par);
@@ -3181,16 +3213,19 @@ hipError_t advance(const EngineDev& E, int max_iters, unsigned int budget_ticks,
 // k_lanes (qz_lanes.h): the boards without walls, 64 per wavefront, beside k_advance's launch for the others (select_opts bit 4)
 hipError_t advance_lanes(const EngineDev& E, int max_iters, unsigned int budget_ticks, int par, hipStream_t s) {
     if (E.select_opts & 32) {
-        // three wavefronts per SIMD (168 registers, no scratch) hold 12 boards per SIMD = 12,288 at a time: the boards without walls of an engine
-        // of up to ~14,000; four (128 registers, 124 bytes of scratch per lane) hold 16,384.  (A/B: QZ_ROWS_WEU)
+        // four wavefronts per SIMD (k_rows<4>: 117 registers, no scratch) = 16 boards per SIMD.  (A/B: QZ_ROWS_WEU 3 / 2)
         static const int weu = getenv("QZ_ROWS_WEU") ? atoi(getenv("QZ_ROWS_WEU")) : 4;
         hipError_t me = hipMemsetAsync(E.rows_list, 0, 2 * sizeof(uint32_t), s);  // (the list is rebuilt for every launch: a board must never be listed twice)
         if (me != hipSuccess) return me;
         hipLaunchKernelGGL(k_rows_scout, dim3((unsigned)((E.n_boards + 63) / 64)), dim3(64), 0, s, E);
-        // As many wavefronts as the chip HOLDS AT ONCE -- every wavefront of the grid must start at the launch's beginning: the deadline
-        // counts from a wavefront's own start --; the boards beyond 4 x that are taken from the queue by rows whose boards left.  Measured
-        // (benchmarks/hip/occupancy_probe.hip, profiles/round6/occupancy_probe_mi355x.txt): an MI355X keeps 3,072 one-wavefront workgroups
-        // of 74..128 registers resident (three per SIMD), not the 4,096 the register file's size suggests.  (A/B: QZ_ROWS_WAVES)
+        // As many wavefronts as find room AT ONCE -- every wavefront of the grid must start at the launch's beginning: the deadline
+        // counts from a wavefront's own start --; the boards beyond 4 x that are taken from the queue by rows whose boards left.
+        // The chip holds 4,096 wavefronts of 128 registers (benchmarks/hip/residency_census.hip), but this launch starts beside
+        // k_advance's for the boards that still have walls: ten thousand 64-register wavefronts come and go in its first tens of
+        // microseconds, a register allocation is contiguous, and two 64-register holes left by two of them are not room for a k_rows
+        // wavefront -- a grid of 3,584 or 4,096 leaves some hundred wavefronts waiting until the first ones END (launches of 5.9-6.2 ms
+        // instead of 3.3).  3,072 (three per SIMD) always find room.  With k_advance's stream held back 40 us (QZ_ADV_HOLD_US, below)
+        // 3,840 fit, for +1.5 % (profiles/round6/rows_hold/).  (A/B: QZ_ROWS_WAVES)
         static const int cap_env = getenv("QZ_ROWS_WAVES") ? atoi(getenv("QZ_ROWS_WAVES")) : 0;
         const int cap = cap_env > 0 ? cap_env : (weu >= 3 ? 3072 : 2048);
         const int need = (E.n_boards + rows::NR - 1) / rows::NR;

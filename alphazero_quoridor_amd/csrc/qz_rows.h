@@ -3,14 +3,14 @@
 // plies in).  Included by qz_kernels.hip.  qz_config.select_opts bit 5; off by default (measured: below).
 //
 // k_advance gives a board a whole wavefront and keeps everything that is the same for the board's 64 lanes in scalar registers.
-// Its throughput is (boards resident) / (time of a board's playout chain), and an MI355X keeps ~4,100-4,600 one-wavefront workgroups
-// of 64 registers + 3.9 KB of LDS resident -- not the 8,192 the register file's size suggests (benchmarks/hip/occupancy_probe.hip,
-// profiles/round6/occupancy_probe_mi355x.txt) -- at ~9 us per playout, 93 % of its SIMDs' vector-issue slots taken (SQ counters:
-// 993 vector + 903 scalar instructions per playout).  A late-game descent is ~15 levels of nodes with two to six children: it uses a
+// Its throughput is (boards resident) / (time of a board's playout chain): 8,192 boards (eight 64-register wavefronts per SIMD) at
+// ~18 us per playout, with the SIMDs' vector pipes 76-81 % and their scalar units ~70 % busy (SQ counters: 911-992 vector + ~900 scalar
+// instructions per playout).  A late-game descent is ~15 levels of nodes with two to six children: it uses a
 // quarter of the 64 lanes of a replay round.  Here a board has a ROW of 16 lanes (what the DPP row operations address), a wavefront
 // carries four boards, and what was wave-uniform is row-uniform: a value every lane of the row holds in a vector register or -- the
-// launch-level state -- one LDS word per row.  128 registers, no scratch, 3.75 KB of LDS per wavefront: the chip holds 3,072 such
-// wavefronts = 12,288 boards at once, three times k_advance's; and the four rows of a wavefront share every instruction they execute
+// launch-level state -- one LDS word per row.  117 registers, no scratch, 3.75 KB of LDS per wavefront: four wavefronts per SIMD by
+// the registers = 16,384 boards; beside k_advance's launch for the boards with walls three per SIMD find room (12,288 boards, see
+// advance_lanes: register fragmentation); and the four rows of a wavefront share every instruction they execute
 // in the same phase -- the loop is written so that they mostly are: all rows start a playout together, replay together (a row whose
 // record confirmed less idles for a round), walk a level together, probe, expand and back up together: 595 vector + 483 scalar
 // instructions per playout.  A row whose board leaves the launch (a leaf for the network, its n_playout playouts done) stores it and
@@ -18,10 +18,13 @@
 // more boards than the chip holds rows.
 //
 // MEASURED (profiles/round6/SUMMARY.md 2): a wavefront's iteration -- four playouts -- takes ~28 us with three wavefronts per SIMD
-// (22 k cycles alone: it is bound by instruction issue as well, at half k_advance's utilisation: three wavefronts hide less latency
-// than k_advance's four and a half), so 12,288 busy rows make 444 M playouts/s inside the launch -- k_advance's 448 M, at 20,480
-// boards instead of 13,312 -- and 322 M per second of a whole round (k_advance: 343 M at 13,312 boards).  Parity with the default at
-// 1.5 x the boards is not a reason to switch: the default stays k_advance.
+// and 22 k cycles alone, ~19 k of them the wavefront's own 4,300 instructions issued one after the other: a wavefront issues at most
+// one instruction per turn of its SIMD, so with three wavefronts the SIMD issues 0.94 instructions per turn where k_advance's eight
+// offer enough of a mix for 1.44 (vector pipe 40 %, scalar unit 32 % busy).  12,288 busy rows make 444 M playouts/s inside the launch
+// -- k_advance's 448 M, at 20,480 boards instead of 13,312 -- and 322 M per second of a whole round (k_advance: 343-347 M at 13,312
+// boards).  Taking 17 % of its vector instructions out (the descriptor's fields by scalar loads of their own) moved it 0.6 %; a grid of
+// 3,840 wavefronts (k_advance's stream held back so that they find room) 1.5 %.  Parity with the default at 1.5 x the boards is not a
+// reason to switch: the default stays k_advance.
 //
 // The algorithm is k_advance's, piece for piece (select_core / expand_node / backup_leaf / the memo, qz_kernels.hip): sixteen descent
 // records per board (lane r of the row holds record r's length), replay rounds of 16 levels (lane = level) instead of 64, the
@@ -131,6 +134,14 @@ __device__ __forceinline__ void rows_boards(EngineDev& E, const int max_iters, c
         const uint32_t n_list0 = min(E.rows_list[0], (uint32_t)E.n_boards);
         if (__ballot(blockIdx.x * (uint32_t)NR + (uint32_t)row < n_list0) == 0ull) return;
     }
+    // the descriptor's fields by scalar loads of their own (QZ_KARG_*, qz_kernels.hip): the hot ones here, the others where a board is
+    // loaded / stored / handed to the miss list, so that no 16-dword piece of the argument segment lives (spilled) across the loop
+    const unsigned long long kp_ = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    QZ_KARG_P(Edge, edge_pool); QZ_KARG_P(uint32_t, path_edges); QZ_KARG_P(unsigned long long, path_blocks); QZ_KARG_P(uint32_t, memo.small);
+    QZ_KARG_P(uint32_t, free_tree); QZ_KARG_P(int, pool_words); QZ_KARG_P(unsigned long long, counters); QZ_KARG_P(uint32_t, rows_list);
+    QZ_KARG_P(uint64_t, root_hb); QZ_KARG_P(uint64_t, root_vb); QZ_KARG_P(uint32_t, tree_ptab);
+    QZ_KARG_S(memo.small_mask); QZ_KARG_S(c_puct); QZ_KARG_S(n_playout); QZ_KARG_S(max_depth); QZ_KARG_S(node_cap); QZ_KARG_S(edge_cap);
+    QZ_KARG_S(tree_pool_pages); QZ_KARG_S(n_boards);
     typedef __attribute__((address_space(3))) RowShared lds_row;
     lds_row* const sh = (lds_row*)&s_row[row];
 #define pt (sh->pt)
@@ -285,6 +296,9 @@ __device__ __forceinline__ void rows_boards(EngineDev& E, const int max_iters, c
     // ---- a board's state into the row (regs_load) + the evaluation it was waiting for; and back to memory (regs_store)
     auto load_board = [&]() {
         asm volatile("" : "+v"(bb));
+        QZ_KARG_P(uint64_t, root_meta); QZ_KARG_P(uint8_t, tree_half); QZ_KARG_P(uint32_t, root_N); QZ_KARG_P(uint32_t, root_ne); QZ_KARG_P(uint32_t, root_eoff);
+        QZ_KARG_P(uint32_t, n_nodes); QZ_KARG_P(uint32_t, n_edges); QZ_KARG_P(uint32_t, tree_npages); QZ_KARG_P(uint32_t, rec_last); QZ_KARG_P(uint32_t, rec_clock);
+        QZ_KARG_P(uint32_t, pl_done); QZ_KARG_P(uint32_t, pend_slot); QZ_KARG_P(uint32_t, rec_len); QZ_KARG_P(uint32_t, rec_stamp);
         const uint64_t rmeta = E.root_meta[bb];
         st_rpos = (uint32_t)(rmeta & 0xFFFFull) | ((uint32_t)((rmeta >> 32) & 0xFFull) << 16);
         const uint32_t half = E.tree_half[bb];
@@ -312,6 +326,11 @@ __device__ __forceinline__ void rows_boards(EngineDev& E, const int max_iters, c
     };
     auto store_board = [&](const bool waiting) {
         wave_sync();
+        QZ_KARG_P(uint32_t, root_N); QZ_KARG_P(uint32_t, root_ne); QZ_KARG_P(uint32_t, root_eoff); QZ_KARG_P(uint32_t, n_nodes); QZ_KARG_P(uint32_t, n_edges);
+        QZ_KARG_P(uint32_t, tree_npages); QZ_KARG_P(uint32_t, rec_last); QZ_KARG_P(uint32_t, rec_clock); QZ_KARG_P(uint32_t, pl_done); QZ_KARG_P(uint32_t, pend_slot);
+        QZ_KARG_P(uint32_t, rec_len); QZ_KARG_P(uint32_t, rec_stamp); QZ_KARG_P(uint32_t, bc_playouts); QZ_KARG_P(uint32_t, bc_terminal); QZ_KARG_P(uint32_t, bc_overflow);
+        QZ_KARG_P(uint32_t, bc_nonfinite); QZ_KARG_P(uint32_t, bc_maxdepth); QZ_KARG_P(uint32_t, bc_memo_hits); QZ_KARG_P(uint32_t, bc_evals);
+        QZ_KARG_P(unsigned long long, bc_levels); QZ_KARG_P(unsigned long long, bc_scanned); QZ_KARG_P(unsigned long long, bc_expanded);
         E.rec_len[(size_t)bb * R + rl] = rlen;
         E.rec_stamp[(size_t)bb * R + rl] = lc[RC_STAMP0 + rl];
         if (rl == 0) {
@@ -359,6 +378,7 @@ __device__ __forceinline__ void rows_boards(EngineDev& E, const int max_iters, c
             // the evaluation this board was waiting for: TreeNode.expand + update_recursive with the network's answer (path from memory)
             const uint32_t slot0 = st_slot0;
             if (slot0 != QZ_NONE) {
+                QZ_KARG_P(uint32_t, miss_mask); QZ_KARG_P(float, miss_p); QZ_KARG_P(float, miss_v); QZ_KARG_P(uint32_t, leaf_pedge); QZ_KARG_P(uint32_t, path_len);
                 const uint32_t m0 = E.miss_mask[(size_t)slot0 * 5];
                 const float pr = E.miss_p[(size_t)slot0 * QZ_N_ACT + (rl < 12 ? rl : 0)];
                 const double value = (double)E.miss_v[slot0];
@@ -762,6 +782,7 @@ __device__ __forceinline__ void rows_boards(EngineDev& E, const int max_iters, c
         }
         // ---- drop_if_too_deep: the reference's RecursionError
         if (E.max_depth > 0 && plen > (uint32_t)E.max_depth) {
+            QZ_KARG_P(uint8_t, status); QZ_KARG_P(unsigned long long, drop_log); QZ_KARG_P(uint32_t, ply); QZ_KARG_P(uint64_t, root_meta);
             if (rl == 0) {
                 E.status[bb] = QZ_ABORTED;
                 atomicAdd(&E.counters[QZ_C_ABORT_DEPTH], 1ull);
@@ -818,6 +839,8 @@ __device__ __forceinline__ void rows_boards(EngineDev& E, const int max_iters, c
         {
             bool waiting = true;
             uint32_t sl = 0u;
+            QZ_KARG_P(int, miss_count); QZ_KARG_P(uint64_t, miss_hb); QZ_KARG_P(uint64_t, miss_vb); QZ_KARG_P(uint64_t, miss_meta); QZ_KARG_P(uint32_t, pend_slot);
+            QZ_KARG_P(uint32_t, leaf_pedge); QZ_KARG_P(uint32_t, path_len);
             if (rl == 0) sl = (uint32_t)atomicAdd(E.miss_count + par, 1);
             sl = rread(sl, 0, lane);
             if (sl >= (uint32_t)E.n_boards) {  // a stale counter (must not happen): the board forgets this descent and repeats it in its next launch

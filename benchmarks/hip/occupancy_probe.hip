@@ -1,5 +1,10 @@
-// How many one-wavefront workgroups of a given register / LDS footprint does an MI355X hold at once?  Every workgroup spins for
-// 1 ms (s_memrealtime); a launch of N workgroups that lasts ~1 ms was resident as a whole, ~2 ms means it was not.
+// NOT a residency probe (it was written as one, and round 6's first reading of it was wrong -- see residency_census.hip, which counts).
+// Every workgroup spins for 1 ms on independent packed FMAs and reads its start time AFTER ~60 vector instructions of set-up; a launch
+// of N wavefronts that lasts ~2 ms was read as "N do not fit".  What it measures instead: the SIMD's arbiter issues the OLDEST ready
+// wavefront first, so once four to five wavefronts of back-to-back FMAs saturate a SIMD's vector pipe, a younger RESIDENT wavefront
+// does not get through its set-up -- does not even read its start time -- until the older ones have left.  The census (start time
+// read by the wavefront's first instruction, a live counter, HW_ID) shows all 8,192 wavefronts of <= 64 registers resident within 3 us
+// of each other, in the same loop.  Kept for that lesson: a wavefront that is resident is not a wavefront that runs.
 //   hipcc --offload-arch=gfx950 -O2 -o occupancy_probe occupancy_probe.hip && ./occupancy_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
