@@ -1,10 +1,10 @@
 #!/bin/bash
 # Round-6 evidence for profiles/round6/: GPU test tier + smoke, the bench line (the driver's command), A/B lines, rocprofv3 kernel stats
 # of the same command, PMC traffic of k_advance<8> (separate FETCH_SIZE / WRITE_SIZE passes, program directly after `--`), a rocprofv3
-# stats file of the rules op at 32,768 boards (C3), the 2-rank line.  PARTS="tests bench ab prof pmc c3 ranks" selects.
+# stats file of the rules op at 32,768 boards (C3), the 2-rank line.  PARTS="tests pmc bench ab prof c3 ranks" selects (the PMC passes run BEFORE the bench line, which cites their file).
 O=gpurun_out/${OUT:-r6final}; mkdir -p $O
 R=$GRAFT_REPO_ROOT
-PARTS=${PARTS:-"tests bench ab prof pmc c3 ranks"}
+PARTS=${PARTS:-"tests pmc bench ab prof c3 ranks"}
 has() { [[ " $PARTS " == *" $1 "* ]]; }
 ulimit -c 0
 if has tests; then
@@ -12,6 +12,20 @@ if has tests; then
   timeout 2400 python -m pytest tests -m gpu -x -q --timeout=900 2>&1 | tail -15 >> $O/pytest_gpu.log; tail -3 $O/pytest_gpu.log
   python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 >> $O/pytest_gpu.log; tail -1 $O/pytest_gpu.log
 fi
+( cd /tmp && export TMPDIR=/tmp
+if has pmc; then
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/$O/pmc_$c -- /usr/bin/python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-c3 --second-line-seconds 0 > $R/$O/pmc_$c.json 2> $R/$O/pmc_$c.err
+  done
+  bpb=$(python3 -c "import json; d=json.load(open('$R/$O/pmc_FETCH_SIZE.json')); print(d['roofline']['algorithmic_bytes_per_launch'] / d['config']['boards_per_gpu'])")
+  cd $R && python3 $R/benchmarks/pmc_traffic.py --fetch $R/$O/pmc_FETCH_SIZE --write $R/$O/pmc_WRITE_SIZE --kernels k_advance --boards 13312 --bytes-per-board $bpb --last 200 \
+     --label "k_advance<8> (13,312 boards, one 3,000-us deadline per launch, n_playout=400, last 200 launches of a bench run)" --out $R/$O/pmc_traffic_advance.json > /dev/null && cat $R/$O/pmc_traffic_advance.json | head -14
+  # (the bench line below cites this file -- and says whether it was measured on the kernels it runs: it must be in place first)
+  mkdir -p $R/profiles/round6 && cp $R/$O/pmc_traffic_advance.json $R/profiles/round6/pmc_traffic_advance.json
+  rm -rf $R/$O/pmc_FETCH_SIZE $R/$O/pmc_WRITE_SIZE
+fi
+)
+cd $R
 if has bench; then
   t0=$(date +%s)
   timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --clock-log $O/clock_log_bench_default.json > $O/bench_default.json 2> $O/bench_default.err; tail -2 $O/bench_default.err | cut -c1-300
@@ -47,13 +61,4 @@ if has c3; then
   s=$(find $R/$O/prof_c3 -name "*kernel_stats.csv" | head -1); cp "$s" $R/$O/c3_kernel_stats_rocprofv3.csv; head -5 $R/$O/c3_kernel_stats_rocprofv3.csv | cut -c1-160
   rm -rf $R/$O/prof_c3
   grep '^{' $R/$O/c3_three_sets.jsonl | cut -c1-160
-fi
-if has pmc; then
-  for c in FETCH_SIZE WRITE_SIZE; do
-    timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/$O/pmc_$c -- /usr/bin/python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-c3 --second-line-seconds 0 > $R/$O/pmc_$c.json 2> $R/$O/pmc_$c.err
-  done
-  bpb=$(python3 -c "import json; d=json.load(open('$R/$O/pmc_FETCH_SIZE.json')); print(d['roofline']['algorithmic_bytes_per_launch'] / d['config']['boards_per_gpu'])")
-  cd $R && python3 $R/benchmarks/pmc_traffic.py --fetch $R/$O/pmc_FETCH_SIZE --write $R/$O/pmc_WRITE_SIZE --kernels k_advance --boards 13312 --bytes-per-board $bpb --last 200 \
-     --label "k_advance<8> (13,312 boards, one 3,000-us deadline per launch, n_playout=400, last 200 launches of a bench run)" --out $R/$O/pmc_traffic_advance.json > /dev/null && cat $R/$O/pmc_traffic_advance.json | head -14
-  rm -rf $R/$O/pmc_FETCH_SIZE $R/$O/pmc_WRITE_SIZE
 fi

@@ -141,7 +141,11 @@ typedef struct {
                                   bit 4 = the boards on which NEITHER player has a wall left are played by k_lanes (csrc/qz_lanes.h: one
                                   LANE per board, the backup folded into the next descent) beside k_advance's launch for the others --
                                   same search results bit for bit (tests/test_gpu_lanes.py); measured 4x slower than k_advance at
-                                  13,312 boards (profiles/round6/SUMMARY.md): the prototype of the other mapping, off by default */
+                                  13,312 boards (profiles/round6/SUMMARY.md): the prototype of the other mapping, off by default,
+                                  bit 5 = those boards are played by k_rows instead (csrc/qz_rows.h: SIXTEEN LANES per board, four boards
+                                  per wavefront, boards from a queue; wins over bit 4) -- same search results bit for bit
+                                  (tests/test_gpu_lanes.py); measured on a par with k_advance inside the launch at 1.5 x the boards and
+                                  6 % behind per round (profiles/round6/SUMMARY.md): off by default */
     /* Leaf-evaluation memo (qz_selfplay_*): log2 of the number of buckets of its two tables; 0 = auto (16,384 small entries
      * -- at most 8 GB -- and 512 big entries per board, rounded up to a power of two), < 0 = no memo (every leaf goes to the network).
      * small: leaves whose mover has no wall left, 4 entries of 128 B per bucket; big: all others, 2 x 640 B. */
