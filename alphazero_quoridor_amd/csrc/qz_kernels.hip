@@ -881,6 +881,12 @@ __device__ __forceinline__ void select_core(EngineDev& E, BoardRegs& S, const in
         // (apply_actions_wave, lane = level) -- round 4 ran that reduction after every replay round and a scalar apply_action per
         // walked level, and kept the board's nine scalars alive across the whole descent of a kernel that has 78 of them.
         // Levels from QZ_PATH_CAP on have no entry: the board is brought up to date there and stepped level by level from then on.
+        // INVARIANT the lazy board rests on: every entry [0, upto) it reads was WRITTEN BY THIS DESCENT (a replayed level is copied
+        // from its record together with its move byte, a walked level is written with the move it chose) -- PM.valid is 0 at a
+        // launch's start, so nothing of an earlier launch's buffer is ever trusted; translate_records keeps the move byte of the
+        // entries it shifts, note_expansion's entry one past a record's end carries none and is never read as a level of the path.
+        // Whoever lets a descent keep entries it did not write (a mirror carried across launches, say) must carry the move bytes too:
+        // a stale byte gives a wrong leaf board, hence a wrong memo key, silently.  (QZ_APPLY_AT_LEAF=0 is the stepped A/B build.)
         bool lazy = QZ_APPLY_AT_LEAF && PM.cap > 0u;
         auto board_from_path = [&](const uint32_t upto) -> uint32_t {  // bd = the root's board + the moves of levels [0, upto); returns the levels' child counts summed
             wave_sync();

@@ -566,9 +566,9 @@ def run_async(R):
         "open_phase": {"plies": open_plies_all, "share_of_board_time": open_rounds_all / max(B * world * rounds, 1), "note": "root's mover still has walls"},
         "mean_descent_depth": d["descent_levels"] / max(d["playouts"], 1), "rounds": rounds, "ms_per_round": round_s * 1e3,
         "roofline": hbm_line(
-            "k_moves + k_advance (one wavefront per board, %d per SIMD: moves of the boards that finished their playouts, then descents -- recorded descents "
-            "replayed 64 levels per round trip, the first unrecorded level selected by the same round --, memo probes, expansions and backups until the board "
-            "needs the network or the budget is used)" % waves, adv_us, adv_bytes,
+            "k_moves + k_advance (one wavefront per board: %d boards per SIMD for at most eight wavefronts resident per SIMD; moves of the boards that finished "
+            "their playouts, then descents -- recorded descents replayed 64 levels per round trip, the first unrecorded level selected by the same round --, "
+            "memo probes, expansions and backups until the board needs the network or the budget is used)" % waves, adv_us, adv_bytes,
             "dependent-load latency and instruction issue, not bandwidth: a playout is a chain of memory round trips (record -> edge blocks -> memo bucket -> "
             "backup) of a single wavefront; %.0f playouts per launch, mean depth %.1f.  The launch lasts its time budget + the last playouts; see DESIGN 3.0"
             % (per_launch["playouts"], d["descent_levels"] / max(d["playouts"], 1)), len(evs),
