@@ -53,7 +53,7 @@ out = {"boards": a.boards, "planes": bool(a.planes), "kernel": a.label, "fetch_s
                      "WRITE_SIZE as is; x1024 B (MI355X_MICROARCH.md, HBM section); summed over the launches of one call",
        "traffic_bytes_per_launch": traffic, "algorithmic_bytes_per_launch": alg, "ratio": traffic / alg,
        "launches_averaged": {"fetch": n_f, "write": n_w}, **tree_sha(),
-       "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), benchmarks/r2_final_job.sh; parsed by benchmarks/pmc_traffic.py"}
+       "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), benchmarks/r6_final_job.sh; parsed by benchmarks/pmc_traffic.py"}
 json.dump(out, open(a.out, "w"), indent=1)
 if a.rows_out:
     with open(a.rows_out, "w") as g:
