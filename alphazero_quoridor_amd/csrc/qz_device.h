@@ -214,7 +214,7 @@ struct EngineDev {
 // A tree's page table, held by the wave: lane l keeps entry l in a register (pt0); entries 64..127 -- a tree of more than
 // 131,072 edge records, which a search of a few hundred playouts per move reaches only past its compaction threshold --
 // are read from the table in memory where they are needed (round 3 kept them in a second register per lane: one of the
-// registers k_advance does not have at eight wavefronts per SIMD).
+// registers k_advance does not have at seven or eight wavefronts per SIMD).
 struct TreeView {
     Edge* pool;
     uint32_t* ptab;   // this tree's table in HBM (QZ_TREE_PT entries)

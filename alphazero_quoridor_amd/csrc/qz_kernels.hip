@@ -2516,6 +2516,9 @@ constexpr uint32_t ADV_LCAP = 320;  // levels of a descent mirrored in LDS (3.75
 // board leaves the launch the moment it meets a leaf for the network -- a board whose mover still has walls after one playout.
 // With four boards per workgroup such a slot stayed empty until its three neighbours were done too.
 constexpr int ADV_WPB = QZ_ADV_WPB;
+#ifndef QZ_ADV_WAVES_BIG
+#define QZ_ADV_WAVES_BIG 7  // wavefronts per SIMD the build of k_advance for engines of more than 4,096 boards aims at (A/B: 8, 6)
+#endif
 #ifndef QZ_ADV_WAVES_SMALL
 #define QZ_ADV_WAVES_SMALL 4  // wavefronts per SIMD the build of k_advance for engines of <= 4,096 boards aims at (A/B: 8 = one build for all sizes)
 #endif
@@ -2770,11 +2773,12 @@ __device__ __forceinline__ void advance_board(EngineDev& E, const int max_iters,
     }
 }
 
-// Two builds of the loop.  k_advance<8>: at most 64 vector registers, EIGHT wavefronts per SIMD -- 8,192 boards at a time on the
-// 1,024 SIMDs: the throughput of the loop is the number of dependent chains the chip holds times the speed of one chain, and a
-// chain is bound by its own latencies (round 3: one / two / four wavefronts per SIMD ran 78.8 / 74.0 / 66.6 playouts per board and
-// round).  k_advance<4>: 73 registers, no spill at all, for engines of up to 4,096 boards, where the extra residency buys nothing
-// and the eight-wave build's few spills cost 9 %.
+// Two builds of the loop.  k_advance<QZ_ADV_WAVES_BIG> for engines of more than 4,096 boards: the loop is bound by its instruction
+// streams (vector pipes and scalar units ~75 % busy, a wavefront waiting for its turn to issue a third of its cycles), so registers
+// that save instructions are worth more than the last wavefront slot: SEVEN wavefronts per SIMD (72 vector / 96 scalar registers
+// allowed, 66 / 94 used, no scratch, 287 spill reloads in the loop) -- 7,168 boards at a time -- run 1.9 % more playouts per second
+// than eight (64 / 80 registers, 12 bytes of scratch, 342 reloads; rounds 4-5's build), six 0.7 % fewer (profiles/round6/SUMMARY.md 7).
+// k_advance<4>: 97 registers, for engines of up to 4,096 boards, where residency beyond four buys nothing.
 template <int W>
 __global__ __launch_bounds__(64 * ADV_WPB) __attribute__((amdgpu_waves_per_eu(W, W))) void k_advance(EngineDev E, int max_iters, unsigned int budget, int par) {
     advance_board(E, max_iters, budget, par);
@@ -3212,7 +3216,7 @@ hipError_t advance(const EngineDev& E, int max_iters, unsigned int budget_ticks,
         if (hold_us > 0) hipLaunchKernelGGL(k_hold, dim3(1), dim3(64), 0, s, (unsigned int)hold_us * 100u);
     }
     const dim3 adv_grid((unsigned)((E.n_boards + ADV_WPB - 1) / ADV_WPB)), adv_block(64 * ADV_WPB);
-    if (E.n_boards > 4096 * QZ_ADV_WAVES_SMALL / 4 || (E.select_opts & 4)) hipLaunchKernelGGL(k_advance<8>, adv_grid, adv_block, 0, s, E, max_iters, budget_ticks, par);
+    if (E.n_boards > 4096 * QZ_ADV_WAVES_SMALL / 4 || (E.select_opts & 4)) hipLaunchKernelGGL(k_advance<QZ_ADV_WAVES_BIG>, adv_grid, adv_block, 0, s, E, max_iters, budget_ticks, par);
     else hipLaunchKernelGGL(k_advance<QZ_ADV_WAVES_SMALL>, adv_grid, adv_block, 0, s, E, max_iters, budget_ticks, par);
     return hipGetLastError();
 }

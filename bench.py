@@ -7,10 +7,10 @@
 
 Workload (config.workload): BASELINE.json configs[3] per GPU -- n_playout=400, 9x9, reference defaults (10 walls, c_puct=5,
 temp=1, Dirichlet 0.3/0.25), random-init policy_value_net in fp32 with the reference's per-leaf BatchNorm statistics; weak
-scaling, finished tuples all-gathered every step.  --boards concurrent boards per GPU (default 13,312: the chip holds 8,192
-wavefronts of k_advance, eight per SIMD; a board leaves its launch when it meets a leaf for the network -- a seventh of them, those
+scaling, finished tuples all-gathered every step.  --boards concurrent boards per GPU (default 13,312: the chip holds 7,168
+wavefronts of k_advance, seven per SIMD; a board leaves its launch when it meets a leaf for the network -- a seventh of them, those
 whose mover still has walls, after one playout -- and its slot goes to the next board: with ONE deadline per launch (--select-opts 8)
-the boards beyond the 8,192nd take the slots in turn; configs[3] names 4,096 as the per-GPU minimum of concurrent boards and
+the boards beyond the 7,168th take the slots in turn; configs[3] names 4,096 as the per-GPU minimum of concurrent boards and
 `--boards 4096` runs exactly that; `--boards 10240 --budget-us 2400 --select-opts 0` is round 4's shape).
 
 DEFAULT ROUTE (--mode async): the asynchronous self-play loop (qz_selfplay_*, include/qz_abi.h): every board runs its 400
@@ -222,8 +222,8 @@ class Run:
             return {"n": len(v), "mean": float(np.mean(v)) if v else None, "median": float(np.median(v)) if v else None}
 
         name = "BASELINE configs[2] as an engine run" if B == 32768 else ("BASELINE configs[1]" if a.playouts == 100 else (
-            "BASELINE configs[3] per GPU" if B == 4096 else "BASELINE configs[3]'s per-GPU workload with %d instead of 4,096 boards per GPU (the engine keeps eight "
-            "k_advance wavefronts per SIMD busy, and the slots of boards that leave a launch early go to the boards beyond the 8,192nd%s; same_loop_at_4096_boards is the literal board count)"
+            "BASELINE configs[3] per GPU" if B == 4096 else "BASELINE configs[3]'s per-GPU workload with %d instead of 4,096 boards per GPU (the engine keeps seven "
+            "k_advance wavefronts per SIMD busy, and the slots of boards that leave a launch early go to the boards beyond the 7,168th%s; same_loop_at_4096_boards is the literal board count)"
             % (B, ", one deadline per launch" if (a.select_opts & 8) else "")))
         label = ("NON-PARITY THROUGHPUT MODE (network products on fp16 operands, p / v ~1e-3 from the reference) -- " if a.nn_dtype == "fp16" else "") + \
                 ("TERMINAL SIGN FIXED (not the reference's mcts.py:125) -- " if a.fix_terminal_sign else "")
@@ -340,7 +340,7 @@ def make_engine(args, net, dev, seed, fix_sign, boards=None, nn_precision=None, 
 
 
 def line_at_4096_boards(args, dev, qdist):
-    """BASELINE configs[3] names 4,096 boards per GPU; the headline runs more (eight wavefronts of k_advance per SIMD + the slots of the boards that leave early).  The same
+    """BASELINE configs[3] names 4,096 boards per GPU; the headline runs more (seven wavefronts of k_advance per SIMD + the slots of the boards that leave early).  The same
     loop at exactly 4,096 boards (k_advance<4>), same phases, a short timed region: so that both are in the driver's line."""
     from alphazero_quoridor_amd.policy_value_net import PolicyValueNet
 
@@ -367,7 +367,7 @@ def line_at_4096_boards(args, dev, qdist):
     st1 = eng.stats()
     d = {k: st1[k] - st0[k] for k in st1}
     eng.close()
-    return {"boards": 4096, "kernel": "k_advance<4> (73 registers, four wavefronts per SIMD)", "rounds": 2560, "seconds": dt, "ms_per_round": dt / 2560 * 1e3,
+    return {"boards": 4096, "kernel": "k_advance<4> (97 registers, four wavefronts per SIMD)", "rounds": 2560, "seconds": dt, "ms_per_round": dt / 2560 * 1e3,
             "plies_per_s": d["plies_played"] / dt, "playouts_per_s": d["playouts"] / dt, "nn_evaluations_per_s": d["nn_evals"] / dt,
             "memo_hit_rate": d["memo_hits"] / max(d["playouts"], 1),
             "budget_us": 1000,
@@ -566,7 +566,7 @@ def run_async(R):
         "open_phase": {"plies": open_plies_all, "share_of_board_time": open_rounds_all / max(B * world * rounds, 1), "note": "root's mover still has walls"},
         "mean_descent_depth": d["descent_levels"] / max(d["playouts"], 1), "rounds": rounds, "ms_per_round": round_s * 1e3,
         "roofline": hbm_line(
-            "k_moves + k_advance (one wavefront per board: %d boards per SIMD for at most eight wavefronts resident per SIMD; moves of the boards that finished "
+            "k_moves + k_advance (one wavefront per board: %d boards per SIMD for at most seven wavefronts resident per SIMD; moves of the boards that finished "
             "their playouts, then descents -- recorded descents replayed 64 levels per round trip, the first unrecorded level selected by the same round --, "
             "memo probes, expansions and backups until the board needs the network or the budget is used)" % waves, adv_us, adv_bytes,
             "dependent-load latency and instruction issue, not bandwidth: a playout is a chain of memory round trips (record -> edge blocks -> memo bucket -> "
@@ -703,7 +703,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--boards", type=int, default=13312, help="concurrent boards per GPU (8,192 = eight k_advance wavefronts per SIMD; 4,096 = BASELINE configs[3]'s number; the sweep behind the default: profiles/round4/SUMMARY.md section 2)")
+    ap.add_argument("--boards", type=int, default=13312, help="concurrent boards per GPU (7,168 = seven k_advance wavefronts per SIMD; 4,096 = BASELINE configs[3]'s number; the sweep behind the default: profiles/round4/SUMMARY.md section 2)")
     ap.add_argument("--playouts", type=int, default=400)
     ap.add_argument("--groups", type=int, default=1, help="split the boards of a GPU into this many independent groups on their own HIP streams")
     ap.add_argument("--mode", default="async", choices=["async", "lockstep"])

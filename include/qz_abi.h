@@ -133,11 +133,11 @@ typedef struct {
     qz_rules_opts rules;       /* formulation of the leaf rules op (all zero = defaults)        */
     int32_t select_opts;       /* A/B switches of the descent kernel (0 = defaults): bit 0 = walk every level (no replay of
                                   recorded descents; same results, the test partner of the records), bit 1 = no readlane
-                                  scan for nodes with <= 8 children, bit 2 = the 64-register build of the asynchronous loop's
-                                  kernel (eight wavefronts per SIMD: what engines above 4,096 boards run) whatever the engine's size,
+                                  scan for nodes with <= 8 children, bit 2 = the build of the asynchronous loop's kernel
+                                  for large engines (seven wavefronts per SIMD: what engines above 4,096 boards run) whatever the engine's size,
                                   bit 3 = qz_selfplay_advance's budget (if >= 100 us) counts from the launch's FIRST wavefront -- one
                                   deadline for all boards -- and the boards take the first slots in turn: for engines of more boards
-                                  than the chip holds wavefronts (8,192), where a board may get its slot in the middle of a launch,
+                                  than the chip holds wavefronts of it (7,168), where a board may get its slot in the middle of a launch,
                                   bit 4 = the boards on which NEITHER player has a wall left are played by k_lanes (csrc/qz_lanes.h: one
                                   LANE per board, the backup folded into the next descent) beside k_advance's launch for the others --
                                   same search results bit for bit (tests/test_gpu_lanes.py); measured 4x slower than k_advance at
