@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-6 evidence for profiles/round6/: GPU test tier + smoke, the bench line (the driver's command), A/B lines, rocprofv3 kernel stats
-# of the same command, PMC traffic of k_advance<8> (separate FETCH_SIZE / WRITE_SIZE passes, program directly after `--`), a rocprofv3
+# of the same command, PMC traffic of k_advance (separate FETCH_SIZE / WRITE_SIZE passes, program directly after `--`), a rocprofv3
 # stats file of the rules op at 32,768 boards (C3), the 2-rank line.  PARTS="tests pmc bench ab prof c3 ranks" selects (the PMC passes run BEFORE the bench line, which cites their file).
 O=gpurun_out/${OUT:-r6final}; mkdir -p $O
 R=$GRAFT_REPO_ROOT
@@ -19,7 +19,7 @@ if has pmc; then
   done
   bpb=$(python3 -c "import json; d=json.load(open('$R/$O/pmc_FETCH_SIZE.json')); print(d['roofline']['algorithmic_bytes_per_launch'] / d['config']['boards_per_gpu'])")
   cd $R && python3 $R/benchmarks/pmc_traffic.py --fetch $R/$O/pmc_FETCH_SIZE --write $R/$O/pmc_WRITE_SIZE --kernels k_advance --boards 13312 --bytes-per-board $bpb --last 200 \
-     --label "k_advance<8> (13,312 boards, one 3,000-us deadline per launch, n_playout=400, last 200 launches of a bench run)" --out $R/$O/pmc_traffic_advance.json > /dev/null && cat $R/$O/pmc_traffic_advance.json | head -14
+     --label "k_advance<7> (13,312 boards, one 3,000-us deadline per launch, n_playout=400, last 200 launches of a bench run)" --out $R/$O/pmc_traffic_advance.json > /dev/null && cat $R/$O/pmc_traffic_advance.json | head -14
   # (the bench line below cites this file -- and says whether it was measured on the kernels it runs: it must be in place first)
   mkdir -p $R/profiles/round6 && cp $R/$O/pmc_traffic_advance.json $R/profiles/round6/pmc_traffic_advance.json
   rm -rf $R/$O/pmc_FETCH_SIZE $R/$O/pmc_WRITE_SIZE

@@ -173,7 +173,7 @@ def test_asynchronous_games_equal_lockstep_games(gpu_device, compact_edges, budg
 
 @pytest.mark.parametrize("select_opts", [0, 8, 24, 40])
 def test_more_boards_than_wavefront_slots_play_the_lockstep_games(gpu_device, select_opts):
-    """The bench's shape: MORE boards (8,704) than the chip holds wavefronts of k_advance<8> (8,192), one wavefront per workgroup --
+    """The bench's shape: MORE boards (8,704) than the chip holds wavefronts of k_advance (7,168: seven per SIMD), one wavefront per workgroup --
     the boards behind the 8,192nd start when a board that needs the network has left -- against the lock-step engine with the
     same seed and board count: every slot's games in the same order with identical (board, pi, z) tuples.  select_opts 8: one
     deadline per launch, boards rotating through the first slots; 24: the boards without walls on k_lanes as well.  Short games

@@ -1,6 +1,6 @@
 """GPU parity AT THE BENCH'S OWN SHAPES ("What's missing" 3 and 4; "Next round" 2 and 7).
 
-  * bench.py's default engine -- 13,312 boards on the 8,192 wavefront slots of k_advance<8>, the real network, one 3,000-us
+  * bench.py's default engine -- 13,312 boards on the 7,168 wavefront slots of k_advance<7>, the real network, one 3,000-us
     deadline per launch (and round 4's shape: 10,240 boards, per-board budgets of 2,400 us) -- against the oracle: every (board -> p, v) the network produced for the subtrees of 64 sampled boards is taken
     from the miss lists (qz_selfplay_misses) and handed to oracle.OracleMCTS (the C restatement of mcts.py:103-151) as its
     policy; three plies of 400 playouts, root visits / float64 Q / float32 P bit-equal.
@@ -54,7 +54,7 @@ def oracle_masks_planes(boards, pool, want_planes=True, chunk=1024):
 def test_bench_shape_real_net_equals_the_oracle(gpu_device, B, BUDGET, select_opts):
     """`python bench.py`'s engine, round 5's default shape (13,312 boards, ONE deadline of 3,000 us per launch, boards taking the
     first slots in turn: select_opts 8) and round 4's (10,240 boards, per-board budgets of 2,400 us): more boards than the 8,192
-    wavefront slots of k_advance<8> (slots are handed from boards that leave a launch to the boards beyond the 8,192nd),
+    wavefront slots of k_advance (slots are handed from boards that leave a launch to the boards beyond the 7,168th),
     n_playout=400, the real network in parity precision, the bench's playout cap.  85 % late-game boards (the mover has no wall left: the memo's regime, 30 playouts
     per launch) and 15 % whose mover has walls (one network round trip per playout), as in a sustained run.  64 boards are
     followed in the oracle: mcts.py's pointer tree fed with the evaluations the ENGINE'S network produced for their subtrees
