@@ -2779,6 +2779,7 @@ __device__ __forceinline__ void advance_board(EngineDev& E, const int max_iters,
 // allowed, 66 / 94 used, no scratch, 287 spill reloads in the loop) -- 7,168 boards at a time -- run 1.9 % more playouts per second
 // than eight (64 / 80 registers, 12 bytes of scratch, 342 reloads; rounds 4-5's build), six 0.7 % fewer (profiles/round6/SUMMARY.md 7).
 // k_advance<4>: 97 registers, for engines of up to 4,096 boards, where residency beyond four buys nothing.
+// (EngineDev must stay the FIRST parameter: advance_board fetches its fields from offset 0 of the kernel-argument segment, QZ_KARG_*)
 template <int W>
 __global__ __launch_bounds__(64 * ADV_WPB) __attribute__((amdgpu_waves_per_eu(W, W))) void k_advance(EngineDev E, int max_iters, unsigned int budget, int par) {
     advance_board(E, max_iters, budget, par);

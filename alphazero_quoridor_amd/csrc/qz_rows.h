@@ -3,9 +3,9 @@
 // plies in).  Included by qz_kernels.hip.  qz_config.select_opts bit 5; off by default (measured: below).
 //
 // k_advance gives a board a whole wavefront and keeps everything that is the same for the board's 64 lanes in scalar registers.
-// Its throughput is (boards resident) / (time of a board's playout chain): 8,192 boards (eight 64-register wavefronts per SIMD) at
-// ~18 us per playout, with the SIMDs' vector pipes 76-81 % and their scalar units ~70 % busy (SQ counters: 911-992 vector + ~900 scalar
-// instructions per playout).  A late-game descent is ~15 levels of nodes with two to six children: it uses a
+// Its throughput is (boards resident) / (time of a board's playout chain): measured at eight 64-register wavefronts per SIMD (8,192
+// boards; seven since, qz_kernels.hip) ~18 us per playout, with the SIMDs' vector pipes 76-81 % and their scalar units ~70 % busy (SQ
+// counters: 911-992 vector + ~900 scalar instructions per playout).  A late-game descent is ~15 levels of nodes with two to six children: it uses a
 // quarter of the 64 lanes of a replay round.  Here a board has a ROW of 16 lanes (what the DPP row operations address), a wavefront
 // carries four boards, and what was wave-uniform is row-uniform: a value every lane of the row holds in a vector register or -- the
 // launch-level state -- one LDS word per row.  117 registers, no scratch, 3.75 KB of LDS per wavefront: four wavefronts per SIMD by
@@ -900,6 +900,7 @@ __device__ __forceinline__ void rows_boards(EngineDev& E, const int max_iters, c
 #undef gwe
 #undef gwb
 // Three builds of the loop: four wavefronts per SIMD (128 registers: sixteen boards per SIMD), three (160), two (256)
+// (EngineDev must stay the FIRST parameter: rows_boards fetches its fields from offset 0 of the kernel-argument segment, QZ_KARG_*)
 template <int WEU>
 __global__ void k_rows(EngineDev E, int max_iters, unsigned int budget, int par);
 template <>
