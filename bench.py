@@ -287,6 +287,7 @@ class Run:
                 L_cpu = float(np.mean(seen)) if seen else None
                 L_src = "NO length sample for n_playout=%d: mean length of the %d games finished in this run (mostly desync games)" % (a.playouts, len(seen))
             out["cpu_baseline"] = cpu_baseline(a.cpu_seconds, a.playouts, L_cpu, L_src, open_share=(out.get("open_phase") or {}).get("share_of_board_time"))
+        out["summary"] = line_summary(out)
         print(json.dumps(out))
 
 
@@ -337,6 +338,32 @@ def make_engine(args, net, dev, seed, fix_sign, boards=None, nn_precision=None, 
     eng = BoardGroups(boards or args.boards, args.groups, make_ev, seed=seed, device=dev, n_playout=args.playouts, c_puct=5, temp=1.0, is_selfplay=1,
                       fix_terminal_sign=fix_sign, select_opts=so, memo=not args.no_memo, max_depth=args.max_depth)
     return eng
+
+
+def line_summary(out):
+    """The line's scalars once more, flat, as its LAST key: the line is ~18 KB and a record that keeps its head and its tail drops the
+    middle -- where plies_per_s and playouts_per_s stand."""
+    cb = out.get("cpu_baseline") or {}
+    rf, c3, nn = out.get("roofline") or {}, out.get("roofline_c3") or {}, out.get("roofline_nn") or {}
+    pps = out.get("playouts_per_s")
+    g = lambda d, *ks: next((d.get(k) for k in ks if d.get(k) is not None), None)
+    return {
+        "plies_per_s": out.get("plies_per_s"), "playouts_per_s": pps, "ms_per_round": out.get("ms_per_round"), "ms_per_step": out.get("ms_per_step"),
+        "games_per_s_value": out.get("value"), "games_per_s_low": out.get("value_low"), "games_per_s_high": out.get("value_high"),
+        "roofline_frac": rf.get("frac"), "roofline_avg_launch_us": rf.get("avg_launch_us"), "roofline_traffic_over_algorithmic":
+            (rf["traffic"] / rf["algorithmic_bytes_per_launch"]) if rf.get("traffic") and rf.get("algorithmic_bytes_per_launch") else None,
+        "roofline_traffic_measured_on_these_kernels": rf.get("traffic_measured_on_these_kernels"),
+        "roofline_c3_frac": c3.get("frac"), "roofline_c3_avg_launch_us": c3.get("avg_launch_us"), "roofline_nn_avg_launch_us": nn.get("avg_launch_us"),
+        "leaves_per_round": nn.get("leaves_per_launch"), "memo_hit_rate": out.get("memo_hit_rate"),
+        "open_phase_share_of_board_time": (out.get("open_phase") or {}).get("share_of_board_time"),
+        "same_loop_at_4096_boards_playouts_per_s": (out.get("same_loop_at_4096_boards") or {}).get("playouts_per_s"),
+        "second_line_fix_terminal_sign_games_per_s": (out.get("second_line_fix_terminal_sign") or {}).get("value"),
+        "second_line_NON_PARITY_fp16_games_per_s": (out.get("second_line_NON_PARITY_fp16") or {}).get("value"),
+        "cpu_port_playouts_per_s_allcores": cb.get("playouts_per_s_allcores"), "cpu_cores": cb.get("cores"),
+        "cpu_reference_estimate_playouts_per_s_allcores": g(cb, "reference_playouts_per_s_allcores"),
+        "gpu_over_cpu_port_playouts": (pps / cb["playouts_per_s_allcores"]) if pps and cb.get("playouts_per_s_allcores") else None,
+        "kernel_sources_sha256": (out.get("provenance") or {}).get("kernel_sources_sha256"),
+    }
 
 
 def line_at_4096_boards(args, dev, qdist):

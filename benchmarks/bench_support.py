@@ -229,8 +229,12 @@ def cpu_baseline(seconds, n_playout, mean_plies_per_game, length_source, open_sh
                   "%d cores as independent processes, per phase (%s); weighted: %s; games/s = playouts/s / %d / %s plies per game (%s)"
                   % (n_playout, per, per, n_proc, ", ".join(by_phase), basis, n_playout, "%.0f" % L if L else "?", length_source),
         "compare_on": "playouts_per_s (length-independent)", "playouts_per_s_1core": pps1, "playouts_per_s_allcores": ppsN,
-        "games_per_s_1core": (pps1 / n_playout / L) if L else None, "by_phase": by_phase, "open_share_used": open_share if have_roots else None,
+        "games_per_s_1core": (pps1 / n_playout / L) if L else None,
     }
+    # (flat copies of the per-phase rates: a record that keeps an object's scalars and drops its nested objects still shows them)
+    for ph, v in by_phase.items():
+        out["playouts_per_s_allcores_" + ph] = v["playouts_per_s_allcores"]
+    out.update({"open_share_used": open_share if have_roots else None, "by_phase": by_phase})
     cal = _load_json(_latest_profile("cpu_calibration.json") or "")
     if cal and cal.get("port_over_reference"):
         r_open = float(cal["port_over_reference"])
@@ -244,6 +248,7 @@ def cpu_baseline(seconds, n_playout, mean_plies_per_game, length_source, open_sh
             est["playouts_per_s_allcores"] = w * by_phase["steady_open"]["playouts_per_s_allcores"] / r_open + (1.0 - w) * by_phase["steady_late"]["playouts_per_s_allcores"] / r_late
         else:
             est["playouts_per_s_1core"], est["playouts_per_s_allcores"] = pps1 / r_open, ppsN / r_open
+        out["reference_playouts_per_s_allcores"] = est["playouts_per_s_allcores"]
         out["reference_estimate"] = est
     return out
 

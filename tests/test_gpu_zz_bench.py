@@ -108,6 +108,16 @@ def test_bench_single_gpu_line_carries_the_contract(gpu_device):
     assert cb["open_share_used"] == pytest.approx(a["open_phase"]["share_of_board_time"]) and cb["by_phase"]["steady_open"]["mean_legal_moves_at_the_roots"] > 20 > cb["by_phase"]["steady_late"]["mean_legal_moves_at_the_roots"]
     w = cb["open_share_used"]
     assert cb["playouts_per_s_allcores"] == pytest.approx(w * cb["by_phase"]["steady_open"]["playouts_per_s_allcores"] + (1 - w) * cb["by_phase"]["steady_late"]["playouts_per_s_allcores"])
+    # flat copies of the per-phase rates (a record that keeps an object's scalars and drops its nested objects still shows them), and
+    # the line's scalars once more as its LAST key (the line is ~18 KB; a record that keeps head and tail drops plies_per_s in the middle)
+    for ph, v in cb["by_phase"].items():
+        assert cb["playouts_per_s_allcores_" + ph] == v["playouts_per_s_allcores"]
+    assert cb["reference_playouts_per_s_allcores"] == cb["reference_estimate"]["playouts_per_s_allcores"]
+    assert list(a)[-1] == "summary"
+    sm = a["summary"]
+    assert sm["plies_per_s"] == a["plies_per_s"] and sm["playouts_per_s"] == a["playouts_per_s"] and sm["roofline_frac"] == a["roofline"]["frac"]
+    assert sm["roofline_c3_frac"] == a["roofline_c3"]["frac"] and sm["cpu_port_playouts_per_s_allcores"] == cb["playouts_per_s_allcores"]
+    assert sm["gpu_over_cpu_port_playouts"] == pytest.approx(a["playouts_per_s"] / cb["playouts_per_s_allcores"]) and all(not isinstance(v, (dict, list)) for v in sm.values())
     assert len(a["per_rank"]) == 1 and a["per_rank"][0]["rank"] == 0 and a["provenance"]["kernel_sources_sha256"]
     assert "games_per_s_steady_state" in a and "games_in_timed_region" in a and len(a["ms_per_step_series"]) == 2
     # the headline names its tracked scalar; the second line's `value` is the stationary estimate from the
