@@ -144,7 +144,7 @@ class qz_nn_weights(C.Structure):
 
 def build(force: bool = False) -> str:
     """Compile libqzero_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("qz_kernels.hip", "qz_abi.hip", "qz_nn.hip", "qz_conv.hip", "qz_rules.h", "qz_movegen_pool.h", "qz_path_rows.h", "qz_lanes.h", "qz_device.h")] + [HEADER]
+    srcs = [os.path.join(CSRC, f) for f in ("qz_kernels.hip", "qz_abi.hip", "qz_nn.hip", "qz_conv.hip", "qz_rules.h", "qz_movegen_pool.h", "qz_path_rows.h", "qz_device.h")] + [HEADER]
     stale = force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if stale:
         subprocess.check_call(["make", "-C", CSRC, "-s"])

@@ -131,7 +131,7 @@ struct qz_engine {
     // qz_selfplay_round: the rules op of the miss list and the finished boards' moves run beside the network's trunk
     hipStream_t side = nullptr, side2 = nullptr;  // (the rules op / the moves: each on a stream of its own beside the network)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
-    hipStream_t lanes = nullptr;           // k_lanes (select_opts bit 4) runs beside k_advance on a stream of its own
+    hipStream_t lanes = nullptr;           // k_rows (select_opts bit 5) runs beside k_advance on a stream of its own
     hipEvent_t ev_lfork = nullptr, ev_ljoin = nullptr;
     size_t memo_small_bytes = 0, memo_big_bytes = 0;
     unsigned flushes = 0;
@@ -967,12 +967,12 @@ int qz_nn_evaluate_w(const qz_boards* boards, const uint8_t* terminal, int64_t n
 }
 
 // ------------------------------------------------------------------ asynchronous self-play
-// k_moves (auto_finish), then the playouts: k_advance for every board -- or, with select_opts bit 4, k_advance for the boards that
-// still have walls and k_lanes (one LANE per board, qz_lanes.h) for the others, side by side on two streams (independent boards;
+// k_moves (auto_finish), then the playouts: k_advance for every board -- or, with select_opts bit 5, k_advance for the boards that
+// still have walls and k_rows (sixteen lanes per board, qz_rows.h) for the others, side by side on two streams (independent boards;
 // the miss list's counter and the page pool are shared through atomics).  Fork / join by events: captures into a HIP graph.
 static int launch_advance(qz_engine* e, int max_playouts, unsigned int ticks, int auto_finish, hipStream_t s) {
     const EngineDev& d = e->dev;
-    if (!(d.select_opts & 48)) {
+    if (!(d.select_opts & 32)) {
         HIP_TRY(qzl::advance(d, max_playouts, ticks, auto_finish, e->par, s));
         return 0;
     }

@@ -124,7 +124,7 @@ struct RulesOpts {
 //                [8..19] p of pawn codes 0..11   [31] of entry 0: the bucket's insert lock
 //   big table:   every other live leaf: buckets of 2 entries x 160 dwords (640 B): [0..5] key  [6] v  [8..12] mask5
 //                [15] of entry 0: lock   [16..155] p[140]
-// Probes (k_advance / k_lanes) and inserts (k_round_tail) never run at the same time (same stream, different launches), so
+// Probes (k_advance / k_rows) and inserts (k_round_tail) never run at the same time (same stream, different launches), so
 // readers need no protocol.  Inserters: a bucket takes ONE insert per round -- its lock word holds the number of the last
 // round in which a wavefront wrote it (QZ_C_ROUNDS | 2^31: never 0), taken by compare-and-swap from the value the bucket was read
 // with; nobody unlocks (memo_insert).  Consequences, all of them about WHEN a board gets an answer, never about what it

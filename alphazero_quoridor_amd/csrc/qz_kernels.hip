@@ -2594,9 +2594,9 @@ __device__ __forceinline__ void advance_board(EngineDev& E, const int max_iters,
             }
         }
     }
-    // select_opts bit 4 / 5: the boards on which neither player has a wall left are k_lanes' (qz_lanes.h: one LANE per board) / k_rows'
+    // select_opts bit 5: the boards on which neither player has a wall left are k_rows'
     // (qz_rows.h: sixteen lanes per board, four boards per wavefront), beside this launch
-    if ((E.select_opts & 48) && ((rfl64(E.root_meta[b]) >> 16) & 0xFFFFull) == 0ull) return;
+    if ((E.select_opts & 32) && ((rfl64(E.root_meta[b]) >> 16) & 0xFFFFull) == 0ull) return;
 #ifndef QZ_BUDGET_PREDICT
 #define QZ_BUDGET_PREDICT 1  // what a board expects its next playout to last: 0 = nothing, 1 = as long as its last one, 2 = the largest of its recent ones (a maximum that decays by a quarter per playout: measured no different from 1, 289.1 against 290.6 M playouts/s; nor is a margin of a quarter or a half of the last playout on top: 309.5 / 309.8 against 309.0 M, launches as long as before -- the launch's overrun of ~100 us is the extreme of ten thousand boards' playout times, not a misprediction of the typical one)
 #endif
@@ -3085,7 +3085,6 @@ __global__ void k_sqrt_table(double* out, int n) {  // self-test helper: device 
     if (i < n) out[i] = sqrt_count((uint32_t)i);  // (what the descents use)
 }
 
-#include "qz_lanes.h"
 #include "qz_rows.h"
 
 }  // namespace
@@ -3221,9 +3220,9 @@ hipError_t advance(const EngineDev& E, int max_iters, unsigned int budget_ticks,
     else hipLaunchKernelGGL(k_advance<QZ_ADV_WAVES_SMALL>, adv_grid, adv_block, 0, s, E, max_iters, budget_ticks, par);
     return hipGetLastError();
 }
-// k_lanes (qz_lanes.h): the boards without walls, 64 per wavefront, beside k_advance's launch for the others (select_opts bit 4)
+// k_rows (qz_rows.h): the boards without walls, four per wavefront, beside k_advance's launch for the others (select_opts bit 5)
 hipError_t advance_lanes(const EngineDev& E, int max_iters, unsigned int budget_ticks, int par, hipStream_t s) {
-    if (E.select_opts & 32) {
+    {
         // four wavefronts per SIMD (k_rows<4>: 117 registers, no scratch) = 16 boards per SIMD.  (A/B: QZ_ROWS_WEU 3 / 2)
         static const int weu = getenv("QZ_ROWS_WEU") ? atoi(getenv("QZ_ROWS_WEU")) : 4;
         hipError_t me = hipMemsetAsync(E.rows_list, 0, 2 * sizeof(uint32_t), s);  // (the list is rebuilt for every launch: a board must never be listed twice)
@@ -3245,7 +3244,6 @@ hipError_t advance_lanes(const EngineDev& E, int max_iters, unsigned int budget_
         else if (weu == 3) hipLaunchKernelGGL(k_rows<3>, g, dim3(64), 0, s, E, max_iters, budget_ticks, par);
         else hipLaunchKernelGGL(k_rows<2>, g, dim3(64), 0, s, E, max_iters, budget_ticks, par);
     }
-    else hipLaunchKernelGGL(k_lanes, dim3((unsigned)((E.n_boards + 63) / 64)), dim3(64), 0, s, E, max_iters, budget_ticks, par);
     return hipGetLastError();
 }
 // the moves of the boards that have done their playouts + the subtree copies they leave (and the slices earlier moves left)

@@ -98,6 +98,8 @@ enum { RC_PLAYOUTS = 0, RC_TERMINAL, RC_OVERFLOW, RC_NONFINITE, RC_MAXDEPTH, RC_
 }  // namespace rows
 
 // the boards k_rows plays this round (lane = board): playing, nobody has a wall left, no subtree copy pending
+// a board k_rows plays: both players out of walls (meta bits 16..31 = walls of player 1 / 2)
+__device__ __forceinline__ bool lanes_eligible(const uint64_t meta) { return ((meta >> 16) & 0xFFFFull) == 0ull; }
 __global__ __launch_bounds__(64) void k_rows_scout(EngineDev E) {
     const int b = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     const bool need = b < E.n_boards && E.status[b] == QZ_PLAYING && lanes_eligible(E.root_meta[b]) && E.reroot_pend[b] == 0u && !(E.release[b] & 2u);

@@ -138,12 +138,11 @@ typedef struct {
                                   bit 3 = qz_selfplay_advance's budget (if >= 100 us) counts from the launch's FIRST wavefront -- one
                                   deadline for all boards -- and the boards take the first slots in turn: for engines of more boards
                                   than the chip holds wavefronts of it (7,168), where a board may get its slot in the middle of a launch,
-                                  bit 4 = the boards on which NEITHER player has a wall left are played by k_lanes (csrc/qz_lanes.h: one
-                                  LANE per board, the backup folded into the next descent) beside k_advance's launch for the others --
-                                  same search results bit for bit (tests/test_gpu_lanes.py); measured 4x slower than k_advance at
-                                  13,312 boards (profiles/round6/SUMMARY.md): the prototype of the other mapping, off by default,
-                                  bit 5 = those boards are played by k_rows instead (csrc/qz_rows.h: SIXTEEN LANES per board, four boards
-                                  per wavefront, boards from a queue; wins over bit 4) -- same search results bit for bit
+                                  bit 4 = reserved (round 6's one-lane-per-board prototype, k_lanes: parity-green, 4x slower than
+                                  k_advance, removed -- profiles/round6/SUMMARY.md 1; ignored),
+                                  bit 5 = the boards on which NEITHER player has a wall left are played by k_rows (csrc/qz_rows.h: SIXTEEN
+                                  LANES per board, four boards per wavefront, boards from a queue) beside k_advance's launch for the
+                                  others -- same search results bit for bit
                                   (tests/test_gpu_lanes.py); measured on a par with k_advance inside the launch at 1.5 x the boards and
                                   6 % behind per round (profiles/round6/SUMMARY.md): off by default */
     /* Leaf-evaluation memo (qz_selfplay_*): log2 of the number of buckets of its two tables; 0 = auto (16,384 small entries

@@ -106,7 +106,7 @@ def _games_by_slot(batches):
     return out
 
 
-@pytest.mark.parametrize("compact_edges,budget_us,pool_pages,select_opts", [(0, 0, 0, 0), (-1, 0, 0, 0), (0, 300, 192 * 60, 0), (-1, 1, 0, 0), (-1, 150, 0, 8), (0, 0, 0, 16), (-1, 1, 0, 16), (0, 0, 0, 32), (-1, 1, 0, 32)])
+@pytest.mark.parametrize("compact_edges,budget_us,pool_pages,select_opts", [(0, 0, 0, 0), (-1, 0, 0, 0), (0, 300, 192 * 60, 0), (-1, 1, 0, 0), (-1, 150, 0, 8), (0, 0, 0, 32), (-1, 1, 0, 32)])
 def test_asynchronous_games_equal_lockstep_games(gpu_device, compact_edges, budget_us, pool_pages, select_opts):
     """Complete self-play games (Dirichlet noise, sampled moves, subtree reuse, continuous refill) from the
     asynchronous loop -- boards on their own clocks, several playouts and whole moves per launch, memo on --
@@ -118,7 +118,7 @@ def test_asynchronous_games_equal_lockstep_games(gpu_device, compact_edges, budg
     wall-clock budget per launch.  Last: always copied under a budget of 1 us -- one playout per launch, and every subtree
     copy stops after its first window of 64 edges and goes on, window by window, in the board's next launches
     (qz_stats.compact_slices).  The fifth case: one deadline per launch (select_opts 8); the last two: the boards without walls on
-    k_lanes (select_opts 16, csrc/qz_lanes.h) beside k_advance's launch for the others.  Afterwards the engine refuses lock-step
+    k_rows (select_opts 32, csrc/qz_rows.h) beside k_advance's launch for the others.  Afterwards the engine refuses lock-step
     calls until it is reset."""
     from alphazero_quoridor_amd import _cabi
     from alphazero_quoridor_amd.engine import SelfPlayEngine
@@ -171,12 +171,12 @@ def test_asynchronous_games_equal_lockstep_games(gpu_device, compact_edges, budg
         asyn.close()
 
 
-@pytest.mark.parametrize("select_opts", [0, 8, 24, 40])
+@pytest.mark.parametrize("select_opts", [0, 8, 40])
 def test_more_boards_than_wavefront_slots_play_the_lockstep_games(gpu_device, select_opts):
     """The bench's shape: MORE boards (8,704) than the chip holds wavefronts of k_advance (7,168: seven per SIMD), one wavefront per workgroup --
-    the boards behind the 8,192nd start when a board that needs the network has left -- against the lock-step engine with the
+    the boards behind the 7,168th start when a board that needs the network has left -- against the lock-step engine with the
     same seed and board count: every slot's games in the same order with identical (board, pi, z) tuples.  select_opts 8: one
-    deadline per launch, boards rotating through the first slots; 24: the boards without walls on k_lanes as well.  Short games
+    deadline per launch, boards rotating through the first slots; 40: the boards without walls on k_rows as well.  Short games
     (terminal sign fixed, 12 playouts)."""
     from alphazero_quoridor_amd.engine import SelfPlayEngine
 

@@ -1,15 +1,15 @@
-"""GPU parity of the two other mappings of the asynchronous loop's kernel, for the boards on which neither player has a wall left:
+"""GPU parity of the other mapping of the asynchronous loop's kernel, for the boards on which neither player has a wall left:
 k_rows (csrc/qz_rows.h, qz_config.select_opts bit 5: SIXTEEN LANES per board, four boards per wavefront -- k_advance's algorithm with
-what was wave-uniform held row-uniform) and k_lanes (csrc/qz_lanes.h, bit 4: ONE LANE per board) -- against oracle.OracleMCTS (the C
-restatement of mcts.py:12-151) and against the wavefront-per-board kernel k_advance, which is pinned on the reference's fixtures by
-test_gpu_async_oracle.py.
+what was wave-uniform held row-uniform) -- against oracle.OracleMCTS (the C restatement of mcts.py:12-151) and against the
+wavefront-per-board kernel k_advance, which is pinned on the reference's fixtures by test_gpu_async_oracle.py.
 
-What differs from k_advance inside a board's search is only WHEN an edge's (N, Q) reaches memory: k_lanes folds the backup of
-playout i into the descent of playout i + 1 (update_recursive, mcts.py:44-62, applied top-down to the edge of each level just before
-TreeNode.select, mcts.py:37-42, reads it) and flushes the levels the new descent does not pass.  So the tests pin root visits,
-float64 Q and float32 P after every ply, bit for bit, in every launch regime (one playout per launch, free-running, 1-us budgets
-that cut every launch short, budgets in between), with stub policies that put terminal leaves inside the trees, and with the real
-network through the memo."""
+(Round 6 also built k_lanes -- ONE LANE per board, the backup of playout i folded into the descent of playout i + 1 -- and ran this
+whole file on it, green; it measured four times slower than k_advance and was removed: profiles/round6/SUMMARY.md 1, the source in
+profiles/round6/ab/qz_lanes.h.removed.txt.)
+
+The tests pin root visits, float64 Q and float32 P after every ply, bit for bit, in every launch regime (one playout per launch,
+free-running, 1-us budgets that cut every launch short, budgets in between), with stub policies that put terminal leaves inside the
+trees, and with the real network through the memo."""
 import os
 import sys
 
@@ -23,9 +23,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "gol
 
 from test_gpu_async_oracle import ORDER, make_engine, stub_round  # noqa: E402
 
-LANES = 16  # qz_config.select_opts bit 4: k_lanes
-ROWS = 32   # bit 5: k_rows
-MAPPINGS = [ROWS, LANES]
+ROWS = 32   # qz_config.select_opts bit 5: k_rows
+MAPPINGS = [ROWS]
 
 
 def _late_boards(n, seed, near_goal=False):
@@ -98,7 +97,7 @@ LANE_REGIMES = [(True, 1, 0), (True, 4096, 0), (False, 4096, 0), (True, 4096, 1)
 @pytest.mark.parametrize("mapping", MAPPINGS)
 @pytest.mark.parametrize("memo,max_playouts,budget_us", LANE_REGIMES)
 def test_lane_kernel_search_equals_the_oracle(gpu_device, memo, max_playouts, budget_us, mapping):
-    """200 late-game boards (no walls left: every board is k_lanes'), hash stub policy, 60 playouts per move, four plies with
+    """200 late-game boards (no walls left: every board is k_rows'), hash stub policy, 60 playouts per move, four plies with
     the kept subtrees carried over (in-place re-roots): visits, Q, P, root visits bit-equal with oracle.OracleMCTS."""
     boards = _late_boards(200, seed=5)
     st = _search_plies(boards, "hash", 60, max_playouts, budget_us, memo, mapping, plies=4)
@@ -134,7 +133,7 @@ def test_lane_kernel_uniform_policy_and_deep_trees(gpu_device, mapping):
 @pytest.mark.parametrize("mapping", MAPPINGS)
 def test_boards_cross_from_the_wavefront_kernel_to_the_lane_kernel(gpu_device, mapping):
     """Games the loop plays ON ITS OWN (moves sampled on the device, subtrees kept in place or compacted) from positions where
-    the players hold one or two walls between them: the boards start on k_advance and move to k_lanes with the ply that places the
+    the players hold one or two walls between them: the boards start on k_advance and move to k_rows with the ply that places the
     last wall, their trees and pending state as they are.  Every harvested game replays in oracle.OracleMCTS ply by ply (pi pins
     every visit count); games restarted from the opening stay on k_advance."""
     import oracle
@@ -193,13 +192,13 @@ def test_boards_cross_from_the_wavefront_kernel_to_the_lane_kernel(gpu_device, m
                     plies += 1
             games += 1
     assert games >= 60 and late_plies > 200, (games, plies, late_plies)
-    print("%d games / %d plies replayed in the oracle, %d plies of them on boards without walls (k_lanes)" % (games, plies, late_plies))
+    print("%d games / %d plies replayed in the oracle, %d plies of them on boards without walls (k_rows)" % (games, plies, late_plies))
 
 
 @pytest.mark.parametrize("mapping", MAPPINGS)
 def test_lane_kernel_real_network_search_equals_the_oracle(gpu_device, mapping):
     """test_gpu_async_oracle's real-network search (64 late-game boards, 400 playouts, three plies, evaluations collected from the
-    miss lists and fed to oracle.OracleMCTS) on k_lanes."""
+    miss lists and fed to oracle.OracleMCTS) on k_rows."""
     import test_gpu_async_oracle as T
 
     T.test_real_network_search_equals_the_oracle_fed_with_the_miss_list_evaluations(gpu_device, mapping)
